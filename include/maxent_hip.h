@@ -1,0 +1,170 @@
+/* maxent_hip.h -- C-ABI of libmaxent_hip.so (MI355X / gfx950)
+ *
+ * Drop-in boundary for the alpha-scan inner solver of TRIQS/maxent.
+ * The reference (pure Python, /root/reference/python) has no FFI; the natural
+ * hook for a batched device solver is the body of
+ *     MaxEntLoop.run                      maxent_loop.py:144-302  (one alpha scan)
+ *     ElementwiseMaxEnt.run_diagonal /
+ *                       run_offdiagonal   elementwise_maxent.py:223-268 (all elements)
+ * i.e. everything between "K.reduce_singular_space()" (maxent_loop.py:184) and
+ * "result.add_result(...)" (maxent_loop.py:258-266).  The entry points below
+ * replace exactly that span:
+ *
+ *   reference                                              | this library
+ *   -------------------------------------------------------+---------------------------
+ *   KernelSVD.U/.S/.V after reduce_singular_space          | mxe_ctx_create(U,S,V)
+ *     kernels.py:53-122                                    |
+ *   NormalChi2(K, G, err)            functions.py:336-377  | mxe_dataset_add (U,err) +
+ *   TauMaxEnt.set_cov rotation       tau_maxent.py:253-325 |   mxe_elements_set (G, D, kind)
+ *   NormalEntropy / PlusMinusEntropy functions.py:491-564  |
+ *   NormalH_of_v / PlusMinusH_of_v   functions.py:720-796  |
+ *   for alpha in alpha_mesh:                               | mxe_solve_chains
+ *      cost_function.set_alpha       maxent_loop.py:243    |   (one chain = one element's
+ *      minimizer.minimize            maxent_loop.py:245    |    warm-started alpha scan)
+ *        LevenbergMinimizer.minimize levenberg_minimizer.py:123-248
+ *        MaxEntCostFunction.f/d/dd   maxent_cost_function.py:68-165
+ *        BryanCostFunction.f/d/dd    bryan_cost_function.py:57-128
+ *      Q_min = cost_function(v)      maxent_loop.py:246    | out_v/out_H/out_chi2/out_S/out_Q
+ *      minimizer.n_iter_last/.converged  maxent_loop.py:254-256 | out_niter/out_converged
+ *
+ * Conventions: plain C, no C++ types; every function returns 0 (MXE_OK) or a
+ * negative error code and never throws or aborts; the caller owns every host
+ * buffer (C-contiguous, row-major); the library owns device memory inside
+ * mxe_ctx.  Calls on one ctx are not re-entrant; different ctxs (devices) may
+ * be driven from different threads.  All arithmetic is IEEE binary64.
+ */
+#ifndef MAXENT_HIP_H
+#define MAXENT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MXE_OK               0
+#define MXE_ERR_ARG         -1   /* bad argument (NULL, size, index)          */
+#define MXE_ERR_HIP         -2   /* a HIP runtime call failed (mxe_last_hip_error) */
+#define MXE_ERR_NODEVICE    -3   /* no usable gfx950 device                   */
+#define MXE_ERR_STATE       -4   /* call order (e.g. solve before elements)   */
+#define MXE_ERR_LIMIT       -5   /* n_s > 128 or LDS budget exceeded          */
+#define MXE_ERR_NUMERIC     -6   /* whitening failed (non-positive error bar) */
+
+#define MXE_ENTROPY_NORMAL     0 /* NormalEntropy + NormalH_of_v              */
+#define MXE_ENTROPY_PLUSMINUS  1 /* PlusMinusEntropy + PlusMinusH_of_v        */
+
+typedef struct mxe_ctx mxe_ctx;
+
+/* Options of the per-alpha minimiser.  Fill with mxe_opts_default() first.
+ * Counterparts: LevenbergMinimizer.__init__ (levenberg_minimizer.py:92-121)
+ * and convergence_methods.py:81-122. */
+typedef struct mxe_opts {
+    int32_t maxiter;      /* max Newton iterations per alpha (reference: 1000)            */
+    int32_t miniter;      /* reference: 0                                                 */
+    double  tol_h;        /* converged when the Newton correction satisfies
+                             ||dH||_2 / ||H||_2 < tol_h   (default 1e-9; 0 = off)         */
+    double  tol_d;        /* MaxDerivativeConvergenceMethod: max|W g| < tol_d (0 = off;
+                             reference default 1e-4)                                      */
+    double  tol_relq;     /* RelativeFunctionChangeConvergenceMethod: |Q0-Q1|/|Q1| <
+                             tol_relq (0 = off; reference default 1e-16)                  */
+    double  step_max;     /* step bound  delta^T W delta <= step_max * sum(D)  (0.2)      */
+    double  mu_first;     /* first non-zero damping, in units of alpha (1e-3)             */
+    double  mu_grow;      /* growth factor of the damping on a rejected step (4)          */
+    double  mu_max;       /* give up on the alpha when mu/alpha exceeds this (1e20)       */
+    int32_t waves_per_chain; /* 0 = choose from the chain count; else 1,2,4,8,16          */
+    int32_t reserved;
+} mxe_opts;
+
+/* ---- library / device ------------------------------------------------- */
+const char* mxe_version(void);
+const char* mxe_strerror(int code);
+int  mxe_device_count(int* n_devices);
+void mxe_opts_default(mxe_opts* opts);
+
+/* ---- context: one per device; holds the truncated SVD of the kernel ---- */
+/* U: n_tau x n_s, S: n_s, V: n_omega x n_s (row-major, as KernelSVD.U/.S/.V
+ * return them, kernels.py:66-94).  U is only used as the default data set 0
+ * together with `err` given to mxe_dataset_add; it may be NULL if every data
+ * set brings its own (rotated) U. */
+int  mxe_ctx_create(int device, int n_tau, int n_omega, int n_s,
+                    const double* U, const double* S, const double* V,
+                    mxe_ctx** out);
+void mxe_ctx_destroy(mxe_ctx* ctx);
+const char* mxe_last_hip_error(mxe_ctx* ctx);
+
+/* ---- data sets: a (U, err) pair = one whitened singular basis ---------- */
+/* U_rot: n_rows x n_s left factor in the (possibly covariance-rotated) data
+ * space (Kernel.transform, kernels.py:160-180); NULL = the ctx's U (then
+ * n_rows must equal n_tau).  err: n_rows standard deviations
+ * (TauMaxEnt.set_error / set_cov, tau_maxent.py:227-288).
+ * Returns the data-set id (>= 0) in *id. */
+int  mxe_dataset_add(mxe_ctx* ctx, int n_rows, const double* U_rot,
+                     const double* err, int* id);
+int  mxe_dataset_clear(mxe_ctx* ctx);
+
+/* ---- elements: the matrix elements of G that will be continued -------- */
+/* dataset_of_elem[e]: data-set id; G: concatenated data vectors, element e
+ * has n_rows(dataset) entries starting at G_offset[e] (already rotated into
+ * the data set's space); D: n_elem x n_omega default models INCLUDING
+ * delta-omega (default_models.py:61-63); entropy[e]: MXE_ENTROPY_*. */
+int  mxe_elements_set(mxe_ctx* ctx, int n_elem, const int32_t* dataset_of_elem,
+                      const double* G, const int64_t* G_offset,
+                      const double* D, const int32_t* entropy);
+
+/* ---- the hot path ------------------------------------------------------ */
+/* n_chain warm-started alpha scans of n_alpha values each.
+ *   elem_of_chain[c]          element index
+ *   alpha_scaled[c*n_alpha+i] alpha * scale_alpha (maxent_loop.py:216-243),
+ *                             in the order they are to be visited
+ *   v0[c*n_s + k]             start vector in the caller's singular basis
+ *                             (maxent_loop.py:196-203)
+ * Outputs (host pointers, any may be NULL), problem p = c*n_alpha + i:
+ *   out_v[p*n_s+k]  optimum in the caller's singular basis
+ *   out_H[p*n_omega+j] hidden image H(v)   out_chi2/out_S/out_Q[p]
+ *   out_niter[p] iterations (minimizer.n_iter_last)   out_converged[p] 0/1
+ *   out_nevals[p] cost evaluation passes spent on p
+ * Blocking: returns after the results are in the host buffers. */
+int  mxe_solve_chains(mxe_ctx* ctx, int n_chain, int n_alpha,
+                      const int32_t* elem_of_chain, const double* alpha_scaled,
+                      const double* v0, const mxe_opts* opts,
+                      double* out_v, double* out_H, double* out_chi2,
+                      double* out_S, double* out_Q, int32_t* out_niter,
+                      int32_t* out_converged, int32_t* out_nevals);
+
+/* Device-resident variant used by bench.py and by multi-GPU drivers:
+ * mxe_chains_upload stages the chain description once; mxe_chains_launch
+ * enqueues one pass of the solver on the ctx stream (inputs already in HBM),
+ * bracketed by HIP events; mxe_sync waits for it; mxe_chains_fetch copies the
+ * results to host buffers (same layout as mxe_solve_chains).
+ * mxe_result_device_ptrs exposes the device result buffers (for an RCCL
+ * gather driven by the caller); layouts as above except v, which is in the
+ * whitened basis with row stride mxe_ns_padded() (use mxe_chains_fetch for
+ * caller-basis v). */
+int  mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
+                       const int32_t* elem_of_chain, const double* alpha_scaled,
+                       const double* v0, const mxe_opts* opts);
+int  mxe_chains_launch(mxe_ctx* ctx);
+int  mxe_sync(mxe_ctx* ctx);
+int  mxe_chains_fetch(mxe_ctx* ctx, double* out_v, double* out_H,
+                      double* out_chi2, double* out_S, double* out_Q,
+                      int32_t* out_niter, int32_t* out_converged,
+                      int32_t* out_nevals);
+int  mxe_result_device_ptrs(mxe_ctx* ctx, void** d_H, void** d_chi2,
+                            void** d_S, void** d_Q, void** d_v,
+                            void** d_niter, void** d_converged);
+int  mxe_ns_padded(mxe_ctx* ctx);
+/* duration of the last mxe_chains_launch in ms (HIP events on the ctx stream) */
+int  mxe_last_kernel_ms(mxe_ctx* ctx, float* ms);
+/* kernel geometry of the last launch: waves per chain, workgroups, LDS bytes */
+int  mxe_last_launch_info(mxe_ctx* ctx, int* waves_per_chain, int* n_workgroups,
+                          int* lds_bytes);
+
+/* ---- output map A = B H (PreblurA_of_H.f, functions.py:999-1001) ------- */
+/* B: n_omega x n_omega row-major.  Applies to the device-resident H of the
+ * last solve; result n_problem x n_omega to host. */
+int  mxe_apply_output_map(mxe_ctx* ctx, const double* B, double* out_A);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAXENT_HIP_H */

@@ -1,0 +1,630 @@
+// maxent_hip.hip -- C-ABI of libmaxent_hip.so (see include/maxent_hip.h)
+//
+// Host side of the drop-in boundary: owns the device, whitens each data set
+// (one-sided Jacobi SVD of diag(1/err) U S, done once per (U, err) pair on
+// the host), stages the singular basis in HBM in the two layouts the kernel
+// streams (V row-major for h = V^T H and the Gram matrix, V^T for u = V v),
+// launches the chain kernel on its own stream and times it with HIP events.
+#include "../../include/maxent_hip.h"
+#include "mxe_kernel.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using mxe::KParams;
+
+namespace {
+
+struct DataSet {
+    int n_rows = 0;
+    bool identity_q = true;
+    std::vector<double> Q;      // n_s x n_s (row-major), caller basis <- whitened basis
+    std::vector<double> c;      // n_s
+    std::vector<double> Uhat;   // n_rows x n_s
+    std::vector<double> err;    // n_rows
+};
+
+template <typename T> struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    hipError_t ensure(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        if (p) { hipFree(p); p = nullptr; n = 0; }
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; n = 0; }
+};
+
+} // namespace
+
+struct mxe_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n_tau = 0, n_omega = 0, n_s = 0, NP = 64, nwp = 0;
+    std::vector<double> U, S, V;
+    std::vector<DataSet> ds;
+    bool ds_dirty = true;
+    // elements (host)
+    int n_elem = 0;
+    std::vector<int> elem_ds, elem_kind;
+    // chains
+    int n_chain = 0, n_alpha = 0;
+    std::vector<int> chain_elem;
+    mxe_opts opts;
+    bool chains_ready = false, launched = false;
+    int last_nw = 0, last_lds = 0;
+    // device
+    DevBuf<double> dV, dVt, dc, dcinv, dghat, dcperp, dD, dsumD, dalpha, dv0;
+    DevBuf<int> delem_ds, delem_kind, dchain_elem;
+    DevBuf<double> dout_v, dout_H, dout_chi2, dout_S, dout_Q, dB, dA;
+    DevBuf<int> dout_niter, dout_conv, dout_nevals;
+    std::string hip_err;
+};
+
+#define HIPCHK(ctx, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { \
+    (ctx)->hip_err = std::string(#call) + ": " + hipGetErrorString(e__); return MXE_ERR_HIP; } } while (0)
+
+namespace {
+
+// One-sided Jacobi (Hestenes) SVD of C (m x n, row-major, m >= 1):
+// C = Uhat diag(c) Q^T.  On exit C's columns hold Uhat*c, Q the rotations.
+// High relative accuracy for columns of wildly different scale, which is
+// exactly the situation of diag(1/err) U S (S spans 1e1 .. 1e-14).
+void jacobi_svd(std::vector<double>& C, int m, int n, std::vector<double>& Q)
+{
+    Q.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) Q[(size_t)i * n + i] = 1.0;
+    const double eps = 2.220446049250313e-16;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < n - 1; ++p) {
+            for (int q = p + 1; q < n; ++q) {
+                double a = 0.0, b = 0.0, g = 0.0;
+                for (int i = 0; i < m; ++i) {
+                    const double x = C[(size_t)i * n + p], y = C[(size_t)i * n + q];
+                    a += x * x; b += y * y; g += x * y;
+                }
+                if (a == 0.0 || b == 0.0) continue;
+                if (std::fabs(g) <= eps * std::sqrt(a * b)) continue;
+                rotated = true;
+                const double zeta = (b - a) / (2.0 * g);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) /
+                                 (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+                for (int i = 0; i < m; ++i) {
+                    const double x = C[(size_t)i * n + p], y = C[(size_t)i * n + q];
+                    C[(size_t)i * n + p] = cs * x - sn * y;
+                    C[(size_t)i * n + q] = sn * x + cs * y;
+                }
+                for (int i = 0; i < n; ++i) {
+                    const double x = Q[(size_t)i * n + p], y = Q[(size_t)i * n + q];
+                    Q[(size_t)i * n + p] = cs * x - sn * y;
+                    Q[(size_t)i * n + q] = sn * x + cs * y;
+                }
+            }
+        }
+        if (!rotated) break;
+    }
+}
+
+int build_dataset(mxe_ctx* ctx, int n_rows, const double* U_rot, const double* err, DataSet& d)
+{
+    const int ns = ctx->n_s;
+    for (int i = 0; i < n_rows; ++i)
+        if (!(err[i] > 0.0) || !std::isfinite(err[i])) return MXE_ERR_NUMERIC;
+    d.n_rows = n_rows;
+    d.err.assign(err, err + n_rows);
+    const double* U = U_rot ? U_rot : ctx->U.data();
+    bool scalar_err = (U_rot == nullptr);
+    for (int i = 1; i < n_rows && scalar_err; ++i) scalar_err = (err[i] == err[0]);
+    d.c.resize(ns);
+    d.Uhat.assign((size_t)n_rows * ns, 0.0);
+    if (scalar_err) {
+        // the ctx's U has orthonormal columns: C = U diag(S/err) already
+        d.identity_q = true;
+        d.Q.clear();
+        for (int k = 0; k < ns; ++k) d.c[k] = ctx->S[k] / err[0];
+        std::copy(U, U + (size_t)n_rows * ns, d.Uhat.begin());
+    } else {
+        d.identity_q = false;
+        std::vector<double> C((size_t)n_rows * ns);
+        for (int i = 0; i < n_rows; ++i)
+            for (int k = 0; k < ns; ++k)
+                C[(size_t)i * ns + k] = U[(size_t)i * ns + k] * ctx->S[k] / err[i];
+        std::vector<double> Q;
+        jacobi_svd(C, n_rows, ns, Q);
+        std::vector<double> nrm(ns);
+        for (int k = 0; k < ns; ++k) {
+            double s = 0.0;
+            for (int i = 0; i < n_rows; ++i) s += C[(size_t)i * ns + k] * C[(size_t)i * ns + k];
+            nrm[k] = std::sqrt(s);
+        }
+        std::vector<int> order(ns);
+        for (int k = 0; k < ns; ++k) order[k] = k;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nrm[a] > nrm[b]; });
+        d.Q.assign((size_t)ns * ns, 0.0);
+        for (int kk = 0; kk < ns; ++kk) {
+            const int k = order[kk];
+            d.c[kk] = nrm[k];
+            for (int i = 0; i < ns; ++i) d.Q[(size_t)i * ns + kk] = Q[(size_t)i * ns + k];
+            if (nrm[k] > 0.0)
+                for (int i = 0; i < n_rows; ++i)
+                    d.Uhat[(size_t)i * ns + kk] = C[(size_t)i * ns + k] / nrm[k];
+        }
+    }
+    double cmax = 0.0;
+    for (int k = 0; k < ns; ++k) cmax = std::max(cmax, d.c[k]);
+    if (!(cmax > 0.0)) return MXE_ERR_NUMERIC;
+    for (int k = 0; k < ns; ++k) d.c[k] = std::max(d.c[k], 1e-150 * cmax);
+    return MXE_OK;
+}
+
+int upload_bases(mxe_ctx* ctx)
+{
+    const int nds = (int)ctx->ds.size(), ns = ctx->n_s, NP = ctx->NP, nw = ctx->n_omega, nwp = ctx->nwp;
+    std::vector<double> hV((size_t)nds * nw * NP, 0.0), hVt((size_t)nds * NP * nwp, 0.0);
+    std::vector<double> hc((size_t)nds * NP, 1.0), hci((size_t)nds * NP, 1.0);
+    for (int d = 0; d < nds; ++d) {
+        const DataSet& D = ctx->ds[d];
+        for (int i = 0; i < nw; ++i) {
+            for (int k = 0; k < ns; ++k) {
+                double val;
+                if (D.identity_q) val = ctx->V[(size_t)i * ns + k];
+                else {
+                    val = 0.0;
+                    for (int j = 0; j < ns; ++j) val += ctx->V[(size_t)i * ns + j] * D.Q[(size_t)j * ns + k];
+                }
+                hV[((size_t)d * nw + i) * NP + k] = val;
+                hVt[((size_t)d * NP + k) * nwp + i] = val;
+            }
+        }
+        for (int k = 0; k < ns; ++k) { hc[(size_t)d * NP + k] = D.c[k]; hci[(size_t)d * NP + k] = 1.0 / D.c[k]; }
+    }
+    HIPCHK(ctx, ctx->dV.ensure(hV.size()));
+    HIPCHK(ctx, ctx->dVt.ensure(hVt.size()));
+    HIPCHK(ctx, ctx->dc.ensure(hc.size()));
+    HIPCHK(ctx, ctx->dcinv.ensure(hci.size()));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dV.p, hV.data(), hV.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dVt.p, hVt.data(), hVt.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dc.p, hc.data(), hc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dcinv.p, hci.data(), hci.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->ds_dirty = false;
+    return MXE_OK;
+}
+
+size_t lds_doubles(int NP, int nwp, int NW, int BS)
+{
+    const int BSP = (BS % 2) ? BS : BS + 1;
+    return (size_t)NP * (NP + 1) + 12 * (size_t)NP + (size_t)NW * NP + (size_t)NW * 8 +
+           5 * (size_t)nwp + (size_t)NW * 2 * mxe::GRAM_R * 8 * BSP;
+}
+
+template <int NW, int BS>
+hipError_t launch_t(const KParams& kp, size_t lds, hipStream_t s)
+{
+    hipError_t e = hipFuncSetAttribute((const void*)mxe::chain_kernel<NW, BS>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((mxe::chain_kernel<NW, BS>), dim3(kp.n_chain), dim3(64 * NW), lds, s, kp);
+    return hipGetLastError();
+}
+
+template <int NW>
+hipError_t launch_bs(int BS, const KParams& kp, size_t lds, hipStream_t s)
+{
+    switch (BS) {
+        case 5: return launch_t<NW, 5>(kp, lds, s);
+        case 6: return launch_t<NW, 6>(kp, lds, s);
+        case 7: return launch_t<NW, 7>(kp, lds, s);
+        default: return launch_t<NW, 8>(kp, lds, s);
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+const char* mxe_version(void) { return "maxent_hip 0.1 (gfx950)"; }
+
+const char* mxe_strerror(int code)
+{
+    switch (code) {
+        case MXE_OK: return "ok";
+        case MXE_ERR_ARG: return "invalid argument";
+        case MXE_ERR_HIP: return "HIP runtime error (see mxe_last_hip_error)";
+        case MXE_ERR_NODEVICE: return "no usable HIP device";
+        case MXE_ERR_STATE: return "call order violated";
+        case MXE_ERR_LIMIT: return "problem exceeds kernel limits (n_s <= 64, LDS budget)";
+        case MXE_ERR_NUMERIC: return "whitening failed (error bars must be finite and > 0)";
+        default: return "unknown error";
+    }
+}
+
+int mxe_device_count(int* n)
+{
+    if (!n) return MXE_ERR_ARG;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return MXE_ERR_NODEVICE; }
+    *n = c;
+    return MXE_OK;
+}
+
+void mxe_opts_default(mxe_opts* o)
+{
+    if (!o) return;
+    o->maxiter = 1000; o->miniter = 0;
+    o->tol_h = 1e-9; o->tol_d = 0.0; o->tol_relq = 0.0;
+    o->step_max = 0.2; o->mu_first = 1e-3; o->mu_grow = 4.0; o->mu_max = 1e20;
+    o->waves_per_chain = 0; o->reserved = 0;
+}
+
+int mxe_ctx_create(int device, int n_tau, int n_omega, int n_s,
+                   const double* U, const double* S, const double* V, mxe_ctx** out)
+{
+    if (!out || !S || !V || n_tau < 1 || n_omega < 1 || n_s < 1) return MXE_ERR_ARG;
+    if (n_s > 64) return MXE_ERR_LIMIT;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MXE_ERR_NODEVICE;
+    if (device < 0 || device >= ndev) return MXE_ERR_ARG;
+    mxe_ctx* ctx = new (std::nothrow) mxe_ctx();
+    if (!ctx) return MXE_ERR_ARG;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return MXE_ERR_NODEVICE; }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx; return MXE_ERR_HIP;
+    }
+    ctx->n_tau = n_tau; ctx->n_omega = n_omega; ctx->n_s = n_s;
+    ctx->NP = 64;
+    ctx->nwp = ((n_omega + 63) / 64) * 64;
+    if (U) ctx->U.assign(U, U + (size_t)n_tau * n_s);
+    ctx->S.assign(S, S + n_s);
+    ctx->V.assign(V, V + (size_t)n_omega * n_s);
+    mxe_opts_default(&ctx->opts);
+    *out = ctx;
+    return MXE_OK;
+}
+
+void mxe_ctx_destroy(mxe_ctx* ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    ctx->dV.release(); ctx->dVt.release(); ctx->dc.release(); ctx->dcinv.release();
+    ctx->dghat.release(); ctx->dcperp.release(); ctx->dD.release(); ctx->dsumD.release();
+    ctx->dalpha.release(); ctx->dv0.release(); ctx->delem_ds.release(); ctx->delem_kind.release();
+    ctx->dchain_elem.release(); ctx->dout_v.release(); ctx->dout_H.release();
+    ctx->dout_chi2.release(); ctx->dout_S.release(); ctx->dout_Q.release();
+    ctx->dout_niter.release(); ctx->dout_conv.release(); ctx->dout_nevals.release();
+    ctx->dB.release(); ctx->dA.release();
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* mxe_last_hip_error(mxe_ctx* ctx) { return ctx ? ctx->hip_err.c_str() : ""; }
+
+int mxe_dataset_add(mxe_ctx* ctx, int n_rows, const double* U_rot, const double* err, int* id)
+{
+    if (!ctx || !err || n_rows < 1) return MXE_ERR_ARG;
+    if (!U_rot && (ctx->U.empty() || n_rows != ctx->n_tau)) return MXE_ERR_ARG;
+    DataSet d;
+    int rc = build_dataset(ctx, n_rows, U_rot, err, d);
+    if (rc != MXE_OK) return rc;
+    ctx->ds.push_back(std::move(d));
+    ctx->ds_dirty = true;
+    ctx->chains_ready = false;
+    if (id) *id = (int)ctx->ds.size() - 1;
+    return MXE_OK;
+}
+
+int mxe_dataset_clear(mxe_ctx* ctx)
+{
+    if (!ctx) return MXE_ERR_ARG;
+    ctx->ds.clear(); ctx->ds_dirty = true; ctx->n_elem = 0; ctx->chains_ready = false;
+    return MXE_OK;
+}
+
+int mxe_elements_set(mxe_ctx* ctx, int n_elem, const int32_t* dataset_of_elem,
+                     const double* G, const int64_t* G_offset,
+                     const double* D, const int32_t* entropy)
+{
+    if (!ctx || n_elem < 1 || !dataset_of_elem || !G || !G_offset || !D || !entropy) return MXE_ERR_ARG;
+    if (ctx->ds.empty()) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int ns = ctx->n_s, NP = ctx->NP, nw = ctx->n_omega, nwp = ctx->nwp;
+    std::vector<double> hghat((size_t)n_elem * NP, 0.0), hcperp(n_elem), hD((size_t)n_elem * nwp, 0.0), hsumD(n_elem);
+    ctx->elem_ds.assign(n_elem, 0); ctx->elem_kind.assign(n_elem, 0);
+    std::vector<double> Gt;
+    for (int e = 0; e < n_elem; ++e) {
+        const int d = dataset_of_elem[e];
+        if (d < 0 || d >= (int)ctx->ds.size()) return MXE_ERR_ARG;
+        if (entropy[e] != MXE_ENTROPY_NORMAL && entropy[e] != MXE_ENTROPY_PLUSMINUS) return MXE_ERR_ARG;
+        const DataSet& DS = ctx->ds[d];
+        const double* Ge = G + G_offset[e];
+        Gt.assign(DS.n_rows, 0.0);
+        for (int i = 0; i < DS.n_rows; ++i) Gt[i] = Ge[i] / DS.err[i];
+        // ghat = Uhat^T Gt ;  c_perp = |Gt - Uhat ghat|^2
+        for (int k = 0; k < ns; ++k) {
+            double s = 0.0;
+            for (int i = 0; i < DS.n_rows; ++i) s += DS.Uhat[(size_t)i * ns + k] * Gt[i];
+            hghat[(size_t)e * NP + k] = s;
+        }
+        double cp = 0.0;
+        for (int i = 0; i < DS.n_rows; ++i) {
+            double r = Gt[i];
+            for (int k = 0; k < ns; ++k) r -= DS.Uhat[(size_t)i * ns + k] * hghat[(size_t)e * NP + k];
+            cp += r * r;
+        }
+        hcperp[e] = cp;
+        double sd = 0.0;
+        for (int i = 0; i < nw; ++i) { hD[(size_t)e * nwp + i] = D[(size_t)e * nw + i]; sd += D[(size_t)e * nw + i]; }
+        hsumD[e] = (entropy[e] == MXE_ENTROPY_PLUSMINUS) ? 2.0 * sd : sd;
+        ctx->elem_ds[e] = d; ctx->elem_kind[e] = entropy[e];
+    }
+    ctx->n_elem = n_elem;
+    HIPCHK(ctx, ctx->dghat.ensure(hghat.size()));
+    HIPCHK(ctx, ctx->dcperp.ensure(n_elem));
+    HIPCHK(ctx, ctx->dD.ensure(hD.size()));
+    HIPCHK(ctx, ctx->dsumD.ensure(n_elem));
+    HIPCHK(ctx, ctx->delem_ds.ensure(n_elem));
+    HIPCHK(ctx, ctx->delem_kind.ensure(n_elem));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dghat.p, hghat.data(), hghat.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dcperp.p, hcperp.data(), (size_t)n_elem * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dD.p, hD.data(), hD.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dsumD.p, hsumD.data(), (size_t)n_elem * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->delem_ds.p, ctx->elem_ds.data(), (size_t)n_elem * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->delem_kind.p, ctx->elem_kind.data(), (size_t)n_elem * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ds_dirty) { int rc = upload_bases(ctx); if (rc != MXE_OK) return rc; }
+    ctx->chains_ready = false;
+    return MXE_OK;
+}
+
+int mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
+                      const int32_t* elem_of_chain, const double* alpha_scaled,
+                      const double* v0, const mxe_opts* opts)
+{
+    if (!ctx || n_chain < 1 || n_alpha < 1 || !elem_of_chain || !alpha_scaled || !v0) return MXE_ERR_ARG;
+    if (ctx->n_elem < 1) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->ds_dirty) { int rc = upload_bases(ctx); if (rc != MXE_OK) return rc; }
+    const int ns = ctx->n_s, NP = ctx->NP, nw = ctx->n_omega;
+    if (opts) ctx->opts = *opts; else mxe_opts_default(&ctx->opts);
+    const mxe_opts& o = ctx->opts;
+    if (o.maxiter < 1 || o.step_max <= 0 || o.mu_first <= 0 || o.mu_grow <= 1.0) return MXE_ERR_ARG;
+    if (o.waves_per_chain != 0 && o.waves_per_chain != 1 && o.waves_per_chain != 2 &&
+        o.waves_per_chain != 4 && o.waves_per_chain != 8) return MXE_ERR_ARG;
+    ctx->chain_elem.assign(elem_of_chain, elem_of_chain + n_chain);
+    std::vector<double> hv0((size_t)n_chain * NP, 0.0);
+    for (int c = 0; c < n_chain; ++c) {
+        const int e = elem_of_chain[c];
+        if (e < 0 || e >= ctx->n_elem) return MXE_ERR_ARG;
+        const DataSet& DS = ctx->ds[ctx->elem_ds[e]];
+        for (int k = 0; k < ns; ++k) {
+            double s;
+            if (DS.identity_q) s = v0[(size_t)c * ns + k];
+            else {   // v' = Q^T v
+                s = 0.0;
+                for (int j = 0; j < ns; ++j) s += DS.Q[(size_t)j * ns + k] * v0[(size_t)c * ns + j];
+            }
+            hv0[(size_t)c * NP + k] = s;
+        }
+    }
+    for (size_t i = 0; i < (size_t)n_chain * n_alpha; ++i)
+        if (!(alpha_scaled[i] > 0.0) || !std::isfinite(alpha_scaled[i])) return MXE_ERR_ARG;
+    const size_t P = (size_t)n_chain * n_alpha;
+    HIPCHK(ctx, ctx->dchain_elem.ensure(n_chain));
+    HIPCHK(ctx, ctx->dalpha.ensure(P));
+    HIPCHK(ctx, ctx->dv0.ensure(hv0.size()));
+    HIPCHK(ctx, ctx->dout_v.ensure(P * NP));
+    HIPCHK(ctx, ctx->dout_H.ensure(P * nw));
+    HIPCHK(ctx, ctx->dout_chi2.ensure(P));
+    HIPCHK(ctx, ctx->dout_S.ensure(P));
+    HIPCHK(ctx, ctx->dout_Q.ensure(P));
+    HIPCHK(ctx, ctx->dout_niter.ensure(P));
+    HIPCHK(ctx, ctx->dout_conv.ensure(P));
+    HIPCHK(ctx, ctx->dout_nevals.ensure(P));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dchain_elem.p, ctx->chain_elem.data(), (size_t)n_chain * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dalpha.p, alpha_scaled, P * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dv0.p, hv0.data(), hv0.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_chain = n_chain; ctx->n_alpha = n_alpha;
+    ctx->chains_ready = true; ctx->launched = false;
+    return MXE_OK;
+}
+
+int mxe_chains_launch(mxe_ctx* ctx)
+{
+    if (!ctx) return MXE_ERR_ARG;
+    if (!ctx->chains_ready) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const mxe_opts& o = ctx->opts;
+    KParams kp;
+    kp.n_omega = ctx->n_omega; kp.n_omega_pad = ctx->nwp; kp.n_s = ctx->n_s; kp.NP = ctx->NP;
+    kp.n_alpha = ctx->n_alpha; kp.n_chain = ctx->n_chain;
+    kp.V = ctx->dV.p; kp.Vt = ctx->dVt.p; kp.c = ctx->dc.p; kp.cinv = ctx->dcinv.p;
+    kp.elem_ds = ctx->delem_ds.p; kp.elem_kind = ctx->delem_kind.p;
+    kp.ghat = ctx->dghat.p; kp.cperp = ctx->dcperp.p; kp.D = ctx->dD.p; kp.sumD = ctx->dsumD.p;
+    kp.chain_elem = ctx->dchain_elem.p; kp.alpha = ctx->dalpha.p; kp.v0 = ctx->dv0.p;
+    kp.out_v = ctx->dout_v.p; kp.out_H = ctx->dout_H.p; kp.out_chi2 = ctx->dout_chi2.p;
+    kp.out_S = ctx->dout_S.p; kp.out_Q = ctx->dout_Q.p; kp.out_niter = ctx->dout_niter.p;
+    kp.out_conv = ctx->dout_conv.p; kp.out_nevals = ctx->dout_nevals.p;
+    kp.maxiter = o.maxiter; kp.miniter = o.miniter;
+    kp.tol_h = o.tol_h; kp.tol_d = o.tol_d; kp.tol_relq = o.tol_relq;
+    kp.step_max = o.step_max; kp.mu_first = o.mu_first; kp.mu_grow = o.mu_grow; kp.mu_max = o.mu_max;
+
+    int BS = (ctx->n_s + 7) / 8; if (BS < 5) BS = 5;
+    int NW = o.waves_per_chain;
+    if (NW == 0) {
+        // fill the 256 CUs x 4 SIMDs: few chains -> more waves per chain
+        const int nc = ctx->n_chain;
+        NW = (nc >= 2048) ? 1 : (nc >= 1024) ? 2 : (nc >= 256) ? 4 : 8;
+    }
+    size_t lds = lds_doubles(ctx->NP, ctx->nwp, NW, BS) * sizeof(double);
+    while (lds > 160 * 1024 && NW > 1) { NW /= 2; lds = lds_doubles(ctx->NP, ctx->nwp, NW, BS) * sizeof(double); }
+    if (lds > 160 * 1024) return MXE_ERR_LIMIT;
+    ctx->last_nw = NW; ctx->last_lds = (int)lds;
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    hipError_t e;
+    switch (NW) {
+        case 1: e = launch_bs<1>(BS, kp, lds, ctx->stream); break;
+        case 2: e = launch_bs<2>(BS, kp, lds, ctx->stream); break;
+        case 4: e = launch_bs<4>(BS, kp, lds, ctx->stream); break;
+        default: e = launch_bs<8>(BS, kp, lds, ctx->stream); break;
+    }
+    HIPCHK(ctx, e);
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->launched = true;
+    return MXE_OK;
+}
+
+int mxe_sync(mxe_ctx* ctx)
+{
+    if (!ctx) return MXE_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MXE_OK;
+}
+
+int mxe_chains_fetch(mxe_ctx* ctx, double* out_v, double* out_H, double* out_chi2,
+                     double* out_S, double* out_Q, int32_t* out_niter,
+                     int32_t* out_converged, int32_t* out_nevals)
+{
+    if (!ctx) return MXE_ERR_ARG;
+    if (!ctx->launched) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t P = (size_t)ctx->n_chain * ctx->n_alpha;
+    const int ns = ctx->n_s, NP = ctx->NP, nw = ctx->n_omega;
+    if (out_H) HIPCHK(ctx, hipMemcpy(out_H, ctx->dout_H.p, P * nw * 8, hipMemcpyDeviceToHost));
+    if (out_chi2) HIPCHK(ctx, hipMemcpy(out_chi2, ctx->dout_chi2.p, P * 8, hipMemcpyDeviceToHost));
+    if (out_S) HIPCHK(ctx, hipMemcpy(out_S, ctx->dout_S.p, P * 8, hipMemcpyDeviceToHost));
+    if (out_Q) HIPCHK(ctx, hipMemcpy(out_Q, ctx->dout_Q.p, P * 8, hipMemcpyDeviceToHost));
+    if (out_niter) HIPCHK(ctx, hipMemcpy(out_niter, ctx->dout_niter.p, P * 4, hipMemcpyDeviceToHost));
+    if (out_converged) HIPCHK(ctx, hipMemcpy(out_converged, ctx->dout_conv.p, P * 4, hipMemcpyDeviceToHost));
+    if (out_nevals) HIPCHK(ctx, hipMemcpy(out_nevals, ctx->dout_nevals.p, P * 4, hipMemcpyDeviceToHost));
+    if (out_v) {
+        std::vector<double> hv(P * NP);
+        HIPCHK(ctx, hipMemcpy(hv.data(), ctx->dout_v.p, P * NP * 8, hipMemcpyDeviceToHost));
+        for (size_t pidx = 0; pidx < P; ++pidx) {
+            const int chain = (int)(pidx / ctx->n_alpha);
+            const DataSet& DS = ctx->ds[ctx->elem_ds[ctx->chain_elem[chain]]];
+            for (int k = 0; k < ns; ++k) {
+                double s;
+                if (DS.identity_q) s = hv[pidx * NP + k];
+                else {   // v = Q v'
+                    s = 0.0;
+                    for (int j = 0; j < ns; ++j) s += DS.Q[(size_t)k * ns + j] * hv[pidx * NP + j];
+                }
+                out_v[pidx * ns + k] = s;
+            }
+        }
+    }
+    return MXE_OK;
+}
+
+int mxe_solve_chains(mxe_ctx* ctx, int n_chain, int n_alpha,
+                     const int32_t* elem_of_chain, const double* alpha_scaled,
+                     const double* v0, const mxe_opts* opts,
+                     double* out_v, double* out_H, double* out_chi2,
+                     double* out_S, double* out_Q, int32_t* out_niter,
+                     int32_t* out_converged, int32_t* out_nevals)
+{
+    int rc = mxe_chains_upload(ctx, n_chain, n_alpha, elem_of_chain, alpha_scaled, v0, opts);
+    if (rc != MXE_OK) return rc;
+    rc = mxe_chains_launch(ctx);
+    if (rc != MXE_OK) return rc;
+    return mxe_chains_fetch(ctx, out_v, out_H, out_chi2, out_S, out_Q, out_niter, out_converged, out_nevals);
+}
+
+int mxe_result_device_ptrs(mxe_ctx* ctx, void** d_H, void** d_chi2, void** d_S, void** d_Q,
+                           void** d_v, void** d_niter, void** d_converged)
+{
+    if (!ctx) return MXE_ERR_ARG;
+    if (!ctx->chains_ready) return MXE_ERR_STATE;
+    if (d_H) *d_H = ctx->dout_H.p;
+    if (d_chi2) *d_chi2 = ctx->dout_chi2.p;
+    if (d_S) *d_S = ctx->dout_S.p;
+    if (d_Q) *d_Q = ctx->dout_Q.p;
+    if (d_v) *d_v = ctx->dout_v.p;
+    if (d_niter) *d_niter = ctx->dout_niter.p;
+    if (d_converged) *d_converged = ctx->dout_conv.p;
+    return MXE_OK;
+}
+
+int mxe_ns_padded(mxe_ctx* ctx) { return ctx ? ctx->NP : MXE_ERR_ARG; }
+
+int mxe_last_kernel_ms(mxe_ctx* ctx, float* ms)
+{
+    if (!ctx || !ms) return MXE_ERR_ARG;
+    if (!ctx->launched) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return MXE_OK;
+}
+
+int mxe_last_launch_info(mxe_ctx* ctx, int* waves_per_chain, int* n_workgroups, int* lds_bytes)
+{
+    if (!ctx) return MXE_ERR_ARG;
+    if (waves_per_chain) *waves_per_chain = ctx->last_nw;
+    if (n_workgroups) *n_workgroups = ctx->n_chain;
+    if (lds_bytes) *lds_bytes = ctx->last_lds;
+    return MXE_OK;
+}
+
+} // extern "C"
+
+// ---- output map A = B H ----------------------------------------------------
+namespace mxe {
+// one workgroup per problem; thread j computes A_j = sum_k B[j][k] H[k]
+// with Bt (= B^T, [k][j]) so that the loads are coalesced along j.
+__global__ __launch_bounds__(256)
+void output_map_kernel(const double* __restrict__ Bt, const double* __restrict__ H,
+                       double* __restrict__ A, int nw)
+{
+    extern __shared__ double hs[];
+    const double* Hp = H + (size_t)blockIdx.x * nw;
+    for (int k = threadIdx.x; k < nw; k += blockDim.x) hs[k] = Hp[k];
+    __syncthreads();
+    for (int j = threadIdx.x; j < nw; j += blockDim.x) {
+        double a0 = 0.0, a1 = 0.0;
+        int k = 0;
+        for (; k + 1 < nw; k += 2) {
+            a0 = fma(Bt[(size_t)k * nw + j], hs[k], a0);
+            a1 = fma(Bt[(size_t)(k + 1) * nw + j], hs[k + 1], a1);
+        }
+        if (k < nw) a0 = fma(Bt[(size_t)k * nw + j], hs[k], a0);
+        A[(size_t)blockIdx.x * nw + j] = a0 + a1;
+    }
+}
+} // namespace mxe
+
+extern "C" int mxe_apply_output_map(mxe_ctx* ctx, const double* B, double* out_A)
+{
+    if (!ctx || !B || !out_A) return MXE_ERR_ARG;
+    if (!ctx->launched) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int nw = ctx->n_omega;
+    const size_t P = (size_t)ctx->n_chain * ctx->n_alpha;
+    std::vector<double> Bt((size_t)nw * nw);
+    for (int j = 0; j < nw; ++j) for (int k = 0; k < nw; ++k) Bt[(size_t)k * nw + j] = B[(size_t)j * nw + k];
+    HIPCHK(ctx, ctx->dB.ensure(Bt.size()));
+    HIPCHK(ctx, ctx->dA.ensure(P * nw));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dB.p, Bt.data(), Bt.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(mxe::output_map_kernel, dim3((unsigned)P), dim3(256), (size_t)nw * 8, ctx->stream,
+                       ctx->dB.p, ctx->dout_H.p, ctx->dA.p, nw);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out_A, ctx->dA.p, P * nw * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MXE_OK;
+}

@@ -1,0 +1,311 @@
+"""ctypes binding of libmaxent_hip.so (include/maxent_hip.h).
+
+This is the only place where Python crosses into native code.  There is no
+CPU fallback: if the shared library is missing or no gfx950 device is
+visible, every entry point raises :class:`MaxEntDeviceError`.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+_LIB = None
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                         'lib', 'libmaxent_hip.so')
+
+ENTROPY_NORMAL = 0
+ENTROPY_PLUSMINUS = 1
+
+
+class MaxEntDeviceError(RuntimeError):
+    pass
+
+
+class MxeOpts(ctypes.Structure):
+    """mirror of ``struct mxe_opts`` (include/maxent_hip.h)."""
+    _fields_ = [('maxiter', ctypes.c_int32),
+                ('miniter', ctypes.c_int32),
+                ('tol_h', ctypes.c_double),
+                ('tol_d', ctypes.c_double),
+                ('tol_relq', ctypes.c_double),
+                ('step_max', ctypes.c_double),
+                ('mu_first', ctypes.c_double),
+                ('mu_grow', ctypes.c_double),
+                ('mu_max', ctypes.c_double),
+                ('waves_per_chain', ctypes.c_int32),
+                ('reserved', ctypes.c_int32)]
+
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int32)
+_lp = ctypes.POINTER(ctypes.c_int64)
+_vp = ctypes.c_void_p
+
+# every symbol include/maxent_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ('mxe_version', ctypes.c_char_p, []),
+    ('mxe_strerror', ctypes.c_char_p, [ctypes.c_int]),
+    ('mxe_device_count', ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    ('mxe_opts_default', None, [ctypes.POINTER(MxeOpts)]),
+    ('mxe_ctx_create', ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, _dp, _dp, _dp,
+                                      ctypes.POINTER(_vp)]),
+    ('mxe_ctx_destroy', None, [_vp]),
+    ('mxe_last_hip_error', ctypes.c_char_p, [_vp]),
+    ('mxe_dataset_add', ctypes.c_int, [_vp, ctypes.c_int, _dp, _dp,
+                                       ctypes.POINTER(ctypes.c_int)]),
+    ('mxe_dataset_clear', ctypes.c_int, [_vp]),
+    ('mxe_elements_set', ctypes.c_int, [_vp, ctypes.c_int, _ip, _dp, _lp, _dp,
+                                        _ip]),
+    ('mxe_solve_chains', ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _ip,
+                                        _dp, _dp, ctypes.POINTER(MxeOpts),
+                                        _dp, _dp, _dp, _dp, _dp, _ip, _ip,
+                                        _ip]),
+    ('mxe_chains_upload', ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _ip,
+                                         _dp, _dp, ctypes.POINTER(MxeOpts)]),
+    ('mxe_chains_launch', ctypes.c_int, [_vp]),
+    ('mxe_sync', ctypes.c_int, [_vp]),
+    ('mxe_chains_fetch', ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _ip, _ip,
+                                        _ip]),
+    ('mxe_result_device_ptrs', ctypes.c_int, [_vp] + [ctypes.POINTER(_vp)] * 7),
+    ('mxe_ns_padded', ctypes.c_int, [_vp]),
+    ('mxe_last_kernel_ms', ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    ('mxe_last_launch_info', ctypes.c_int, [_vp] +
+     [ctypes.POINTER(ctypes.c_int)] * 3),
+    ('mxe_apply_output_map', ctypes.c_int, [_vp, _dp, _dp]),
+]
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Load libmaxent_hip.so and declare every prototype. Raises if missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_LIB_PATH):
+        raise MaxEntDeviceError(
+            'HIP library not built: {} is missing. Run '
+            '`python -c "import __graft_entry__ as g; g.build()"` or '
+            '`make -C maxent_amd/csrc`. There is no CPU fallback.'.format(
+                _LIB_PATH))
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)      # AttributeError if a symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _LIB = lib
+    return lib
+
+
+def device_count():
+    lib = load_library()
+    n = ctypes.c_int(0)
+    lib.mxe_device_count(ctypes.byref(n))
+    return n.value
+
+
+def default_opts(**kw):
+    lib = load_library()
+    o = MxeOpts()
+    lib.mxe_opts_default(ctypes.byref(o))
+    for k, val in kw.items():
+        if not hasattr(o, k):
+            raise TypeError('unknown solver option {!r}'.format(k))
+        setattr(o, k, val)
+    return o
+
+
+def _c(a, dtype=np.float64):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _p(a):
+    if a is None:
+        return None
+    if a.dtype == np.float64:
+        return a.ctypes.data_as(_dp)
+    if a.dtype == np.int32:
+        return a.ctypes.data_as(_ip)
+    if a.dtype == np.int64:
+        return a.ctypes.data_as(_lp)
+    raise TypeError(a.dtype)
+
+
+class DeviceContext(object):
+    """One solver context on one GPU: holds the truncated SVD of the kernel.
+
+    Parameters mirror ``mxe_ctx_create``: ``U`` (n_tau x n_s), ``S`` (n_s),
+    ``V`` (n_omega x n_s) as ``KernelSVD.U/.S/.V`` give them after
+    ``reduce_singular_space`` (reference kernels.py:53-122).
+    """
+
+    def __init__(self, U, S, V, device=0):
+        self._lib = load_library()
+        self._h = _vp(None)
+        S = _c(S)
+        V = _c(V)
+        self.n_s = int(S.shape[0])
+        self.n_omega = int(V.shape[0])
+        if V.shape[1] != self.n_s:
+            raise ValueError('V must be n_omega x n_s')
+        if U is not None:
+            U = _c(U)
+            if U.shape[1] != self.n_s:
+                raise ValueError('U must be n_tau x n_s')
+            self.n_tau = int(U.shape[0])
+        else:
+            self.n_tau = 1
+        if device_count() < 1:
+            raise MaxEntDeviceError('no HIP device visible; the solver has no '
+                                    'CPU fallback')
+        self._check(self._lib.mxe_ctx_create(
+            int(device), self.n_tau, self.n_omega, self.n_s,
+            _p(U), _p(S), _p(V), ctypes.byref(self._h)), 'mxe_ctx_create')
+        self.device = int(device)
+        self._n_chain = 0
+        self._n_alpha = 0
+        self._ds_rows = []
+
+    # -- plumbing ------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.mxe_strerror(rc).decode()
+            if rc == -2 and self._h:
+                msg += ': ' + self._lib.mxe_last_hip_error(self._h).decode()
+            raise MaxEntDeviceError('{} failed: {}'.format(what, msg))
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self._lib.mxe_ctx_destroy(self._h)
+            self._h = _vp(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data sets and elements ------------------------------------------
+    def add_dataset(self, err, U_rot=None):
+        """(U, err) pair -> whitened basis; returns the data-set id."""
+        if U_rot is not None:
+            U_rot = _c(U_rot)
+            n_rows = U_rot.shape[0]
+        else:
+            n_rows = self.n_tau
+        err = _c(np.asarray(err, dtype=float) * np.ones(n_rows))
+        i = ctypes.c_int(-1)
+        self._check(self._lib.mxe_dataset_add(self._h, int(n_rows), _p(U_rot),
+                                              _p(err), ctypes.byref(i)),
+                    'mxe_dataset_add')
+        self._ds_rows.append(int(n_rows))
+        return i.value
+
+    def clear_datasets(self):
+        self._check(self._lib.mxe_dataset_clear(self._h), 'mxe_dataset_clear')
+        self._ds_rows = []
+
+    def set_elements(self, dataset_of_elem, G_list, D, entropy):
+        """G_list: one data vector per element (already in its data set's
+        rotated space); D: n_elem x n_omega (including delta-omega)."""
+        ds = _c(dataset_of_elem, np.int32)
+        n_elem = len(ds)
+        offs = np.zeros(n_elem, dtype=np.int64)
+        chunks = []
+        pos = 0
+        for e in range(n_elem):
+            g = _c(G_list[e]).ravel()
+            if g.shape[0] != self._ds_rows[ds[e]]:
+                raise ValueError('G of element {} has length {}, its data set '
+                                 'has {} rows'.format(e, g.shape[0],
+                                                      self._ds_rows[ds[e]]))
+            offs[e] = pos
+            pos += g.shape[0]
+            chunks.append(g)
+        G = _c(np.concatenate(chunks))
+        D = _c(D).reshape(n_elem, self.n_omega)
+        ent = _c(entropy, np.int32)
+        self._check(self._lib.mxe_elements_set(self._h, n_elem, _p(ds), _p(G),
+                                               _p(offs), _p(D), _p(ent)),
+                    'mxe_elements_set')
+        self.n_elem = n_elem
+
+    # -- the hot path ----------------------------------------------------
+    def upload_chains(self, elem_of_chain, alpha_scaled, v0, opts=None):
+        el = _c(elem_of_chain, np.int32)
+        al = _c(alpha_scaled)
+        if al.ndim == 1:
+            al = np.ascontiguousarray(np.broadcast_to(al, (len(el), al.shape[0])))
+        n_chain, n_alpha = al.shape
+        v0 = _c(v0).reshape(n_chain, self.n_s)
+        if opts is None:
+            opts = default_opts()
+        self._check(self._lib.mxe_chains_upload(self._h, n_chain, n_alpha,
+                                                _p(el), _p(al), _p(v0),
+                                                ctypes.byref(opts)),
+                    'mxe_chains_upload')
+        self._n_chain, self._n_alpha = n_chain, n_alpha
+
+    def launch(self):
+        self._check(self._lib.mxe_chains_launch(self._h), 'mxe_chains_launch')
+
+    def sync(self):
+        self._check(self._lib.mxe_sync(self._h), 'mxe_sync')
+
+    def fetch(self, want_v=True, want_H=True):
+        nc, na = self._n_chain, self._n_alpha
+        out = dict(
+            chi2=np.empty((nc, na)), S=np.empty((nc, na)), Q=np.empty((nc, na)),
+            n_iter=np.empty((nc, na), dtype=np.int32),
+            converged=np.empty((nc, na), dtype=np.int32),
+            n_evals=np.empty((nc, na), dtype=np.int32))
+        v = np.empty((nc, na, self.n_s)) if want_v else None
+        H = np.empty((nc, na, self.n_omega)) if want_H else None
+        self._check(self._lib.mxe_chains_fetch(
+            self._h, _p(v), _p(H), _p(out['chi2']), _p(out['S']), _p(out['Q']),
+            _p(out['n_iter']), _p(out['converged']), _p(out['n_evals'])),
+            'mxe_chains_fetch')
+        out['v'] = v
+        out['H'] = H
+        return out
+
+    def solve_chains(self, elem_of_chain, alpha_scaled, v0, opts=None,
+                     want_v=True, want_H=True):
+        """Blocking solve: upload, one launch, fetch (``mxe_solve_chains``)."""
+        self.upload_chains(elem_of_chain, alpha_scaled, v0, opts)
+        self.launch()
+        return self.fetch(want_v, want_H)
+
+    def apply_output_map(self, B):
+        B = _c(B).reshape(self.n_omega, self.n_omega)
+        A = np.empty((self._n_chain, self._n_alpha, self.n_omega))
+        self._check(self._lib.mxe_apply_output_map(self._h, _p(B), _p(A)),
+                    'mxe_apply_output_map')
+        return A
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float(0)
+        self._check(self._lib.mxe_last_kernel_ms(self._h, ctypes.byref(ms)),
+                    'mxe_last_kernel_ms')
+        return float(ms.value)
+
+    def last_launch_info(self):
+        a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        self._check(self._lib.mxe_last_launch_info(self._h, ctypes.byref(a),
+                                                   ctypes.byref(b),
+                                                   ctypes.byref(c)),
+                    'mxe_last_launch_info')
+        return dict(waves_per_chain=a.value, n_workgroups=b.value,
+                    lds_bytes=c.value)
+
+    def result_device_ptrs(self):
+        ptrs = [_vp(None) for _ in range(7)]
+        self._check(self._lib.mxe_result_device_ptrs(
+            self._h, *[ctypes.byref(x) for x in ptrs]),
+            'mxe_result_device_ptrs')
+        names = ['H', 'chi2', 'S', 'Q', 'v', 'n_iter', 'converged']
+        return dict(zip(names, [x.value for x in ptrs]))

@@ -1,0 +1,219 @@
+"""Kernels of the analytic continuation and their SVD staging (host side).
+
+``G_i = sum_j K_ij H_j`` with ``H = A * delta_omega``.  The kernel matrix is
+filled and decomposed once on the host with numpy/LAPACK; the truncated
+factors ``U, S, V`` are what :class:`maxent_amd.device.DeviceContext` stages
+in HBM.  Public names and semantics follow the reference's ``kernels`` module
+(reference python/kernels.py:37-413): ``KernelSVD``, ``Kernel``,
+``DataKernel``, ``TauKernel``, ``PreblurKernel``.
+"""
+
+import numpy as np
+
+from .preblur import get_preblur
+
+
+class KernelSVD(object):
+    """Matrix with a lazily computed thin SVD ``K = U diag(S) V^T``.
+
+    ``V`` is stored as ``n_omega x n_s`` (reference kernels.py:53-64).
+    """
+
+    def __init__(self, K=None):
+        self._U = self._S = self._V = None
+        self._K = K
+        self._last_threshold = None
+
+    def _invalidate_svd(self):
+        self._U = self._S = self._V = None
+
+    def svd(self):
+        if self._U is None:
+            U, S, Vh = np.linalg.svd(self.K, full_matrices=False)
+            self._U, self._S, self._V = U, S, Vh.transpose()
+        return (self._U, self._S, self._V)
+
+    @property
+    def U(self):
+        return self.svd()[0]
+
+    @property
+    def S(self):
+        return self.svd()[1]
+
+    @property
+    def V(self):
+        return self.svd()[2]
+
+    @property
+    def K(self):
+        return self._K
+
+    def reduce_singular_space(self, threshold=1.e-14):
+        """Drop singular values below the ABSOLUTE ``threshold``
+        (reference kernels.py:101-122); a later call with a smaller
+        threshold recomputes the SVD."""
+        if self._last_threshold is not None:
+            if threshold is None or threshold < self._last_threshold:
+                self._invalidate_svd()
+        self._last_threshold = threshold
+        keep = np.where(self.S >= threshold)[0]
+        self._U = self._U[:, keep]
+        self._S = self._S[keep]
+        self._V = self._V[:, keep]
+        return self
+
+
+class Kernel(KernelSVD):
+    """Kernel on an omega mesh with an optional left rotation ``T``
+    (covariance eigenbasis; reference kernels.py:125-180)."""
+
+    def __init__(self):
+        super(Kernel, self).__init__()
+        self.omega = None
+        self._T = None
+
+    @property
+    def K_delta(self):
+        """K * delta_omega, never rotated: ``G_rec = K_delta A``."""
+        return self._K_delta
+
+    @property
+    def data_variable(self):
+        raise NotImplementedError('Use a subclass of Kernel')
+
+    def parameter_change(self):
+        self._fill_values()
+
+    def _fill_values(self):
+        raise NotImplementedError('Use a subclass of Kernel')
+
+    def transform(self, T_):
+        """Left-multiply K (and U) by ``T_``, given as the absolute rotation
+        with respect to the unrotated kernel; ``None`` undoes it."""
+        if T_ is None:
+            if self._T is None:
+                return
+            T = self._T.conjugate().transpose()
+        elif self._T is not None:
+            T = np.dot(T_, self._T.conjugate().transpose())
+        else:
+            T = T_
+        self._T = T_
+        self._U = np.dot(T, self.U)
+        self._K = np.dot(T, self._K)
+
+
+class DataKernel(Kernel):
+    """Kernel given as a matrix (reference kernels.py:183-207)."""
+
+    def __init__(self, data_variable, omega, K):
+        super(DataKernel, self).__init__()
+        self._data_variable = data_variable
+        self.omega = omega
+        self._K = K
+        self._K_delta = K * omega.delta[np.newaxis, :]
+
+    @property
+    def data_variable(self):
+        return self._data_variable
+
+
+class TauKernel(Kernel):
+    r"""Fermionic imaginary-time kernel
+    :math:`K(\tau,\omega) = -e^{-\tau\omega}/(1+e^{-\beta\omega})`
+    (reference kernels.py:210-280).  ``beta`` defaults to ``tau[-1]``."""
+
+    def __init__(self, tau, omega, beta=None):
+        super(TauKernel, self).__init__()
+        self.tau = tau
+        self.omega = omega
+        self.beta = beta
+        self._fill_values()
+
+    def _fill_values(self):
+        self._invalidate_svd()
+        tau = np.asarray(self.tau, dtype=float)
+        w = np.asarray(self.omega, dtype=float)
+        beta = tau[-1] if self.beta is None else self.beta
+        ww = w[np.newaxis, :] * np.ones((len(tau), 1))
+        tt = tau[:, np.newaxis] * np.ones((1, len(w)))
+        pos = ww >= 0.0
+        K = np.empty(ww.shape)
+        # two algebraically equal forms, each overflow-free on its half-axis
+        K[pos] = -np.exp(-ww[pos] * tt[pos]) / (np.exp(-beta * ww[pos]) + 1.0)
+        neg = np.logical_not(pos)
+        K[neg] = -np.exp(ww[neg] * (beta - tt[neg])) / \
+            (1.0 + np.exp(beta * ww[neg]))
+        self._K = K
+        self._K_delta = K * self.omega.delta[np.newaxis, :]
+        T = self._T
+        self._T = None
+        self.transform(T)
+
+    @property
+    def data_variable(self):
+        return self.tau
+
+    @data_variable.setter
+    def data_variable(self, value):
+        self.tau = value
+
+
+class PreblurKernel(Kernel):
+    """``K' = K diag(delta) B`` for the preblur formalism; ``K_delta`` stays
+    un-blurred (reference kernels.py:349-413)."""
+
+    def __init__(self, K, b):
+        KernelSVD.__init__(self)
+        self._T = None
+        self.kernel = K
+        self._b = b
+        self._fill_values()
+
+    def parameter_change(self):
+        self.kernel.parameter_change()
+        self._fill_values()
+
+    def _fill_values(self):
+        self._invalidate_svd()
+        self._B = get_preblur(self.omega, self._b)
+        self._K = np.dot(self.kernel.K,
+                         self._B * self.omega.delta[:, np.newaxis])
+        self._K_delta = self.kernel.K_delta
+
+    def transform(self, T):
+        self.kernel.transform(T)
+        self._fill_values()
+
+    @property
+    def _T(self):
+        return self.kernel._T
+
+    @_T.setter
+    def _T(self, value):
+        pass
+
+    @property
+    def b(self):
+        return self._b
+
+    @property
+    def B(self):
+        return self._B
+
+    def get_omega(self):
+        return self.kernel.omega
+
+    def set_omega(self, omega):
+        self.kernel.omega = omega
+
+    omega = property(get_omega, set_omega)
+
+    @property
+    def data_variable(self):
+        return self.kernel.data_variable
+
+    @data_variable.setter
+    def data_variable(self, value):
+        self.kernel.data_variable = value
