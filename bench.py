@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""bench.py -- alpha-solves/s of the MI355X alpha-scan solver.
+
+A "step" is one pass of the hot path (one launch of the chain kernel) over one
+batch of synthetic input that is already resident in HBM.  At N=1 the workload
+is BASELINE.json's cfg4 batch on ONE GPU: 16x16 matrix elements x 100 alpha
+(25 600 alpha-solves; n_tau=200, n_omega=500, fp64) -- the batch the
+north-star target is quoted on.  For N>1 every rank solves its own 16x16x100
+batch (different noise seed per rank: weak scaling, no data-path collective
+inside the solve); after each pass the per-alpha results chi2/S/Q/H are
+gathered on rank 0 with one RCCL gather, inside the timed region.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 under
+``python -m torch.distributed.run``); rank 0 prints ONE JSON line.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from maxent_amd import device, synthetic, hostprep   # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+N_EVAL_NOMINAL = {'normal': 160, 'plusminus': 84}
+
+
+def build_batch(n_orb, n_tau, n_omega, n_alpha, rank):
+    """Synthetic cfg3/cfg4 batch -> staged DeviceContext."""
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(n_orb, n_tau, n_omega,
+                                                noise_seed=2025 + rank)
+    t0 = time.perf_counter()
+    K.reduce_singular_space(1e-14)
+    t_svd = time.perf_counter() - t0
+    D = synthetic.flat_D(omega)
+    err = synthetic.SIGMA * np.ones(n_tau)
+    alphas = np.array(synthetic.alpha_mesh(n_alpha)) * n_tau
+    elems = [(i, j) for i in range(n_orb) for j in range(n_orb)]
+    kinds = [device.ENTROPY_NORMAL if i == j else device.ENTROPY_PLUSMINUS
+             for (i, j) in elems]
+    v0n = hostprep.initial_v(K.V, D, omega.delta, device.ENTROPY_NORMAL)
+    v0p = hostprep.initial_v(K.V, D, omega.delta, device.ENTROPY_PLUSMINUS)
+    v0 = np.stack([v0n if k == device.ENTROPY_NORMAL else v0p for k in kinds])
+    return dict(tau=tau, omega=omega, K=K, Gmat=Gmat, D=D, err=err,
+                alphas=alphas, elems=elems, kinds=kinds, v0=v0, t_svd=t_svd)
+
+
+def stage(batch, dev):
+    K = batch['K']
+    ctx = device.DeviceContext(K.U, K.S, K.V, device=dev)
+    ds = ctx.add_dataset(batch['err'])
+    n_elem = len(batch['elems'])
+    ctx.set_elements([ds] * n_elem,
+                     [batch['Gmat'][i, j] for (i, j) in batch['elems']],
+                     np.tile(batch['D'], (n_elem, 1)), batch['kinds'])
+    return ctx
+
+
+class _DevArray(object):
+    """zero-copy view of a library-owned device buffer for torch."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr,
+                                             data=(int(ptr), False), version=2)
+
+
+def cpu_baseline(batch, out_gpu, n_chains=2):
+    """The oracle port of the reference's algorithm, timed on the host on a
+    bounded sample (first diagonal + first off-diagonal element, all alphas).
+    Also reports how far the GPU result is from it and from the
+    extended-precision truth on that sample."""
+    from oracle import ref_numpy as R, hp_truth
+    K = batch['K']
+    n_alpha = len(batch['alphas'])
+    n_tau = len(batch['tau'])
+    mesh = batch['alphas'] / n_tau
+    picks = [0, 1][:n_chains]
+    t_total, solves, err_ref, err_truth = 0.0, 0, 0.0, 0.0
+    for c in picks:
+        i, j = batch['elems'][c]
+        ent = 'normal' if batch['kinds'][c] == device.ENTROPY_NORMAL else 'plusminus'
+        p = R.Problem(np.array(K.K), K.U, K.S, K.V, batch['Gmat'][i, j],
+                      batch['err'], batch['D'], entropy=ent)
+        timing = []
+        ref = R.alpha_loop(p, batch['omega'].delta, mesh, timing=timing)
+        t_total += timing[0]
+        solves += n_alpha
+        H = out_gpu['H'][c]
+        err_ref = max(err_ref, float(np.max(
+            np.linalg.norm(H - ref['H'], axis=1) / np.linalg.norm(ref['H'], axis=1))))
+        for ia in (0, n_alpha // 2, n_alpha - 1):
+            _, Ht = hp_truth.polish(p.K, p.G, p.err, p.D, p.V, p.S,
+                                    batch['alphas'][ia], out_gpu['v'][c, ia],
+                                    ent, iters=4)
+            err_truth = max(err_truth, float(np.linalg.norm(H[ia] - Ht) /
+                                             np.linalg.norm(Ht)))
+    return dict(value=solves / t_total, unit='alpha-solves/s', cores=1,
+                kind='port',
+                sample='oracle/ref_numpy.py (step-faithful numpy port of '
+                       'LevenbergMinimizer + MaxEntCostFunction) on elements '
+                       '(0,0) normal and (0,1) plusminus x %d alpha, %.1f s'
+                       % (n_alpha, t_total),
+                gpu_vs_port_max_rel_l2=err_ref,
+                gpu_vs_extended_precision_truth_max_rel_l2=err_truth)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--n-orb', type=int, default=16)
+    ap.add_argument('--n-tau', type=int, default=200)
+    ap.add_argument('--n-omega', type=int, default=500)
+    ap.add_argument('--n-alpha', type=int, default=100)
+    ap.add_argument('--waves-per-chain', type=int, default=0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if rank == 0:
+            print('bench.py: --gpus %d but WORLD_SIZE=%d; launch with '
+                  'python -m torch.distributed.run --nproc-per-node %d'
+                  % (args.gpus, world, args.gpus), file=sys.stderr)
+        if args.gpus > 1:
+            sys.exit(2)
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    if device.device_count() < 1:
+        raise SystemExit('bench.py needs a GPU: the solver has no CPU fallback')
+
+    batch = build_batch(args.n_orb, args.n_tau, args.n_omega, args.n_alpha, rank)
+    ctx = stage(batch, local_rank)
+    n_chain = len(batch['elems'])
+    P = n_chain * args.n_alpha
+    opts = device.default_opts(waves_per_chain=args.waves_per_chain)
+    ctx.upload_chains(np.arange(n_chain, dtype=np.int32), batch['alphas'],
+                      batch['v0'], opts)
+
+    gather_bufs = None
+    if world > 1:
+        import torch
+        ptrs = ctx.result_device_ptrs()
+        nw = args.n_omega
+        tH = torch.as_tensor(_DevArray(ptrs['H'], (P, nw), '<f8'), device='cuda')
+        tS = [torch.as_tensor(_DevArray(ptrs[k], (P,), '<f8'), device='cuda')
+              for k in ('chi2', 'S', 'Q')]
+        if rank == 0:
+            gH = [torch.empty_like(tH) for _ in range(world)]
+            gS = [[torch.empty_like(t) for _ in range(world)] for t in tS]
+        else:
+            gH, gS = None, [None, None, None]
+        gather_bufs = (tH, tS, gH, gS)
+
+    def one_step():
+        ctx.launch()
+        ctx.sync()
+        if world > 1:
+            tH, tS, gH, gS = gather_bufs
+            dist.gather(tH, gH, dst=0)
+            for t, g in zip(tS, gS):
+                dist.gather(t, g, dst=0)
+
+    def barrier():
+        if world > 1:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+        kernel_ms.append(ctx.last_kernel_ms())
+    if world > 1:
+        import torch
+        torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    out = ctx.fetch()
+    info = ctx.last_launch_info()
+    n_conv = int(out['converged'].sum())
+    total_solves = P * world
+    value = total_solves * args.steps / elapsed
+    k_ms = float(np.mean(kernel_ms))
+
+    # algorithmic bytes per launch: one cost evaluation pass
+    # streams V once: B_eval = n_omega*n_s*8 + 2*n_omega*8
+    n_s = ctx.n_s
+    b_eval = args.n_omega * n_s * 8 + 2 * args.n_omega * 8
+    n_diag = sum(1 for k in batch['kinds'] if k == device.ENTROPY_NORMAL)
+    n_off = n_chain - n_diag
+    bytes_nominal = args.n_alpha * b_eval * (n_diag * N_EVAL_NOMINAL['normal'] +
+                                             n_off * N_EVAL_NOMINAL['plusminus'])
+    bytes_actual = float(out['n_evals'].sum()) * b_eval
+    # every Newton iteration also streams V once more for the Gram matrix
+    bytes_streamed = float(out['n_evals'].sum() + out['n_iter'].sum()) * b_eval
+    achieved = bytes_nominal / (k_ms * 1e-3) / 1e9
+    roofline = dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS,
+                    unit='GB/s', frac=achieved / HBM_PEAK_GBS, traffic=None,
+                    kernel='mxe::chain_kernel', kernel_ms=k_ms,
+                    definition='SURVEY 8d: nominal reference work (160/84 '
+                               'evaluation passes per alpha-solve) x 232 KB '
+                               '/ kernel time',
+                    achieved_actual_evals=bytes_actual / (k_ms * 1e-3) / 1e9,
+                    achieved_streamed_incl_gram=bytes_streamed / (k_ms * 1e-3) / 1e9,
+                    evals_per_solve=float(out['n_evals'].mean()),
+                    newton_iters_per_solve=float(out['n_iter'].mean()),
+                    fp64_gflops_gram=float(out['n_iter'].sum()) * 2.0 *
+                    args.n_omega * n_s * n_s / (k_ms * 1e-3) / 1e9)
+
+    line = dict(metric='alpha-solves/s', value=value, unit='alpha-solves/s',
+                n_gpus=world, steps=args.steps, warmup=args.warmup,
+                ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
+                scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
+                config=dict(workload='cfg4: ElementwiseMaxEnt %dx%d G(tau), %d '
+                                     'chains x %d alpha = %d alpha-solves per GPU, '
+                                     'n_tau=%d n_omega=%d n_s=%d'
+                                     % (args.n_orb, args.n_orb, n_chain,
+                                        args.n_alpha, P, args.n_tau,
+                                        args.n_omega, n_s),
+                            waves_per_chain=info['waves_per_chain'],
+                            lds_bytes=info['lds_bytes'],
+                            converged=n_conv, problems=P,
+                            gather='torch.distributed nccl gather to rank 0'
+                            if world > 1 else 'none (1 GPU)',
+                            svd_seconds_host=batch['t_svd']),
+                roofline=roofline)
+    if world == 1 and not args.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline(batch, out)
+    else:
+        line['cpu_baseline'] = None
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
