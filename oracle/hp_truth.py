@@ -17,8 +17,8 @@ cost function written with the *full* kernel K exactly as the reference does
     g(v) = V^T [ K^T ((K H - G)/err^2) + alpha (log H+ - log D) ],
     log(H+/D) = V v  exactly for H = D e^{Vv} (normal) and for H+ (plusminus)
 
-The step is preconditioned with the singular-space Hessian, which only
-affects the speed of convergence, not the fixed point.
+The Newton matrix is the exact Jacobian of g, M W + alpha I with
+M = V^T K^T diag(1/err^2) K V, also in extended precision.
 """
 
 import numpy as np
@@ -26,20 +26,22 @@ import numpy as np
 LD = np.longdouble
 
 
-def _chol_solve(A, b):
+def _lu_solve(A, b):
+    """Gaussian elimination with partial pivoting in extended precision."""
+    A = A.copy()
+    b = b.copy()
     n = len(b)
-    L = np.zeros((n, n), dtype=LD)
-    for j in range(n):
-        s = A[j, j] - np.dot(L[j, :j], L[j, :j])
-        L[j, j] = np.sqrt(s)
-        for i in range(j + 1, n):
-            L[i, j] = (A[i, j] - np.dot(L[i, :j], L[j, :j])) / L[j, j]
-    y = np.zeros(n, dtype=LD)
-    for i in range(n):
-        y[i] = (b[i] - np.dot(L[i, :i], y[:i])) / L[i, i]
+    for k in range(n):
+        p = k + int(np.argmax(np.abs(A[k:, k])))
+        if p != k:
+            A[[k, p]] = A[[p, k]]
+            b[[k, p]] = b[[p, k]]
+        f = A[k + 1:, k] / A[k, k]
+        A[k + 1:, k:] -= f[:, None] * A[k, k:][None, :]
+        b[k + 1:] -= f * b[k]
     x = np.zeros(n, dtype=LD)
     for i in range(n - 1, -1, -1):
-        x[i] = (y[i] - np.dot(L[i + 1:, i], x[i + 1:])) / L[i, i]
+        x[i] = (b[i] - np.dot(A[i, i + 1:], x[i + 1:])) / A[i, i]
     return x
 
 
@@ -47,7 +49,7 @@ def polish(K, G, err, D, V, S, alpha, v0, entropy='normal', iters=5,
            history=None):
     """Newton-polish ``v0`` (in the basis V, V^T V = 1) in extended precision.
 
-    ``S``: singular values of K (only used to precondition).  Returns
+    ``S``: unused (kept for call compatibility).  Returns
     ``(v, H)`` rounded to binary64.
     """
     err = np.asarray(err, dtype=float) * np.ones(len(G))
@@ -58,9 +60,9 @@ def polish(K, G, err, D, V, S, alpha, v0, entropy='normal', iters=5,
     V_ = V.astype(LD)
     v = np.asarray(v0).astype(LD)
     a = LD(alpha)
-    # preconditioner scale: c_k ~ S_k / typical error
-    c_ = (np.asarray(S) / np.exp(np.mean(np.log(err)))).astype(LD)
-    c_ = np.maximum(c_, LD(1e-150) * c_.max())
+    # exact singular-space curvature of chi2/2:  M = V^T K^T diag(1/err^2) K V
+    KV = K_ @ V_
+    M = (KV / e_[:, None] ** 2).T @ KV
 
     def state(v):
         u = V_ @ v
@@ -79,8 +81,10 @@ def polish(K, G, err, D, V, S, alpha, v0, entropy='normal', iters=5,
         r = (K_ @ H - G_) / e_ ** 2
         g = V_.T @ (K_.T @ r) + a * v
         W = (V_.T * w) @ V_
-        A = (c_[:, None] * W * c_[None, :]) + a * np.eye(len(c_), dtype=LD)
-        dl = c_ * _chol_solve(A, g / c_)
+        # exact Newton step:  d g / d v = M W + alpha I  (row-equilibrated)
+        J = M @ W + a * np.eye(len(v), dtype=LD)
+        sc = 1 / np.max(np.abs(J), axis=1)
+        dl = _lu_solve(J * sc[:, None], g * sc)
         if history is not None:
             history.append((float(np.abs(g).max()),
                             float(np.linalg.norm(w * (V_ @ dl)) /

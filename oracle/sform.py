@@ -34,9 +34,10 @@ The damped Newton step the kernel takes is Bryan's: with a = alpha + mu,
 
 which is the reference's MaxEntCostFunction step (W M W + alpha W + damping)
 delta = W g with the damping taken in the entropy metric (mu W instead of
-the reference's mu I, levenberg_minimizer.py:185-192).  mu is steered by the
-gain ratio of actual to predicted reduction instead of the reference's
-multiplicative scan; the fixed point (g' = 0) is the same.
+the reference's mu I, levenberg_minimizer.py:185-192).  mu starts at 0 (pure Newton) and is raised only until
+Bryan's step bound  delta^T W delta <= 0.2 sum(D)  holds and the trial point
+is finite, instead of the reference's multiplicative scan for a monotone
+decrease of Q; the fixed point (g' = 0) is the same.
 """
 
 import numpy as np
@@ -113,88 +114,89 @@ def gram(basis, w):
 
 
 class KernelOptions(object):
-    def __init__(self, maxiter=1000, tol_d=1e-4, tol_relQ=1e-16,
-                 tol_pred=1e-17, mu_factor0=0.0, nu=2.0, max_reject=60,
-                 miniter=0):
+    """mirror of ``mxe_opts`` (include/maxent_hip.h)."""
+
+    def __init__(self, maxiter=1000, miniter=0, tol_h=1e-9, tol_d=0.0,
+                 tol_relq=0.0, step_max=0.2, mu_first=1e-3, mu_grow=4.0,
+                 mu_max=1e20):
         self.maxiter = maxiter
-        self.tol_d = tol_d            # max |W g| < tol_d  (MaxDerivative)
-        self.tol_relQ = tol_relQ      # |Q0-Q1|/|Q1| < tol_relQ
-        self.tol_pred = tol_pred      # predicted decrease < tol_pred*|Q|:
-        #                               the Newton step is below round-off
-        self.mu_factor0 = mu_factor0  # initial mu / alpha
-        self.nu = nu
-        self.max_reject = max_reject
         self.miniter = miniter
+        self.tol_h = tol_h            # |w o V delta| / |H| < tol_h
+        self.tol_d = tol_d            # max |W g| < tol_d  (MaxDerivative)
+        self.tol_relq = tol_relq      # |Q0-Q1|/|Q1| < tol_relq
+        self.step_max = step_max      # delta^T W delta <= step_max * sum(D)
+        self.mu_first = mu_first
+        self.mu_grow = mu_grow
+        self.mu_max = mu_max
 
 
-def solve_alpha(basis, el, alpha, v, opts, stats=None):
-    """numpy model of one alpha-solve of the HIP kernel (same control flow)."""
-    ev = evaluate(basis, el, alpha, v)
-    n_evals = 1
-    n_chol = 0
-    mu = opts.mu_factor0 * alpha
-    nu = opts.nu
-    Q0 = np.nan
-    converged = False
+def solve_alpha(basis, el, alpha, v, ev, opts, stats=None):
+    """numpy model of one alpha-solve of the HIP kernel (same control flow as
+    maxent_amd/csrc/mxe_kernel.hip.h).  ``ev``: evaluation at ``v`` (it does
+    not depend on alpha, so the chain carries it over)."""
     c = basis.c
-    it = -1
+    sumD = el.D.sum() * (1.0 if el.entropy == 'normal' else 2.0)
+    n_evals = 0
+    n_chol = 0
+    converged = False
+    Qprev = np.nan
+    Q = 0.5 * ev['chi2'] - alpha * ev['S']
+    n_iter = 0
     for it in range(opts.maxiter):
         g = c * ev['rho'] + alpha * v
+        rhs = ev['rho'] + alpha * v / c
         W = gram(basis, ev['w'])
-        d = np.dot(W, g)
-        maxd = np.max(np.abs(d))
-        conv = maxd < opts.tol_d
-        if not np.isnan(Q0):
-            conv = conv or abs(abs(Q0 - ev['Q']) / ev['Q']) < opts.tol_relQ
-        if conv and it >= opts.miniter:
+        stop = False
+        if opts.tol_d > 0 and np.max(np.abs(np.dot(W, g))) < opts.tol_d:
+            stop = True
+        if opts.tol_relq > 0 and it > 0 and \
+                abs(abs(Qprev - Q) / Q) < opts.tol_relq:
+            stop = True
+        if stop and it >= opts.miniter:
             converged = True
             break
-        rhs = ev['rho'] + alpha * v / c
         B = c[:, None] * W * c[None, :]
+        mu = 0.0
         accepted = False
-        for rej in range(opts.max_reject):
-            a = alpha + mu
-            A = B + a * np.eye(len(c))
+        while True:
+            good = True
             try:
-                L = np.linalg.cholesky(A)
+                L = np.linalg.cholesky(B + (alpha + mu) * np.eye(len(c)))
                 n_chol += 1
             except np.linalg.LinAlgError:
-                mu = max(mu * nu, alpha * 1e-3)
-                nu *= 2
-                continue
-            z = np.linalg.solve(L.T, np.linalg.solve(L, rhs))
-            delta = c * z
-            vt = v - delta
-            evt = evaluate(basis, el, alpha, vt)
-            n_evals += 1
-            Wd = np.dot(W, delta)
-            pred = 0.5 * (np.dot(g, Wd) + mu * np.dot(delta, Wd))
-            actual = ev['Q'] - evt['Q']
-            if pred <= opts.tol_pred * abs(ev['Q']):
-                # stalled at round-off: the current point is the answer
-                converged = True
-                break
-            ok = np.isfinite(evt['Q']) and (actual > 0 or
-                                            abs(actual) <= 1e-15 * abs(ev['Q']))
-            if ok:
-                rho_gain = actual / pred if pred > 0 else 1.0
-                # Nielsen's update
-                mu = mu * max(1.0 / 3.0, 1.0 - (2.0 * rho_gain - 1.0) ** 3)
-                if mu < 1e-8 * alpha:
-                    mu = 0.0
-                nu = opts.nu
-                Q0 = ev['Q']
-                v = vt
-                ev = evt
+                good = False
+            if good:
+                z = np.linalg.solve(L.T, np.linalg.solve(L, rhs))
+                delta = c * z
+                Wd = np.dot(W, delta)
+                if not (np.dot(delta, Wd) <= opts.step_max * sumD):
+                    good = False
+            if good:
+                evt = evaluate(basis, el, alpha, v - delta)
+                n_evals += 1
+                if not np.isfinite(evt['Q']):
+                    good = False
+            if good:
                 accepted = True
                 break
-            mu = max(mu * nu, alpha * 1e-3)
-            nu *= 2
-        if converged or not accepted:
+            mu = opts.mu_first * alpha if mu == 0.0 else mu * opts.mu_grow
+            if not (mu <= opts.mu_max * alpha):
+                break
+        if not accepted:
+            break
+        dH = ev['w'] * np.dot(basis.V, delta)
+        relH = np.linalg.norm(dH) / np.linalg.norm(ev['H'])
+        v = v - delta
+        ev = evt
+        Qprev = Q
+        Q = 0.5 * ev['chi2'] - alpha * ev['S']
+        n_iter += 1
+        if opts.tol_h > 0 and relH < opts.tol_h and n_iter > opts.miniter:
+            converged = True
             break
     if stats is not None:
-        stats.append((it + 1, n_evals, n_chol))
-    return v, ev, it + 1, converged
+        stats.append((n_iter, n_evals, n_chol))
+    return v, ev, n_iter, converged
 
 
 def alpha_chain(basis, el, alphas_scaled, v0, opts=None, stats=None):
@@ -211,13 +213,14 @@ def alpha_chain(basis, el, alphas_scaled, v0, opts=None, stats=None):
                n_iter=np.zeros(X, dtype=int),
                converged=np.zeros(X, dtype=bool))
     v = np.array(v0, dtype=float)
+    ev = evaluate(basis, el, alphas_scaled[0], v)
     for ia, a in enumerate(alphas_scaled):
-        v, ev, n_iter, conv = solve_alpha(basis, el, a, v, opts, stats)
+        v, ev, n_iter, conv = solve_alpha(basis, el, a, v, ev, opts, stats)
         out['v'][ia] = v
         out['H'][ia] = ev['H']
         out['chi2'][ia] = ev['chi2']
         out['S'][ia] = ev['S']
-        out['Q'][ia] = ev['Q']
+        out['Q'][ia] = 0.5 * ev['chi2'] - a * ev['S']
         out['n_iter'][ia] = n_iter
         out['converged'][ia] = conv
     return out

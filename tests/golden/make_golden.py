@@ -1,0 +1,345 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REAL reference.
+
+Runs only in the build container (reads /root/reference, which does not exist
+on the GPU box).  It
+  1. assembles an importable ``triqs_maxent`` package in a temp dir exactly as
+     the reference's CMake would with USE_TRIQS=OFF (SURVEY.md 8c recipe),
+  2. runs the reference on seeded inputs and on the data files of its own
+     tests (g_tau_semicircular.dat, elementwise_g_tau.npz, srvo3_*.dat),
+  3. checks that oracle/ref_numpy.py reproduces the reference bit for bit
+     (identical per-alpha iteration counts; H, chi2, S, Q identical),
+  4. polishes the reference optimum in extended precision (oracle/hp_truth.py)
+     to obtain a golden H that is good to ~1e-12,
+  5. writes small .npz fixtures (inputs, U/S/V, reference outputs, truth).
+
+Usage:  python tests/golden/make_golden.py
+"""
+
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+os.environ['MPLBACKEND'] = 'Agg'
+
+
+def import_reference():
+    tmp = tempfile.mkdtemp(prefix='maxent_ref_')
+    pkg = os.path.join(tmp, 'triqs_maxent')
+    shutil.copytree(os.path.join(REF, 'python'), pkg)
+    subprocess.check_call(['chmod', '-R', 'u+w', pkg])
+    os.remove(os.path.join(pkg, 'CMakeLists.txt'))
+    for src, subs in (('triqs_support.py.in', {'@TRIQS_V2@': 'OFF', '@TRIQS_V1@': 'OFF',
+                                               '@USE_TRIQS@': 'OFF'}),
+                      ('version.py.in', {'@MAXENT_VERSION@': '1.2.0', '@TRIQS_GIT_HASH@': '',
+                                         '@MAXENT_GIT_HASH@': ''})):
+        text = open(os.path.join(pkg, src)).read()
+        for k, v in subs.items():
+            text = text.replace(k, v)
+        open(os.path.join(pkg, src[:-3]), 'w').write(text)
+        os.remove(os.path.join(pkg, src))
+    with open(os.path.join(tmp, 'decorator.py'), 'w') as f:
+        f.write('import functools\n'
+                'def decorate(func, caller):\n'
+                '    @functools.wraps(func)\n'
+                '    def wrapper(*a, **k):\n'
+                '        return caller(func, *a, **k)\n'
+                '    return wrapper\n')
+    sys.path.insert(0, tmp)
+    import triqs_maxent
+    return triqs_maxent, tmp
+
+
+tm_mod, TMP = import_reference()
+from triqs_maxent import *                                    # noqa: E402,F401,F403
+from triqs_maxent.minimizers.convergence_methods import *     # noqa: E402,F401,F403
+from oracle import ref_numpy as R, hp_truth                   # noqa: E402
+
+TESTDATA = os.path.join(REF, 'test', 'python')
+
+
+def record_v(tm):
+    """record a copy of v after every alpha (MaxEntResult.v aliases)."""
+    vs, its, conv = [], [], []
+    orig = tm.minimizer.minimize
+
+    def wrapped(f, v):
+        r = orig(f, v)
+        vs.append(np.array(r, copy=True))
+        its.append(tm.minimizer.n_iter_last)
+        conv.append(bool(tm.minimizer.converged))
+        return r
+    tm.minimizer.minimize = wrapped
+    return vs, its, conv
+
+
+def truth_rows(p, alphas_scaled, vs, entropy, rows):
+    out = np.empty((len(rows), len(p.D)))
+    for n, ia in enumerate(rows):
+        _, H = hp_truth.polish(p.K, p.G, p.err, p.D, p.V, p.S, alphas_scaled[ia],
+                               vs[ia], entropy, iters=5)
+        out[n] = H
+    return out
+
+
+def check_port(p, delta, mesh, res, its, scale_alpha='Ndata', A_of_H=None, opts=None):
+    out = R.alpha_loop(p, delta, np.array(mesh), opts=opts, scale_alpha=scale_alpha,
+                       A_of_H=A_of_H)
+    assert list(out['n_iter']) == list(its), 'oracle port: iteration counts differ'
+    for k in ('H', 'A', 'chi2', 'S', 'Q', 'alpha'):
+        a, b = np.asarray(getattr(res, k)), out[k]
+        assert np.allclose(a, b, rtol=1e-12, atol=0), 'oracle port differs in ' + k
+    return out
+
+
+def single_case(name, n_tau, n_w, n_alpha, cf, rows, off=False, err=1e-4, preblur_b=None,
+                tau_err=False):
+    beta = 40.0
+    rng = np.random.RandomState(1234)
+    tau = np.linspace(0, beta, n_tau)
+    omega = HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=n_w)
+    K = TauKernel(tau=tau, omega=omega, beta=beta)
+    if off:
+        A = 0.3 * (np.exp(-(omega - 1.0) ** 2 / (2 * 0.5 ** 2)) -
+                   np.exp(-(omega + 1.5) ** 2 / (2 * 0.8 ** 2)))
+    else:
+        A = 0.6 * np.exp(-(omega - 1.0) ** 2 / (2 * 0.5 ** 2)) + \
+            0.4 * np.exp(-(omega + 1.5) ** 2 / (2 * 0.8 ** 2))
+        A /= np.trapezoid(A, omega)
+    G = K.K_delta @ np.array(A) + 1e-4 * rng.randn(n_tau)
+    tm = TauMaxEnt(cost_function=cf)
+    tm.set_verbosity(VerbosityFlags.Quiet)
+    tm.omega = omega
+    tm.set_G_tau_data(tau, G)
+    if tau_err:
+        errv = err * (1 + 0.5 * np.sin(np.arange(n_tau)))
+        tm.set_error(errv)
+    else:
+        errv = err * np.ones(n_tau)
+        tm.set_error(err)
+    B = None
+    if preblur_b is not None:
+        tm.A_of_H = PreblurA_of_H(b=preblur_b, omega=tm.omega)
+        tm.K = PreblurKernel(K=tm.K, b=preblur_b)
+        B = np.array(tm.A_of_H._B)
+    tm.alpha_mesh = LogAlphaMesh(alpha_min=1e-2, alpha_max=1e4, n_points=n_alpha)
+    vs, its, conv = record_v(tm)
+    res = tm.run()
+    ent = 'plusminus' if cf == 'plusminus' else 'normal'
+    form = 'bryan' if cf == 'bryan' else 'maxent'
+    Kmat = np.array(tm.K.K)
+    p = R.Problem(Kmat, tm.K.U, tm.K.S, tm.K.V, G, errv, np.array(tm.D.D), entropy=ent, form=form)
+    check_port(p, omega.delta, tm.alpha_mesh, res, its, A_of_H=B)
+    alphas_scaled = np.array(res.alpha)
+    Htruth = truth_rows(p, alphas_scaled, vs, ent, rows)
+    e = np.linalg.norm(np.array(res.H)[rows] - Htruth, axis=1) / np.linalg.norm(Htruth, axis=1)
+    print('%-28s n_s=%d iters=%d  ref-vs-truth max %.2e' % (name, len(tm.K.S), sum(its), e.max()))
+    d = dict(tau=tau, omega=np.array(omega), delta=omega.delta, beta=beta, G=G, err=errv,
+             D=np.array(tm.D.D), alpha=alphas_scaled, U=tm.K.U, S=tm.K.S, V=tm.K.V,
+             entropy=ent, form=form, rows=np.array(rows),
+             H_ref=np.array(res.H)[rows], A_ref=np.array(res.A)[rows],
+             chi2_ref=np.array(res.chi2), S_ref=np.array(res.S), Q_ref=np.array(res.Q),
+             n_iter_ref=np.array(its), converged_ref=np.array(conv),
+             v_ref=np.array(vs)[rows], H_truth=Htruth,
+             linefit_alpha_index=res.analyzer_results['LineFitAnalyzer']['alpha_index'],
+             chi2curv_alpha_index=res.analyzer_results['Chi2CurvatureAnalyzer']['alpha_index'],
+             A_out_linefit=res.analyzer_results['LineFitAnalyzer']['A_out'],
+             A_out_chi2curv=res.analyzer_results['Chi2CurvatureAnalyzer']['A_out'],
+             A_out_entropy=res.analyzer_results['EntropyAnalyzer']['A_out'])
+    if B is not None:
+        d['B'] = B
+        d['preblur_b'] = preblur_b
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **d)
+
+
+def kat_tau_maxent():
+    """reference test/python/tau_maxent.py:34-47,134-135 (known answer:
+    5 log-probabilities to 6 decimals)."""
+    np.random.seed(9)
+    tm = TauMaxEnt(probability='normal')
+    tm.set_verbosity(VerbosityFlags.Quiet)
+    tm.set_G_tau_file(os.path.join(TESTDATA, 'g_tau_semicircular.dat'))
+    tm.set_G_tau_data(tm.tau, tm.G + 1.e-3 * np.random.randn(len(tm.G)))
+    tm.alpha_mesh = LogAlphaMesh(alpha_min=0.08, n_points=5)
+    tm.omega = HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=200)
+    tm.set_error(1.e-3)
+    vs, its, conv = record_v(tm)
+    res = tm.run()
+    kat = [-8476.52812836, -2343.02752796, -704.28318351, -280.26627323, -175.30592555]
+    np.testing.assert_almost_equal(res.probability, kat, 6)
+    G = np.array(tm.G)
+    p = R.Problem(np.array(tm.K.K), tm.K.U, tm.K.S, tm.K.V, G, np.array(tm.err),
+                  np.array(tm.D.D))
+    out = check_port(p, tm.omega.delta, tm.alpha_mesh, res, its)
+    lp = [R.log_probability(p, a, v) for a, v in zip(out['alpha'], out['v'])]
+    np.testing.assert_almost_equal(lp, kat, 6)
+    rows = list(range(5))
+    Htruth = truth_rows(p, np.array(res.alpha), vs, 'normal', rows)
+    print('%-28s n_s=%d iters=%d' % ('kat_tau_maxent', len(tm.K.S), sum(its)))
+    np.savez_compressed(os.path.join(HERE, 'kat_tau_maxent.npz'),
+                        tau=np.array(tm.tau), omega=np.array(tm.omega), delta=tm.omega.delta,
+                        G=G, err=np.array(tm.err), D=np.array(tm.D.D), alpha=np.array(res.alpha),
+                        U=tm.K.U, S=tm.K.S, V=tm.K.V, entropy='normal', form='maxent',
+                        rows=np.array(rows), H_ref=np.array(res.H), A_ref=np.array(res.A),
+                        chi2_ref=np.array(res.chi2), S_ref=np.array(res.S), Q_ref=np.array(res.Q),
+                        n_iter_ref=np.array(its), converged_ref=np.array(conv),
+                        v_ref=np.array(vs), H_truth=Htruth,
+                        probability_ref=np.array(res.probability), probability_kat=np.array(kat),
+                        G_clean_file=np.loadtxt(os.path.join(TESTDATA, 'g_tau_semicircular.dat')))
+
+
+def kat_huge_alpha():
+    """reference test/python/huge_alpha.py:30-50: alpha -> 1e10 gives H -> D."""
+    np.random.seed(77)
+    tm = TauMaxEnt()
+    tm.set_verbosity(VerbosityFlags.Quiet)
+    tm.set_G_tau_file(os.path.join(TESTDATA, 'g_tau_semicircular.dat'))
+    tm.set_G_tau_data(tm.tau, tm.G + 1.e-4 * np.random.randn(len(tm.G)))
+    tm.alpha_mesh = LogAlphaMesh(alpha_min=1e10 - 1, alpha_max=1e10, n_points=5)
+    tm.set_error(5.e-4)
+    tm.reduce_singular_space = 1.e-16
+    vs, its, conv = record_v(tm)
+    res = tm.run()
+    assert np.max(res.H - tm.D.D) < 1e-6
+    print('%-28s n_s=%d iters=%d' % ('kat_huge_alpha', len(tm.K.S), sum(its)))
+    np.savez_compressed(os.path.join(HERE, 'kat_huge_alpha.npz'),
+                        tau=np.array(tm.tau), omega=np.array(tm.omega), delta=tm.omega.delta,
+                        G=np.array(tm.G), err=np.array(tm.err), D=np.array(tm.D.D),
+                        alpha=np.array(res.alpha), U=tm.K.U, S=tm.K.S, V=tm.K.V,
+                        entropy='normal', form='maxent', H_ref=np.array(res.H),
+                        chi2_ref=np.array(res.chi2), S_ref=np.array(res.S), Q_ref=np.array(res.Q),
+                        n_iter_ref=np.array(its))
+
+
+def kat_srvo3():
+    """reference test/python/srvo3_mesh_and_ALPS.py:37-51,100: Bryan cost
+    function, n_tau = n_omega = 500, Lorentzian mesh; A(alpha_1) equals the
+    ALPS 'maxspec' column to 2 decimals."""
+    gt = np.loadtxt(os.path.join(TESTDATA, 'srvo3_mesh_and_ALPS_gtau.dat'))
+    ms = np.loadtxt(os.path.join(TESTDATA, 'srvo3_mesh_and_ALPS_maxspec.dat'))
+    tm = TauMaxEnt(cost_function='bryan')
+    tm.set_verbosity(VerbosityFlags.Quiet)
+    tm.set_G_tau_data(gt[:, 0], gt[:, 1])
+    tm.set_error(gt[:, 2])
+    tm.omega = LorentzianOmegaMesh(omega_min=-15, omega_max=15, n_points=500)
+    n_tau = len(gt)
+    tm.alpha_mesh = LogAlphaMesh(alpha_min=5.514845959 / n_tau, alpha_max=100, n_points=2)
+    vs, its, conv = record_v(tm)
+    res = tm.run()
+    dmax = np.max(np.abs(res.A[1, :] - np.interp(np.array(tm.omega), ms[:, 0], ms[:, 1])))
+    p = R.Problem(np.array(tm.K.K), tm.K.U, tm.K.S, tm.K.V, np.array(tm.G), np.array(tm.err),
+                  np.array(tm.D.D), form='bryan')
+    check_port(p, tm.omega.delta, tm.alpha_mesh, res, its)
+    Htruth = truth_rows(p, np.array(res.alpha), vs, 'normal', [0, 1])
+    print('%-28s n_s=%d iters=%d  max|A-ALPS|=%.2e' % ('kat_srvo3', len(tm.K.S), sum(its), dmax))
+    np.savez_compressed(os.path.join(HERE, 'kat_srvo3.npz'),
+                        tau=gt[:, 0], omega=np.array(tm.omega), delta=tm.omega.delta,
+                        G=np.array(tm.G), err=np.array(tm.err), D=np.array(tm.D.D),
+                        alpha=np.array(res.alpha), U=tm.K.U, S=tm.K.S, V=tm.K.V,
+                        entropy='normal', form='bryan', rows=np.array([0, 1]),
+                        H_ref=np.array(res.H), A_ref=np.array(res.A), chi2_ref=np.array(res.chi2),
+                        S_ref=np.array(res.S), Q_ref=np.array(res.Q), n_iter_ref=np.array(its),
+                        converged_ref=np.array(conv), v_ref=np.array(vs), H_truth=Htruth,
+                        alps_maxspec=ms)
+
+
+def elementwise_case():
+    """reference test/python/elementwise_maxent.py:101-188 on its own fixture
+    elementwise_g_tau.npz (2x2x201, beta=400)."""
+    with np.load(os.path.join(TESTDATA, 'elementwise_g_tau.npz')) as data:
+        tau = data['tau']
+        G_tau_noise = data['G_tau_noise']
+        G_w_rot = data['G_w_rot']
+        w = data['w']
+    noise = 1e-3
+    out = {}
+    for name, cls, herm in (('ew', ElementwiseMaxEnt, False), ('pm', PoormanMaxEnt, False)):
+        ew = cls(use_hermiticity=herm)
+        ew.set_verbosity(VerbosityFlags.Quiet)
+        ew.set_G_tau_data(tau, G_tau_noise)
+        ew.omega = HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=80)
+        ew.alpha_mesh = LogAlphaMesh(alpha_min=0.05, alpha_max=500, n_points=8)
+        ew.set_error(noise)
+        res = ew.run()
+        out[name + '_A'] = np.array(res.A)
+        out[name + '_H'] = np.array(res.H)
+        out[name + '_chi2'] = np.array(res.chi2)
+        out[name + '_S'] = np.array(res.S)
+        out[name + '_Q'] = np.array(res.Q)
+        out[name + '_A_out'] = np.array(res.A_out)
+        out[name + '_alpha'] = np.array(res.alpha)
+        out[name + '_linefit_idx'] = np.array(
+            [[res.analyzer_results[i][j]['LineFitAnalyzer']['alpha_index'] for j in range(2)]
+             for i in range(2)])
+        K = ew.maxent_diagonal.K
+        out['U'], out['S'], out['V'] = K.U, K.S, K.V
+        out['omega'] = np.array(ew.omega)
+        out['delta'] = ew.omega.delta
+        out['D'] = np.array(ew.maxent_diagonal.D.D)
+    print('%-28s n_s=%d' % ('elementwise', len(out['S'])))
+    np.savez_compressed(os.path.join(HERE, 'elementwise.npz'), tau=tau, G_tau_noise=G_tau_noise,
+                        noise=noise, w_exact=w[::25], A01_exact=(-1.0 / np.pi * np.imag(G_w_rot[:, 0, 1]))[::25],
+                        **out)
+
+
+def cov_case():
+    """TauMaxEnt.set_cov (tau_maxent.py:253-288): full covariance -> rotated problem."""
+    n_tau, n_w, n_alpha = 60, 120, 12
+    beta = 40.0
+    rng = np.random.RandomState(4321)
+    tau = np.linspace(0, beta, n_tau)
+    omega = HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=n_w)
+    K = TauKernel(tau=tau, omega=omega, beta=beta)
+    A = 0.6 * np.exp(-(omega - 1.0) ** 2 / (2 * 0.5 ** 2)) + 0.4 * np.exp(-(omega + 1.5) ** 2 / (2 * 0.8 ** 2))
+    A /= np.trapezoid(A, omega)
+    # correlated noise: cov = L L^T
+    L = 1e-4 * (np.eye(n_tau) + 0.3 * np.diag(np.ones(n_tau - 1), 1) + 0.1 * rng.randn(n_tau, n_tau) / np.sqrt(n_tau))
+    cov = L @ L.T
+    G = K.K_delta @ np.array(A) + L @ rng.randn(n_tau)
+    tm = TauMaxEnt()
+    tm.set_verbosity(VerbosityFlags.Quiet)
+    tm.omega = omega
+    tm.set_G_tau_data(tau, G)
+    tm.set_cov(cov)
+    tm.alpha_mesh = LogAlphaMesh(alpha_min=1e-2, alpha_max=1e3, n_points=n_alpha)
+    vs, its, conv = record_v(tm)
+    res = tm.run()
+    p = R.Problem(np.array(tm.K.K), tm.K.U, tm.K.S, tm.K.V, np.array(tm.G), np.array(tm.err),
+                  np.array(tm.D.D))
+    check_port(p, omega.delta, tm.alpha_mesh, res, its)
+    rows = list(range(n_alpha))
+    Htruth = truth_rows(p, np.array(res.alpha), vs, 'normal', rows)
+    e = np.linalg.norm(np.array(res.H) - Htruth, axis=1) / np.linalg.norm(Htruth, axis=1)
+    print('%-28s n_s=%d iters=%d  ref-vs-truth max %.2e' % ('cov', len(tm.K.S), sum(its), e.max()))
+    np.savez_compressed(os.path.join(HERE, 'cov.npz'), tau=tau, omega=np.array(omega),
+                        delta=omega.delta, beta=beta, G_orig=G, cov=cov, G_rot=np.array(tm.G),
+                        err_rot=np.array(tm.err), K_rot=np.array(tm.K.K), U_rot=tm.K.U, S=tm.K.S,
+                        V=tm.K.V, D=np.array(tm.D.D), alpha=np.array(res.alpha),
+                        H_ref=np.array(res.H), A_ref=np.array(res.A), chi2_ref=np.array(res.chi2),
+                        S_ref=np.array(res.S), Q_ref=np.array(res.Q), n_iter_ref=np.array(its),
+                        v_ref=np.array(vs), H_truth=Htruth, G_rec_ref=np.array(res.G_rec))
+
+
+if __name__ == '__main__':
+    single_case('cfg1_normal', 100, 200, 20, 'normal', list(range(20)))
+    single_case('cfg1_bryan', 100, 200, 20, 'bryan', list(range(20)))
+    single_case('cfg1_plusminus', 100, 200, 20, 'plusminus', list(range(20)), off=True)
+    single_case('cfg1_tauerr', 100, 200, 20, 'normal', list(range(20)), tau_err=True)
+    single_case('cfg5_preblur_pm', 100, 200, 20, 'plusminus', list(range(20)), off=True,
+                preblur_b=0.1)
+    single_case('cfg2_normal', 200, 500, 100, 'normal', list(range(0, 100, 9)) + [99])
+    kat_tau_maxent()
+    kat_huge_alpha()
+    kat_srvo3()
+    elementwise_case()
+    cov_case()
+    shutil.rmtree(TMP, ignore_errors=True)
+    print('fixtures written to', HERE)
