@@ -1,0 +1,330 @@
+"""Element-wise MaxEnt for matrix-valued G(tau): the batching boundary.
+
+``ElementwiseMaxEnt`` / ``DiagonalMaxEnt`` / ``PoormanMaxEnt`` keep the
+reference's surface and semantics (reference python/elementwise_maxent.py:
+58-653): two workers -- diagonal elements with the normal entropy,
+off-diagonal ones with the plus-minus entropy --, attribute shadowing onto
+both, hermiticity shortcut (i > j skipped), real and imaginary parts as
+separate real problems, per-element errors or covariances, and Poorman's
+default model D_ij = sqrt(A_ii A_jj) + eps from the analyzed diagonals.
+
+What is different is the execution: the reference runs the elements one after
+the other, each with a fresh kernel fill and SVD.  Here
+``run_diagonal`` and ``run_offdiagonal`` each collect the alpha scans of all
+their elements and hand them to the device as ONE launch of the chain kernel
+(one chain per element, :func:`maxent_amd.maxent_loop.solve_elements`); the
+kernel matrix is filled and decomposed once.  Poorman's method keeps its
+ordering constraint: diagonals (including their analyzers) finish before the
+off-diagonal launch is assembled.
+"""
+
+from datetime import datetime
+
+import numpy as np
+
+from .default_models import DataDefaultModel
+from .logtaker import VerbosityFlags
+from .maxent_loop import solve_elements
+from .maxent_result import MaxEntResult
+from .tau_maxent import TauMaxEnt
+
+
+class CallableMethodCheck(object):
+    """call the same method on both workers; the results must agree."""
+
+    def __init__(self, name, fun1, fun2):
+        self.name, self.fun1, self.fun2 = name, fun1, fun2
+
+    def __call__(self, *args, **kwargs):
+        r1 = self.fun1(*args, **kwargs)
+        r2 = self.fun2(*args, **kwargs)
+        if np.all(r1 == r2):
+            return r1
+        raise Exception('Element {n} not uniquely defined. Use '
+                        'self.maxent_diagonal.{n} or '
+                        'self.maxent_offdiagonal.{n}!'.format(n=self.name))
+
+
+class ElementwiseMaxEnt(object):
+    maxent_diagonal = None
+    maxent_offdiagonal = None
+
+    def __init__(self, use_hermiticity=True, use_complex=False, **kwargs):
+        self.maxent_diagonal = TauMaxEnt(**kwargs)
+        self.maxent_offdiagonal = TauMaxEnt(cost_function='plusminus',
+                                            **kwargs)
+        self.set_G_element = None
+        self.determine_shape = None
+        self.G_mat = None
+        self.maxent_result = None
+        self.use_hermiticity = use_hermiticity
+        self.use_complex = use_complex
+        self.last_launches = []
+
+    # ---- attribute shadowing onto both workers -------------------------
+    def __getattr__(self, name):
+        d = getattr(object.__getattribute__(self, 'maxent_diagonal'), name)
+        o = getattr(object.__getattribute__(self, 'maxent_offdiagonal'), name)
+        if callable(d) and callable(o):
+            return CallableMethodCheck(name, d, o)
+        if np.all(d == o):
+            return d
+        raise Exception('Element {n} not uniquely defined. Use '
+                        'self.maxent_diagonal.{n} or '
+                        'self.maxent_offdiagonal.{n}!'.format(n=name))
+
+    def __setattr__(self, name, value):
+        if hasattr(self.maxent_diagonal, name) and \
+                hasattr(self.maxent_offdiagonal, name):
+            setattr(self.maxent_offdiagonal, name, value)
+            setattr(self.maxent_diagonal, name, value)
+        else:
+            object.__setattr__(self, name, value)
+
+    # ---- result object ---------------------------------------------------
+    def prepare_maxent_result(self, overwrite=False):
+        if self.maxent_result is None or overwrite:
+            self.maxent_result = MaxEntResult(
+                matrix_structure=self.determine_shape(self.G_mat),
+                element_wise=True,
+                use_hermiticity=self.use_hermiticity,
+                complex_elements=self.use_complex)
+
+    # ---- single element (one chain) ---------------------------------------
+    def _worker_for(self, element):
+        return self.maxent_diagonal if element[0] == element[1] \
+            else self.maxent_offdiagonal
+
+    def _load_element(self, worker, element, re):
+        i, j = element
+        self.set_G_element(worker, self.G_mat, (i, j),
+                           True if i == j else re)
+        self.put_error(worker, self.get_error((i, j)))
+
+    def run_element(self, element, re=True):
+        """one matrix element, like the reference's ``run_element``
+        (elementwise_maxent.py:170-221)."""
+        self.prepare_maxent_result(overwrite=False)
+        i, j = element
+        worker = self._worker_for(element)
+        if i != j and self.use_hermiticity and i > j:
+            worker.logtaker.message(
+                VerbosityFlags.ElementInfo,
+                'Element {} {} not calculated, can be determined from '
+                'hermiticity'.format(i, j))
+            return self.maxent_result
+        worker.logtaker.message(VerbosityFlags.ElementInfo,
+                                'Calling MaxEnt for element {} {}'.format(i, j))
+        self._load_element(worker, element, re)
+        worker.run(result=self.maxent_result, matrix_element=(i, j),
+                   complex_index=0 if re else 1)
+        return self.maxent_result
+
+    # ---- batched phases --------------------------------------------------
+    def _run_batch(self, worker, jobs, per_job_D=None):
+        """``jobs``: list of (element, re).  All scans in one launch."""
+        self.prepare_maxent_result(overwrite=False)
+        res = self.maxent_result
+        loop = worker.maxent_loop
+        specs, live = [], []
+        for n, (element, re) in enumerate(jobs):
+            if per_job_D is not None:
+                worker.set_D(per_job_D[n])
+            self._load_element(worker, element, re)
+            cidx = 0 if re else 1
+            if loop.below_threshold():
+                key = tuple(element) + ((cidx,) if self.use_complex else ())
+                res._zero_elements.append(key)
+                worker.logtaker.error_message(
+                    'G below threshold, not performing the calculation.')
+                continue
+            spec = loop.make_spec()
+            spec['A_map'] = loop.A_of_H
+            specs.append(spec)
+            live.append((element, cidx))
+        if not specs:
+            return res
+        if res._default_analyzer_name is None and loop.analyzers:
+            res._default_analyzer_name = loop.analyzers[0].name
+        t0 = datetime.now()
+        for (element, cidx) in live:
+            res.start_timing(element, cidx, time=t0)
+        sols, info = solve_elements(loop.K, specs, loop.minimizer,
+                                    device_id=loop.device_id)
+        self.last_launches.append(info)
+        t1 = datetime.now()
+        per_alpha = (t1 - t0) / max(1, len(specs) * len(specs[0]['alpha']))
+        for spec, sol, (element, cidx) in zip(specs, sols, live):
+            worker.logtaker.message(
+                VerbosityFlags.ElementInfo,
+                'Element {} {}{}'.format(element[0], element[1],
+                                         '' if cidx == 0 else ' (imaginary part)'))
+            loop.log_alpha_lines(sol)
+            rec = loop.make_record(spec, sol)
+            rec['run_times'] = [per_alpha] * len(sol['alpha'])
+            res.add_element_results(rec, element, cidx)
+            res.end_timing(element, cidx, time=t1)
+            res.analyze(loop.analyzers, element, cidx)
+        worker.logtaker.message(
+            VerbosityFlags.Timing,
+            '{} alpha scans x {} alpha in one launch: kernel {:.3f} ms',
+            len(specs), len(specs[0]['alpha']), info['kernel_ms'])
+        return res
+
+    def _diag_jobs(self):
+        return [((i, i), True) for i in range(self.shape[0])]
+
+    def _offdiag_jobs(self):
+        jobs = []
+        for i in range(self.shape[0]):
+            for j in range(self.shape[1]):
+                if i == j or (self.use_hermiticity and i > j):
+                    continue
+                for re in ([True, False] if self.use_complex else [True]):
+                    jobs.append(((i, j), re))
+        return jobs
+
+    def run_diagonal(self):
+        """all diagonal elements (reference elementwise_maxent.py:223-242)."""
+        self.maxent_diagonal.logtaker.message(
+            VerbosityFlags.ElementInfo, 'Calculating diagonal elements.')
+        res = self._run_batch(self.maxent_diagonal, self._diag_jobs())
+        if self.use_complex:
+            for i in range(self.shape[0]):
+                if (i, i, 1) not in res._zero_elements:
+                    res._zero_elements.append((i, i, 1))
+        return res
+
+    def run_offdiagonal(self):
+        """all off-diagonal elements (reference elementwise_maxent.py:244-268)."""
+        self.maxent_offdiagonal.logtaker.message(
+            VerbosityFlags.ElementInfo, 'Calculating off-diagonal elements.')
+        return self._run_batch(self.maxent_offdiagonal, self._offdiag_jobs())
+
+    def run(self):
+        self.run_diagonal()
+        self.run_offdiagonal()
+        return self.maxent_result
+
+    # ---- input ----------------------------------------------------------------
+    def set_G(self, G_mat, set_G_element, determine_shape):
+        """generic entry: ``set_G_element(maxent, G_mat, elem, re)`` feeds one
+        element to a worker (reference elementwise_maxent.py:287-315)."""
+        self.G_mat = G_mat
+        self.set_G_element = set_G_element
+        self.determine_shape = determine_shape
+        self.maxent_result = None
+
+    def set_G_tau(self, *args, **kwargs):
+        raise NotImplementedError('set_G_tau needs TRIQS Green functions; '
+                                  'use set_G_tau_data')
+
+    set_G_iw = set_G_tau
+
+    def set_G_tau_data(self, tau, G_tau, *args, **kwargs):
+        """``G_tau``: (M, N, T) array (reference elementwise_maxent.py:373-395)."""
+        def feed(maxent, G_mat, elem, re):
+            g = G_mat[1][elem]
+            maxent.set_G_tau_data(G_mat[0], np.real(g) if re else np.imag(g),
+                                  *args, **kwargs)
+        self.set_G((tau, G_tau), feed, lambda G_mat: G_mat[1].shape[:2])
+
+    def set_G_tau_filename_pattern(self, filename, dimension, tau_col=0,
+                                   G_col_re=1, G_col_im=2, *args, **kwargs):
+        """one file per element, name with ``{i}`` and ``{j}``
+        (reference elementwise_maxent.py:397-436)."""
+        def feed(maxent, G_mat, elem, re):
+            maxent.set_G_tau_file(G_mat.format(i=elem[0], j=elem[1]), tau_col,
+                                  G_col_re if re else G_col_im, *args, **kwargs)
+        self.set_G(filename, feed, lambda G_mat: dimension)
+
+    def set_G_tau_filenames(self, filenames, tau_col=0, G_col_re=1,
+                            G_col_im=2, *args, **kwargs):
+        """2-d array of file names (reference elementwise_maxent.py:438-470)."""
+        def feed(maxent, G_mat, elem, re):
+            maxent.set_G_tau_file(G_mat[elem[0]][elem[1]], tau_col,
+                                  G_col_re if re else G_col_im, *args, **kwargs)
+        self.set_G(filenames, feed, lambda G_mat: np.shape(G_mat))
+
+    def set_error(self, error):
+        """float, (T,) or (M, N, T) (reference elementwise_maxent.py:472-487)."""
+        self.error = error
+        self.error_dimension = 1
+        self.put_error = lambda maxent, err: maxent.set_error(err)
+
+    def get_error(self, elem):
+        if isinstance(self.error, float):
+            return self.error
+        if len(np.shape(self.error)) == self.error_dimension:
+            return self.error
+        return self.error[elem]
+
+    def set_cov(self, cov):
+        """(T, T) or (M, N, T, T) (reference elementwise_maxent.py:502-515)."""
+        self.error_dimension = 2
+        self.error = cov
+        self.put_error = lambda maxent, err: maxent.set_cov(err)
+
+    def get_tau(self):
+        d = self.maxent_diagonal.get_data_variable()
+        o = self.maxent_offdiagonal.get_data_variable()
+        if np.all(d == o):
+            return d
+        raise Exception('tau not uniquely defined. Use self.maxent_diagonal.tau '
+                        'or self.maxent_offdiagonal.tau!')
+
+    def set_tau(self, tau, **kwargs):
+        self.maxent_diagonal.set_tau(tau, **kwargs)
+        self.maxent_offdiagonal.set_tau(tau, **kwargs)
+
+    tau = property(get_tau, set_tau)
+
+    @property
+    def shape(self):
+        try:
+            return self.determine_shape(self.G_mat)
+        except Exception as e:
+            raise Exception('Cannot determine shape. ({})'.format(e))
+
+
+class DiagonalMaxEnt(ElementwiseMaxEnt):
+    """diagonal elements only (reference elementwise_maxent.py:549-559)."""
+
+    def run(self):
+        self.run_diagonal()
+        return self.maxent_result
+
+    def run_offdiagonal(self):
+        raise TypeError('DiagonalMaxEnt cannot run for off-diagonals.')
+
+
+class PoormanMaxEnt(ElementwiseMaxEnt):
+    r"""off-diagonals with :math:`D_{ij} = \sqrt{A_{ii}A_{jj}} + \epsilon`
+    from the analyzed diagonals (reference elementwise_maxent.py:562-653)."""
+
+    def __init__(self, analyzer_offdiag_D='LineFitAnalyzer',
+                 D_add_constant=1.e-6, *args, **kwargs):
+        super(PoormanMaxEnt, self).__init__(*args, **kwargs)
+        self.analyzer_offdiag_D = analyzer_offdiag_D
+        self.D_add_constant = D_add_constant
+
+    def run_offdiagonal(self):
+        self.prepare_maxent_result(overwrite=False)
+        self.maxent_offdiagonal.logtaker.message(
+            VerbosityFlags.ElementInfo,
+            'Calculating off-diagonal elements using default model from '
+            'diagonal solution')
+        ar = self.maxent_result.analyzer_results
+        jobs = self._offdiag_jobs()
+        models = []
+        for (i, j), re in jobs:
+            if self.use_complex:
+                A1 = ar[i][i][0][self.analyzer_offdiag_D]['A_out']
+                A2 = ar[j][j][0][self.analyzer_offdiag_D]['A_out']
+            else:
+                A1 = ar[i][i][self.analyzer_offdiag_D]['A_out']
+                A2 = ar[j][j][self.analyzer_offdiag_D]['A_out']
+            models.append(DataDefaultModel(
+                np.sqrt(A1 * A2) + self.D_add_constant, self.omega))
+        return self._run_batch(self.maxent_offdiagonal, jobs,
+                               per_job_D=models)

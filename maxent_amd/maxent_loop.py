@@ -1,0 +1,369 @@
+"""The alpha loop, batched on the device.
+
+``MaxEntLoop.run`` keeps the reference's signature, order of operations and
+return value (reference python/maxent_loop.py:144-302): G-threshold skip,
+``K.reduce_singular_space``, the "Minimal chi2" header, the start vector
+``v0 = H_of_v.inv(D * delta)``, the ``scale_alpha`` rule, one log line per
+alpha, timing, and finally ``result.analyze(analyzers)``.  What changes is the
+body of the loop ``for alpha in alpha_mesh: v = minimizer.minimize(Q, v)``
+(:241-245): the whole warm-started scan is one *chain* handed to
+``libmaxent_hip.so`` (``mxe_solve_chains``), and several scans -- the matrix
+elements of ``ElementwiseMaxEnt`` -- go down in a single launch through
+:func:`solve_elements`.
+"""
+
+from datetime import datetime, timedelta
+
+import numpy as np
+
+from . import device
+from .alpha_meshes import LogAlphaMesh
+from .analyzers import (LineFitAnalyzer, Chi2CurvatureAnalyzer,
+                        EntropyAnalyzer, BryanAnalyzer, ClassicAnalyzer)
+from .cost_functions import MaxEntCostFunction, BryanCostFunction
+from .functions import PlusMinusEntropy, PlusMinusH_of_v
+from .logtaker import Logtaker, VerbosityFlags
+from .maxent_result import MaxEntResult
+from .minimizers import LevenbergMinimizer
+from .probabilities import NormalLogProbability
+
+
+# --------------------------------------------------------------------------
+#  device batch
+# --------------------------------------------------------------------------
+
+def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0):
+    """Solve the alpha scans of several elements in ONE kernel launch.
+
+    ``K``: kernel whose singular space has been reduced (U, S, V staged once).
+    ``specs``: list of dicts with keys
+        G (data vector in the element's data space), err (same length),
+        U_rot (left factor if that space is rotated, else None),
+        D (default model incl. delta), kind (device.ENTROPY_*),
+        v0 (start vector), alpha (scaled alphas, in visiting order).
+    All specs must have the same number of alphas.
+    Returns (list of per-spec dicts(alpha, v, H, chi2, S, Q, n_iter,
+    converged, n_evals), info dict).
+    """
+    if not specs:
+        return [], dict(kernel_ms=0.0)
+    n_alpha = len(specs[0]['alpha'])
+    for s in specs:
+        if len(s['alpha']) != n_alpha:
+            raise ValueError('all elements of a batch need the same number '
+                             'of alpha values')
+    ctx = device.DeviceContext(K.U if K._T is None else None, K.S, K.V,
+                               device=device_id)
+    try:
+        ds_ids = []
+        cache = []
+        for s in specs:
+            err = np.asarray(s['err'], dtype=float) * np.ones(len(s['G']))
+            U_rot = s.get('U_rot')
+            found = None
+            for (e0, u0, i0) in cache:
+                if u0 is U_rot and e0.shape == err.shape and np.array_equal(e0, err):
+                    found = i0
+                    break
+            if found is None:
+                if U_rot is None and K._T is not None:
+                    U_rot = K.U
+                found = ctx.add_dataset(err, U_rot)
+                cache.append((err, s.get('U_rot'), found))
+            ds_ids.append(found)
+        ctx.set_elements(ds_ids, [s['G'] for s in specs],
+                         np.stack([np.asarray(s['D'], dtype=float) for s in specs]),
+                         [s['kind'] for s in specs])
+        opts = minimizer.to_opts(waves_per_chain=waves_per_chain)
+        out = ctx.solve_chains(np.arange(len(specs), dtype=np.int32),
+                               np.stack([np.asarray(s['alpha'], dtype=float) for s in specs]),
+                               np.stack([np.asarray(s['v0'], dtype=float) for s in specs]),
+                               opts)
+        info = dict(kernel_ms=ctx.last_kernel_ms())
+        info.update(ctx.last_launch_info())
+    finally:
+        ctx.close()
+    res = []
+    for c, s in enumerate(specs):
+        res.append(dict(alpha=np.asarray(s['alpha'], dtype=float),
+                        v=out['v'][c], H=out['H'][c], chi2=out['chi2'][c],
+                        S=out['S'][c], Q=out['Q'][c],
+                        n_iter=out['n_iter'][c],
+                        converged=out['converged'][c].astype(bool),
+                        n_evals=out['n_evals'][c]))
+    return res, info
+
+
+def solve_single(cost_function, v0, minimizer, device_id=0):
+    """``Minimizer.minimize(function, v0)`` for one alpha on the device."""
+    cf = cost_function
+    if cf._alpha is None:
+        raise Exception('call set_alpha on the cost function first')
+    K = cf.K
+    K.S        # trigger the SVD if needed
+    spec = dict(G=cf.G, err=cf.err, U_rot=(K.U if K._T is not None else None),
+                D=cf.D.D, kind=cf.entropy_kind, v0=np.asarray(v0, dtype=float),
+                alpha=np.array([cf._alpha], dtype=float))
+    res, _ = solve_elements(K, [spec], minimizer, device_id=device_id)
+    r = res[0]
+    return r['v'][0], dict(n_iter=r['n_iter'][0], converged=r['converged'][0])
+
+
+# --------------------------------------------------------------------------
+#  MaxEntLoop
+# --------------------------------------------------------------------------
+
+class MaxEntLoop(object):
+    """alpha loop of one data vector (reference maxent_loop.py:33-140)."""
+
+    def __init__(self, cost_function=None, minimizer=None, alpha_mesh=None,
+                 probability=None, analyzers=None, logtaker=None,
+                 G_threshold=1.e-10, reduce_singular_space=1.e-14,
+                 A_init=None, interactive=True, scale_alpha='Ndata',
+                 device_id=0):
+        if cost_function is None:
+            cost_function = MaxEntCostFunction()
+        elif isinstance(cost_function, str):
+            name = cost_function.lower()
+            if name == 'normal':
+                cost_function = MaxEntCostFunction()
+            elif name == 'plusminus':
+                cost_function = MaxEntCostFunction(S=PlusMinusEntropy(),
+                                                   H_of_v=PlusMinusH_of_v())
+            elif name == 'bryan':
+                cost_function = BryanCostFunction()
+            else:
+                raise Exception('Unknown cost_function str {}.'.format(
+                    cost_function))
+        self.cost_function = cost_function
+        self.minimizer = minimizer if minimizer is not None \
+            else LevenbergMinimizer()
+        self.alpha_mesh = alpha_mesh if alpha_mesh is not None \
+            else LogAlphaMesh()
+        self.logtaker = logtaker if logtaker is not None else Logtaker()
+        if isinstance(probability, str):
+            if probability.lower() == 'normal':
+                probability = NormalLogProbability()
+            else:
+                raise Exception('Unknown probability str {}.'.format(probability))
+        self.probability = probability
+        if analyzers is None:
+            analyzers = [LineFitAnalyzer(), Chi2CurvatureAnalyzer(),
+                         EntropyAnalyzer()]
+            if self.probability is not None:
+                analyzers += [BryanAnalyzer(), ClassicAnalyzer()]
+        self.analyzers = analyzers
+        self.G_threshold = G_threshold
+        self.interactive = interactive
+        self.A_init = A_init
+        self.reduce_singular_space = reduce_singular_space
+        self.scale_alpha = scale_alpha
+        self.device_id = device_id
+        self.last_launch = None
+
+    # ---- pieces of run(), also used by the element-wise driver --------
+    def _alpha_scale(self):
+        """reference maxent_loop.py:216-232."""
+        if self.scale_alpha is None:
+            return 1.0
+        if isinstance(self.scale_alpha, str):
+            if self.scale_alpha.lower() == 'ndata':
+                return float(len(self.G))
+            raise Exception('Unknown value {} for scale_alpha'.format(
+                self.scale_alpha))
+        return float(self.scale_alpha)
+
+    def below_threshold(self):
+        return np.max(np.abs(self.G)) < self.G_threshold
+
+    def make_spec(self):
+        """everything the device needs for this loop's current G/err/D/K."""
+        assert self.err is not None, 'No error specified'
+        self.K.reduce_singular_space(self.reduce_singular_space)
+        start = (self.D.D if self.A_init is None else
+                 np.asarray(self.A_init)) * self.omega.delta
+        v0 = self.H_of_v.inv(np.array(start, dtype=float))
+        scale = self._alpha_scale()
+        K = self.K
+        return dict(G=np.array(self.G, dtype=float),
+                    err=np.array(self.err, dtype=float) * np.ones(len(self.G)),
+                    U_rot=(K.U if K._T is not None else None),
+                    D=np.array(self.D.D, dtype=float),
+                    kind=self.cost_function.entropy_kind,
+                    v0=v0,
+                    alpha=np.asarray(self.alpha_mesh, dtype=float) * scale,
+                    scale_alpha=scale,
+                    G_orig=np.array(self.cost_function.G_orig, dtype=float),
+                    data_variable=np.array(self.data_variable, dtype=float),
+                    T=K._T)
+
+    def make_record(self, spec, sol):
+        """MaxEntResult arrays of one finished scan (maxent_result.py:835-967)."""
+        A = self.A_of_H.f(sol['H'])
+        rec = dict(sol)
+        rec['A'] = A
+        rec['G'] = spec['G']
+        rec['G_orig'] = spec['G_orig']
+        rec['data_variable'] = spec['data_variable']
+        rec['G_rec'] = np.dot(A, self.K.K_delta.T)
+        rec['omega'] = self.omega
+        X = len(sol['alpha'])
+        if self.probability is not None:
+            K = self.K
+            u = np.dot(sol['v'], K.V.T)
+            Dd = spec['D'][np.newaxis, :]
+            w = Dd * np.exp(u) if spec['kind'] == device.ENTROPY_NORMAL \
+                else Dd * (np.exp(u) + np.exp(-u))
+            rec['probability'] = self.probability.evaluate(
+                K.U, K.S, K.V, spec['err'], sol['alpha'], w, sol['Q'])
+        else:
+            rec['probability'] = np.full(X, np.nan)
+        return rec
+
+    def log_alpha_lines(self, sol):
+        """reference maxent_loop.py:248-257, 286-289."""
+        n = len(sol['alpha'])
+        width = int(np.ceil(np.log10(max(n, 2))))
+        for i in range(n):
+            self.logtaker.message(
+                VerbosityFlags.AlphaLoop,
+                'alpha[{:' + str(width) + 'd}] = {:16.8e}, chi2 = {:16.8e}, n_iter={:8d}{}',
+                i, sol['alpha'][i], sol['chi2'][i], int(sol['n_iter'][i]),
+                ' ' if sol['converged'][i] else '!')
+        if not np.all(sol['converged']):
+            self.logtaker.message(
+                VerbosityFlags.AlphaLoop,
+                '\n! ... The minimizer did not converge. Results might be wrong.\n')
+        self.minimizer.n_iter_last = int(sol['n_iter'][-1])
+        self.minimizer.n_iter += int(np.sum(sol['n_iter']))
+        self.minimizer.converged = bool(sol['converged'][-1])
+
+    # ---- main entry ------------------------------------------------------
+    def run(self, result=None, matrix_element=None, complex_index=None):
+        """Run the alpha scan; returns the :class:`MaxEntResult` (or None if
+        max|G| < G_threshold, in which case the element is recorded in
+        ``result.zero_elements``)."""
+        if self.below_threshold():
+            if result is not None and matrix_element is not None:
+                result._zero_elements.append(matrix_element)
+            self.logtaker.error_message(
+                'G below threshold, not performing the calculation.')
+            return None
+        self.logtaker.welcome_message()
+        spec = self.make_spec()
+        if self.logtaker.verbose & VerbosityFlags.Header:
+            A_min = np.linalg.lstsq(self.K.K, self.G, rcond=-1)[0]
+            self.logtaker.message(VerbosityFlags.Header, 'Minimal chi2: {}',
+                                  self.chi2.f(A_min))
+            self.logtaker.message(
+                VerbosityFlags.Header, 'scaling alpha by a factor {}{}',
+                spec['scale_alpha'],
+                ' (number of data points)' if isinstance(self.scale_alpha, str) else '')
+        if result is None:
+            result = MaxEntResult()
+        if result._default_analyzer_name is None and self.analyzers:
+            result._default_analyzer_name = self.analyzers[0].name
+        self.check_consistency()
+        result.start_timing(matrix_element, complex_index)
+        t0 = datetime.now()
+        sols, info = solve_elements(self.K, [spec], self.minimizer,
+                                    device_id=self.device_id)
+        self.last_launch = info
+        sol = sols[0]
+        self.log_alpha_lines(sol)
+        rec = self.make_record(spec, sol)
+        dt = (datetime.now() - t0) / max(len(sol['alpha']), 1)
+        rec['run_times'] = [dt] * len(sol['alpha'])
+        result.add_element_results(rec, matrix_element, complex_index)
+        run_time = result.end_timing(matrix_element, complex_index)
+        self.logtaker.message(VerbosityFlags.Timing,
+                              'MaxEnt loop finished in {}', run_time)
+        result.analyze(self.analyzers, matrix_element, complex_index)
+        return result
+
+    # ---- helpers ----------------------------------------------------------
+    def check_consistency(self):
+        """all children must refer to the same grids (reference
+        maxent_loop.py:306-337)."""
+        cf = self.cost_function
+        assert cf.chi2.K is cf.H_of_v.K
+        assert np.all(np.asarray(cf.K.omega) == np.asarray(self.omega))
+        assert np.all(np.asarray(cf.D.omega) == np.asarray(self.omega))
+        assert np.all(np.asarray(cf.S.omega) == np.asarray(self.omega))
+        assert np.all(np.asarray(cf.H_of_v.omega) == np.asarray(self.omega))
+        assert np.all(np.asarray(cf.A_of_H.omega) == np.asarray(self.omega))
+        assert np.all(cf.H_of_v.D.D == cf.S.D.D)
+        assert len(self.G) == np.asarray(cf.K.K).shape[0], \
+            'G and K do not have the same number of data points'
+        assert len(self.D.D) == np.asarray(cf.K.K).shape[1]
+
+    def set_verbosity(self, verbosity=None, add=None, remove=None,
+                      change_callback=True):
+        if verbosity is not None:
+            self.logtaker.verbose = verbosity
+        if add is not None:
+            self.logtaker.verbose |= add
+        if remove is not None:
+            self.logtaker.verbose &= ~remove
+
+    # attribute forwarding to the cost function (maxent_loop.py:384-502)
+    def _fwd(name):                                            # noqa: N805
+        def getter(self):
+            return getattr(self.cost_function, 'get_' + name)()
+
+        def setter(self, value):
+            getattr(self.cost_function, 'set_' + name)(value)
+        return getter, setter
+
+    get_K, _set_K = _fwd('K')
+    get_G, _set_G = _fwd('G')
+    get_err, _set_err = _fwd('err')
+    get_omega, _set_omega = _fwd('omega')
+    get_data_variable, _set_dv = _fwd('data_variable')
+    get_D, _set_D = _fwd('D')
+    get_chi2, _set_chi2 = _fwd('chi2')
+    get_S, _set_S = _fwd('S')
+    get_H_of_v, _set_H_of_v = _fwd('H_of_v')
+    get_A_of_H, _set_A_of_H = _fwd('A_of_H')
+    del _fwd
+
+    def set_K(self, K, **kw):
+        self.cost_function.set_K(K, **kw)
+
+    def set_G(self, G, **kw):
+        self.cost_function.set_G(G, **kw)
+
+    def set_err(self, err, **kw):
+        self.cost_function.set_err(err, **kw)
+
+    def set_omega(self, omega, **kw):
+        self.cost_function.set_omega(omega, **kw)
+
+    def set_data_variable(self, data_variable, **kw):
+        self.cost_function.set_data_variable(data_variable, **kw)
+
+    def set_D(self, D, **kw):
+        self.cost_function.set_D(D, **kw)
+
+    def set_chi2(self, chi2, **kw):
+        self.cost_function.set_chi2(chi2, **kw)
+
+    def set_S(self, S, **kw):
+        self.cost_function.set_S(S, **kw)
+
+    def set_H_of_v(self, H_of_v, **kw):
+        self.cost_function.set_H_of_v(H_of_v, **kw)
+
+    def set_A_of_H(self, A_of_H, **kw):
+        self.cost_function.set_A_of_H(A_of_H, **kw)
+
+    K = property(get_K, set_K)
+    G = property(get_G, set_G)
+    err = property(get_err, set_err)
+    omega = property(get_omega, set_omega)
+    data_variable = property(get_data_variable, set_data_variable)
+    D = property(get_D, set_D)
+    chi2 = property(get_chi2, set_chi2)
+    S = property(get_S, set_S)
+    H_of_v = property(get_H_of_v, set_H_of_v)
+    A_of_H = property(get_A_of_H, set_A_of_H)

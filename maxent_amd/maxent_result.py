@@ -1,0 +1,451 @@
+"""Result container with the reference's field layout.
+
+``MaxEntResult`` exposes the same fields, shapes and NaN conventions as the
+reference's (reference python/maxent_result.py:157-188, 688-1081):
+
+scalar run          alpha (X,)  v (X,n_s)  A,H (X,n_omega)  chi2,S,Q,probability
+                    (X,)  G,G_orig,data_variable (n_tau,)  G_rec (X,n_tau)
+element-wise run    the same with a prefix (M,N) or (M,N,2); NaN where an
+                    element was not calculated; H and A of a missing (i,j)
+                    are mirrored from (j,i) when ``use_hermiticity`` is set
+                    (imaginary part negated) -- maxent_result.py:733-747;
+``A_out``           from the default analyzer, zeros for ``zero_elements``,
+                    hermitian mirror -- maxent_result.py:314-366.
+
+The reference stores one cost-function object per (element, alpha) and
+reduces lazily; here the device hands back whole arrays per element, which are
+stored as they are (the reference's own on-disk form ``MaxEntResultData`` is
+exactly that).  ``v`` holds the correct per-alpha vectors (the reference's
+``v`` has every row equal to the last alpha's).
+"""
+
+import copy
+from collections import OrderedDict
+from datetime import datetime, timedelta
+from itertools import product
+
+import numpy as np
+
+from .alpha_meshes import DataAlphaMesh
+from .omega_meshes import DataOmegaMesh
+
+_ALL_FIELDS = ['alpha', 'v', 'chi2', 'S', 'A', 'Q', 'omega', 'probability',
+               'analyzer_results', 'run_times', 'run_time_total',
+               'matrix_structure', 'effective_matrix_structure',
+               'element_wise', 'complex_elements', 'use_hermiticity', 'G',
+               'data_variable', 'G_rec', 'H', 'default_analyzer_name',
+               'zero_elements', 'G_orig']
+
+
+def _nested(shape, fill):
+    if not shape:
+        return fill()
+    return [_nested(shape[1:], fill) for _ in range(shape[0])]
+
+
+class MaxEntResultData(object):
+    """plain-array form of a result; picklable (reference
+    maxent_result.py:157-685)."""
+
+    def __init__(self, matrix_structure=None, element_wise=True,
+                 complex_elements=False, use_hermiticity=True):
+        self._all_fields = list(_ALL_FIELDS)
+        self._matrix_structure = None if matrix_structure is None \
+            else tuple(matrix_structure)
+        self._complex_elements = complex_elements
+        self._element_wise = element_wise
+        self._use_hermiticity = use_hermiticity
+        self._default_analyzer_name = None
+        self._zero_elements = []
+        self._saved = dict()
+
+    def __getattr__(self, name):
+        if name == '_saved':
+            raise AttributeError(name)
+        saved = self.__dict__.get('_saved', {})
+        if name in saved:
+            return saved[name]
+        raise AttributeError("'{}' object has no attribute '{}'".format(
+            type(self).__name__, name))
+
+    # ---- element access ---------------------------------------------
+    def _get_element(self, array, matrix_element):
+        if self.matrix_structure is None:
+            assert matrix_element is None, \
+                'Cannot give matrix_element when matrix_structure is None'
+            return array
+        if not self.element_wise:
+            assert matrix_element is None, \
+                'Cannot give matrix_element when element_wise is False'
+            return array
+        assert matrix_element is not None, 'matrix_element must be given'
+        ret = array
+        for i in matrix_element:
+            ret = ret[i]
+        return ret
+
+    # ---- field bookkeeping (h5 / pickle subset) -----------------------
+    def include_only(self, fields):
+        self._all_fields = []
+        self.include(fields)
+
+    def include(self, fields):
+        for field in fields:
+            if field not in _ALL_FIELDS:
+                raise AttributeError('Unknown field: {}'.format(field))
+            if field not in self._all_fields:
+                self._all_fields.append(field)
+
+    def exclude(self, fields):
+        for field in fields:
+            if field not in _ALL_FIELDS:
+                raise AttributeError('Unknown field: {}'.format(field))
+            if field in self._all_fields:
+                self._all_fields.remove(field)
+
+    # ---- analyzers ----------------------------------------------------
+    def get_default_analyzer(self, analyzer=None):
+        if analyzer is None:
+            analyzer = self.default_analyzer_name
+        if analyzer is None:
+            analyzer = 'LineFitAnalyzer'
+        if self.matrix_structure is None or not self.element_wise:
+            return self.analyzer_results[analyzer]
+        ret = np.empty(self.effective_matrix_structure, dtype=object)
+        for elem in product(*map(range, self.effective_matrix_structure)):
+            try:
+                ret[elem] = self._get_element(self.analyzer_results,
+                                              elem)[analyzer]
+            except KeyError:
+                ret[elem] = None
+        return ret
+
+    default_analyzer = property(get_default_analyzer)
+
+    def get_A_out(self, analyzer=None):
+        da = self.get_default_analyzer(analyzer)
+        if self.matrix_structure is None or not self.element_wise:
+            return da['A_out']
+        n_omega = len(self.omega)
+        ems = self.effective_matrix_structure
+        A_out = np.full(tuple(ems) + (n_omega,), np.nan)
+        for elem in self.zero_elements:
+            A_out[elem] = 0.0
+        for elem in product(*map(range, ems)):
+            src, sign = elem, 1.0
+            if da[elem] is None and self.use_hermiticity:
+                t = list(elem)
+                t[0], t[1] = t[1], t[0]
+                if self.complex_elements and t[-1] == 1:
+                    sign = -1.0
+                src = tuple(t)
+            if da[src] is not None and not isinstance(da[src], str):
+                A_out[elem] = sign * da[src]['A_out']
+        if self.complex_elements:
+            return A_out[..., 0, :] + 1.0j * A_out[..., 1, :]
+        return A_out
+
+    A_out = property(get_A_out)
+
+    # ---- persistence ----------------------------------------------------
+    def __reduce_to_dict__(self):
+        ret = dict(all_fields=list(self._all_fields))
+        for key in self._all_fields:
+            val = getattr(self, key)
+            ret[key] = 'None' if val is None else val
+
+        def conv(t):
+            if isinstance(t, timedelta):
+                return dict(days=t.days, seconds=t.seconds,
+                            microseconds=t.microseconds)
+            if isinstance(t, float):
+                return t
+            if isinstance(t, np.ndarray):
+                return [conv(x) for x in t.tolist()] if t.ndim else conv(t.item())
+            return [conv(x) for x in t]
+        if 'run_times' in ret:
+            ret['run_times'] = conv(ret['run_times'])
+        if 'run_time_total' in ret:
+            ret['run_time_total'] = conv(ret['run_time_total'])
+        return ret
+
+    @classmethod
+    def __factory_from_dict__(cls, name, D):
+        self = cls()
+        D = dict(D)
+
+        def unconv(t):
+            if isinstance(t, dict):
+                return timedelta(**t)
+            if isinstance(t, float):
+                return t
+            return [unconv(x) for x in t]
+        if 'run_times' in D:
+            D['run_times'] = unconv(D['run_times'])
+        if 'run_time_total' in D:
+            D['run_time_total'] = unconv(D['run_time_total'])
+        if 'omega' in D and not isinstance(D['omega'], str):
+            D['omega'] = DataOmegaMesh(np.asarray(D['omega']))
+        if 'alpha' in D and not isinstance(D['alpha'], str):
+            D['alpha'] = DataAlphaMesh(np.asarray(D['alpha']))
+        if 'all_fields' in D:
+            self._all_fields = D.pop('all_fields')
+        for key, val in D.items():
+            self._saved[key] = None if (isinstance(val, str) and val == 'None') else val
+        for key in ('matrix_structure', 'element_wise', 'complex_elements',
+                    'use_hermiticity', 'default_analyzer_name',
+                    'zero_elements'):
+            if key in self._saved:
+                setattr(self, '_' + key, self._saved[key])
+        return self
+
+    # fields that live in ``_saved`` for a pure data object
+    @property
+    def matrix_structure(self):
+        return self._matrix_structure
+
+    @property
+    def element_wise(self):
+        return self._element_wise
+
+    @property
+    def complex_elements(self):
+        return self._complex_elements
+
+    @property
+    def use_hermiticity(self):
+        return self._use_hermiticity
+
+    @property
+    def default_analyzer_name(self):
+        return self._default_analyzer_name
+
+    @property
+    def zero_elements(self):
+        return self._zero_elements
+
+    @property
+    def effective_matrix_structure(self):
+        if self._matrix_structure is None:
+            return None
+        if self._element_wise and self._complex_elements:
+            return tuple(self._matrix_structure) + (2,)
+        return tuple(self._matrix_structure)
+
+
+class MaxEntResult(MaxEntResultData):
+    """live result that the solver fills element by element."""
+
+    def __init__(self, matrix_structure=None, element_wise=True,
+                 complex_elements=False, use_hermiticity=True):
+        super(MaxEntResult, self).__init__(matrix_structure, element_wise,
+                                           complex_elements, use_hermiticity)
+        self._records = OrderedDict()       # key (tuple or None) -> dict
+        self._analysis = OrderedDict()      # key -> {name: AnalyzerResult}
+        self._start = dict()
+        self._end = dict()
+        self._cache = dict()
+
+    # ---- filling -------------------------------------------------------
+    def _key(self, matrix_element, complex_index):
+        if self.matrix_structure is None or not self.element_wise:
+            return None
+        key = tuple(matrix_element)
+        if self.complex_elements and complex_index is not None \
+                and len(key) == 2:
+            key = key + (complex_index,)
+        return key
+
+    def add_element_results(self, record, matrix_element=None,
+                            complex_index=None):
+        """Store the arrays of one finished alpha scan.  ``record`` needs the
+        keys alpha, v, H, A, chi2, S, Q, G, G_orig, data_variable, G_rec,
+        omega and optionally probability, n_iter, converged, run_times."""
+        key = self._key(matrix_element, complex_index)
+        if self.matrix_structure is not None and self.element_wise:
+            assert key is not None, 'matrix_element must be given'
+        self._records[key] = record
+        self._cache = dict()
+
+    def start_timing(self, matrix_element=None, complex_index=None, time=None):
+        self._start[self._key(matrix_element, complex_index)] = \
+            time or datetime.now()
+
+    def end_timing(self, matrix_element=None, complex_index=None, time=None):
+        key = self._key(matrix_element, complex_index)
+        self._end[key] = time or datetime.now()
+        return self._end[key] - self._start.get(key, self._end[key])
+
+    def analyze(self, analyzers, matrix_element=None, complex_index=None):
+        """run the analyzers on one element; a ``ValueError`` of an analyzer
+        is stored as its message (reference maxent_result.py:793-822)."""
+        key = self._key(matrix_element, complex_index)
+        out = OrderedDict()
+        for analyzer in analyzers:
+            try:
+                res = analyzer.analyze(self, key)
+                res.maxent_result = self
+                out[res['name']] = res
+            except ValueError as e:
+                out[analyzer.name] = str(e)
+        self._analysis[key] = out
+        self._cache.pop('analyzer_results', None)
+
+    # ---- assembling ------------------------------------------------------
+    def _reference_record(self):
+        if not self._records:
+            raise AttributeError('no results have been added yet')
+        best = None
+        for rec in self._records.values():
+            if best is None or len(rec['alpha']) > len(best['alpha']):
+                best = rec
+        return best
+
+    @property
+    def _n_alphas(self):
+        if self._matrix_structure is None:
+            rec = self._records.get(None)
+            return 0 if rec is None else len(rec['alpha'])
+        ret = np.zeros(self.effective_matrix_structure, dtype=int)
+        for key, rec in self._records.items():
+            ret[key] = len(rec['alpha'])
+        return ret
+
+    def _assemble(self, name, mirror=False, per_alpha=True):
+        if name in self._cache:
+            return self._cache[name]
+        if self.matrix_structure is None or not self.element_wise:
+            arr = np.asarray(self._records[None][name])
+        else:
+            ref = self._reference_record()
+            X = len(ref['alpha'])
+            tail = np.asarray(ref[name]).shape[1:] if per_alpha \
+                else np.asarray(ref[name]).shape
+            ems = tuple(self.effective_matrix_structure)
+            shape = ems + ((X,) if per_alpha else ()) + tuple(tail)
+            arr = np.full(shape, np.nan)
+            for key, rec in self._records.items():
+                val = np.asarray(rec[name], dtype=float)
+                if per_alpha:
+                    arr[key][:len(val)] = val
+                else:
+                    arr[key] = val
+            if mirror and self.use_hermiticity:
+                for elem in product(*map(range, self._matrix_structure)):
+                    if elem == elem[::-1]:
+                        continue
+                    if np.all(np.isnan(arr[elem])):
+                        arr[elem] = arr[elem[::-1]]
+                        if self.complex_elements:
+                            arr[elem + (1,)] = -arr[elem + (1,)]
+        self._cache[name] = arr
+        return arr
+
+    @property
+    def alpha(self):
+        return np.asarray(self._reference_record()['alpha'])
+
+    @property
+    def omega(self):
+        return self._reference_record()['omega']
+
+    @property
+    def v(self):
+        return self._assemble('v')
+
+    @property
+    def chi2(self):
+        return self._assemble('chi2')
+
+    @property
+    def S(self):
+        return self._assemble('S')
+
+    @property
+    def Q(self):
+        return self._assemble('Q')
+
+    @property
+    def H(self):
+        return self._assemble('H', mirror=True)
+
+    @property
+    def A(self):
+        return self._assemble('A', mirror=True)
+
+    @property
+    def G_rec(self):
+        return self._assemble('G_rec')
+
+    @property
+    def G(self):
+        return self._assemble('G', per_alpha=False)
+
+    @property
+    def G_orig(self):
+        return self._assemble('G_orig', per_alpha=False)
+
+    @property
+    def data_variable(self):
+        return self._assemble('data_variable', per_alpha=False)
+
+    @property
+    def probability(self):
+        return self._assemble('probability')
+
+    @property
+    def n_iter(self):
+        """Newton iterations per (element, alpha) (not in the reference)."""
+        return self._assemble('n_iter')
+
+    @property
+    def converged(self):
+        return self._assemble('converged')
+
+    def _nested_from(self, table, fill):
+        if self.matrix_structure is None or not self.element_wise:
+            return table.get(None, fill())
+        ems = self.effective_matrix_structure
+        out = _nested(ems, fill)
+        for key, val in table.items():
+            node = out
+            for i in key[:-1]:
+                node = node[i]
+            node[key[-1]] = val
+        return out
+
+    @property
+    def analyzer_results(self):
+        if 'analyzer_results' not in self._cache:
+            self._cache['analyzer_results'] = self._nested_from(self._analysis, dict)
+        return self._cache['analyzer_results']
+
+    @property
+    def run_times(self):
+        return self._nested_from(
+            {k: list(r.get('run_times', [])) for k, r in self._records.items()}, list)
+
+    @property
+    def run_time_total(self):
+        tot = {k: self._end[k] - self._start[k] for k in self._end if k in self._start}
+        return self._nested_from(tot, lambda: timedelta(0))
+
+    @property
+    def data(self):
+        """detached :class:`MaxEntResultData` with plain arrays (for pickle /
+        h5; reference maxent_result.py:1069-1081)."""
+        d = self.__reduce_to_dict__()
+        d = copy.deepcopy({k: v for k, v in d.items() if k != 'analyzer_results'})
+        ar = self.analyzer_results
+
+        def strip(x):
+            if isinstance(x, dict):
+                if 'name' in x or not x:
+                    y = type(x)(x)
+                    return y
+                return {k: strip(v) for k, v in x.items()}
+            if isinstance(x, list):
+                return [strip(y) for y in x]
+            return x
+        d['analyzer_results'] = strip(ar)
+        return MaxEntResultData.__factory_from_dict__('MaxEntResultData', d)

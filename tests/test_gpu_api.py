@@ -1,0 +1,253 @@
+"""GPU parity of the drop-in API (TauMaxEnt / ElementwiseMaxEnt / MaxEntResult)
+against the golden vectors generated from the reference.
+
+Tolerances: the north-star gate is 1e-6 relative L2 on A(omega) against the
+reference's fixed point, for which ``H_truth`` (extended-precision polish of
+the reference's own optimum, tests/golden/make_golden.py) is the golden
+value.  Against the reference's *raw* outputs the bound is the reference's
+own convergence spread (<= 5e-5, see test_oracle_golden.py).
+"""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+import maxent_amd as mx
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+GATE = 1e-6
+REF_SPREAD = 5e-5
+
+
+def load(name):
+    with np.load(os.path.join(GOLD, name + '.npz'), allow_pickle=False) as d:
+        return {k: d[k] for k in d.files}
+
+
+def rel_l2(a, b):
+    return np.linalg.norm(a - b, axis=-1) / np.linalg.norm(b, axis=-1)
+
+
+def make_tm(g, cost_function):
+    tm = mx.TauMaxEnt(cost_function=cost_function)
+    tm.set_verbosity(mx.VerbosityFlags.Quiet)
+    tm.omega = mx.DataOmegaMesh(g['omega'])
+    tm.set_G_tau_data(g['tau'], g['G'])
+    tm.set_error(g['err'])
+    return tm
+
+
+CASES = [('cfg1_normal', 'normal'), ('cfg1_bryan', 'bryan'),
+         ('cfg1_plusminus', 'plusminus'), ('cfg1_tauerr', 'normal'),
+         ('cfg2_normal', 'normal')]
+
+
+@pytest.mark.parametrize('name,cf', CASES)
+def test_tau_maxent_matches_golden(name, cf):
+    g = load(name)
+    n_tau = len(g['tau'])
+    tm = make_tm(g, cf)
+    tm.alpha_mesh = mx.DataAlphaMesh(g['alpha'] / n_tau)
+    res = tm.run()
+    rows = g['rows']
+    assert np.all(res.converged)
+    np.testing.assert_allclose(res.alpha, g['alpha'], rtol=1e-14)
+    # the gate: H (and A = H/delta) against the fixed point
+    e = rel_l2(res.H[rows], g['H_truth'])
+    assert e.max() < GATE, e.max()
+    eA = rel_l2(res.A[rows], g['H_truth'] / g['delta'])
+    assert eA.max() < GATE
+    # reference raw outputs: within the reference's own spread
+    assert rel_l2(res.H[rows], g['H_ref']).max() < REF_SPREAD
+    np.testing.assert_allclose(res.chi2, g['chi2_ref'], rtol=REF_SPREAD)
+    np.testing.assert_allclose(res.Q, g['Q_ref'], rtol=1e-7)
+    np.testing.assert_allclose(res.S, g['S_ref'], rtol=REF_SPREAD, atol=1e-9)
+    # analyzers pick the same alpha as the reference's
+    ar = res.analyzer_results
+    assert ar['LineFitAnalyzer']['alpha_index'] == int(g['linefit_alpha_index'])
+    assert ar['Chi2CurvatureAnalyzer']['alpha_index'] == int(g['chi2curv_alpha_index'])
+    assert rel_l2(res.A_out, g['A_out_linefit']) < REF_SPREAD
+    # MaxEntResult layout (reference maxent_result.py:835-967)
+    X, nw, ntau = len(g['alpha']), len(g['omega']), n_tau
+    assert res.A.shape == (X, nw) and res.H.shape == (X, nw)
+    assert res.v.shape[0] == X and res.chi2.shape == (X,)
+    assert res.G.shape == (ntau,) and res.G_rec.shape == (X, ntau)
+    assert res.data_variable.shape == (ntau,)
+
+
+def test_preblur_plusminus():
+    g = load('cfg5_preblur_pm')
+    n_tau = len(g['tau'])
+    tm = make_tm(g, 'plusminus')
+    b = float(g['preblur_b'])
+    tm.A_of_H = mx.PreblurA_of_H(b=b, omega=tm.omega)
+    tm.K = mx.PreblurKernel(K=tm.K, b=b)
+    tm.alpha_mesh = mx.DataAlphaMesh(g['alpha'] / n_tau)
+    res = tm.run()
+    assert np.all(res.converged)
+    np.testing.assert_allclose(tm.A_of_H.matrix(), g['B'], rtol=1e-12)
+    assert rel_l2(res.H, g['H_truth']).max() < GATE
+    A_truth = g['H_truth'] @ g['B'].T
+    assert rel_l2(res.A, A_truth).max() < GATE
+    assert rel_l2(res.A, g['A_ref']).max() < REF_SPREAD
+
+
+def test_known_answer_log_probability():
+    """reference test/python/tau_maxent.py:134-135 (6 decimals)."""
+    g = load('kat_tau_maxent')
+    tm = mx.TauMaxEnt(probability='normal')
+    tm.set_verbosity(mx.VerbosityFlags.Quiet)
+    tm.set_G_tau_data(g['tau'], g['G'])
+    tm.alpha_mesh = mx.LogAlphaMesh(alpha_min=0.08, n_points=5)
+    tm.omega = mx.HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=200)
+    tm.set_error(1.e-3)
+    res = tm.run()
+    np.testing.assert_allclose(res.alpha, g['alpha'], rtol=1e-14)
+    assert rel_l2(res.H, g['H_truth']).max() < GATE
+    np.testing.assert_almost_equal(res.probability, g['probability_kat'], 4)
+    np.testing.assert_allclose(res.probability, g['probability_ref'], rtol=1e-7)
+    assert 'BryanAnalyzer' in res.analyzer_results
+    assert 'alpha_index' in res.analyzer_results['ClassicAnalyzer']
+
+
+def test_srvo3_bryan_matches_alps():
+    """reference test/python/srvo3_mesh_and_ALPS.py:100."""
+    g = load('kat_srvo3')
+    tm = mx.TauMaxEnt(cost_function='bryan')
+    tm.set_verbosity(mx.VerbosityFlags.Quiet)
+    tm.set_G_tau_data(g['tau'], g['G'])
+    tm.set_error(g['err'])
+    tm.omega = mx.LorentzianOmegaMesh(omega_min=-15, omega_max=15, n_points=500)
+    tm.alpha_mesh = mx.LogAlphaMesh(alpha_min=5.514845959 / len(g['tau']),
+                                    alpha_max=100, n_points=2)
+    res = tm.run()
+    assert np.all(res.converged)
+    ms = g['alps_maxspec']
+    assert np.max(np.abs(res.A[1] - np.interp(g['omega'], ms[:, 0], ms[:, 1]))) < 1e-2
+    assert rel_l2(res.H, g['H_truth']).max() < GATE
+    assert rel_l2(res.A, g['A_ref']).max() < REF_SPREAD
+
+
+def test_huge_alpha_reproduces_default_model():
+    """reference test/python/huge_alpha.py:43-50 (n_s = 100 > 64)."""
+    g = load('kat_huge_alpha')
+    tm = mx.TauMaxEnt()
+    tm.set_verbosity(mx.VerbosityFlags.Quiet)
+    tm.set_G_tau_data(g['tau'], g['G'])
+    tm.alpha_mesh = mx.LogAlphaMesh(alpha_min=1e10 - 1, alpha_max=1e10, n_points=5)
+    tm.set_error(5.e-4)
+    tm.reduce_singular_space = 1.e-16
+    res = tm.run()
+    assert np.max(res.H - tm.D.D) < 1e-6
+    assert rel_l2(res.H, g['H_ref']).max() < 1e-8
+
+
+def test_covariance_rotation():
+    g = load('cov')
+    tm = mx.TauMaxEnt()
+    tm.set_verbosity(mx.VerbosityFlags.Quiet)
+    tm.omega = mx.DataOmegaMesh(g['omega'])
+    tm.set_G_tau_data(g['tau'], g['G_orig'])
+    tm.set_cov(g['cov'])
+    n_rot = len(g['G_rot'])
+    tm.alpha_mesh = mx.DataAlphaMesh(g['alpha'] / n_rot)
+    res = tm.run()
+    assert np.all(res.converged)
+    assert rel_l2(res.H, g['H_truth']).max() < GATE
+    assert rel_l2(res.H, g['H_ref']).max() < REF_SPREAD
+    np.testing.assert_allclose(res.G_orig, g['G_orig'])
+    assert res.G.shape == (n_rot,)
+    assert rel_l2(res.G_rec, g['G_rec_ref']).max() < REF_SPREAD
+
+
+def _ew(cls, g, herm, error=None):
+    ew = cls(use_hermiticity=herm)
+    ew.set_verbosity(mx.VerbosityFlags.Quiet)
+    ew.set_G_tau_data(g['tau'], g['G_tau_noise'])
+    ew.omega = mx.HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=80)
+    ew.alpha_mesh = mx.LogAlphaMesh(alpha_min=0.05, alpha_max=500, n_points=8)
+    ew.set_error(float(g['noise']) if error is None else error)
+    return ew
+
+
+def test_elementwise_drivers():
+    """reference test/python/elementwise_maxent.py:101-188."""
+    g = load('elementwise')
+    r_ew = _ew(mx.ElementwiseMaxEnt, g, False).run()
+    r_herm = _ew(mx.ElementwiseMaxEnt, g, True,
+                 error=float(g['noise']) * np.ones(g['G_tau_noise'].shape)).run()
+    r_di = _ew(mx.DiagonalMaxEnt, g, True).run()
+    r_pm = _ew(mx.PoormanMaxEnt, g, False).run()
+    pm_h = _ew(mx.PoormanMaxEnt, g, True)
+    r_pm_herm = pm_h.run()
+    r_pm_herm.data        # must be callable
+    # hermiticity copies exactly
+    assert np.all(r_herm.A_out[0, 1] == r_herm.A_out[1, 0])
+    assert np.all(r_pm_herm.A_out[0, 1] == r_pm_herm.A_out[1, 0])
+    for i in (0, 1):
+        for j in (0, 1):
+            lfa = r_pm.analyzer_results[i][j]['LineFitAnalyzer']
+            np.testing.assert_array_equal(r_pm.A_out[i, j], lfa['A_out'])
+            np.testing.assert_allclose(r_ew.A[i, j], r_herm.A[i, j], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(r_pm.A[i, j], r_pm_herm.A[i, j], rtol=1e-9, atol=1e-12)
+            if i == j:
+                np.testing.assert_allclose(r_di.A[i, i], r_ew.A[i, i], rtol=1e-12)
+                np.testing.assert_allclose(r_di.A[i, i], r_pm.A[i, i], rtol=1e-12)
+    # against the reference's outputs (its own spread)
+    assert r_ew.A.shape == g['ew_A'].shape == (2, 2, 8, 80)
+    for name, r in (('ew', r_ew), ('pm', r_pm)):
+        assert rel_l2(r.A, g[name + '_A']).max() < 2e-4
+        np.testing.assert_allclose(r.chi2, g[name + '_chi2'], rtol=1e-4)
+        np.testing.assert_allclose(r.alpha, g[name + '_alpha'], rtol=1e-13)
+        idx = np.array([[r.analyzer_results[i][j]['LineFitAnalyzer']['alpha_index']
+                         for j in (0, 1)] for i in (0, 1)])
+        np.testing.assert_array_equal(idx, g[name + '_linefit_idx'])
+        assert rel_l2(r.A_out, g[name + '_A_out']).max() < 2e-4
+    # Poorman is closer to the exact off-diagonal than plain element-wise
+    w, A01 = g['w_exact'], g['A01_exact']
+    om = np.asarray(r_pm.omega)
+    d_pm = np.sum(np.abs(A01 - np.interp(w, om, r_pm.A_out[0, 1])))
+    d_ew = np.sum(np.abs(A01 - np.interp(w, om, r_ew.A_out[0, 1])))
+    assert d_pm < d_ew
+    # norms (reference: 2 decimals)
+    assert abs(np.trapezoid(r_pm.A_out[0, 1], om)) < 1e-2
+    assert abs(np.trapezoid(r_ew.A_out[0, 0], om) - 1) < 1e-2
+    # NaN layout before the off-diagonals are there
+    assert np.all(np.isnan(r_di.A[0, 1])) and r_di.A.shape == (2, 2, 8, 80)
+
+
+def test_result_data_pickles():
+    g = load('cfg1_normal')
+    tm = make_tm(g, 'normal')
+    tm.alpha_mesh = mx.LogAlphaMesh(alpha_min=1e-1, alpha_max=1e2, n_points=6)
+    res = tm.run()
+    d = pickle.loads(pickle.dumps(res.data))
+    for f in ('alpha', 'A', 'H', 'chi2', 'S', 'Q', 'G', 'G_rec', 'v'):
+        np.testing.assert_array_equal(getattr(d, f), getattr(res, f))
+    assert d.default_analyzer_name == 'LineFitAnalyzer'
+    np.testing.assert_array_equal(d.A_out, res.A_out)
+
+
+def test_single_minimize_call_and_reference_stopping_rule():
+    """Minimizer.minimize(function, v0) for one alpha; the reference's own
+    stopping rule (max|dQ| < 1e-4 | rel. change < 1e-16) is available."""
+    g = load('cfg1_normal')
+    conv = mx.MaxDerivativeConvergenceMethod(1e-4) | \
+        mx.RelativeFunctionChangeConvergenceMethod(1e-16)
+    tm = mx.TauMaxEnt(minimizer=mx.LevenbergMinimizer(convergence=conv))
+    tm.set_verbosity(mx.VerbosityFlags.Quiet)
+    tm.omega = mx.DataOmegaMesh(g['omega'])
+    tm.set_G_tau_data(g['tau'], g['G'])
+    tm.set_error(g['err'])
+    tm.alpha_mesh = mx.DataAlphaMesh(g['alpha'] / len(g['tau']))
+    res = tm.run()
+    assert np.all(res.converged)
+    assert rel_l2(res.H, g['H_truth']).max() < 1e-4      # reference-like accuracy
+    cf = tm.cost_function
+    cf.set_alpha(g['alpha'][3])
+    v = tm.minimizer.minimize(cf, res.v[2].copy())
+    assert tm.minimizer.converged and tm.minimizer.n_iter_last >= 1
+    H = cf.H_of_v.f(v)
+    assert np.linalg.norm(H - g['H_truth'][3]) / np.linalg.norm(g['H_truth'][3]) < 1e-4
