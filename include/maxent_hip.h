@@ -71,6 +71,8 @@ typedef struct mxe_opts {
     double  mu_first;     /* first non-zero damping, in units of alpha (1e-3)             */
     double  mu_grow;      /* growth factor of the damping on a rejected step (4)          */
     double  mu_max;       /* give up on the alpha when mu/alpha exceeds this (1e20)       */
+    double  decouple_tol; /* theta: singular directions with c_k^2 max(w) <= theta*alpha
+                             take the diagonal Newton step (1e-6; 0 = full n_s block)      */
     int32_t waves_per_chain; /* 0 = choose from the chain count; else 1,2,4,8,16          */
     int32_t reserved;
 } mxe_opts;

@@ -63,7 +63,7 @@ struct mxe_ctx {
     DevBuf<double> dV, dVt, dc, dcinv, dghat, dcperp, dD, dsumD, dalpha, dv0;
     DevBuf<int> delem_ds, delem_kind, dchain_elem;
     DevBuf<double> dout_v, dout_H, dout_chi2, dout_S, dout_Q, dB, dA;
-    DevBuf<int> dout_niter, dout_conv, dout_nevals;
+    DevBuf<int> dout_niter, dout_conv, dout_nevals, dout_nact;
     std::string hip_err;
 };
 
@@ -168,7 +168,7 @@ int build_dataset(mxe_ctx* ctx, int n_rows, const double* U_rot, const double* e
 int upload_bases(mxe_ctx* ctx)
 {
     const int nds = (int)ctx->ds.size(), ns = ctx->n_s, NP = ctx->NP, nw = ctx->n_omega, nwp = ctx->nwp;
-    std::vector<double> hV((size_t)nds * nw * NP, 0.0), hVt((size_t)nds * NP * nwp, 0.0);
+    std::vector<double> hV((size_t)nds * nwp * NP, 0.0), hVt((size_t)nds * NP * nwp, 0.0);
     std::vector<double> hc((size_t)nds * NP, 1.0), hci((size_t)nds * NP, 1.0);
     for (int d = 0; d < nds; ++d) {
         const DataSet& D = ctx->ds[d];
@@ -180,7 +180,7 @@ int upload_bases(mxe_ctx* ctx)
                     val = 0.0;
                     for (int j = 0; j < ns; ++j) val += ctx->V[(size_t)i * ns + j] * D.Q[(size_t)j * ns + k];
                 }
-                hV[((size_t)d * nw + i) * NP + k] = val;
+                hV[((size_t)d * nwp + i) * NP + k] = val;
                 hVt[((size_t)d * NP + k) * nwp + i] = val;
             }
         }
@@ -199,32 +199,27 @@ int upload_bases(mxe_ctx* ctx)
     return MXE_OK;
 }
 
-size_t lds_doubles(int NP, int nwp, int NW, int BS)
+size_t lds_doubles(int NP, int nwp, int NW)
 {
-    const int BSP = (BS % 2) ? BS : BS + 1;
-    return (size_t)NP * (NP + 1) + 12 * (size_t)NP + (size_t)NW * NP + (size_t)NW * 8 +
-           5 * (size_t)nwp + (size_t)NW * 2 * mxe::GRAM_R * 8 * BSP;
+    const int SROW = (NP / 4) * mxe::GBLK;
+    return (size_t)NP * (NP + 1) + 11 * (size_t)NP + (size_t)NW * NP + (size_t)NW * 8 +
+           5 * (size_t)nwp + (size_t)NW * 2 * mxe::GRAM_R * SROW;
 }
 
-template <int NW, int BS>
+template <int NW, int NAB>
 hipError_t launch_t(const KParams& kp, size_t lds, hipStream_t s)
 {
-    hipError_t e = hipFuncSetAttribute((const void*)mxe::chain_kernel<NW, BS>,
+    hipError_t e = hipFuncSetAttribute((const void*)mxe::chain_kernel<NW, NAB>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mxe::chain_kernel<NW, BS>), dim3(kp.n_chain), dim3(64 * NW), lds, s, kp);
+    hipLaunchKernelGGL((mxe::chain_kernel<NW, NAB>), dim3(kp.n_chain), dim3(64 * NW), lds, s, kp);
     return hipGetLastError();
 }
 
 template <int NW>
-hipError_t launch_bs(int BS, const KParams& kp, size_t lds, hipStream_t s)
+hipError_t launch_nab(int NP, const KParams& kp, size_t lds, hipStream_t s)
 {
-    switch (BS) {
-        case 5: return launch_t<NW, 5>(kp, lds, s);
-        case 6: return launch_t<NW, 6>(kp, lds, s);
-        case 7: return launch_t<NW, 7>(kp, lds, s);
-        default: return launch_t<NW, 8>(kp, lds, s);
-    }
+    return (NP == 64) ? launch_t<NW, 2>(kp, lds, s) : launch_t<NW, 4>(kp, lds, s);
 }
 
 } // namespace
@@ -241,7 +236,7 @@ const char* mxe_strerror(int code)
         case MXE_ERR_HIP: return "HIP runtime error (see mxe_last_hip_error)";
         case MXE_ERR_NODEVICE: return "no usable HIP device";
         case MXE_ERR_STATE: return "call order violated";
-        case MXE_ERR_LIMIT: return "problem exceeds kernel limits (n_s <= 64, LDS budget)";
+        case MXE_ERR_LIMIT: return "problem exceeds kernel limits (n_s <= 128, 160 KB LDS per chain)";
         case MXE_ERR_NUMERIC: return "whitening failed (error bars must be finite and > 0)";
         default: return "unknown error";
     }
@@ -263,6 +258,7 @@ void mxe_opts_default(mxe_opts* o)
     o->maxiter = 1000; o->miniter = 0;
     o->tol_h = 1e-9; o->tol_d = 0.0; o->tol_relq = 0.0;
     o->step_max = 0.2; o->mu_first = 1e-3; o->mu_grow = 4.0; o->mu_max = 1e20;
+    o->decouple_tol = 1e-6;
     o->waves_per_chain = 0; o->reserved = 0;
 }
 
@@ -270,7 +266,7 @@ int mxe_ctx_create(int device, int n_tau, int n_omega, int n_s,
                    const double* U, const double* S, const double* V, mxe_ctx** out)
 {
     if (!out || !S || !V || n_tau < 1 || n_omega < 1 || n_s < 1) return MXE_ERR_ARG;
-    if (n_s > 64) return MXE_ERR_LIMIT;
+    if (n_s > 128) return MXE_ERR_LIMIT;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MXE_ERR_NODEVICE;
     if (device < 0 || device >= ndev) return MXE_ERR_ARG;
@@ -283,7 +279,7 @@ int mxe_ctx_create(int device, int n_tau, int n_omega, int n_s,
         delete ctx; return MXE_ERR_HIP;
     }
     ctx->n_tau = n_tau; ctx->n_omega = n_omega; ctx->n_s = n_s;
-    ctx->NP = 64;
+    ctx->NP = (n_s <= 64) ? 64 : 128;
     ctx->nwp = ((n_omega + 63) / 64) * 64;
     if (U) ctx->U.assign(U, U + (size_t)n_tau * n_s);
     ctx->S.assign(S, S + n_s);
@@ -302,7 +298,7 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
     ctx->dalpha.release(); ctx->dv0.release(); ctx->delem_ds.release(); ctx->delem_kind.release();
     ctx->dchain_elem.release(); ctx->dout_v.release(); ctx->dout_H.release();
     ctx->dout_chi2.release(); ctx->dout_S.release(); ctx->dout_Q.release();
-    ctx->dout_niter.release(); ctx->dout_conv.release(); ctx->dout_nevals.release();
+    ctx->dout_niter.release(); ctx->dout_conv.release(); ctx->dout_nevals.release(); ctx->dout_nact.release();
     ctx->dB.release(); ctx->dA.release();
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -400,7 +396,7 @@ int mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
     const int ns = ctx->n_s, NP = ctx->NP, nw = ctx->n_omega;
     if (opts) ctx->opts = *opts; else mxe_opts_default(&ctx->opts);
     const mxe_opts& o = ctx->opts;
-    if (o.maxiter < 1 || o.step_max <= 0 || o.mu_first <= 0 || o.mu_grow <= 1.0) return MXE_ERR_ARG;
+    if (o.maxiter < 1 || o.step_max <= 0 || o.mu_first <= 0 || o.mu_grow <= 1.0 || o.decouple_tol < 0) return MXE_ERR_ARG;
     if (o.waves_per_chain != 0 && o.waves_per_chain != 1 && o.waves_per_chain != 2 &&
         o.waves_per_chain != 4 && o.waves_per_chain != 8) return MXE_ERR_ARG;
     ctx->chain_elem.assign(elem_of_chain, elem_of_chain + n_chain);
@@ -433,6 +429,7 @@ int mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
     HIPCHK(ctx, ctx->dout_niter.ensure(P));
     HIPCHK(ctx, ctx->dout_conv.ensure(P));
     HIPCHK(ctx, ctx->dout_nevals.ensure(P));
+    HIPCHK(ctx, ctx->dout_nact.ensure(P));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dchain_elem.p, ctx->chain_elem.data(), (size_t)n_chain * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dalpha.p, alpha_scaled, P * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dv0.p, hv0.data(), hv0.size() * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -461,25 +458,25 @@ int mxe_chains_launch(mxe_ctx* ctx)
     kp.maxiter = o.maxiter; kp.miniter = o.miniter;
     kp.tol_h = o.tol_h; kp.tol_d = o.tol_d; kp.tol_relq = o.tol_relq;
     kp.step_max = o.step_max; kp.mu_first = o.mu_first; kp.mu_grow = o.mu_grow; kp.mu_max = o.mu_max;
+    kp.theta = o.decouple_tol; kp.out_nact = ctx->dout_nact.p;
 
-    int BS = (ctx->n_s + 7) / 8; if (BS < 5) BS = 5;
     int NW = o.waves_per_chain;
     if (NW == 0) {
         // fill the 256 CUs x 4 SIMDs: few chains -> more waves per chain
         const int nc = ctx->n_chain;
         NW = (nc >= 2048) ? 1 : (nc >= 1024) ? 2 : (nc >= 256) ? 4 : 8;
     }
-    size_t lds = lds_doubles(ctx->NP, ctx->nwp, NW, BS) * sizeof(double);
-    while (lds > 160 * 1024 && NW > 1) { NW /= 2; lds = lds_doubles(ctx->NP, ctx->nwp, NW, BS) * sizeof(double); }
+    size_t lds = lds_doubles(ctx->NP, ctx->nwp, NW) * sizeof(double);
+    while (lds > 160 * 1024 && NW > 1) { NW /= 2; lds = lds_doubles(ctx->NP, ctx->nwp, NW) * sizeof(double); }
     if (lds > 160 * 1024) return MXE_ERR_LIMIT;
     ctx->last_nw = NW; ctx->last_lds = (int)lds;
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     hipError_t e;
     switch (NW) {
-        case 1: e = launch_bs<1>(BS, kp, lds, ctx->stream); break;
-        case 2: e = launch_bs<2>(BS, kp, lds, ctx->stream); break;
-        case 4: e = launch_bs<4>(BS, kp, lds, ctx->stream); break;
-        default: e = launch_bs<8>(BS, kp, lds, ctx->stream); break;
+        case 1: e = launch_nab<1>(ctx->NP, kp, lds, ctx->stream); break;
+        case 2: e = launch_nab<2>(ctx->NP, kp, lds, ctx->stream); break;
+        case 4: e = launch_nab<4>(ctx->NP, kp, lds, ctx->stream); break;
+        default: e = launch_nab<8>(ctx->NP, kp, lds, ctx->stream); break;
     }
     HIPCHK(ctx, e);
     HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));

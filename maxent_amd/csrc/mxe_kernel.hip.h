@@ -3,9 +3,9 @@
 // One workgroup of NW wavefronts solves one chain = the warm-started alpha
 // scan of one matrix element (reference: maxent_loop.py:241-245 around
 // levenberg_minimizer.py:123-248).  All state of the chain lives in LDS and
-// registers; HBM/L2 traffic is the shared singular basis V (streamed once per
-// mat-vec / Gram pass, L2 resident), the element's D and ghat, and the
-// per-alpha results.
+// registers; the shared singular basis V is streamed from L2 (it is read by
+// every chain and never leaves the XCD's L2 once warm), the element's D and
+// ghat come from HBM once, the per-alpha results go to HBM once.
 //
 // Mathematics (whitened singular basis, see DESIGN.md and oracle/sform.py):
 //   u = V v,  H = D e^u | D(e^u - e^-u),  w = H | D(e^u + e^-u)
@@ -15,26 +15,36 @@
 //   Newton step (Bryan):  (c W c + (alpha+mu) I) z = rho + alpha v / c,
 //   delta = c*z, accepted when delta^T W delta <= step_max * sum(D) and the
 //   trial point is finite; converged when |w * V delta| / |H| < tol_h.
+//
+// Active subspace: the singular weights c_k decay exponentially.  For the
+// directions with c_k^2 max(w) <= theta (alpha+mu) the Newton matrix is
+// (alpha+mu) I to relative accuracy theta, so only the leading n_act x n_act
+// block of W is assembled and factorised; the remaining components take the
+// diagonal step z_k = rhs_k/(alpha+mu).  This changes the Newton matrix (an
+// inexact Newton method with contraction ~theta), never the residual g whose
+// zero defines the answer.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace mxe {
 
 constexpr int WAVE = 64;
-constexpr int GRAM_R = 4;        // rows staged per wave per Gram tile
+constexpr int GRAM_R = 4;         // rows staged per wave per Gram tile
+constexpr int GBLK = 6;           // staged doubles per 4-column block (16-B aligned, bank spread)
 
 struct KParams {
     int n_omega;        // number of frequencies
     int n_omega_pad;    // multiple of 64
     int n_s;            // kept singular values (<= NP)
-    int NP;             // padded n_s (row stride of V): 64
+    int NP;             // padded n_s (row stride of V): 64 or 128
     int n_alpha;
     int n_chain;
     // basis arrays, indexed by data-set id
-    const double* V;     // [n_ds][n_omega][NP]      zero padded columns
+    const double* V;     // [n_ds][n_omega_pad][NP]  zero padded rows and columns
     const double* Vt;    // [n_ds][NP][n_omega_pad]  zero padded
-    const double* c;     // [n_ds][NP]               padded with 1
+    const double* c;     // [n_ds][NP]               descending, padded with 1
     const double* cinv;  // [n_ds][NP]
     // elements
     const int* elem_ds;     // [n_elem]
@@ -56,9 +66,10 @@ struct KParams {
     int* out_niter;
     int* out_conv;
     int* out_nevals;
+    int* out_nact;      // [P] size of the active block at the last iteration
     // options
     int maxiter, miniter;
-    double tol_h, tol_d, tol_relq, step_max, mu_first, mu_grow, mu_max;
+    double tol_h, tol_d, tol_relq, step_max, mu_first, mu_grow, mu_max, theta;
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -74,61 +85,73 @@ __device__ __forceinline__ double wave_sum(double x) {
     return x;
 }
 
-__device__ __forceinline__ double wave_bcast(double x, int lane) {
-    return __shfl(x, lane, WAVE);
+__device__ __forceinline__ double wave_max(double x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fmax(x, __shfl_xor(x, off, WAVE));
+    return x;
 }
 
-// block-wide sum of NV values per thread; result valid in every thread.
-template <int NW, int NV>
-__device__ __forceinline__ void block_sum(double (&x)[NV], double* red /*[NW*NV]*/) {
-#pragma unroll
-    for (int q = 0; q < NV; ++q) x[q] = wave_sum(x[q]);
-    if (NW == 1) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __syncthreads();
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < NV; ++q) red[wave * NV + q] = x[q];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-        double s = 0.0;
-#pragma unroll
-        for (int wv = 0; wv < NW; ++wv) s += red[wv * NV + q];
-        x[q] = s;
-    }
+// broadcast lane `src` (wave-uniform index) of x to all lanes via v_readlane
+__device__ __forceinline__ double wave_bcast(double x, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+    return __hiloint2double(hi, lo);
 }
 
 template <int NW> __device__ __forceinline__ void block_sync() {
     if (NW == 1) wave_sync(); else __syncthreads();
 }
 
-// position of singular index k inside a staged Gram row: blocks of BS padded
-// to an odd stride so that the 8 block bases fall on distinct LDS banks.
-template <int BS> struct GramLayout {
-    static constexpr int BSP = (BS % 2) ? BS : BS + 1;
-    static constexpr int ROW = 8 * BSP;
-    __device__ static __forceinline__ int pos(int k) { return (k / BS) * BSP + (k % BS); }
-};
+// block-wide reduction of NV sums and one max; results valid in every thread.
+template <int NW, int NV>
+__device__ __forceinline__ void block_reduce(double (&x)[NV], double& mx, double* red /*[NW*(NV+1)]*/) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) x[q] = wave_sum(x[q]);
+    mx = wave_max(mx);
+    if (NW == 1) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) red[wave * (NV + 1) + q] = x[q];
+        red[wave * (NV + 1) + NV] = mx;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        double s = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) s += red[wv * (NV + 1) + q];
+        x[q] = s;
+    }
+    double m = red[NV];
+#pragma unroll
+    for (int wv = 1; wv < NW; ++wv) m = fmax(m, red[wv * (NV + 1) + NV]);
+    mx = m;
+}
 
-template <int NW, int BS>
+// NW  wavefronts per chain
+// NAB padded singular dimension in units of 32 (2 -> NP = 64, 4 -> NP = 128)
+template <int NW, int NAB>
 __global__ __launch_bounds__(64 * NW)
 void chain_kernel(const KParams p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int T = WAVE * NW;
-    using GL = GramLayout<BS>;
+    constexpr int NP = 32 * NAB;          // padded n_s == capacity of the active block
+    constexpr int LD = NP + 1;            // row stride of Wm (odd: conflict-free column walks)
+    constexpr int RPL = NP / 64;          // rows per lane in the factorisation
+    constexpr int SROW = (NP / 4) * GBLK; // staged doubles per Gram row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chain = blockIdx.x;
     if (chain >= p.n_chain) return;
 
-    const int NP = p.NP, LD = NP + 1, ns = p.n_s;
+    const int ns = p.n_s;
     const int nw = p.n_omega, nwp = p.n_omega_pad;
 
-    // ---- LDS carve ----
-    double* Wm   = lds;                    // [NP][LD]  upper+diag: W ; strict lower: L
-    double* dinv = Wm + NP * LD;           // [NP] 1/L_jj
+    // ---- LDS carve (all offsets multiples of 2 doubles) ----
+    double* Wm   = lds;                      // [NP][LD] upper+diag: W ; strict lower: L
+    double* dinv = Wm + NP * LD;             // [NP] 1/L_jj   (NP*LD is even: 16-B alignment kept)
     double* v    = dinv + NP;
     double* dl   = v + NP;
     double* g    = dl + NP;
@@ -139,244 +162,329 @@ void chain_kernel(const KParams p)
     double* gh   = ci + NP;
     double* rho  = gh + NP;
     double* rhot = rho + NP;
-    double* Wd   = rhot + NP;
-    double* hpart = Wd + NP;               // [NW][NP]
-    double* red  = hpart + NW * NP;        // [NW*8]
-    double* u    = red + NW * 8;           // [nwp]
+    double* hpart = rhot + NP;               // [NW][NP]
+    double* red  = hpart + NW * NP;          // [NW*8]
+    double* u    = red + NW * 8;             // [nwp]
     double* ut   = u + nwp;
     double* w    = ut + nwp;
     double* wt   = w + nwp;
     double* Hs   = wt + nwp;
-    double* stage = Hs + nwp;              // [NW][2][GRAM_R][GL::ROW]
+    double* stage = Hs + nwp;                // [NW][2 (x,y)][GRAM_R][SROW]
 
     const int elem = p.chain_elem[chain];
     const int ds = p.elem_ds[elem];
     const int kind = p.elem_kind[elem];
-    const double* __restrict__ V  = p.V  + (size_t)ds * nw * NP;
+    const double* __restrict__ V  = p.V  + (size_t)ds * nwp * NP;
     const double* __restrict__ Vt = p.Vt + (size_t)ds * NP * nwp;
     const double* __restrict__ Dg = p.D + (size_t)elem * nwp;
     const double cperp = p.cperp[elem];
     const double step_lim = p.step_max * p.sumD[elem];
 
-    if (tid < NP) {
-        cc[tid] = p.c[ds * NP + tid];
-        ci[tid] = p.cinv[ds * NP + tid];
-        gh[tid] = p.ghat[(size_t)elem * NP + tid];
-        v[tid]  = p.v0[(size_t)chain * NP + tid];
-        dl[tid] = 0.0;
+    for (int k = tid; k < NP; k += T) {
+        cc[k] = p.c[ds * NP + k];
+        ci[k] = p.cinv[ds * NP + k];
+        gh[k] = p.ghat[(size_t)elem * NP + k];
+        v[k]  = p.v0[(size_t)chain * NP + k];
+        dl[k] = 0.0;
     }
     block_sync<NW>();
 
     // ------------------------------------------------------------------
-    // evaluation pass.  trial u = u_base - V*dl (dl == 0, u_base == nullptr:
-    // u = V v from scratch).  Fills ut, wt, Hs, rhot; returns chi2, S,
-    // |w o V dl|^2 (with the OLD w) and |H_trial|^2.
+    // evaluation pass: trial u = u - V*vec (from_scratch: u = V*vec).
+    // Fills ut, wt, Hs, rhot; returns chi2, S, |w_old o V vec|^2, |H_t|^2,
+    // max(w_t).  Each thread owns two adjacent omega rows (16-B loads of V^T).
     // ------------------------------------------------------------------
     auto eval_pass = [&](const double* vec, bool from_scratch,
-                         double& chi2, double& S, double& dH2, double& Hn2) {
-        double part[3] = {0.0, 0.0, 0.0};   // S, dH2, Hn2
-        for (int i = tid; i < nwp; i += T) {
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                         double& chi2, double& S, double& dH2, double& Hn2, double& wmax) {
+        double pS = 0.0, pdH = 0.0, pHn = 0.0, pwm = 0.0;
+        for (int i = 2 * tid; i < nwp; i += 2 * T) {
+            double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
             const double* col = Vt + i;
             int k = 0;
-            for (; k + 3 < ns; k += 4) {
-                a0 = fma(col[(size_t)(k + 0) * nwp], vec[k + 0], a0);
-                a1 = fma(col[(size_t)(k + 1) * nwp], vec[k + 1], a1);
-                a2 = fma(col[(size_t)(k + 2) * nwp], vec[k + 2], a2);
-                a3 = fma(col[(size_t)(k + 3) * nwp], vec[k + 3], a3);
+#pragma unroll 4
+            for (; k + 1 < ns; k += 2) {
+                const double2 x0 = *reinterpret_cast<const double2*>(col + (size_t)k * nwp);
+                const double2 x1 = *reinterpret_cast<const double2*>(col + (size_t)(k + 1) * nwp);
+                const double q0 = vec[k], q1 = vec[k + 1];
+                a0 = fma(x0.x, q0, a0); b0 = fma(x0.y, q0, b0);
+                a1 = fma(x1.x, q1, a1); b1 = fma(x1.y, q1, b1);
             }
-            for (; k < ns; ++k) a0 = fma(col[(size_t)k * nwp], vec[k], a0);
-            const double vd = (a0 + a1) + (a2 + a3);
-            double ui;
-            if (from_scratch) ui = vd;
-            else {
-                ui = u[i] - vd;
-                const double t = w[i] * vd;
-                part[1] = fma(t, t, part[1]);
+            if (k < ns) {
+                const double2 x0 = *reinterpret_cast<const double2*>(col + (size_t)k * nwp);
+                a0 = fma(x0.x, vec[k], a0); b0 = fma(x0.y, vec[k], b0);
             }
-            const double Di = Dg[i];
-            double Hi, wi, Si;
-            if (kind == 0) {
-                const double e = exp(ui);
-                Hi = Di * e; wi = Hi;
-                Si = Hi - Di - Hi * ui;
-            } else {
-                const double ep = exp(ui), em = exp(-ui);
-                const double Hp = Di * ep, Hm = Di * em;
-                Hi = Hp - Hm; wi = Hp + Hm;
-                Si = (Hp - Di - Hp * ui) + (Hm - Di + Hm * ui);
+            const double vd2[2] = {a0 + a1, b0 + b1};
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int ii = i + r;
+                const double vd = vd2[r];
+                double ui;
+                if (from_scratch) ui = vd;
+                else {
+                    ui = u[ii] - vd;
+                    const double t = w[ii] * vd;
+                    pdH = fma(t, t, pdH);
+                }
+                const double Di = Dg[ii];
+                double Hi, wi, Si;
+                if (kind == 0) {
+                    const double e = exp(ui);
+                    Hi = Di * e; wi = Hi;
+                    Si = Hi - Di - Hi * ui;
+                } else {
+                    const double ep = exp(ui), em = exp(-ui);
+                    const double Hp = Di * ep, Hm = Di * em;
+                    Hi = Hp - Hm; wi = Hp + Hm;
+                    Si = (Hp - Di - Hp * ui) + (Hm - Di + Hm * ui);
+                }
+                if (ii >= nw) { Hi = 0.0; wi = 0.0; Si = 0.0; }
+                ut[ii] = ui; wt[ii] = wi; Hs[ii] = Hi;
+                pS += Si;
+                pHn = fma(Hi, Hi, pHn);
+                pwm = fmax(pwm, wi);     // NaN-ignoring; non-finite states are caught through Q
             }
-            if (i >= nw) { Hi = 0.0; wi = 0.0; Si = 0.0; }
-            ut[i] = ui; wt[i] = wi; Hs[i] = Hi;
-            part[0] += Si;
-            part[2] = fma(Hi, Hi, part[2]);
         }
         block_sync<NW>();                    // Hs complete
-        // h = V^T H : lane = singular index, rows split over the waves
+        // h = V^T H : rows split over the waves; lanes 0-31 take even rows,
+        // lanes 32-63 odd rows, each lane two adjacent singular columns
+        // (16-B loads); the two half-waves are summed with one shuffle.
         {
-            const int rows_per = (nw + NW - 1) / NW;
+            const int rows_per = (((nw + NW - 1) / NW) + 1) & ~1;
             const int r0 = wave * rows_per;
-            const int r1 = min(nw, r0 + rows_per);
-            double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-            const double* Vc = V + lane;
-            int i = r0;
-            for (; i + 3 < r1; i += 4) {
-                b0 = fma(Vc[(size_t)(i + 0) * NP], Hs[i + 0], b0);
-                b1 = fma(Vc[(size_t)(i + 1) * NP], Hs[i + 1], b1);
-                b2 = fma(Vc[(size_t)(i + 2) * NP], Hs[i + 2], b2);
-                b3 = fma(Vc[(size_t)(i + 3) * NP], Hs[i + 3], b3);
+            const int r1 = min(nwp, r0 + rows_per);
+            const int half = lane >> 5, cl = lane & 31;
+#pragma unroll
+            for (int cb = 0; cb < NP / 64; ++cb) {
+                double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
+                const double* Vc = V + 64 * cb + 2 * cl;
+                int i = r0 + half;
+#pragma unroll 4
+                for (; i + 2 < r1; i += 4) {
+                    const double2 x0 = *reinterpret_cast<const double2*>(Vc + (size_t)i * NP);
+                    const double2 x1 = *reinterpret_cast<const double2*>(Vc + (size_t)(i + 2) * NP);
+                    const double h0 = Hs[i], h1 = Hs[i + 2];
+                    s0 = fma(x0.x, h0, s0); s1 = fma(x0.y, h0, s1);
+                    t0 = fma(x1.x, h1, t0); t1 = fma(x1.y, h1, t1);
+                }
+                for (; i < r1; i += 2) {
+                    const double2 x0 = *reinterpret_cast<const double2*>(Vc + (size_t)i * NP);
+                    const double h0 = Hs[i];
+                    s0 = fma(x0.x, h0, s0); s1 = fma(x0.y, h0, s1);
+                }
+                s0 += t0; s1 += t1;
+                s0 += __shfl_xor(s0, 32, WAVE);
+                s1 += __shfl_xor(s1, 32, WAVE);
+                if (half == 0) {
+                    hpart[wave * NP + 64 * cb + 2 * cl] = s0;
+                    hpart[wave * NP + 64 * cb + 2 * cl + 1] = s1;
+                }
             }
-            for (; i < r1; ++i) b0 = fma(Vc[(size_t)i * NP], Hs[i], b0);
-            hpart[wave * NP + lane] = (b0 + b1) + (b2 + b3);
         }
         block_sync<NW>();
         double r2 = 0.0;
-        if (tid < NP) {
+        for (int k = tid; k < NP; k += T) {
             double h = 0.0;
 #pragma unroll
-            for (int wv = 0; wv < NW; ++wv) h += hpart[wv * NP + tid];
-            const double r = (tid < ns) ? cc[tid] * h - gh[tid] : 0.0;
-            rhot[tid] = r;
-            r2 = r * r;
+            for (int wv = 0; wv < NW; ++wv) h += hpart[wv * NP + k];
+            const double r = (k < ns) ? cc[k] * h - gh[k] : 0.0;
+            rhot[k] = r;
+            r2 = fma(r, r, r2);
         }
-        double x4[4] = {part[0], part[1], part[2], r2};
-        block_sum<NW, 4>(x4, red);
-        S = x4[0]; dH2 = x4[1]; Hn2 = x4[2]; chi2 = x4[3] + cperp;
+        double x4[4] = {pS, pdH, pHn, r2};
+        block_reduce<NW, 4>(x4, pwm, red);
+        S = x4[0]; dH2 = x4[1]; Hn2 = x4[2]; chi2 = x4[3] + cperp; wmax = pwm;
     };
 
     auto accept_trial = [&]() {
         for (int i = tid; i < nwp; i += T) { u[i] = ut[i]; w[i] = wt[i]; }
-        if (tid < NP) { v[tid] -= dl[tid]; rho[tid] = rhot[tid]; }
+        for (int k = tid; k < NP; k += T) { v[k] -= dl[k]; rho[k] = rhot[k]; }
         block_sync<NW>();
     };
 
     // ------------------------------------------------------------------
-    // Gram matrix W = V^T diag(w) V -> Wm (upper triangle + diagonal)
-    // lane (br, bc) of every wave owns the BS x BS block (br, bc); the waves
-    // split the omega rows; partial blocks are summed through LDS.
+    // Gram matrix of the active block: W_aa = V_a^T diag(w) V_a -> Wm
+    // (upper triangle + diagonal).  Lane (br, bc) of every wave owns one
+    // 4 x 4 register tile in each 32 x 32 super-block; the waves split the
+    // omega rows; rows are staged through LDS (double buffered), operands
+    // are fetched with 16-byte LDS reads.
     // ------------------------------------------------------------------
-    auto gram = [&]() {
+    auto gram_sweep = [&](auto PTag, const int* psr, const int* psc) {
+        constexpr int P = decltype(PTag)::value;     // super-block pairs per sweep
         const int br = lane >> 3, bc = lane & 7;
-        double acc[BS][BS];
+        double acc[P][4][4];
 #pragma unroll
-        for (int j = 0; j < BS; ++j)
+        for (int q = 0; q < P; ++q)
 #pragma unroll
-            for (int k = 0; k < BS; ++k) acc[j][k] = 0.0;
-        double* xs = stage + (size_t)wave * 2 * GRAM_R * GL::ROW;
-        double* ys = xs + GRAM_R * GL::ROW;
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[q][j][k] = 0.0;
+        double* xs = stage + (size_t)wave * 2 * GRAM_R * SROW;
+        double* ys = xs + GRAM_R * SROW;
         const int n_tiles = (nw + GRAM_R - 1) / GRAM_R;
-        const int mypos = GL::pos(lane);
-        const bool stager = lane < 8 * BS;
-        for (int t = wave; t < n_tiles; t += NW) {
+        double val[RPL][GRAM_R], wv_[GRAM_R];
+        auto load_tile = [&](int t) {          // global -> registers (columns lane, lane+64)
             const int i0 = t * GRAM_R;
-            double val[GRAM_R], wv_[GRAM_R];
 #pragma unroll
             for (int r = 0; r < GRAM_R; ++r) {
-                const int i = i0 + r;
-                const bool ok = (i < nw);
-                val[r] = ok ? V[(size_t)i * NP + lane] : 0.0;
-                wv_[r] = ok ? w[i] : 0.0;
+                const int i = i0 + r;            // < n_omega_pad (zero rows beyond n_omega)
+                wv_[r] = w[i];
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) val[q][r] = V[(size_t)i * NP + lane + 64 * q];
             }
-            wave_sync();                     // previous tile fully consumed
-            if (stager) {
+        };
+        auto store_tile = [&]() {              // registers -> LDS (x = w*V, y = V)
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+                const int k = lane + 64 * q;
+                const int pos = (k >> 2) * GBLK + (k & 3);
 #pragma unroll
                 for (int r = 0; r < GRAM_R; ++r) {
-                    ys[r * GL::ROW + mypos] = val[r];
-                    xs[r * GL::ROW + mypos] = val[r] * wv_[r];
+                    ys[r * SROW + pos] = val[q][r];
+                    xs[r * SROW + pos] = val[q][r] * wv_[r];
                 }
             }
+        };
+        int t = wave;
+        if (t < n_tiles) load_tile(t);
+        for (; t < n_tiles; t += NW) {
+            wave_sync();                            // previous tile fully consumed
+            store_tile();
             wave_sync();
+            if (t + NW < n_tiles) load_tile(t + NW); // global loads in flight during the FMAs
 #pragma unroll
             for (int r = 0; r < GRAM_R; ++r) {
-                double x[BS], y[BS];
 #pragma unroll
-                for (int j = 0; j < BS; ++j) x[j] = xs[r * GL::ROW + br * GL::BSP + j];
+                for (int q = 0; q < P; ++q) {
+                    const double2* xp = reinterpret_cast<const double2*>(xs + r * SROW + (8 * psr[q] + br) * GBLK);
+                    const double2* yp = reinterpret_cast<const double2*>(ys + r * SROW + (8 * psc[q] + bc) * GBLK);
+                    const double2 xa = xp[0], xb = xp[1], ya = yp[0], yb = yp[1];
+                    const double x[4] = {xa.x, xa.y, xb.x, xb.y};
+                    const double y[4] = {ya.x, ya.y, yb.x, yb.y};
 #pragma unroll
-                for (int k = 0; k < BS; ++k) y[k] = ys[r * GL::ROW + bc * GL::BSP + k];
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int j = 0; j < BS; ++j)
-#pragma unroll
-                    for (int k = 0; k < BS; ++k) acc[j][k] = fma(x[j], y[k], acc[j][k]);
+                        for (int k = 0; k < 4; ++k) acc[q][j][k] = fma(x[j], y[k], acc[q][j][k]);
+                }
             }
         }
         // reduce over the waves into Wm (upper + diagonal)
         for (int wv = 0; wv < NW; ++wv) {
-            if (wave == wv && br <= bc) {
+            if (wave == wv) {
 #pragma unroll
-                for (int j = 0; j < BS; ++j)
+                for (int q = 0; q < P; ++q) {
+                    if (psr[q] == psc[q] && br > bc) continue;
 #pragma unroll
-                    for (int k = 0; k < BS; ++k) {
-                        const int row = br * BS + j, col = bc * BS + k;
-                        if (row <= col && col < NP) {
-                            if (wv == 0) Wm[row * LD + col] = acc[j][k];
-                            else Wm[row * LD + col] += acc[j][k];
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int row = 32 * psr[q] + 4 * br + j, col = 32 * psc[q] + 4 * bc + k;
+                            if (row <= col) {
+                                if (wv == 0) Wm[row * LD + col] = acc[q][j][k];
+                                else Wm[row * LD + col] += acc[q][j][k];
+                            }
                         }
-                    }
+                }
             }
             block_sync<NW>();
         }
     };
 
-    // symmetric mat-vec  out = W x  (W in upper+diag of Wm), threads < NP
-    auto symv = [&](const double* x, double* out) {
-        if (tid < NP) {
-            double s0 = 0.0, s1 = 0.0;
-            const int i = tid;
-            int j = 0;
-            for (; j < i && j < ns; ++j) s0 = fma(Wm[j * LD + i], x[j], s0);   // column i
-            for (j = i; j < ns; ++j) s1 = fma(Wm[i * LD + j], x[j], s1);       // row i
-            out[i] = (i < ns) ? s0 + s1 : 0.0;
+    auto gram = [&](int n_act) {
+        const int nsb = (n_act + 31) >> 5;
+        if (nsb == 1) {
+            const int sr[1] = {0}, sc[1] = {0};
+            gram_sweep(std::integral_constant<int, 1>{}, sr, sc);
+        } else if (nsb == 2) {
+            const int sr[3] = {0, 0, 1}, sc[3] = {0, 1, 1};
+            gram_sweep(std::integral_constant<int, 3>{}, sr, sc);
+        } else if (NAB > 2) {
+            // rare slow path (n_act > 64): sweep the upper super-block pairs three at a time
+            int sr[3], sc[3], cnt = 0;
+            for (int a = 0; a < nsb; ++a)
+                for (int b2 = a; b2 < nsb; ++b2) {
+                    sr[cnt] = a; sc[cnt] = b2; ++cnt;
+                    if (cnt == 3) { gram_sweep(std::integral_constant<int, 3>{}, sr, sc); cnt = 0; }
+                }
+            for (int q = 0; q < cnt; ++q) {
+                const int s1[1] = {sr[q]}, s2[1] = {sc[q]};
+                gram_sweep(std::integral_constant<int, 1>{}, s1, s2);
+            }
         }
     };
 
     // ------------------------------------------------------------------
-    // wave 0: Cholesky of A = c W c + a I (left-looking, lane = row), with
-    // the right-hand side carried along as an extra row, then the back
-    // substitution.  L goes to the strict lower triangle of Wm, 1/L_jj to
-    // dinv.  Result z in zz[].  Returns false on a non-positive pivot.
+    // wave 0: Cholesky of A = c W c + a I on the active block (left-looking,
+    // lane = row, RPL rows per lane), forward and back substitution.
+    // L -> strict lower triangle of Wm, 1/L_jj -> dinv, solution -> zz.
     // ------------------------------------------------------------------
-    auto chol_solve = [&](double a) -> bool {
+    auto chol_solve = [&](double a, int n_act) -> bool {
         bool ok = true;
         if (wave == 0) {
-            const int i = lane;
-            const double ci_ = (i < ns) ? cc[i] : 0.0;
-            double yacc = 0.0;                 // forward substitution of rhs, lane j holds y_j
-            for (int j = 0; j < ns; ++j) {
-                double s;
-                if (i > j)       s = ci_ * Wm[j * LD + i] * cc[j];
-                else if (i == j) s = fma(ci_ * Wm[j * LD + j], ci_, a);
-                else             s = 0.0;
-                double r = rhs[j];             // rhs row (uniform)
-                double s0 = 0.0, s1 = 0.0, r0 = 0.0;
-                if (i >= j && i < ns) {
-                    int k = 0;
-                    for (; k + 1 < j; k += 2) {
-                        s0 = fma(Wm[i * LD + k],     Wm[j * LD + k],     s0);
-                        s1 = fma(Wm[i * LD + k + 1], Wm[j * LD + k + 1], s1);
+            double ci_[RPL];
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; ci_[q] = (i < n_act) ? cc[i] : 0.0; }
+            for (int j = 0; j < n_act; ++j) {
+                const double cj = cc[j];
+                double s[RPL];
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) {
+                    const int i = lane + 64 * q;
+                    double sv = 0.0;
+                    if (i >= j && i < n_act) {
+                        const double wij = Wm[j * LD + i];
+                        sv = (i == j) ? fma(ci_[q] * wij, ci_[q], a) : ci_[q] * wij * cj;
+                        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                        const double* Li = Wm + i * LD;
+                        const double* Lj = Wm + j * LD;
+                        int k = 0;
+                        for (; k + 3 < j; k += 4) {
+                            s0 = fma(Li[k],     Lj[k],     s0);
+                            s1 = fma(Li[k + 1], Lj[k + 1], s1);
+                            s2 = fma(Li[k + 2], Lj[k + 2], s2);
+                            s3 = fma(Li[k + 3], Lj[k + 3], s3);
+                        }
+                        for (; k < j; ++k) s0 = fma(Li[k], Lj[k], s0);
+                        sv -= (s0 + s1) + (s2 + s3);
                     }
-                    if (k < j) s0 = fma(Wm[i * LD + k], Wm[j * LD + k], s0);
+                    s[q] = sv;
                 }
-                // rhs row: sum_k y_k L_jk, y_k lives in lane k -> wave reduction
-                {
-                    const double t = (i < j) ? yacc * Wm[j * LD + i] : 0.0;
-                    r0 = wave_sum(t);
-                }
-                s -= (s0 + s1);
-                const double piv = wave_bcast(s, j);
+                const double piv = wave_bcast(s[j >> 6], j & 63);
                 if (!(piv > 0.0)) { ok = false; break; }
                 const double inv = 1.0 / sqrt(piv);
-                if (i == j) { dinv[j] = inv; yacc = (r - r0) * inv; }
-                if (i > j && i < ns) Wm[i * LD + j] = s * inv;
+                if (lane == 0) dinv[j] = inv;
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i > j && i < n_act) Wm[i * LD + j] = s[q] * inv;
+                }
                 wave_sync();
             }
             if (ok) {
-                // back substitution L^T z = y ; lane i holds residual r_i
-                double ri = (i < ns) ? yacc : 0.0;
-                for (int j = ns - 1; j >= 0; --j) {
-                    const double zj = wave_bcast(ri, j) * dinv[j];
-                    if (i == j) zz[j] = zj;
-                    if (i < j) ri = fma(-Wm[j * LD + i], zj, ri);
+                // forward: L y = rhs (column oriented; lane holds residual rows)
+                double r[RPL];
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; r[q] = (i < n_act) ? rhs[i] : 0.0; }
+                for (int j = 0; j < n_act; ++j) {
+                    const double yj = wave_bcast(r[j >> 6], j & 63) * dinv[j];
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q) {
+                        const int i = lane + 64 * q;
+                        if (i == j) r[q] = yj;
+                        else if (i > j && i < n_act) r[q] = fma(-Wm[i * LD + j], yj, r[q]);
+                    }
                 }
+                // backward: L^T z = y
+                for (int j = n_act - 1; j >= 0; --j) {
+                    const double zj = wave_bcast(r[j >> 6], j & 63) * dinv[j];
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q) {
+                        const int i = lane + 64 * q;
+                        if (i == j) r[q] = zj;
+                        else if (i < j) r[q] = fma(-Wm[j * LD + i], zj, r[q]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; if (i < n_act) zz[i] = r[q]; }
             }
         }
         if (NW > 1) {
@@ -390,48 +498,65 @@ void chain_kernel(const KParams p)
         return ok;
     };
 
+    // symmetric mat-vec on the active block: out = W_aa x_a  (threads < NP)
+    auto symv = [&](const double* x, double* out, int n_act) {
+        for (int i = tid; i < NP; i += T) {
+            double s0 = 0.0, s1 = 0.0;
+            if (i < n_act) {
+                for (int j = 0; j < i; ++j) s0 = fma(Wm[j * LD + i], x[j], s0);
+                for (int j = i; j < n_act; ++j) s1 = fma(Wm[i * LD + j], x[j], s1);
+            }
+            out[i] = s0 + s1;
+        }
+    };
+
     // ------------------------------------------------------------------
     // initial state: u = V v0
     // ------------------------------------------------------------------
-    double chi2, S, dH2, Hn2;
-    eval_pass(v, true, chi2, S, dH2, Hn2);
+    double chi2, S, dH2, Hn2, wmax;
+    eval_pass(v, true, chi2, S, dH2, Hn2, wmax);
     accept_trial();                 // dl == 0: v unchanged
     int nevals_pending = 1;
 
     for (int ia = 0; ia < p.n_alpha; ++ia) {
         const double alpha = p.alpha[(size_t)chain * p.n_alpha + ia];
-        int n_iter = 0, conv = 0, nevals = nevals_pending;
+        int n_iter = 0, conv = 0, nevals = nevals_pending, n_act_last = 0;
         nevals_pending = 0;
         double Qprev = __builtin_nan("");
         double Q = 0.5 * chi2 - alpha * S;
         bool failed = false;
 
         for (int it = 0; it < p.maxiter && !failed; ++it) {
-            if (tid < NP) {
-                const double vv = v[tid], r = rho[tid];
-                g[tid]   = (tid < ns) ? fma(cc[tid], r, alpha * vv) : 0.0;
-                rhs[tid] = (tid < ns) ? fma(alpha * vv, ci[tid], r) : 0.0;
+            for (int k = tid; k < NP; k += T) {
+                const double vv = v[k], r = rho[k];
+                g[k]   = (k < ns) ? fma(cc[k], r, alpha * vv) : 0.0;
+                rhs[k] = (k < ns) ? fma(alpha * vv, ci[k], r) : 0.0;
             }
-            gram();                 // ends with a block sync
+            // active block for mu = 0 (the largest it can be in this iteration)
+            int n_act0;
+            {
+                const double thr = p.theta * alpha / fmax(wmax, 1e-300);
+                int cnt = 0;
+                for (int k = lane; k < ns; k += 64) cnt += (cc[k] * cc[k] > thr) ? 1 : 0;
+                n_act0 = (int)wave_sum((double)cnt);
+                if (p.theta <= 0.0) n_act0 = ns;
+                if (n_act0 < 1) n_act0 = 1;
+                if (n_act0 > NP) n_act0 = NP;
+            }
+            block_sync<NW>();
+            gram(n_act0);               // ends with a block sync
+            n_act_last = n_act0;
             // reference-style criteria (convergence_methods.py:81-122)
             bool stop = false;
             if (p.tol_d > 0.0) {
-                symv(g, Wd);
-                double m[1] = {0.0};
+                symv(g, zz, n_act0);
                 block_sync<NW>();
-                if (tid < ns) m[0] = fabs(Wd[tid]);
-                // max over the block via sum of a 0/1 test is not enough: do a max reduce
-                double mx = m[0];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, WAVE));
-                if (NW > 1) {
-                    __syncthreads();
-                    if (lane == 0) red[wave] = mx;
-                    __syncthreads();
-                    mx = red[0];        // only wave 0 holds tid < NP
-                    __syncthreads();
-                }
+                double mx = 0.0;
+                for (int k = tid; k < n_act0; k += T) mx = fmax(mx, fabs(zz[k]));
+                double none[1] = {0.0};
+                block_reduce<NW, 1>(none, mx, red);
                 if (mx < p.tol_d) stop = true;
+                block_sync<NW>();
             }
             if (p.tol_relq > 0.0 && it > 0) {
                 if (fabs(fabs(Qprev - Q) / Q) < p.tol_relq) stop = true;
@@ -440,23 +565,32 @@ void chain_kernel(const KParams p)
 
             // ---- damped Newton step with Bryan's step bound ----
             double mu = 0.0;
-            double chi2t = 0.0, St = 0.0, dH2t = 0.0, Hn2t = 0.0;
+            double chi2t = 0.0, St = 0.0, dH2t = 0.0, Hn2t = 0.0, wmaxt = 0.0;
             bool accepted = false;
             while (true) {
-                const bool okc = chol_solve(alpha + mu);
+                const double a = alpha + mu;
+                const bool okc = chol_solve(a, n_act0);
                 bool good = okc;
                 if (okc) {
-                    if (tid < NP) dl[tid] = (tid < ns) ? cc[tid] * zz[tid] : 0.0;
-                    block_sync<NW>();
-                    symv(dl, Wd);
-                    block_sync<NW>();
+                    // delta = c z ; inactive directions: z = rhs / a
                     double nrm = 0.0;
-                    if (tid < NP) nrm = dl[tid] * Wd[tid];
+                    for (int k = tid; k < NP; k += T) {
+                        double z = 0.0;
+                        if (k < n_act0) {
+                            z = zz[k];
+                            nrm += z * (rhs[k] - a * z);     // z^T (c W c) z = delta^T W delta
+                        } else if (k < ns) {
+                            z = rhs[k] / a;
+                        }
+                        dl[k] = (k < ns) ? cc[k] * z : 0.0;
+                    }
                     double x1[1] = {nrm};
-                    block_sum<NW, 1>(x1, red);
+                    double dummy = 0.0;
+                    block_reduce<NW, 1>(x1, dummy, red);
+                    block_sync<NW>();
                     if (!(x1[0] <= step_lim)) good = false;
                     if (good) {
-                        eval_pass(dl, false, chi2t, St, dH2t, Hn2t);
+                        eval_pass(dl, false, chi2t, St, dH2t, Hn2t, wmaxt);
                         ++nevals;
                         const double Qt = 0.5 * chi2t - alpha * St;
                         if (!(fabs(Qt) <= 1.7e308)) good = false;   // NaN / inf
@@ -469,7 +603,7 @@ void chain_kernel(const KParams p)
             if (!accepted) { failed = true; break; }
             const double relH = sqrt(dH2t / Hn2);
             accept_trial();
-            chi2 = chi2t; S = St; Hn2 = Hn2t;
+            chi2 = chi2t; S = St; Hn2 = Hn2t; wmax = wmaxt;
             Qprev = Q;
             Q = 0.5 * chi2 - alpha * S;
             ++n_iter;
@@ -485,7 +619,7 @@ void chain_kernel(const KParams p)
                 Ho[i] = (kind == 0) ? Di * exp(ui) : Di * exp(ui) - Di * exp(-ui);
             }
         }
-        if (p.out_v && tid < NP) p.out_v[prob * NP + tid] = v[tid];
+        if (p.out_v) for (int k = tid; k < NP; k += T) p.out_v[prob * NP + k] = v[k];
         if (tid == 0) {
             p.out_chi2[prob] = chi2;
             p.out_S[prob] = S;
@@ -493,6 +627,7 @@ void chain_kernel(const KParams p)
             p.out_niter[prob] = n_iter;
             p.out_conv[prob] = conv;
             p.out_nevals[prob] = nevals;
+            p.out_nact[prob] = n_act_last;
         }
     }
 }

@@ -33,6 +33,7 @@ class MxeOpts(ctypes.Structure):
                 ('mu_first', ctypes.c_double),
                 ('mu_grow', ctypes.c_double),
                 ('mu_max', ctypes.c_double),
+                ('decouple_tol', ctypes.c_double),
                 ('waves_per_chain', ctypes.c_int32),
                 ('reserved', ctypes.c_int32)]
 
