@@ -64,6 +64,7 @@ struct mxe_ctx {
     DevBuf<int> delem_ds, delem_kind, dchain_elem;
     DevBuf<double> dout_v, dout_H, dout_chi2, dout_S, dout_Q, dB, dA;
     DevBuf<int> dout_niter, dout_conv, dout_nevals, dout_nact;
+    DevBuf<long long> dprof;
     std::string hip_err;
 };
 
@@ -459,6 +460,12 @@ int mxe_chains_launch(mxe_ctx* ctx)
     kp.tol_h = o.tol_h; kp.tol_d = o.tol_d; kp.tol_relq = o.tol_relq;
     kp.step_max = o.step_max; kp.mu_first = o.mu_first; kp.mu_grow = o.mu_grow; kp.mu_max = o.mu_max;
     kp.theta = o.decouple_tol; kp.out_nact = ctx->dout_nact.p;
+    kp.prof = nullptr;
+#ifdef MXE_PROFILE
+    HIPCHK(ctx, ctx->dprof.ensure((size_t)ctx->n_chain * 8));
+    HIPCHK(ctx, hipMemsetAsync(ctx->dprof.p, 0, (size_t)ctx->n_chain * 64, ctx->stream));
+    kp.prof = ctx->dprof.p;
+#endif
 
     int NW = o.waves_per_chain;
     if (NW == 0) {
@@ -580,6 +587,17 @@ int mxe_last_launch_info(mxe_ctx* ctx, int* waves_per_chain, int* n_workgroups, 
 }
 
 } // extern "C"
+
+#ifdef MXE_PROFILE
+// diagnostic build only: per-chain phase cycle counters of the last launch
+extern "C" int mxe_prof_fetch(mxe_ctx* ctx, long long* out /*[n_chain][8]*/)
+{
+    if (!ctx || !out) return MXE_ERR_ARG;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(out, ctx->dprof.p, (size_t)ctx->n_chain * 64, hipMemcpyDeviceToHost));
+    return MXE_OK;
+}
+#endif
 
 // ---- output map A = B H ----------------------------------------------------
 namespace mxe {

@@ -70,7 +70,19 @@ struct KParams {
     // options
     int maxiter, miniter;
     double tol_h, tol_d, tol_relq, step_max, mu_first, mu_grow, mu_max, theta;
+    long long* prof;    // [n_chain][8] phase cycle counters (diagnostic build only)
 };
+
+#if defined(MXE_PROFILE) && defined(MXE_PROFILE_EVAL)
+#define MXE_STAMP_E(idx) do { const long long t__ = clock64(); if (tid == 0) prof_acc[idx] += t__ - prof_t; prof_t = t__; } while (0)
+#else
+#define MXE_STAMP_E(idx) do {} while (0)
+#endif
+#ifdef MXE_PROFILE
+#define MXE_STAMP(idx) do { const long long t__ = clock64(); if (tid == 0) prof_acc[idx] += t__ - prof_t; prof_t = t__; } while (0)
+#else
+#define MXE_STAMP(idx) do {} while (0)
+#endif
 
 __device__ __forceinline__ void wave_sync() {
     // orders LDS traffic between the lanes of one wavefront
@@ -180,6 +192,10 @@ void chain_kernel(const KParams p)
     const double cperp = p.cperp[elem];
     const double step_lim = p.step_max * p.sumD[elem];
 
+#ifdef MXE_PROFILE
+    long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_t = clock64();
+#endif
     for (int k = tid; k < NP; k += T) {
         cc[k] = p.c[ds * NP + k];
         ci[k] = p.cinv[ds * NP + k];
@@ -201,7 +217,7 @@ void chain_kernel(const KParams p)
             double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
             const double* col = Vt + i;
             int k = 0;
-#pragma unroll 4
+#pragma unroll 8
             for (; k + 1 < ns; k += 2) {
                 const double2 x0 = *reinterpret_cast<const double2*>(col + (size_t)k * nwp);
                 const double2 x1 = *reinterpret_cast<const double2*>(col + (size_t)(k + 1) * nwp);
@@ -245,6 +261,7 @@ void chain_kernel(const KParams p)
             }
         }
         block_sync<NW>();                    // Hs complete
+        MXE_STAMP_E(3);
         // h = V^T H : rows split over the waves; lanes 0-31 take even rows,
         // lanes 32-63 odd rows, each lane two adjacent singular columns
         // (16-B loads); the two half-waves are summed with one shuffle.
@@ -281,6 +298,7 @@ void chain_kernel(const KParams p)
             }
         }
         block_sync<NW>();
+        MXE_STAMP_E(4);
         double r2 = 0.0;
         for (int k = tid; k < NP; k += T) {
             double h = 0.0;
@@ -293,6 +311,7 @@ void chain_kernel(const KParams p)
         double x4[4] = {pS, pdH, pHn, r2};
         block_reduce<NW, 4>(x4, pwm, red);
         S = x4[0]; dH2 = x4[1]; Hn2 = x4[2]; chi2 = x4[3] + cperp; wmax = pwm;
+        MXE_STAMP_E(5);
     };
 
     auto accept_trial = [&]() {
@@ -389,7 +408,96 @@ void chain_kernel(const KParams p)
         }
     };
 
+    // ------------------------------------------------------------------
+    // Gram matrix on the matrix cores: W_aa = (w o V_a)^T V_a as rank-4
+    // updates of 16 x 16 tiles with v_mfma_f64_16x16x4_f64.  Operand layout
+    // (one f64 per lane): A[m = l&15][k = l>>4], B[k = l>>4][n = l&15], so a
+    // lane simply loads V[i0 + (l>>4)][16 t + (l&15)] -- four 128-byte row
+    // segments per wave, straight from L2, no LDS staging.  The upper tile
+    // pairs (mt <= nt) are accumulated; C/D layout of the f64 form:
+    // col = l&15, row = (l>>4) + 4 r.
+    // ------------------------------------------------------------------
+    auto gram_mfma = [&](auto NTTag) {
+        constexpr int NT = decltype(NTTag)::value;       // 16-column tiles covering the active block
+        constexpr int NPAIR = NT * (NT + 1) / 2;
+        constexpr int DEPTH = 4;                         // row groups in flight
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        d4 acc[NPAIR];
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+        const int kq = lane >> 4, cn = lane & 15;
+        const int n_groups = nwp >> 2;                   // 4 omega rows per MFMA (zero rows beyond n_omega)
+        const double* Vl = V + (size_t)kq * NP + cn;
+        double f[DEPTH][NT], wv_[DEPTH];
+        auto load_group = [&](int d, int gidx) {
+            const int i0 = 4 * gidx;
+            wv_[d] = w[i0 + kq];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) f[d][t] = Vl[(size_t)i0 * NP + 16 * t];
+        };
+        int gidx = wave;
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) if (gidx + d * NW < n_groups) load_group(d, gidx + d * NW);
+        for (; gidx < n_groups; gidx += DEPTH * NW) {
+            double fc[DEPTH][NT], wc[DEPTH];
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                wc[d] = wv_[d];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) fc[d][t] = f[d][t];
+            }
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int gn = gidx + (DEPTH + d) * NW;
+                if (gn < n_groups) load_group(d, gn);   // next chunk's loads fly during the MFMAs
+            }
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                if (gidx + d * NW < n_groups) {
+                    double a[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) a[t] = fc[d][t] * wc[d];
+                    int q = 0;
+#pragma unroll
+                    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                        for (int nt = mt; nt < NT; ++nt) {
+                            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], fc[d][nt], acc[q], 0, 0, 0);
+                            ++q;
+                        }
+                }
+            }
+        }
+        for (int wv = 0; wv < NW; ++wv) {
+            if (wave == wv) {
+                int q = 0;
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                    for (int nt = mt; nt < NT; ++nt) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * mt + kq + 4 * r, col = 16 * nt + cn;
+                            if (wv == 0) Wm[row * LD + col] = acc[q][r];
+                            else Wm[row * LD + col] += acc[q][r];
+                        }
+                        ++q;
+                    }
+            }
+            block_sync<NW>();
+        }
+    };
+
     auto gram = [&](int n_act) {
+#ifndef MXE_GRAM_VALU
+        {
+            const int ntile = (n_act + 15) >> 4;
+            if (ntile <= 1) { gram_mfma(std::integral_constant<int, 1>{}); return; }
+            if (ntile == 2) { gram_mfma(std::integral_constant<int, 2>{}); return; }
+            if (ntile == 3) { gram_mfma(std::integral_constant<int, 3>{}); return; }
+            if (ntile == 4) { gram_mfma(std::integral_constant<int, 4>{}); return; }
+        }
+#endif
         const int nsb = (n_act + 31) >> 5;
         if (nsb == 1) {
             const int sr[1] = {0}, sc[1] = {0};
@@ -420,28 +528,40 @@ void chain_kernel(const KParams p)
     auto chol_solve = [&](double a, int n_act) -> bool {
         bool ok = true;
         if (wave == 0) {
+            // The right-hand side rides along as one more row (index n_act) of
+            // the matrix being factorised: its "L" entries are y = L^-1 rhs.
+            const bool fused = (n_act < 64 * RPL);
+            const int n_rows = fused ? n_act + 1 : n_act;
             double ci_[RPL];
 #pragma unroll
             for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; ci_[q] = (i < n_act) ? cc[i] : 0.0; }
+            double* Ly = Wm + n_act * LD;               // row n_act: y (fused) -- inside Wm when n_act < NP
             for (int j = 0; j < n_act; ++j) {
                 const double cj = cc[j];
+                const double rj = rhs[j];
                 double s[RPL];
 #pragma unroll
                 for (int q = 0; q < RPL; ++q) {
                     const int i = lane + 64 * q;
                     double sv = 0.0;
-                    if (i >= j && i < n_act) {
-                        const double wij = Wm[j * LD + i];
-                        sv = (i == j) ? fma(ci_[q] * wij, ci_[q], a) : ci_[q] * wij * cj;
+                    if (i >= j && i < n_rows) {
+                        if (i < n_act) {
+                            const double wij = Wm[j * LD + i];
+                            sv = (i == j) ? fma(ci_[q] * wij, ci_[q], a) : ci_[q] * wij * cj;
+                        } else {
+                            sv = rj;
+                        }
                         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
                         const double* Li = Wm + i * LD;
                         const double* Lj = Wm + j * LD;
                         int k = 0;
-                        for (; k + 3 < j; k += 4) {
-                            s0 = fma(Li[k],     Lj[k],     s0);
-                            s1 = fma(Li[k + 1], Lj[k + 1], s1);
-                            s2 = fma(Li[k + 2], Lj[k + 2], s2);
-                            s3 = fma(Li[k + 3], Lj[k + 3], s3);
+                        for (; k + 7 < j; k += 8) {
+                            const double l0 = Li[k], l1 = Li[k + 1], l2 = Li[k + 2], l3 = Li[k + 3];
+                            const double l4 = Li[k + 4], l5 = Li[k + 5], l6 = Li[k + 6], l7 = Li[k + 7];
+                            const double m0 = Lj[k], m1 = Lj[k + 1], m2 = Lj[k + 2], m3 = Lj[k + 3];
+                            const double m4 = Lj[k + 4], m5 = Lj[k + 5], m6 = Lj[k + 6], m7 = Lj[k + 7];
+                            s0 = fma(l0, m0, s0); s1 = fma(l1, m1, s1); s2 = fma(l2, m2, s2); s3 = fma(l3, m3, s3);
+                            s0 = fma(l4, m4, s0); s1 = fma(l5, m5, s1); s2 = fma(l6, m6, s2); s3 = fma(l7, m7, s3);
                         }
                         for (; k < j; ++k) s0 = fma(Li[k], Lj[k], s0);
                         sv -= (s0 + s1) + (s2 + s3);
@@ -450,41 +570,148 @@ void chain_kernel(const KParams p)
                 }
                 const double piv = wave_bcast(s[j >> 6], j & 63);
                 if (!(piv > 0.0)) { ok = false; break; }
-                const double inv = 1.0 / sqrt(piv);
+                // 1/sqrt(piv): hardware estimate + two Newton steps (full binary64 accuracy)
+                double inv = __builtin_amdgcn_rsq(piv);
+                inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+                inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
                 if (lane == 0) dinv[j] = inv;
 #pragma unroll
                 for (int q = 0; q < RPL; ++q) {
                     const int i = lane + 64 * q;
-                    if (i > j && i < n_act) Wm[i * LD + j] = s[q] * inv;
+                    if (i > j && i < n_rows) Wm[i * LD + j] = s[q] * inv;
                 }
                 wave_sync();
             }
             if (ok) {
-                // forward: L y = rhs (column oriented; lane holds residual rows)
                 double r[RPL];
+                if (fused) {
 #pragma unroll
-                for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; r[q] = (i < n_act) ? rhs[i] : 0.0; }
-                for (int j = 0; j < n_act; ++j) {
-                    const double yj = wave_bcast(r[j >> 6], j & 63) * dinv[j];
+                    for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; r[q] = (i < n_act) ? Ly[i] : 0.0; }
+                } else {
+                    // forward: L y = rhs (column oriented; lane holds residual rows)
 #pragma unroll
-                    for (int q = 0; q < RPL; ++q) {
-                        const int i = lane + 64 * q;
-                        if (i == j) r[q] = yj;
-                        else if (i > j && i < n_act) r[q] = fma(-Wm[i * LD + j], yj, r[q]);
+                    for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; r[q] = (i < n_act) ? rhs[i] : 0.0; }
+                    for (int j = 0; j < n_act; ++j) {
+                        const double yj = wave_bcast(r[j >> 6], j & 63) * dinv[j];
+#pragma unroll
+                        for (int q = 0; q < RPL; ++q) {
+                            const int i = lane + 64 * q;
+                            if (i == j) r[q] = yj;
+                            else if (i > j && i < n_act) r[q] = fma(-Wm[i * LD + j], yj, r[q]);
+                        }
                     }
                 }
-                // backward: L^T z = y
+                // backward: L^T z = y ; 1/L_jj in a register of lane j, the row of L
+                // needed by step j is fetched one step ahead
+                double di[RPL];
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; di[q] = (i < n_act) ? dinv[i] : 0.0; }
+                double lnext[RPL];
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) {
+                    const int i = lane + 64 * q;
+                    lnext[q] = (i < n_act - 1) ? Wm[(n_act - 1) * LD + i] : 0.0;
+                }
                 for (int j = n_act - 1; j >= 0; --j) {
-                    const double zj = wave_bcast(r[j >> 6], j & 63) * dinv[j];
+                    double lcur[RPL];
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q) {
+                        lcur[q] = lnext[q];
+                        const int i = lane + 64 * q;
+                        lnext[q] = (j > 0 && i < j - 1) ? Wm[(j - 1) * LD + i] : 0.0;
+                    }
+                    const double zj = wave_bcast(r[j >> 6] * di[j >> 6], j & 63);
 #pragma unroll
                     for (int q = 0; q < RPL; ++q) {
                         const int i = lane + 64 * q;
                         if (i == j) r[q] = zj;
-                        else if (i < j) r[q] = fma(-Wm[j * LD + i], zj, r[q]);
+                        else if (i < j) r[q] = fma(-lcur[q], zj, r[q]);
                     }
                 }
 #pragma unroll
                 for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; if (i < n_act) zz[i] = r[q]; }
+            }
+        }
+        if (NW > 1) {
+            if (tid == 0) red[0] = ok ? 1.0 : 0.0;
+            __syncthreads();
+            ok = red[0] != 0.0;
+            __syncthreads();
+        } else {
+            wave_sync();
+        }
+        return ok;
+    };
+
+    // ------------------------------------------------------------------
+    // wave 0, active block of at most N <= 64 rows: Cholesky entirely in
+    // registers.  Lane i holds row i of A = c W c + a I (N doubles, static
+    // indices: the j and k loops are fully unrolled); right-looking
+    // elimination with the pivot column broadcast through v_readlane, the
+    // right-hand side carried as one more column (forward substitution for
+    // free).  L is then parked in the strict lower triangle of Wm for the
+    // back substitution.  Rows >= n_act are padded with the identity.
+    // ------------------------------------------------------------------
+    auto chol_solve_reg = [&](auto NTag, double a, int n_act) -> bool {
+        constexpr int N = decltype(NTag)::value;
+        bool ok = true;
+        if (wave == 0) {
+            const int i = lane;
+            const bool live = i < n_act;
+            const double ci_ = live ? cc[i] : 0.0;
+            double A[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                // lower triangle of row i: A_ij = c_i W_ji c_j (j < i), stored as W[j][i]
+                double x = 0.0;
+                if (live && j <= i && j < n_act) x = ci_ * Wm[j * LD + i] * cc[j];
+                if (j == i) x = live ? x + a : 1.0;
+                A[j] = x;
+            }
+            double b = live ? rhs[i] : 0.0;
+            double dinv_i = 1.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const double piv = wave_bcast(A[j], j);
+                if (!(piv > 0.0)) ok = false;
+                // the factor only preconditions the (inexact) Newton step: the
+                // hardware 1/sqrt estimate plus one Newton-Raphson step is plenty
+                double inv = __builtin_amdgcn_rsq(piv);
+                inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+                if (i == j) dinv_i = inv;
+                const double lij = (i > j) ? A[j] * inv : 0.0;    // column j of L (rows > j)
+                A[j] = lij;
+                const double yj = wave_bcast(b, j) * inv;          // y_j = (b_j - ...)/L_jj
+                if (i == j) b = yj;
+                b = fma(-lij, yj, b);
+                // trailing update, broadcasts batched eight at a time so that the
+                // v_readlane -> v_fma SGPR hazard slots are filled with work
+#pragma unroll
+                for (int k0 = j + 1; k0 < N; k0 += 8) {
+                    double lk[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (k0 + q < N) lk[q] = wave_bcast(lij, k0 + q);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (k0 + q < N) A[k0 + q] = fma(-lij, lk[q], A[k0 + q]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (ok) {
+                // park L for the transposed solve: L[i][j], j < i
+#pragma unroll
+                for (int j = 0; j < N; ++j) if (j < i && i < n_act) Wm[i * LD + j] = A[j];
+                wave_sync();
+                double r = b;                                       // y_i
+                double lnext = (i < n_act - 1) ? Wm[(n_act - 1) * LD + i] : 0.0;
+                for (int j = n_act - 1; j >= 0; --j) {
+                    const double lcur = lnext;
+                    lnext = (j > 0 && i < j - 1) ? Wm[(j - 1) * LD + i] : 0.0;
+                    const double zj = wave_bcast(r * dinv_i, j);
+                    if (i == j) r = zj;
+                    else if (i < j) r = fma(-lcur, zj, r);
+                }
+                if (live) zz[i] = r;
             }
         }
         if (NW > 1) {
@@ -544,7 +771,9 @@ void chain_kernel(const KParams p)
                 if (n_act0 > NP) n_act0 = NP;
             }
             block_sync<NW>();
+            MXE_STAMP(0);
             gram(n_act0);               // ends with a block sync
+            MXE_STAMP(1);
             n_act_last = n_act0;
             // reference-style criteria (convergence_methods.py:81-122)
             bool stop = false;
@@ -569,7 +798,12 @@ void chain_kernel(const KParams p)
             bool accepted = false;
             while (true) {
                 const double a = alpha + mu;
-                const bool okc = chol_solve(a, n_act0);
+                bool okc;
+                if (n_act0 <= 16) okc = chol_solve_reg(std::integral_constant<int, 16>{}, a, n_act0);
+                else if (n_act0 <= 24) okc = chol_solve_reg(std::integral_constant<int, 24>{}, a, n_act0);
+                else if (n_act0 <= 32) okc = chol_solve_reg(std::integral_constant<int, 32>{}, a, n_act0);
+                else okc = chol_solve(a, n_act0);
+                MXE_STAMP(2);
                 bool good = okc;
                 if (okc) {
                     // delta = c z ; inactive directions: z = rhs / a
@@ -589,8 +823,10 @@ void chain_kernel(const KParams p)
                     block_reduce<NW, 1>(x1, dummy, red);
                     block_sync<NW>();
                     if (!(x1[0] <= step_lim)) good = false;
+                    MXE_STAMP(3);
                     if (good) {
                         eval_pass(dl, false, chi2t, St, dH2t, Hn2t, wmaxt);
+                        MXE_STAMP(4);
                         ++nevals;
                         const double Qt = 0.5 * chi2t - alpha * St;
                         if (!(fabs(Qt) <= 1.7e308)) good = false;   // NaN / inf
@@ -603,6 +839,7 @@ void chain_kernel(const KParams p)
             if (!accepted) { failed = true; break; }
             const double relH = sqrt(dH2t / Hn2);
             accept_trial();
+            MXE_STAMP(5);
             chi2 = chi2t; S = St; Hn2 = Hn2t; wmax = wmaxt;
             Qprev = Q;
             Q = 0.5 * chi2 - alpha * S;
@@ -629,7 +866,11 @@ void chain_kernel(const KParams p)
             p.out_nevals[prob] = nevals;
             p.out_nact[prob] = n_act_last;
         }
+        MXE_STAMP(6);
     }
+#ifdef MXE_PROFILE
+    if (tid == 0 && p.prof) for (int q = 0; q < 8; ++q) p.prof[(size_t)chain * 8 + q] = prof_acc[q];
+#endif
 }
 
 } // namespace mxe

@@ -11,8 +11,10 @@ import os
 import numpy as np
 
 _LIB = None
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)),
-                         'lib', 'libmaxent_hip.so')
+_LIB_PATH = os.environ.get(
+    'MAXENT_AMD_LIB',
+    os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib',
+                 'libmaxent_hip.so'))
 
 ENTROPY_NORMAL = 0
 ENTROPY_PLUSMINUS = 1
