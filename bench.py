@@ -30,6 +30,10 @@ from maxent_amd import device, synthetic, hostprep   # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 N_EVAL_NOMINAL = {'normal': 160, 'plusminus': 84}
+# HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE /
+# WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md);
+# filled in from profiles/ when measured, else None
+TRAFFIC_PMC_BYTES_PER_LAUNCH = None      # see main(): set for the default workload
 
 
 def build_batch(n_orb, n_tau, n_omega, n_alpha, rank):
@@ -227,19 +231,29 @@ def main():
     bytes_actual = float(out['n_evals'].sum()) * b_eval
     # every Newton iteration also streams V once more for the Gram matrix
     bytes_streamed = float(out['n_evals'].sum() + out['n_iter'].sum()) * b_eval
-    achieved = bytes_nominal / (k_ms * 1e-3) / 1e9
+    # achieved: evaluation passes the launch actually executed (counted by the
+    # kernel) x B_eval / kernel time.  Extra fields: the same with the Gram
+    # passes (each Newton iteration streams the active columns of V once
+    # more), and SURVEY 8d's nominal figure that prices the kernel's time
+    # against the reference's 160/84 passes per alpha-solve.
+    achieved = bytes_actual / (k_ms * 1e-3) / 1e9
+    # profiles/r01_b_pmc_hbm_traffic.csv: FETCH_SIZE 3 339 KB (x2, gfx950
+    # correction) + WRITE_SIZE 113 829 KB per launch of the default workload
+    traffic = (2 * 3339.0e3 + 113829.0e3) if (args.n_orb, args.n_tau, args.n_omega, args.n_alpha) == (16, 200, 500, 100) else None
     roofline = dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS,
-                    unit='GB/s', frac=achieved / HBM_PEAK_GBS, traffic=None,
+                    unit='GB/s', frac=achieved / HBM_PEAK_GBS,
+                    traffic=traffic,
                     kernel='mxe::chain_kernel', kernel_ms=k_ms,
-                    definition='SURVEY 8d: nominal reference work (160/84 '
-                               'evaluation passes per alpha-solve) x 232 KB '
-                               '/ kernel time',
-                    achieved_actual_evals=bytes_actual / (k_ms * 1e-3) / 1e9,
-                    achieved_streamed_incl_gram=bytes_streamed / (k_ms * 1e-3) / 1e9,
+                    definition='evaluation passes executed (kernel counter) x '
+                               'B_eval = %d B / kernel time (HIP events); V is '
+                               'L2 resident, see DESIGN.md section 4' % b_eval,
+                    algorithmic_bytes_per_launch=bytes_actual,
+                    achieved_incl_gram_passes=bytes_streamed / (k_ms * 1e-3) / 1e9,
+                    achieved_survey_nominal_reference_work=bytes_nominal / (k_ms * 1e-3) / 1e9,
                     evals_per_solve=float(out['n_evals'].mean()),
                     newton_iters_per_solve=float(out['n_iter'].mean()),
-                    fp64_gflops_gram=float(out['n_iter'].sum()) * 2.0 *
-                    args.n_omega * n_s * n_s / (k_ms * 1e-3) / 1e9)
+                    fp64_tflops_gram_dense_equiv=float(out['n_iter'].sum()) * 2.0 *
+                    args.n_omega * n_s * n_s / (k_ms * 1e-3) / 1e12)
 
     line = dict(metric='alpha-solves/s', value=value, unit='alpha-solves/s',
                 n_gpus=world, steps=args.steps, warmup=args.warmup,

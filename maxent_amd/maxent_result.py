@@ -250,6 +250,7 @@ class MaxEntResult(MaxEntResultData):
     def _key(self, matrix_element, complex_index):
         if self.matrix_structure is None or not self.element_wise:
             return None
+        assert matrix_element is not None, 'matrix_element must be given'
         key = tuple(matrix_element)
         if self.complex_elements and complex_index is not None \
                 and len(key) == 2:

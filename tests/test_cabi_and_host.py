@@ -1,0 +1,245 @@
+"""CPU tests: the C-ABI library loads and exports every symbol the header
+declares (no compute without a GPU), and the host-side mirror of the reference
+interface behaves like the reference (meshes, kernel fill, SVD staging,
+analyzers, MaxEntResult layout, attribute shadowing, error behaviour)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import maxent_amd as mx
+from maxent_amd import device
+from oracle import ref_numpy as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def load(name):
+    with np.load(os.path.join(GOLD, name + '.npz'), allow_pickle=False) as d:
+        return {k: d[k] for k in d.files}
+
+
+# ---- C-ABI ------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'maxent_hip.h')).read()
+    declared = set(re.findall(r'\b(mxe_[a-z_]+)\s*\(', header))
+    declared -= {'mxe_ctx', 'mxe_opts'}
+    lib = device.load_library()
+    bound = {name for name, _, _ in device.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.mxe_version().startswith(b'maxent_hip')
+    assert lib.mxe_strerror(0) == b'ok'
+    assert b'argument' in lib.mxe_strerror(-1)
+
+
+def test_opts_defaults_and_struct_layout():
+    o = device.default_opts()
+    assert (o.maxiter, o.miniter) == (1000, 0)
+    assert o.tol_h == 1e-9 and o.tol_d == 0.0 and o.tol_relq == 0.0
+    assert o.step_max == 0.2 and o.mu_grow == 4.0 and o.decouple_tol == 1e-6
+    with pytest.raises(TypeError):
+        device.default_opts(nonsense=1)
+
+
+def test_no_gpu_fails_loudly_not_silently():
+    if device.device_count() > 0:
+        pytest.skip('a GPU is visible')
+    with pytest.raises(device.MaxEntDeviceError):
+        device.DeviceContext(np.eye(3), np.ones(3), np.eye(3))
+    tm = mx.TauMaxEnt()
+    tm.set_verbosity(mx.VerbosityFlags.Quiet)
+    tau = np.linspace(0, 10, 20)
+    tm.set_G_tau_data(tau, -0.5 * np.ones(20))
+    tm.set_error(1e-3)
+    with pytest.raises(device.MaxEntDeviceError):
+        tm.run()          # no CPU fallback
+
+
+# ---- host mirror of the reference interface ------------------------------------
+def test_meshes_default_model_kernel_match_reference_bitwise():
+    g = load('cfg1_normal')
+    w = mx.HyperbolicOmegaMesh(-10, 10, 200)
+    np.testing.assert_array_equal(np.asarray(w), g['omega'])
+    np.testing.assert_array_equal(w.delta, g['delta'])
+    np.testing.assert_array_equal(mx.FlatDefaultModel(w).D, g['D'])
+    K = mx.TauKernel(g['tau'], w, 40.0)
+    Kref, Kdref = R.tau_kernel(g['tau'], g['omega'], 40.0)
+    np.testing.assert_array_equal(K.K, Kref)
+    np.testing.assert_array_equal(K.K_delta, Kdref)
+    np.testing.assert_allclose(np.asarray(mx.LogAlphaMesh(1e-2, 1e4, 20)) * 100, g['alpha'], rtol=1e-15)
+    s = load('kat_srvo3')
+    np.testing.assert_allclose(np.asarray(mx.LorentzianOmegaMesh(-15, 15, 500)), s['omega'], atol=1e-13)
+    assert list(mx.LinearAlphaMesh(1, 3, 3)) == [3.0, 2.0, 1.0]
+    assert list(mx.DataAlphaMesh([1.0, 5.0, 2.0])) == [5.0, 2.0, 1.0]
+
+
+def test_svd_staging_and_truncation():
+    """reference test/python/tau_kernel.py:64-81."""
+    g = load('cfg1_normal')
+    K = mx.TauKernel(g['tau'], mx.DataOmegaMesh(g['omega']), 40.0)
+    assert np.max(np.abs(np.dot(K.U * K.S, K.V.T) - K.K)) < 1e-13
+    n_full = len(K.S)
+    thr = np.median(K.S)
+    K.reduce_singular_space(thr)
+    assert len(K.S) == (n_full + 1) // 2 and K.U.shape[1] == len(K.S) == K.V.shape[1]
+    K.reduce_singular_space(1e-14)           # smaller threshold: recomputes the SVD
+    assert len(K.S) == len(g['S'])
+    np.testing.assert_allclose(K.S, g['S'], rtol=1e-10, atol=1e-16)
+
+
+def test_preblur_matrix_matches_reference():
+    g = load('cfg5_preblur_pm')
+    w = mx.DataOmegaMesh(g['omega'])
+    np.testing.assert_allclose(mx.get_preblur(w, float(g['preblur_b'])), g['B'], rtol=1e-13)
+    K = mx.PreblurKernel(mx.TauKernel(g['tau'], w, 40.0), float(g['preblur_b']))
+    Kref = R.preblur_kernel(R.tau_kernel(g['tau'], g['omega'], 40.0)[0], g['omega'], float(g['preblur_b']))[0]
+    np.testing.assert_allclose(K.K, Kref, rtol=1e-13)
+    np.testing.assert_array_equal(K.K_delta, K.kernel.K_delta)
+
+
+def test_covariance_rotation_of_the_facade():
+    g = load('cov')
+    tm = mx.TauMaxEnt()
+    tm.omega = mx.DataOmegaMesh(g['omega'])
+    tm.set_G_tau_data(g['tau'], g['G_orig'])
+    tm.set_cov(g['cov'])
+    np.testing.assert_allclose(np.abs(tm.G), np.abs(g['G_rot']), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(tm.err, g['err_rot'], rtol=1e-10)
+    assert tm.K.K.shape == g['K_rot'].shape
+    spec = tm.maxent_loop.make_spec()
+    assert spec['U_rot'] is not None and spec['U_rot'].shape[0] == len(g['G_rot'])
+    np.testing.assert_allclose(spec['alpha'], np.asarray(tm.alpha_mesh) * len(g['G_rot']))
+    tm.set_error(1e-3)                      # undoes the rotation
+    assert tm.K._T is None and len(tm.G) == len(g['G_orig'])
+    np.testing.assert_allclose(tm.G, g['G_orig'], rtol=1e-12, atol=1e-15)
+
+
+def test_start_vector_has_the_reference_quirk():
+    """v0 = H_of_v.inv(D * delta): delta applied twice (maxent_loop.py:196-203)."""
+    g = load('cfg1_plusminus')
+    from maxent_amd import hostprep
+    for kind, ent in ((device.ENTROPY_NORMAL, 'normal'), (device.ENTROPY_PLUSMINUS, 'plusminus')):
+        p = R.Problem(np.zeros((len(g['G']), len(g['D']))), g['U'], g['S'], g['V'], g['G'], g['err'],
+                      g['D'], entropy=ent)
+        np.testing.assert_allclose(hostprep.initial_v(g['V'], g['D'], g['delta'], kind),
+                                   R.initial_v(p, g['delta']), rtol=1e-13, atol=1e-15)
+
+
+def test_attribute_shadowing_and_errors():
+    tm = mx.TauMaxEnt(cost_function='bryan')
+    assert isinstance(tm.cost_function, mx.BryanCostFunction)
+    with pytest.raises(Exception):
+        mx.TauMaxEnt(cost_function='nonsense')
+    w = mx.LinearOmegaMesh(-5, 5, 30)
+    tm.omega = w
+    assert tm.K.K.shape[1] == 30 and len(tm.D.D) == 30 and tm.maxent_loop.omega is w
+    tm.alpha_mesh = mx.LogAlphaMesh(0.1, 10, 4)
+    assert len(tm.maxent_loop.alpha_mesh) == 4
+    with pytest.raises(Exception):
+        tm.set_error(np.ones(3))             # wrong length
+    ew = mx.ElementwiseMaxEnt()
+    ew.omega = w
+    assert ew.maxent_diagonal.omega is w and ew.maxent_offdiagonal.omega is w
+    assert ew.maxent_offdiagonal.cost_function.entropy_kind == device.ENTROPY_PLUSMINUS
+    assert ew.maxent_diagonal.cost_function.entropy_kind == device.ENTROPY_NORMAL
+    ew.set_G_tau_data(np.linspace(0, 1, 5), np.zeros((3, 3, 5)))
+    assert ew.shape == (3, 3)
+    ew.set_error(0.1)
+    assert ew.get_error((0, 1)) == 0.1
+    ew.set_error(np.ones((3, 3, 5)) * np.arange(3)[:, None, None])
+    assert np.all(ew.get_error((2, 1)) == 2.0)
+    with pytest.raises(TypeError):
+        mx.DiagonalMaxEnt().run_offdiagonal()
+    with pytest.raises(NotImplementedError):
+        mx.LevenbergMinimizer(marquardt=True)
+
+
+def test_minimizer_options_map_to_kernel_options():
+    m = mx.LevenbergMinimizer(convergence=mx.MaxDerivativeConvergenceMethod(1e-4) |
+                              mx.RelativeFunctionChangeConvergenceMethod(1e-16), maxiter=77)
+    o = m.to_opts()
+    assert (o.maxiter, o.tol_d, o.tol_relq, o.tol_h) == (77, 1e-4, 1e-16, 0.0)
+    o = mx.LevenbergMinimizer().to_opts(waves_per_chain=2)
+    assert o.tol_h == 1e-9 and o.tol_d == 0.0 and o.waves_per_chain == 2
+
+
+def test_analyzers_pick_like_the_reference():
+    """alpha_index / A_out of LineFit, Chi2Curvature, Entropy on the
+    reference's own chi2(alpha), S(alpha), A(alpha)."""
+    for name in ('cfg1_normal', 'cfg1_bryan', 'cfg1_plusminus', 'cfg1_tauerr', 'cfg2_normal'):
+        g = load(name)
+        if g['A_ref'].shape[0] != len(g['alpha']):
+            continue
+        res = mx.MaxEntResult()
+        X = len(g['alpha'])
+        res.add_element_results(dict(alpha=g['alpha'], v=np.zeros((X, 2)), H=g['H_ref'], A=g['A_ref'],
+                                     chi2=g['chi2_ref'], S=g['S_ref'], Q=g['Q_ref'], G=g['G'],
+                                     G_orig=g['G'], data_variable=g['tau'], G_rec=np.zeros((X, len(g['G']))),
+                                     omega=mx.DataOmegaMesh(g['omega']), probability=np.full(X, np.nan)))
+        res.analyze([mx.LineFitAnalyzer(), mx.Chi2CurvatureAnalyzer(), mx.EntropyAnalyzer(),
+                     mx.BryanAnalyzer(), mx.ClassicAnalyzer()])
+        ar = res.analyzer_results
+        assert ar['LineFitAnalyzer']['alpha_index'] == int(g['linefit_alpha_index'])
+        assert ar['Chi2CurvatureAnalyzer']['alpha_index'] == int(g['chi2curv_alpha_index'])
+        np.testing.assert_array_equal(ar['LineFitAnalyzer']['A_out'], g['A_out_linefit'])
+        np.testing.assert_array_equal(ar['Chi2CurvatureAnalyzer']['A_out'], g['A_out_chi2curv'])
+        np.testing.assert_array_equal(ar['EntropyAnalyzer']['A_out'], g['A_out_entropy'])
+        assert 'A_out' not in ar['BryanAnalyzer']       # no probability -> info only
+        res._default_analyzer_name = 'LineFitAnalyzer'
+        np.testing.assert_array_equal(res.A_out, g['A_out_linefit'])
+
+
+def test_linefit_equals_polyfit_formulation():
+    rng = np.random.RandomState(3)
+    x = np.log(np.logspace(3, -1, 40))
+    y = np.log(50 + np.exp(1.3 * x + 2) + 0.01 * rng.rand(40))
+    idx, (p1, p2) = mx.analyzers.fit_piecewise(x, y)
+    # brute force with np.polyfit like the reference (linefit_analyzer.py:28-87)
+    best = None
+    for i in range(2, 38):
+        c1, r1 = np.polyfit(x[:i], y[:i], 1, full=True)[:2]
+        c2, r2 = np.polyfit(x[i:], y[i:], 0, full=True)[:2]
+        tot = (r1[0] if len(r1) else 0.0) + (r2[0] if len(r2) else 0.0)
+        if best is None or tot < best[0]:
+            best = (tot, c1, c2)
+    np.testing.assert_allclose(p1, best[1], rtol=1e-8)
+    np.testing.assert_allclose(p2, best[2], rtol=1e-8)
+    xc = (best[2][0] - best[1][1]) / best[1][0]
+    assert idx == int(np.argmin(np.abs(x - xc)))
+
+
+def test_matrix_result_layout_and_hermiticity():
+    """reference test/python/matrix_maxent_result.py:60-126."""
+    X, W, T, Sn = 4, 6, 5, 3
+    om = mx.LinearOmegaMesh(-1, 1, W)
+
+    def rec(scale, X=X):
+        return dict(alpha=np.logspace(1, -1, X), v=np.ones((X, Sn)) * scale, H=np.ones((X, W)) * scale,
+                    A=np.ones((X, W)) * scale, chi2=np.ones(X) * scale, S=-np.ones(X), Q=np.ones(X),
+                    G=np.ones(T), G_orig=np.ones(T), data_variable=np.arange(T, dtype=float),
+                    G_rec=np.ones((X, T)), omega=om, probability=np.full(X, np.nan))
+    res = mx.MaxEntResult(matrix_structure=(2, 2), use_hermiticity=True)
+    with pytest.raises(AssertionError):
+        res.add_element_results(rec(1.0))                 # matrix_element missing
+    res.add_element_results(rec(1.0), (0, 0))
+    res.add_element_results(rec(2.0, X=3), (0, 1))        # fewer alphas -> NaN padded
+    assert res.A.shape == (2, 2, X, W) and res.v.shape == (2, 2, X, Sn)
+    assert res.chi2.shape == (2, 2, X) and res.G.shape == (2, 2, T) and res.G_rec.shape == (2, 2, X, T)
+    assert np.all(np.isnan(res.chi2[1, 1])) and np.isnan(res.chi2[0, 1, 3]) and res.chi2[0, 1, 2] == 2.0
+    np.testing.assert_array_equal(res.A[1, 0], res.A[0, 1])       # hermitian mirror for A and H only
+    assert np.all(np.isnan(res.chi2[1, 0]))
+    np.testing.assert_array_equal(res._n_alphas, [[4, 3], [0, 0]])
+    res.analyze([mx.EntropyAnalyzer()], (0, 0))
+    res._default_analyzer_name = 'EntropyAnalyzer'
+    res._zero_elements.append((1, 1))
+    A_out = res.A_out
+    assert A_out.shape == (2, 2, W) and np.all(A_out[1, 1] == 0.0) and np.all(np.isnan(A_out[0, 1]))
+    cres = mx.MaxEntResult(matrix_structure=(2, 2), complex_elements=True)
+    cres.add_element_results(rec(1.0), (0, 1), 0)
+    cres.add_element_results(rec(3.0), (0, 1), 1)
+    assert cres.A.shape == (2, 2, 2, X, W)
+    np.testing.assert_array_equal(cres.A[1, 0, 1], -cres.A[0, 1, 1])   # conjugate
