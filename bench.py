@@ -125,6 +125,8 @@ def main():
     ap.add_argument('--n-omega', type=int, default=500)
     ap.add_argument('--n-alpha', type=int, default=100)
     ap.add_argument('--waves-per-chain', type=int, default=0)
+    ap.add_argument('--chains-per-wg', type=int, default=0)
+    ap.add_argument('--alpha-split', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -155,7 +157,9 @@ def main():
     ctx = stage(batch, local_rank)
     n_chain = len(batch['elems'])
     P = n_chain * args.n_alpha
-    opts = device.default_opts(waves_per_chain=args.waves_per_chain)
+    opts = device.default_opts(waves_per_chain=args.waves_per_chain,
+                               chains_per_wg=args.chains_per_wg,
+                               alpha_split=args.alpha_split)
     ctx.upload_chains(np.arange(n_chain, dtype=np.int32), batch['alphas'],
                       batch['v0'], opts)
 
@@ -266,6 +270,7 @@ def main():
                                         args.n_alpha, P, args.n_tau,
                                         args.n_omega, n_s),
                             waves_per_chain=info['waves_per_chain'],
+                            workgroups=info['n_workgroups'],
                             lds_bytes=info['lds_bytes'],
                             converged=n_conv, problems=P,
                             gather='torch.distributed nccl gather to rank 0'

@@ -73,7 +73,13 @@ typedef struct mxe_opts {
     double  mu_max;       /* give up on the alpha when mu/alpha exceeds this (1e20)       */
     double  decouple_tol; /* theta: singular directions with c_k^2 max(w) <= theta*alpha
                              take the diagonal Newton step (1e-6; 0 = full n_s block)      */
-    int32_t waves_per_chain; /* 0 = choose from the chain count; else 1,2,4,8,16          */
+    int32_t waves_per_chain; /* one-chain-per-workgroup layout: wavefronts per chain;
+                                0 = choose from the chain count; else 1,2,4,8             */
+    int32_t chains_per_wg;   /* 0 = auto; 1 = one chain per workgroup; 4 = four chains of
+                                one data set per workgroup in lock-step (shared V loads)   */
+    int32_t alpha_split;     /* cut every alpha scan into this many cold-started pieces
+                                (more chains to fill the GPU; results are path independent);
+                                0 = auto (only when fewer than 1024 chains), 1 = never      */
     int32_t reserved;
 } mxe_opts;
 

@@ -7,6 +7,7 @@
 // launches the chain kernel on its own stream and times it with HIP events.
 #include "../../include/maxent_hip.h"
 #include "mxe_kernel.hip.h"
+#include "mxe_kernel_mc.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -53,15 +54,18 @@ struct mxe_ctx {
     // elements (host)
     int n_elem = 0;
     std::vector<int> elem_ds, elem_kind;
+    std::vector<double> h_sumD;
     // chains
     int n_chain = 0, n_alpha = 0;
-    std::vector<int> chain_elem;
+    std::vector<int> chain_elem;      // per parent chain
+    std::vector<int> sub_elem, sub_prob0, sub_len, sub_v0, wg_chains;   // per launched (sub-)chain
+    int n_sub = 0, n_wg = 0, mc_na = 0;
     mxe_opts opts;
     bool chains_ready = false, launched = false;
     int last_nw = 0, last_lds = 0;
     // device
     DevBuf<double> dV, dVt, dc, dcinv, dghat, dcperp, dD, dsumD, dalpha, dv0;
-    DevBuf<int> delem_ds, delem_kind, dchain_elem;
+    DevBuf<int> delem_ds, delem_kind, dchain_elem, dsub_prob0, dsub_len, dsub_v0, dwg_chains;
     DevBuf<double> dout_v, dout_H, dout_chi2, dout_S, dout_Q, dB, dA;
     DevBuf<int> dout_niter, dout_conv, dout_nevals, dout_nact;
     DevBuf<long long> dprof;
@@ -260,7 +264,7 @@ void mxe_opts_default(mxe_opts* o)
     o->tol_h = 1e-9; o->tol_d = 0.0; o->tol_relq = 0.0;
     o->step_max = 0.2; o->mu_first = 1e-3; o->mu_grow = 4.0; o->mu_max = 1e20;
     o->decouple_tol = 1e-6;
-    o->waves_per_chain = 0; o->reserved = 0;
+    o->waves_per_chain = 0; o->chains_per_wg = 0; o->alpha_split = 0; o->reserved = 0;
 }
 
 int mxe_ctx_create(int device, int n_tau, int n_omega, int n_s,
@@ -297,7 +301,7 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
     ctx->dV.release(); ctx->dVt.release(); ctx->dc.release(); ctx->dcinv.release();
     ctx->dghat.release(); ctx->dcperp.release(); ctx->dD.release(); ctx->dsumD.release();
     ctx->dalpha.release(); ctx->dv0.release(); ctx->delem_ds.release(); ctx->delem_kind.release();
-    ctx->dchain_elem.release(); ctx->dout_v.release(); ctx->dout_H.release();
+    ctx->dchain_elem.release(); ctx->dsub_prob0.release(); ctx->dsub_len.release(); ctx->dsub_v0.release(); ctx->dwg_chains.release(); ctx->dout_v.release(); ctx->dout_H.release();
     ctx->dout_chi2.release(); ctx->dout_S.release(); ctx->dout_Q.release();
     ctx->dout_niter.release(); ctx->dout_conv.release(); ctx->dout_nevals.release(); ctx->dout_nact.release();
     ctx->dB.release(); ctx->dA.release();
@@ -368,6 +372,7 @@ int mxe_elements_set(mxe_ctx* ctx, int n_elem, const int32_t* dataset_of_elem,
         ctx->elem_ds[e] = d; ctx->elem_kind[e] = entropy[e];
     }
     ctx->n_elem = n_elem;
+    ctx->h_sumD = hsumD;
     HIPCHK(ctx, ctx->dghat.ensure(hghat.size()));
     HIPCHK(ctx, ctx->dcperp.ensure(n_elem));
     HIPCHK(ctx, ctx->dD.ensure(hD.size()));
@@ -400,6 +405,8 @@ int mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
     if (o.maxiter < 1 || o.step_max <= 0 || o.mu_first <= 0 || o.mu_grow <= 1.0 || o.decouple_tol < 0) return MXE_ERR_ARG;
     if (o.waves_per_chain != 0 && o.waves_per_chain != 1 && o.waves_per_chain != 2 &&
         o.waves_per_chain != 4 && o.waves_per_chain != 8) return MXE_ERR_ARG;
+    if (o.chains_per_wg != 0 && o.chains_per_wg != 1 && o.chains_per_wg != 4) return MXE_ERR_ARG;
+    if (o.alpha_split < 0) return MXE_ERR_ARG;
     ctx->chain_elem.assign(elem_of_chain, elem_of_chain + n_chain);
     std::vector<double> hv0((size_t)n_chain * NP, 0.0);
     for (int c = 0; c < n_chain; ++c) {
@@ -419,7 +426,73 @@ int mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
     for (size_t i = 0; i < (size_t)n_chain * n_alpha; ++i)
         if (!(alpha_scaled[i] > 0.0) || !std::isfinite(alpha_scaled[i])) return MXE_ERR_ARG;
     const size_t P = (size_t)n_chain * n_alpha;
-    HIPCHK(ctx, ctx->dchain_elem.ensure(n_chain));
+    // ---- (sub-)chains: an alpha scan may be cut into pieces that are cold-started
+    //      from the same v0 (the minimiser of each alpha does not depend on the path)
+    int split = o.alpha_split;
+    if (split <= 0) {
+        split = 1;
+        const int want = (1024 + n_chain - 1) / n_chain;
+        while (split * 2 <= want && split * 2 <= 8 && n_alpha / (split * 2) >= 12) split *= 2;
+    }
+    if (split > n_alpha) split = n_alpha;
+    ctx->sub_elem.clear(); ctx->sub_prob0.clear(); ctx->sub_len.clear(); ctx->sub_v0.clear();
+    for (int c = 0; c < n_chain; ++c) {
+        for (int sidx = 0; sidx < split; ++sidx) {
+            const int a0 = (int)((long long)n_alpha * sidx / split), a1 = (int)((long long)n_alpha * (sidx + 1) / split);
+            if (a1 <= a0) continue;
+            ctx->sub_elem.push_back(elem_of_chain[c]);
+            ctx->sub_prob0.push_back(c * n_alpha + a0);
+            ctx->sub_len.push_back(a1 - a0);
+            ctx->sub_v0.push_back(c);
+        }
+    }
+    ctx->n_sub = (int)ctx->sub_elem.size();
+    // ---- layout: four chains of one data set per workgroup when there are enough
+    int layout = o.chains_per_wg;
+    ctx->mc_na = 0;
+    if (layout == 0) layout = (ctx->n_sub >= 768) ? 4 : 1;
+    if (layout == 4 && (NP != 64 || o.tol_d > 0.0 || o.decouple_tol <= 0.0)) layout = 1;
+    if (layout == 4) {
+        // capacity of the active block: the kernel clamps n_act to NA, and the
+        // first neglected direction couples with relative strength
+        // c_NA^2 wmax / alpha (wmax <= sum w ~ max(1, sum D)); accept NA when that
+        // is below 1e-2 for every chain (inexact Newton, contraction ~1e-2).
+        double worst32 = 0.0, worst48 = 0.0;
+        for (int sc = 0; sc < ctx->n_sub; ++sc) {
+            const int e = ctx->sub_elem[sc];
+            const DataSet& DS = ctx->ds[ctx->elem_ds[e]];
+            double amin = 1e300;
+            for (int i = 0; i < ctx->sub_len[sc]; ++i) amin = std::min(amin, alpha_scaled[ctx->sub_prob0[sc] + i]);
+            const double wbound = std::max(1.0, ctx->h_sumD[e]);
+            if (ns > 32) worst32 = std::max(worst32, DS.c[32] * DS.c[32] * wbound / amin);
+            if (ns > 48) worst48 = std::max(worst48, DS.c[48] * DS.c[48] * wbound / amin);
+        }
+        if (worst32 <= 1e-2) ctx->mc_na = 32; else if (worst48 <= 1e-2) ctx->mc_na = 48; else layout = 1;
+        if (layout == 4) {
+            const size_t doubles = (size_t)4 * ctx->mc_na * (ctx->mc_na + 1) + 6 * 4 * 64 + 2 * 64 + 64 * 4 + 4 * 4 * 64 + 4 * 32 +
+                                   (size_t)3 * ctx->nwp * 4;
+            if (doubles * sizeof(double) > 160 * 1024 - 256) { layout = 1; ctx->mc_na = 0; }
+        }
+    }
+    ctx->wg_chains.clear();
+    if (layout == 4) {
+        // group by data set, four per workgroup, -1 pads
+        std::vector<std::vector<int>> by_ds(ctx->ds.size());
+        for (int sc = 0; sc < ctx->n_sub; ++sc) by_ds[ctx->elem_ds[ctx->sub_elem[sc]]].push_back(sc);
+        for (auto& g : by_ds) {
+            // longest pieces first within a group of four does not matter; keep order
+            for (size_t i0 = 0; i0 < g.size(); i0 += 4)
+                for (int q = 0; q < 4; ++q) ctx->wg_chains.push_back(i0 + q < g.size() ? g[i0 + q] : -1);
+        }
+        ctx->n_wg = (int)ctx->wg_chains.size() / 4;
+    } else {
+        ctx->n_wg = ctx->n_sub;
+    }
+    HIPCHK(ctx, ctx->dchain_elem.ensure(ctx->n_sub));
+    HIPCHK(ctx, ctx->dsub_prob0.ensure(ctx->n_sub));
+    HIPCHK(ctx, ctx->dsub_len.ensure(ctx->n_sub));
+    HIPCHK(ctx, ctx->dsub_v0.ensure(ctx->n_sub));
+    HIPCHK(ctx, ctx->dwg_chains.ensure(std::max<size_t>(ctx->wg_chains.size(), 1)));
     HIPCHK(ctx, ctx->dalpha.ensure(P));
     HIPCHK(ctx, ctx->dv0.ensure(hv0.size()));
     HIPCHK(ctx, ctx->dout_v.ensure(P * NP));
@@ -431,7 +504,12 @@ int mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
     HIPCHK(ctx, ctx->dout_conv.ensure(P));
     HIPCHK(ctx, ctx->dout_nevals.ensure(P));
     HIPCHK(ctx, ctx->dout_nact.ensure(P));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->dchain_elem.p, ctx->chain_elem.data(), (size_t)n_chain * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dchain_elem.p, ctx->sub_elem.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_prob0.p, ctx->sub_prob0.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_len.p, ctx->sub_len.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_v0.p, ctx->sub_v0.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (!ctx->wg_chains.empty())
+        HIPCHK(ctx, hipMemcpyAsync(ctx->dwg_chains.p, ctx->wg_chains.data(), ctx->wg_chains.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dalpha.p, alpha_scaled, P * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dv0.p, hv0.data(), hv0.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -453,6 +531,8 @@ int mxe_chains_launch(mxe_ctx* ctx)
     kp.elem_ds = ctx->delem_ds.p; kp.elem_kind = ctx->delem_kind.p;
     kp.ghat = ctx->dghat.p; kp.cperp = ctx->dcperp.p; kp.D = ctx->dD.p; kp.sumD = ctx->dsumD.p;
     kp.chain_elem = ctx->dchain_elem.p; kp.alpha = ctx->dalpha.p; kp.v0 = ctx->dv0.p;
+    kp.chain_prob0 = ctx->dsub_prob0.p; kp.chain_len = ctx->dsub_len.p; kp.chain_v0 = ctx->dsub_v0.p;
+    kp.n_chain = ctx->n_sub;
     kp.out_v = ctx->dout_v.p; kp.out_H = ctx->dout_H.p; kp.out_chi2 = ctx->dout_chi2.p;
     kp.out_S = ctx->dout_S.p; kp.out_Q = ctx->dout_Q.p; kp.out_niter = ctx->dout_niter.p;
     kp.out_conv = ctx->dout_conv.p; kp.out_nevals = ctx->dout_nevals.p;
@@ -462,30 +542,49 @@ int mxe_chains_launch(mxe_ctx* ctx)
     kp.theta = o.decouple_tol; kp.out_nact = ctx->dout_nact.p;
     kp.prof = nullptr;
 #ifdef MXE_PROFILE
-    HIPCHK(ctx, ctx->dprof.ensure((size_t)ctx->n_chain * 8));
-    HIPCHK(ctx, hipMemsetAsync(ctx->dprof.p, 0, (size_t)ctx->n_chain * 64, ctx->stream));
+    HIPCHK(ctx, ctx->dprof.ensure((size_t)ctx->n_sub * 8));
+    HIPCHK(ctx, hipMemsetAsync(ctx->dprof.p, 0, (size_t)ctx->n_sub * 64, ctx->stream));
     kp.prof = ctx->dprof.p;
 #endif
-
-    int NW = o.waves_per_chain;
-    if (NW == 0) {
-        // fill the 256 CUs x 4 SIMDs: few chains -> more waves per chain
-        const int nc = ctx->n_chain;
-        NW = (nc >= 2048) ? 1 : (nc >= 1024) ? 2 : (nc >= 256) ? 4 : 8;
-    }
-    size_t lds = lds_doubles(ctx->NP, ctx->nwp, NW) * sizeof(double);
-    while (lds > 160 * 1024 && NW > 1) { NW /= 2; lds = lds_doubles(ctx->NP, ctx->nwp, NW) * sizeof(double); }
-    if (lds > 160 * 1024) return MXE_ERR_LIMIT;
-    ctx->last_nw = NW; ctx->last_lds = (int)lds;
-    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     hipError_t e;
-    switch (NW) {
-        case 1: e = launch_nab<1>(ctx->NP, kp, lds, ctx->stream); break;
-        case 2: e = launch_nab<2>(ctx->NP, kp, lds, ctx->stream); break;
-        case 4: e = launch_nab<4>(ctx->NP, kp, lds, ctx->stream); break;
-        default: e = launch_nab<8>(ctx->NP, kp, lds, ctx->stream); break;
+    if (ctx->mc_na > 0) {
+        // four chains per workgroup, lock-step (mxe_kernel_mc.hip.h)
+        const int NA = ctx->mc_na;
+        const size_t doubles = (size_t)4 * NA * (NA + 1) + 6 * 4 * 64 + 2 * 64 + 64 * 4 + 4 * 4 * 64 + 4 * 32 +
+                               (size_t)3 * ctx->nwp * 4;
+        const size_t lds = doubles * sizeof(double);
+        if (lds > 160 * 1024 - 256) return MXE_ERR_LIMIT;
+        mxe::MCExtra ex; ex.wg_chains = ctx->dwg_chains.p; ex.n_wg = ctx->n_wg;
+        ctx->last_nw = 4; ctx->last_lds = (int)lds;
+        HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        if (NA == 32) {
+            e = hipFuncSetAttribute((const void*)mxe::chain_kernel_mc<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<32>), dim3(ctx->n_wg), dim3(256), lds, ctx->stream, kp, ex); e = hipGetLastError(); }
+        } else {
+            e = hipFuncSetAttribute((const void*)mxe::chain_kernel_mc<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<48>), dim3(ctx->n_wg), dim3(256), lds, ctx->stream, kp, ex); e = hipGetLastError(); }
+        }
+        HIPCHK(ctx, e);
+    } else {
+        int NW = o.waves_per_chain;
+        if (NW == 0) {
+            // fill the 256 CUs x 4 SIMDs: few chains -> more waves per chain
+            const int nc = ctx->n_sub;
+            NW = (nc >= 2048) ? 1 : (nc >= 1024) ? 2 : (nc >= 256) ? 4 : 8;
+        }
+        size_t lds = lds_doubles(ctx->NP, ctx->nwp, NW) * sizeof(double);
+        while (lds > 160 * 1024 && NW > 1) { NW /= 2; lds = lds_doubles(ctx->NP, ctx->nwp, NW) * sizeof(double); }
+        if (lds > 160 * 1024) return MXE_ERR_LIMIT;
+        ctx->last_nw = NW; ctx->last_lds = (int)lds;
+        HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        switch (NW) {
+            case 1: e = launch_nab<1>(ctx->NP, kp, lds, ctx->stream); break;
+            case 2: e = launch_nab<2>(ctx->NP, kp, lds, ctx->stream); break;
+            case 4: e = launch_nab<4>(ctx->NP, kp, lds, ctx->stream); break;
+            default: e = launch_nab<8>(ctx->NP, kp, lds, ctx->stream); break;
+        }
+        HIPCHK(ctx, e);
     }
-    HIPCHK(ctx, e);
     HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->launched = true;
     return MXE_OK;
@@ -581,7 +680,7 @@ int mxe_last_launch_info(mxe_ctx* ctx, int* waves_per_chain, int* n_workgroups, 
 {
     if (!ctx) return MXE_ERR_ARG;
     if (waves_per_chain) *waves_per_chain = ctx->last_nw;
-    if (n_workgroups) *n_workgroups = ctx->n_chain;
+    if (n_workgroups) *n_workgroups = ctx->n_wg;
     if (lds_bytes) *lds_bytes = ctx->last_lds;
     return MXE_OK;
 }
@@ -594,7 +693,7 @@ extern "C" int mxe_prof_fetch(mxe_ctx* ctx, long long* out /*[n_chain][8]*/)
 {
     if (!ctx || !out) return MXE_ERR_ARG;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipMemcpy(out, ctx->dprof.p, (size_t)ctx->n_chain * 64, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out, ctx->dprof.p, (size_t)ctx->n_sub * 64, hipMemcpyDeviceToHost));
     return MXE_OK;
 }
 #endif

@@ -55,9 +55,12 @@ struct KParams {
     const double* sumD;     // [n_elem]  sum(D) (x2 for plusminus)
     // chains
     const int* chain_elem;  // [n_chain]
-    const double* alpha;    // [n_chain][n_alpha]
-    const double* v0;       // [n_chain][NP]   whitened basis
-    // outputs, problem p = chain*n_alpha + i
+    const int* chain_prob0; // [n_chain] first problem (index into alpha[] and the outputs)
+    const int* chain_len;   // [n_chain] number of alphas of the (sub-)chain
+    const int* chain_v0;    // [n_chain] row of v0[] to start from
+    const double* alpha;    // [P]
+    const double* v0;       // [n_parent][NP]   whitened basis
+    // outputs, problem p = chain_prob0[chain] + i
     double* out_v;      // [P][NP]  whitened basis
     double* out_H;      // [P][n_omega]
     double* out_chi2;   // [P]
@@ -200,7 +203,7 @@ void chain_kernel(const KParams p)
         cc[k] = p.c[ds * NP + k];
         ci[k] = p.cinv[ds * NP + k];
         gh[k] = p.ghat[(size_t)elem * NP + k];
-        v[k]  = p.v0[(size_t)chain * NP + k];
+        v[k]  = p.v0[(size_t)p.chain_v0[chain] * NP + k];
         dl[k] = 0.0;
     }
     block_sync<NW>();
@@ -745,8 +748,9 @@ void chain_kernel(const KParams p)
     accept_trial();                 // dl == 0: v unchanged
     int nevals_pending = 1;
 
-    for (int ia = 0; ia < p.n_alpha; ++ia) {
-        const double alpha = p.alpha[(size_t)chain * p.n_alpha + ia];
+    const int prob0 = p.chain_prob0[chain], clen = p.chain_len[chain];
+    for (int ia = 0; ia < clen; ++ia) {
+        const double alpha = p.alpha[(size_t)prob0 + ia];
         int n_iter = 0, conv = 0, nevals = nevals_pending, n_act_last = 0;
         nevals_pending = 0;
         double Qprev = __builtin_nan("");
@@ -830,6 +834,10 @@ void chain_kernel(const KParams p)
                         ++nevals;
                         const double Qt = 0.5 * chi2t - alpha * St;
                         if (!(fabs(Qt) <= 1.7e308)) good = false;   // NaN / inf
+                        // an undamped Newton step may overshoot (it recovers
+                        // quadratically); a step that needed damping must not
+                        // make Q worse, or a cold start can land far out
+                        else if (mu > 0.0 && Qt > Q) good = false;
                     }
                 }
                 if (good) { accepted = true; break; }
@@ -848,7 +856,7 @@ void chain_kernel(const KParams p)
         }
 
         // ---- results of this alpha (MaxEntResult fields, maxent_result.py:835-967)
-        const size_t prob = (size_t)chain * p.n_alpha + ia;
+        const size_t prob = (size_t)prob0 + ia;
         if (p.out_H) {
             double* Ho = p.out_H + prob * nw;
             for (int i = tid; i < nw; i += T) {

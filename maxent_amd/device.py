@@ -37,6 +37,8 @@ class MxeOpts(ctypes.Structure):
                 ('mu_max', ctypes.c_double),
                 ('decouple_tol', ctypes.c_double),
                 ('waves_per_chain', ctypes.c_int32),
+                ('chains_per_wg', ctypes.c_int32),
+                ('alpha_split', ctypes.c_int32),
                 ('reserved', ctypes.c_int32)]
 
 

@@ -174,8 +174,11 @@ def solve_alpha(basis, el, alpha, v, ev, opts, stats=None):
             if good:
                 evt = evaluate(basis, el, alpha, v - delta)
                 n_evals += 1
-                if not np.isfinite(evt['Q']):
+                Qt = 0.5 * evt['chi2'] - alpha * evt['S']
+                if not np.isfinite(Qt):
                     good = False
+                elif mu > 0.0 and Qt > Q:
+                    good = False      # a damped step must not make Q worse
             if good:
                 accepted = True
                 break

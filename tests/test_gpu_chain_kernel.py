@@ -23,13 +23,16 @@ def _setup(n_tau, n_omega, entropy='normal', err=None):
     return tau, omega, K, G, err, D, p
 
 
-@pytest.mark.parametrize('n_tau,n_omega,n_alpha,entropy,nw', [
-    (100, 200, 20, 'normal', 0),
-    (200, 500, 100, 'normal', 4),
-    (200, 500, 100, 'normal', 1),
-    (200, 500, 100, 'plusminus', 2),
+@pytest.mark.parametrize('n_tau,n_omega,n_alpha,entropy,nw,layout,split', [
+    (100, 200, 20, 'normal', 0, 0, 0),
+    (200, 500, 100, 'normal', 4, 1, 1),
+    (200, 500, 100, 'normal', 1, 1, 1),
+    (200, 500, 100, 'plusminus', 2, 1, 1),
+    (200, 500, 100, 'normal', 0, 4, 1),       # four-chains-per-workgroup kernel, 1 chain (3 empty slots)
+    (200, 500, 100, 'plusminus', 0, 4, 5),    # ... with the alpha scan cut into 5 cold-started pieces
+    (200, 500, 100, 'normal', 8, 1, 8),
 ])
-def test_chain_matches_kernel_model_and_truth(n_tau, n_omega, n_alpha, entropy, nw):
+def test_chain_matches_kernel_model_and_truth(n_tau, n_omega, n_alpha, entropy, nw, layout, split):
     tau, omega, K, G, err, D, p = _setup(n_tau, n_omega, entropy)
     alphas = np.array(synthetic.alpha_mesh(n_alpha)) * n_tau
     v0 = R.initial_v(p, omega.delta)
@@ -41,7 +44,8 @@ def test_chain_matches_kernel_model_and_truth(n_tau, n_omega, n_alpha, entropy, 
     ctx.set_elements([ds], [G], D[np.newaxis, :],
                      [device.ENTROPY_PLUSMINUS if entropy == 'plusminus' else device.ENTROPY_NORMAL])
     out = ctx.solve_chains([0], alphas, v0[np.newaxis, :],
-                           device.default_opts(waves_per_chain=nw))
+                           device.default_opts(waves_per_chain=nw, chains_per_wg=layout,
+                                               alpha_split=split))
     assert out['converged'].all()
     H = out['H'][0]
     assert np.all(np.isfinite(H))
@@ -59,4 +63,33 @@ def test_chain_matches_kernel_model_and_truth(n_tau, n_omega, n_alpha, entropy, 
         assert abs(R.S_f(p, Hr) - out['S'][0, ia]) < 1e-8 * max(1.0, abs(out['S'][0, ia]))
     print('n_iter total', out['n_iter'].sum(), 'evals', out['n_evals'].sum(),
           'kernel ms', ctx.last_kernel_ms(), ctx.last_launch_info())
+    ctx.close()
+
+
+def test_four_chain_kernel_equals_single_chain_kernel():
+    """a 3x3 matrix problem (mixed normal / plusminus chains in one workgroup)
+    through both layouts; per-alpha results agree to the convergence level."""
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(3, 120, 300)
+    K.reduce_singular_space(1e-14)
+    D = synthetic.flat_D(omega)
+    err = synthetic.SIGMA * np.ones(120)
+    alphas = np.array(synthetic.alpha_mesh(40)) * 120
+    elems = [(i, j) for i in range(3) for j in range(3)]
+    kinds = [device.ENTROPY_NORMAL if i == j else device.ENTROPY_PLUSMINUS for i, j in elems]
+    from maxent_amd import hostprep
+    v0 = np.stack([hostprep.initial_v(K.V, D, omega.delta, k) for k in kinds])
+    ctx = device.DeviceContext(K.U, K.S, K.V)
+    ds = ctx.add_dataset(err)
+    ctx.set_elements([ds] * 9, [Gmat[i, j] for i, j in elems], np.tile(D, (9, 1)), kinds)
+    a = ctx.solve_chains(np.arange(9), alphas, v0, device.default_opts(chains_per_wg=1, alpha_split=1))
+    b = ctx.solve_chains(np.arange(9), alphas, v0, device.default_opts(chains_per_wg=4, alpha_split=1))
+    c = ctx.solve_chains(np.arange(9), alphas, v0, device.default_opts(chains_per_wg=4, alpha_split=4))
+    for o in (a, b, c):
+        assert o['converged'].all()
+    assert ctx.last_launch_info()['n_workgroups'] == 9      # 36 pieces, four per workgroup
+    for o in (b, c):
+        assert rel_l2(o['H'], a['H']).max() < 1e-8
+        np.testing.assert_allclose(o['chi2'], a['chi2'], rtol=1e-9)
+        np.testing.assert_allclose(o['Q'], a['Q'], rtol=1e-10)
+    np.testing.assert_array_equal(a['n_iter'], b['n_iter'])
     ctx.close()
