@@ -59,7 +59,8 @@ struct mxe_ctx {
     int n_chain = 0, n_alpha = 0;
     std::vector<int> chain_elem;      // per parent chain
     std::vector<int> sub_elem, sub_prob0, sub_len, sub_v0, wg_chains;   // per launched (sub-)chain
-    int n_sub = 0, n_wg = 0, mc_na = 0;
+    int n_sub = 0, n_wg = 0, mc_na = 0, n_queue = 0;
+    std::vector<int> queue;
     mxe_opts opts;
     bool chains_ready = false, launched = false;
     int last_nw = 0, last_lds = 0;
@@ -69,6 +70,7 @@ struct mxe_ctx {
     DevBuf<double> dout_v, dout_H, dout_chi2, dout_S, dout_Q, dB, dA;
     DevBuf<int> dout_niter, dout_conv, dout_nevals, dout_nact;
     DevBuf<long long> dprof;
+    DevBuf<int> dqueue, dcounter;
     std::string hip_err;
 };
 
@@ -301,7 +303,7 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
     ctx->dV.release(); ctx->dVt.release(); ctx->dc.release(); ctx->dcinv.release();
     ctx->dghat.release(); ctx->dcperp.release(); ctx->dD.release(); ctx->dsumD.release();
     ctx->dalpha.release(); ctx->dv0.release(); ctx->delem_ds.release(); ctx->delem_kind.release();
-    ctx->dchain_elem.release(); ctx->dsub_prob0.release(); ctx->dsub_len.release(); ctx->dsub_v0.release(); ctx->dwg_chains.release(); ctx->dout_v.release(); ctx->dout_H.release();
+    ctx->dchain_elem.release(); ctx->dsub_prob0.release(); ctx->dsub_len.release(); ctx->dsub_v0.release(); ctx->dwg_chains.release(); ctx->dqueue.release(); ctx->dcounter.release(); ctx->dout_v.release(); ctx->dout_H.release();
     ctx->dout_chi2.release(); ctx->dout_S.release(); ctx->dout_Q.release();
     ctx->dout_niter.release(); ctx->dout_conv.release(); ctx->dout_nevals.release(); ctx->dout_nact.release();
     ctx->dB.release(); ctx->dA.release();
@@ -474,20 +476,46 @@ int mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
             if (doubles * sizeof(double) > 160 * 1024 - 256) { layout = 1; ctx->mc_na = 0; }
         }
     }
-    ctx->wg_chains.clear();
+    ctx->wg_chains.clear(); ctx->queue.clear(); ctx->n_queue = 0;
     if (layout == 4) {
-        // group by data set, four per workgroup, -1 pads
-        std::vector<std::vector<int>> by_ds(ctx->ds.size());
-        for (int sc = 0; sc < ctx->n_sub; ++sc) by_ds[ctx->elem_ds[ctx->sub_elem[sc]]].push_back(sc);
-        for (auto& g : by_ds) {
-            // longest pieces first within a group of four does not matter; keep order
-            for (size_t i0 = 0; i0 < g.size(); i0 += 4)
-                for (int q = 0; q < 4; ++q) ctx->wg_chains.push_back(i0 + q < g.size() ? g[i0 + q] : -1);
+        bool one_ds = true;
+        for (int sc = 1; sc < ctx->n_sub; ++sc)
+            if (ctx->elem_ds[ctx->sub_elem[sc]] != ctx->elem_ds[ctx->sub_elem[0]]) { one_ds = false; break; }
+        if (one_ds) {
+            // dynamic layout: a persistent grid takes pieces from a queue, most
+            // expensive first (normal entropy and small alpha cost more iterations)
+            std::vector<double> cost(ctx->n_sub);
+            for (int sc = 0; sc < ctx->n_sub; ++sc) {
+                const int e = ctx->sub_elem[sc];
+                double amin = 1e300;
+                for (int i = 0; i < ctx->sub_len[sc]; ++i) amin = std::min(amin, alpha_scaled[ctx->sub_prob0[sc] + i]);
+                cost[sc] = ctx->sub_len[sc] * (ctx->elem_kind[e] == MXE_ENTROPY_NORMAL ? 4.0 : 3.0) +
+                           (ctx->elem_kind[e] == MXE_ENTROPY_NORMAL ? 16.0 : 6.0) - 1e-3 * std::log10(amin);
+            }
+            ctx->queue.resize(ctx->n_sub);
+            for (int sc = 0; sc < ctx->n_sub; ++sc) ctx->queue[sc] = sc;
+            std::stable_sort(ctx->queue.begin(), ctx->queue.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+            ctx->n_queue = ctx->n_sub;
+            hipDeviceProp_t prop;
+            HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+            const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            ctx->n_wg = std::min((ctx->n_sub + 3) / 4, n_cu);
+        } else {
+            // static layout: group by data set, four per workgroup, -1 pads
+            std::vector<std::vector<int>> by_ds(ctx->ds.size());
+            for (int sc = 0; sc < ctx->n_sub; ++sc) by_ds[ctx->elem_ds[ctx->sub_elem[sc]]].push_back(sc);
+            for (auto& g : by_ds)
+                for (size_t i0 = 0; i0 < g.size(); i0 += 4)
+                    for (int q = 0; q < 4; ++q) ctx->wg_chains.push_back(i0 + q < g.size() ? g[i0 + q] : -1);
+            ctx->n_wg = (int)ctx->wg_chains.size() / 4;
         }
-        ctx->n_wg = (int)ctx->wg_chains.size() / 4;
     } else {
         ctx->n_wg = ctx->n_sub;
     }
+    HIPCHK(ctx, ctx->dqueue.ensure(std::max<size_t>(ctx->queue.size(), 1)));
+    HIPCHK(ctx, ctx->dcounter.ensure(1));
+    if (!ctx->queue.empty())
+        HIPCHK(ctx, hipMemcpyAsync(ctx->dqueue.p, ctx->queue.data(), ctx->queue.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, ctx->dchain_elem.ensure(ctx->n_sub));
     HIPCHK(ctx, ctx->dsub_prob0.ensure(ctx->n_sub));
     HIPCHK(ctx, ctx->dsub_len.ensure(ctx->n_sub));
@@ -555,6 +583,8 @@ int mxe_chains_launch(mxe_ctx* ctx)
         const size_t lds = doubles * sizeof(double);
         if (lds > 160 * 1024 - 256) return MXE_ERR_LIMIT;
         mxe::MCExtra ex; ex.wg_chains = ctx->dwg_chains.p; ex.n_wg = ctx->n_wg;
+        ex.queue = ctx->dqueue.p; ex.n_queue = ctx->n_queue; ex.counter = ctx->dcounter.p;
+        HIPCHK(ctx, hipMemsetAsync(ctx->dcounter.p, 0, sizeof(int), ctx->stream));
         ctx->last_nw = 4; ctx->last_lds = (int)lds;
         HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         if (NA == 32) {

@@ -27,8 +27,11 @@ namespace mxe {
 constexpr int MCC = 4;            // chains per workgroup == wavefronts per workgroup
 
 struct MCExtra {
-    const int* wg_chains;         // [n_wg][MCC] chain ids, -1 = empty slot
+    const int* wg_chains;         // static layout: [n_wg][MCC] chain ids, -1 = empty slot
     int n_wg;
+    const int* queue;             // dynamic layout: chain ids in the order they are handed out
+    int n_queue;                  //   (0 = static layout)
+    int* counter;                 //   next queue position (zeroed before every launch)
 };
 
 template <int NA>                 // capacity of the active block: 32 or 48
@@ -64,25 +67,38 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     __shared__ double s_mu[MCC];                 // damping the home wave ended up with
     int* s_nact = s_flag; int* s_ok = s_flag + MCC; int* s_scr = s_flag + 2 * MCC; int* s_act = s_flag + 3 * MCC;
 
-    // ---- chains of this workgroup ----
+    // ---- chains of this workgroup (slots are refilled from the queue in the dynamic layout) ----
+    __shared__ int s_claim[MCC];
     int chain[MCC], elem[MCC], kind[MCC];
     double cperp[MCC], step_lim[MCC];
     const double* Dg[MCC];
-    int ds = 0;
+    const bool dynamic = x.n_queue > 0;
+    if (dynamic) {
+        if (lane == 0) {
+            const int idx = atomicAdd(x.counter, 1);
+            s_claim[wave] = (idx < x.n_queue) ? x.queue[idx] : -1;
+        }
+        __syncthreads();
+    }
+    int first_valid = -1;
 #pragma unroll
     for (int q = 0; q < MCC; ++q) {
-        chain[q] = x.wg_chains[blockIdx.x * MCC + q];
-        const int e = (chain[q] >= 0) ? p.chain_elem[chain[q]] : p.chain_elem[x.wg_chains[blockIdx.x * MCC]];
+        chain[q] = dynamic ? s_claim[q] : x.wg_chains[blockIdx.x * MCC + q];
+        if (chain[q] >= 0 && first_valid < 0) first_valid = chain[q];
+    }
+    if (first_valid < 0) return;                 // nothing left for this workgroup
+#pragma unroll
+    for (int q = 0; q < MCC; ++q) {
+        const int e = p.chain_elem[(chain[q] >= 0) ? chain[q] : first_valid];
         elem[q] = e;
         kind[q] = p.elem_kind[e];
         cperp[q] = p.cperp[e];
         step_lim[q] = p.step_max * p.sumD[e];
         Dg[q] = p.D + (size_t)e * nwp;
     }
-    ds = p.elem_ds[elem[0]];
+    const int ds = p.elem_ds[elem[0]];
     const double* __restrict__ V  = p.V  + (size_t)ds * nwp * NP;
     const double* __restrict__ Vt = p.Vt + (size_t)ds * NP * nwp;
-
     // thread (wave q, lane k) owns component k of chain q in the small vectors
     {
         const int q = wave, k = lane;
@@ -126,7 +142,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     // updates ui, wi, Hi in place; rho; returns per-chain sums.
     // ------------------------------------------------------------------
     auto eval_pass = [&](double (&oS)[MCC], double (&odH)[MCC], double (&oHn)[MCC],
-                         double (&or2)[MCC], double (&owm)[MCC]) {
+                         double (&owm)[MCC]) {
         double pS[MCC], pdH[MCC], pHn[MCC], pwm[MCC];
 #pragma unroll
         for (int q = 0; q < MCC; ++q) { pS[q] = 0.0; pdH[q] = 0.0; pHn[q] = 0.0; pwm[q] = 0.0; }
@@ -183,38 +199,6 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 }
             }
         }
-        __syncthreads();                         // Hi complete
-        // h_q = V^T H_q : rows split over the waves (half-waves take even/odd
-        // rows), each lane two adjacent singular columns, four chains per load
-        {
-            const int rows_per = (((nw + MCC - 1) / MCC) + 1) & ~1;
-            const int r0 = wave * rows_per;
-            const int r1 = min(nwp, r0 + rows_per);
-            const int half = lane >> 5, cl = lane & 31;
-            double s[MCC][2];
-#pragma unroll
-            for (int q = 0; q < MCC; ++q) { s[q][0] = 0.0; s[q][1] = 0.0; }
-            const double* Vc = V + 2 * cl;
-#pragma unroll 4
-            for (int i = r0 + half; i < r1; i += 2) {
-                const double2 xv = *reinterpret_cast<const double2*>(Vc + (size_t)i * NP);
-                const double2 h01 = *reinterpret_cast<const double2*>(Hi + i * MCC);
-                const double2 h23 = *reinterpret_cast<const double2*>(Hi + i * MCC + 2);
-                s[0][0] = fma(xv.x, h01.x, s[0][0]); s[0][1] = fma(xv.y, h01.x, s[0][1]);
-                s[1][0] = fma(xv.x, h01.y, s[1][0]); s[1][1] = fma(xv.y, h01.y, s[1][1]);
-                s[2][0] = fma(xv.x, h23.x, s[2][0]); s[2][1] = fma(xv.y, h23.x, s[2][1]);
-                s[3][0] = fma(xv.x, h23.y, s[3][0]); s[3][1] = fma(xv.y, h23.y, s[3][1]);
-            }
-#pragma unroll
-            for (int q = 0; q < MCC; ++q) {
-                s[q][0] += __shfl_xor(s[q][0], 32, WAVE);
-                s[q][1] += __shfl_xor(s[q][1], 32, WAVE);
-                if (half == 0) {
-                    hpart[(wave * MCC + q) * NP + 2 * cl] = s[q][0];
-                    hpart[(wave * MCC + q) * NP + 2 * cl + 1] = s[q][1];
-                }
-            }
-        }
         // partial sums of the row pass: one wave reduction per value
 #pragma unroll
         for (int q = 0; q < MCC; ++q) {
@@ -228,19 +212,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 red[wave * 32 + q * 4 + 2] = pHn[q]; red[wave * 32 + q * 4 + 3] = pwm[q];
             }
         }
-        __syncthreads();
-        // rho of chain q on its home wave
-        {
-            const int q = wave, k = lane;
-            double h = 0.0;
-#pragma unroll
-            for (int wv = 0; wv < MCC; ++wv) h += hpart[(wv * MCC + q) * NP + k];
-            const double r = (k < ns) ? cc[k] * h - gh[q * NP + k] : 0.0;
-            rho[q * NP + k] = r;
-            const double r2 = wave_sum(r * r);
-            if (lane == 0) red[wave * 32 + 16] = r2;       // slot 16 of wave q = |rho_q|^2
-        }
-        __syncthreads();
+        __syncthreads();                         // Hi, wi, ui and the partial sums complete
 #pragma unroll
         for (int q = 0; q < MCC; ++q) {
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -250,49 +222,55 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 a2 += red[wv * 32 + q * 4 + 2]; a3 = fmax(a3, red[wv * 32 + q * 4 + 3]);
             }
             oS[q] = a0; odH[q] = a1; oHn[q] = a2; owm[q] = a3;
-            or2[q] = red[q * 32 + 16];
         }
-        __syncthreads();                         // red / hpart free again
     };
 
     // ------------------------------------------------------------------
-    // Gram matrices of CP chains at a time on the matrix cores (see
-    // mxe_kernel.hip.h); V fragments are loaded once per row group and
-    // scaled by each chain's w.  Partial tiles are added into Wm[chain] in
-    // four rotating phases (wave wv -> chain (wv + phase) mod 4).
+    // fused pass over V (row major), once per round, for the state the row
+    // pass just produced:  h_q = V^T H_q  (all columns, VALU) and the Gram
+    // matrices W_q = V_a^T diag(w_q) V_a of the NT leading 16-column tiles
+    // (matrix cores, see mxe_kernel.hip.h).  A lane holds
+    // V[i0 + (l>>4)][16 t + (l&15)] for the four tiles t of a 4-row group --
+    // the MFMA operand layout -- and uses the same registers for both.
+    // Partial Gram tiles go to Wm[chain] in four rotating phases; h is
+    // reduced over the lane groups and the waves; rho and |rho|^2 follow.
     // ------------------------------------------------------------------
-    auto gram_mc = [&](auto NTTag, auto CPTag, int q0) {
+    auto fused_pass = [&](auto NTTag, double (&or2)[MCC]) {
         constexpr int NT = decltype(NTTag)::value;
-        constexpr int CP = decltype(CPTag)::value;
         constexpr int NPAIR = NT * (NT + 1) / 2;
-        constexpr int DEPTH = 4;
-        d4 acc[CP][NPAIR];
+        constexpr int DEPTH = 2;
+        d4 acc[MCC][NPAIR];
+        double hp[MCC][4];
 #pragma unroll
-        for (int c = 0; c < CP; ++c)
+        for (int c = 0; c < MCC; ++c) {
 #pragma unroll
             for (int pr = 0; pr < NPAIR; ++pr) acc[c][pr] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) hp[c][t] = 0.0;
+        }
         const int kq = lane >> 4, cn = lane & 15;
         const int n_groups = nwp >> 2;
         const double* Vl = V + (size_t)kq * NP + cn;
-        double f[DEPTH][NT], wq[DEPTH][CP];
+        double f[DEPTH][4];
+        double2 hw[DEPTH][4];                    // [0,1] = H of chains 01 / 23, [2,3] = w of chains 01 / 23
         auto load_group = [&](int d, int gidx) {
             const int i0 = 4 * gidx;
+            const double2* hptr = reinterpret_cast<const double2*>(Hi + (size_t)(i0 + kq) * MCC);
+            const double2* wptr = reinterpret_cast<const double2*>(wi + (size_t)(i0 + kq) * MCC);
+            hw[d][0] = hptr[0]; hw[d][1] = hptr[1]; hw[d][2] = wptr[0]; hw[d][3] = wptr[1];
 #pragma unroll
-            for (int c = 0; c < CP; ++c) wq[d][c] = wi[(i0 + kq) * MCC + q0 + c];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) f[d][t] = Vl[(size_t)i0 * NP + 16 * t];
+            for (int t = 0; t < 4; ++t) f[d][t] = Vl[(size_t)i0 * NP + 16 * t];
         };
         int gidx = wave;
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) if (gidx + d * MCC < n_groups) load_group(d, gidx + d * MCC);
         for (; gidx < n_groups; gidx += DEPTH * MCC) {
-            double fc[DEPTH][NT], wc[DEPTH][CP];
+            double fc[DEPTH][4];
+            double2 hc[DEPTH][4];
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
 #pragma unroll
-                for (int c = 0; c < CP; ++c) wc[d][c] = wq[d][c];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) fc[d][t] = f[d][t];
+                for (int t = 0; t < 4; ++t) { fc[d][t] = f[d][t]; hc[d][t] = hw[d][t]; }
             }
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
@@ -302,11 +280,15 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
                 if (gidx + d * MCC < n_groups) {
+                    const double Hq[MCC] = {hc[d][0].x, hc[d][0].y, hc[d][1].x, hc[d][1].y};
+                    const double wq[MCC] = {hc[d][2].x, hc[d][2].y, hc[d][3].x, hc[d][3].y};
 #pragma unroll
-                    for (int c = 0; c < CP; ++c) {
+                    for (int c = 0; c < MCC; ++c) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) hp[c][t] = fma(fc[d][t], Hq[c], hp[c][t]);
                         double a[NT];
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) a[t] = fc[d][t] * wc[d][c];
+                        for (int t = 0; t < NT; ++t) a[t] = fc[d][t] * wq[c];
                         int pr = 0;
 #pragma unroll
                         for (int mt = 0; mt < NT; ++mt)
@@ -319,12 +301,22 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 }
             }
         }
+        // h: sum the four row-residue lane groups, then the waves
+#pragma unroll
+        for (int c = 0; c < MCC; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                double v_ = hp[c][t];
+                v_ += __shfl_xor(v_, 16, WAVE);
+                v_ += __shfl_xor(v_, 32, WAVE);
+                if (kq == 0) hpart[(wave * MCC + c) * NP + 16 * t + cn] = v_;
+            }
+        // Gram tiles: four rotating phases (wave wv adds into chain (wv + phase) mod 4)
         for (int ph = 0; ph < MCC; ++ph) {
 #pragma unroll
-            for (int c = 0; c < CP; ++c) {
-                const int qc = q0 + c;
-                if (((qc - wave) & (MCC - 1)) == ph) {
-                    double* Wq = Wm + (size_t)qc * NA * LD;
+            for (int c = 0; c < MCC; ++c) {
+                if (((c - wave) & (MCC - 1)) == ph) {
+                    double* Wq = Wm + (size_t)c * NA * LD;
                     int pr = 0;
 #pragma unroll
                     for (int mt = 0; mt < NT; ++mt)
@@ -344,6 +336,28 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             }
             __syncthreads();
         }
+        // rho of chain q on its home wave (hpart complete after the first phase barrier)
+        {
+            const int q = wave, k = lane;
+            double h = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < MCC; ++wv) h += hpart[(wv * MCC + q) * NP + k];
+            const double r = (k < ns) ? cc[k] * h - gh[q * NP + k] : 0.0;
+            rho[q * NP + k] = r;
+            const double r2 = wave_sum(r * r);
+            if (lane == 0) red[wave * 32 + 16] = r2;       // slot 16 of wave q = |rho_q|^2
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < MCC; ++q) or2[q] = red[q * 32 + 16];
+        __syncthreads();                         // red / hpart free again
+    };
+
+    auto fused = [&](int n_cover, double (&or2)[MCC]) {
+        const int ntile = (n_cover + 15) >> 4;
+        if (ntile <= 1) fused_pass(std::integral_constant<int, 1>{}, or2);
+        else if (ntile == 2 || NA <= 32) fused_pass(std::integral_constant<int, 2>{}, or2);
+        else fused_pass(std::integral_constant<int, (NA > 32 ? 3 : 2)>{}, or2);
     };
 
     // ------------------------------------------------------------------
@@ -409,12 +423,26 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         return ok;
     };
 
+    // columns the next Newton block of chain q can need (alpha may advance to the next one)
+    auto cover_of = [&](int q, double wm) -> int {
+        const double an = (ia[q] + 1 < clen[q]) ? p.alpha[(size_t)prob0[q] + ia[q] + 1] : alpha[q];
+        const double thr = p.theta * fmin(an, alpha[q]) / fmax(wm, 1e-300);
+        int cnt = 0;
+        for (int k = 0; k < ns; ++k) cnt += (cc[k] * cc[k] > thr) ? 1 : 0;
+        if (p.theta <= 0.0) cnt = ns;
+        return min(cnt + 1, NA);
+    };
+
     // ------------------------------------------------------------------
     // round 0: evaluation from scratch for every chain
     // ------------------------------------------------------------------
     {
         double oS[MCC], odH[MCC], oHn[MCC], or2[MCC], owm[MCC];
-        eval_pass(oS, odH, oHn, or2, owm);
+        eval_pass(oS, odH, oHn, owm);
+        int cover = 1;
+#pragma unroll
+        for (int q = 0; q < MCC; ++q) if (active[q]) cover = max(cover, cover_of(q, owm[q]));
+        fused(cover, or2);
 #pragma unroll
         for (int q = 0; q < MCC; ++q) {
             chi2[q] = or2[q] + cperp[q]; S[q] = oS[q]; Hn2[q] = oHn[q]; wmax[q] = owm[q];
@@ -423,9 +451,43 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         }
     }
 
-    int guard = 0;
-    const int guard_max = p.n_alpha * (p.maxiter + 64) + 64;
-    while ((active[0] || active[1] || active[2] || active[3]) && guard++ < guard_max) {
+    long long guard = 0;
+    bool exhausted = !dynamic;
+    const long long guard_max = (long long)(dynamic ? x.n_queue : 1) * p.n_alpha * (p.maxiter + 64) + 64;
+    while ((active[0] || active[1] || active[2] || active[3] || !exhausted) && guard++ < guard_max) {
+        // ---- 0. dynamic layout: idle slots take the next piece from the queue ----
+        if (dynamic && !exhausted && !(active[0] && active[1] && active[2] && active[3])) {
+            bool idle_q = false;
+#pragma unroll
+            for (int q = 0; q < MCC; ++q) if (q == wave) idle_q = !active[q];
+            if (lane == 0) {
+                int c = -2;                               // -2: slot busy
+                if (idle_q) { const int idx = atomicAdd(x.counter, 1); c = (idx < x.n_queue) ? x.queue[idx] : -1; }
+                s_claim[wave] = c;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < MCC; ++q) {
+                const int c = s_claim[q];
+                if (c == -1) exhausted = true;
+                if (c >= 0) {
+                    chain[q] = c;
+                    const int e = p.chain_elem[c];
+                    elem[q] = e; kind[q] = p.elem_kind[e]; cperp[q] = p.cperp[e];
+                    step_lim[q] = p.step_max * p.sumD[e]; Dg[q] = p.D + (size_t)e * nwp;
+                    active[q] = true; scratch[q] = true;
+                    ia[q] = 0; n_iter[q] = 0; nevals[q] = 0; it_alpha[q] = 0; nact_last[q] = 0;
+                    prob0[q] = p.chain_prob0[c]; clen[q] = p.chain_len[c];
+                    alpha[q] = p.alpha[(size_t)prob0[q]];
+                    mu[q] = 0.0; Qprev[q] = __builtin_nan("");
+                    if (wave == q) {
+                        gh[q * NP + lane] = p.ghat[(size_t)e * NP + lane];
+                        vv[q * NP + lane] = p.v0[(size_t)p.chain_v0[c] * NP + lane];
+                    }
+                }
+            }
+            __syncthreads();
+        }
         // ---- 1. right-hand sides and active blocks (home waves) ----
         {
             const int q = wave, k = lane;
@@ -448,21 +510,8 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             nact[q] = s_nact[q];
             if (active[q] && !scratch[q]) namax = max(namax, nact[q]);
         }
-        const bool any_newton = (active[0] && !scratch[0]) || (active[1] && !scratch[1]) ||
-                                (active[2] && !scratch[2]) || (active[3] && !scratch[3]);
 
         MXE_STAMP(0);
-        // ---- 2. Gram matrices ----
-        if (any_newton) {
-            const int ntile = (namax + 15) >> 4;
-            if (ntile <= 1) gram_mc(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, 0);
-            else if (ntile == 2) gram_mc(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{}, 0);
-            else if constexpr (NA > 32) {
-                gram_mc(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{}, 0);
-                gram_mc(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{}, 2);
-            }
-        }
-
         MXE_STAMP(1);
         // ---- 3. home wave: factorise, solve, step, Bryan's bound ----
         {
@@ -510,7 +559,14 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         MXE_STAMP(2);
         // ---- 4. shared evaluation pass ----
         double oS[MCC], odH[MCC], oHn[MCC], or2[MCC], owm[MCC];
-        eval_pass(oS, odH, oHn, or2, owm);
+        eval_pass(oS, odH, oHn, owm);
+        MXE_STAMP(3);
+        {
+            int cover = 1;
+#pragma unroll
+            for (int q = 0; q < MCC; ++q) if (active[q]) cover = max(cover, cover_of(q, owm[q]));
+            fused(cover, or2);
+        }
 
         MXE_STAMP(4);
         // ---- 5. accept / converge / advance (scalars in every thread, LDS by home wave) ----
