@@ -433,8 +433,10 @@ int mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
     int split = o.alpha_split;
     if (split <= 0) {
         split = 1;
-        const int want = (1024 + n_chain - 1) / n_chain;
-        while (split * 2 <= want && split * 2 <= 8 && n_alpha / (split * 2) >= 12) split *= 2;
+        // enough pieces for two per chain slot of a full GPU (256 CUs x 4 slots),
+        // none shorter than 6 alphas (a cold start costs about as much as 2-3 alphas)
+        const int want = (2048 + n_chain - 1) / n_chain;
+        while (split * 2 <= want && split * 2 <= 16 && n_alpha / (split * 2) >= 6) split *= 2;
     }
     if (split > n_alpha) split = n_alpha;
     ctx->sub_elem.clear(); ctx->sub_prob0.clear(); ctx->sub_len.clear(); ctx->sub_v0.clear();

@@ -3,28 +3,32 @@
 // Same mathematics as mxe_kernel.hip.h (see there and DESIGN.md).  What is
 // different is how the work is laid on the CU:
 //
-//  * a workgroup of 4 wavefronts owns 4 chains that share one data set
-//    (one V).  Every load of V in the evaluation pass and in the Gram update
-//    feeds all four chains (the passes are L2->CU bandwidth bound, 448 KB per
-//    chain and iteration otherwise);
-//  * wave q is the "home" of chain q: it factorises chain q's Newton matrix
-//    (register Cholesky), takes the step, decides acceptance / convergence and
-//    writes chain q's results -- four factorisations run side by side on the
-//    four SIMDs instead of one wave working and three waiting;
+//  * a workgroup of 4 wavefronts owns 4 chain slots that share one data set
+//    (one V).  Every load of V feeds all four chains: the row pass streams
+//    V^T once (u = u - V delta for the four steps), the fused pass streams V
+//    once and produces both h = V^T H (VALU) and the Gram matrices
+//    W = V_a^T diag(w) V_a (f64 MFMA) of the four trial points from the same
+//    registers;
+//  * wave q is the "home" of slot q: it keeps the slot's scalars in its own
+//    registers, factorises the slot's Newton matrix (register Cholesky), takes
+//    the step, decides acceptance / convergence and writes the results --
+//    four factorisations run side by side on the four SIMDs;
 //  * per-chain state in LDS is interleaved [row][chain] so that one 16-byte
-//    LDS read serves two chains.
+//    LDS read serves two chains;
+//  * the grid is persistent: a slot that has finished its piece of an alpha
+//    scan takes the next piece from a queue (most expensive first).
 //
-// A round = one Newton iteration for every chain that is still active.  A
-// chain whose trial point is not finite is restored from its v (evaluation
-// from scratch) in the next round with a larger damping; a chain whose step
-// violates Bryan's bound re-solves with a larger damping and sits the round
-// out (delta = 0).
+// A round = one Newton iteration for every busy slot.  The Gram matrix of a
+// trial point is computed speculatively in the same pass that evaluates it;
+// if the trial is rejected (not finite, or a damped step that made Q worse)
+// the slot is restored from its v (evaluation from scratch) in the next round
+// and retries with a larger damping.
 #pragma once
 #include "mxe_kernel.hip.h"
 
 namespace mxe {
 
-constexpr int MCC = 4;            // chains per workgroup == wavefronts per workgroup
+constexpr int MCC = 4;            // chain slots per workgroup == wavefronts per workgroup
 
 struct MCExtra {
     const int* wg_chains;         // static layout: [n_wg][MCC] chain ids, -1 = empty slot
@@ -42,10 +46,13 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     constexpr int T = 64 * MCC;
     constexpr int NP = 64;
     constexpr int LD = NA + 1;
+    constexpr int NT = NA / 16;                   // 16-column tiles of the Gram block
+    constexpr int NPAIR = NT * (NT + 1) / 2;
     typedef double d4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if ((int)blockIdx.x >= x.n_wg) return;
     const int ns = p.n_s, nw = p.n_omega, nwp = p.n_omega_pad;
+    const bool dynamic = x.n_queue > 0;
 
     // ---- LDS carve ----
     double* Wm   = lds;                          // [MCC][NA][LD]
@@ -57,312 +64,86 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     double* dlc  = rho + MCC * NP;               // [MCC][NP]   step per chain (chain major)
     double* cc   = dlc + MCC * NP;               // [NP]
     double* ci   = cc + NP;                      // [NP]
-    double* vecI = ci + NP;                      // [NP][MCC]   step / v, chain minor (u-pass operand)
+    double* vecI = ci + NP;                      // [NP][MCC]   step / v, chain minor (row-pass operand)
     double* hpart = vecI + NP * MCC;             // [MCC waves][MCC chains][NP]
     double* red  = hpart + MCC * MCC * NP;       // [MCC waves][32]
     double* ui   = red + MCC * 32;               // [nwp][MCC]
     double* wi   = ui + (size_t)nwp * MCC;       // [nwp][MCC]
     double* Hi   = wi + (size_t)nwp * MCC;       // [nwp][MCC]
-    __shared__ int s_flag[4 * MCC];              // nact[4], ok[4], scratch[4], active[4]
-    __shared__ double s_mu[MCC];                 // damping the home wave ended up with
-    int* s_nact = s_flag; int* s_ok = s_flag + MCC; int* s_scr = s_flag + 2 * MCC; int* s_act = s_flag + 3 * MCC;
+    __shared__ int s_elem[MCC], s_act[MCC], s_scr[MCC], s_exh, s_new;
 
-    // ---- chains of this workgroup (slots are refilled from the queue in the dynamic layout) ----
-    __shared__ int s_claim[MCC];
-    int chain[MCC], elem[MCC], kind[MCC];
-    double cperp[MCC], step_lim[MCC];
-    const double* Dg[MCC];
-    const bool dynamic = x.n_queue > 0;
-    if (dynamic) {
-        if (lane == 0) {
-            const int idx = atomicAdd(x.counter, 1);
-            s_claim[wave] = (idx < x.n_queue) ? x.queue[idx] : -1;
+    // ---- slot state: lives in the registers of the home wave only ----
+    int my_elem = 0, my_prob0 = 0, my_clen = 0, my_ia = 0, my_niter = 0, my_nevals = 0, my_nact = 0;
+    double my_alpha = 1.0, my_mu = 0.0, my_chi2 = 0.0, my_S = 0.0, my_Hn2 = 1.0, my_wmax = 1.0, my_Q = 0.0;
+    double my_Qprev = __builtin_nan(""), my_cperp = 0.0, my_steplim = 0.0;
+    bool my_active = false, my_scratch = false;
+
+    auto start_piece = [&](int c) {              // home wave: take chain (piece) c into this slot
+        my_elem = p.chain_elem[c];
+        my_cperp = p.cperp[my_elem];
+        my_steplim = p.step_max * p.sumD[my_elem];
+        my_prob0 = p.chain_prob0[c]; my_clen = p.chain_len[c];
+        my_ia = 0; my_niter = 0; my_nevals = 0; my_nact = 0;
+        my_alpha = p.alpha[(size_t)my_prob0];
+        my_mu = 0.0; my_Qprev = __builtin_nan("");
+        my_active = true; my_scratch = true;
+        gh[wave * NP + lane] = p.ghat[(size_t)my_elem * NP + lane];
+        vv[wave * NP + lane] = p.v0[(size_t)p.chain_v0[c] * NP + lane];
+        if (lane == 0) { s_elem[wave] = my_elem; s_act[wave] = 1; s_scr[wave] = 1; s_new = 1; }
+    };
+
+    // ---- first pieces ----
+    if (tid == 0) { s_exh = dynamic ? 0 : 1; s_new = 0; }
+    __syncthreads();
+    {
+        int c;
+        if (dynamic) {
+            int idx = 0;
+            if (lane == 0) idx = atomicAdd(x.counter, 1);
+            idx = __builtin_amdgcn_readfirstlane(idx);
+            c = (idx < x.n_queue) ? x.queue[idx] : -1;
+        } else {
+            c = x.wg_chains[blockIdx.x * MCC + wave];
         }
-        __syncthreads();
+        if (c >= 0) start_piece(c);
+        else {
+            // empty slot: evaluates v = 0 of a neighbour's element every round (finite, never used)
+            gh[wave * NP + lane] = 0.0; vv[wave * NP + lane] = 0.0;
+            if (lane == 0) { s_elem[wave] = -1; s_act[wave] = 0; s_scr[wave] = 1; }
+        }
     }
-    int first_valid = -1;
+    dlc[wave * NP + lane] = 0.0;
+    __syncthreads();
+    int any_elem = -1;
 #pragma unroll
-    for (int q = 0; q < MCC; ++q) {
-        chain[q] = dynamic ? s_claim[q] : x.wg_chains[blockIdx.x * MCC + q];
-        if (chain[q] >= 0 && first_valid < 0) first_valid = chain[q];
-    }
-    if (first_valid < 0) return;                 // nothing left for this workgroup
-#pragma unroll
-    for (int q = 0; q < MCC; ++q) {
-        const int e = p.chain_elem[(chain[q] >= 0) ? chain[q] : first_valid];
-        elem[q] = e;
-        kind[q] = p.elem_kind[e];
-        cperp[q] = p.cperp[e];
-        step_lim[q] = p.step_max * p.sumD[e];
-        Dg[q] = p.D + (size_t)e * nwp;
-    }
-    const int ds = p.elem_ds[elem[0]];
+    for (int q = 0; q < MCC; ++q) if (s_elem[q] >= 0 && any_elem < 0) any_elem = s_elem[q];
+    if (any_elem < 0) return;                    // nothing for this workgroup
+    const int ds = p.elem_ds[any_elem];
     const double* __restrict__ V  = p.V  + (size_t)ds * nwp * NP;
     const double* __restrict__ Vt = p.Vt + (size_t)ds * NP * nwp;
-    // thread (wave q, lane k) owns component k of chain q in the small vectors
-    {
-        const int q = wave, k = lane;
-        if (q == 0) { cc[k] = p.c[ds * NP + k]; ci[k] = p.cinv[ds * NP + k]; }
-        gh[q * NP + k] = p.ghat[(size_t)elem[q] * NP + k];
-        const double v0 = (chain[q] >= 0) ? p.v0[(size_t)p.chain_v0[chain[q]] * NP + k] : 0.0;
-        vv[q * NP + k] = v0;
-        vecI[k * MCC + q] = v0;
-        dlc[q * NP + k] = 0.0;
-        if (lane == 0) { s_act[q] = (chain[q] >= 0) ? 1 : 0; s_scr[q] = 1; s_ok[q] = 0; s_nact[q] = 1; }
-    }
+    if (wave == 0) { cc[lane] = p.c[ds * NP + lane]; ci[lane] = p.cinv[ds * NP + lane]; }
+    int kind[MCC];
+    const double* Dg[MCC];
+    auto refresh_slots = [&]() {
+#pragma unroll
+        for (int q = 0; q < MCC; ++q) {
+            const int e = (s_elem[q] >= 0) ? s_elem[q] : any_elem;
+            kind[q] = p.elem_kind[e];
+            Dg[q] = p.D + (size_t)e * nwp;
+        }
+    };
+    refresh_slots();
     __syncthreads();
 
 #ifdef MXE_PROFILE
     long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long prof_t = clock64();
     long long prof_rounds = 0;
-#define prof_rounds_inc() (++prof_rounds)
-#else
-#define prof_rounds_inc() ((void)0)
 #endif
-    // per-chain scalars, identical in every thread
-    double alpha[MCC], mu[MCC], chi2[MCC], S[MCC], Hn2[MCC], wmax[MCC], Q[MCC], Qprev[MCC], relH[MCC];
-    int ia[MCC], n_iter[MCC], nevals[MCC], it_alpha[MCC], nact_last[MCC], prob0[MCC], clen[MCC];
-    bool active[MCC], scratch[MCC];
-#pragma unroll
-    for (int q = 0; q < MCC; ++q) {
-        active[q] = chain[q] >= 0; scratch[q] = true;
-        ia[q] = 0; n_iter[q] = 0; nevals[q] = 0; it_alpha[q] = 0; nact_last[q] = 0;
-        prob0[q] = active[q] ? p.chain_prob0[chain[q]] : 0;
-        clen[q] = active[q] ? p.chain_len[chain[q]] : 0;
-        alpha[q] = active[q] ? p.alpha[(size_t)prob0[q]] : 1.0;
-        mu[q] = 0.0; chi2[q] = 0.0; S[q] = 0.0; Hn2[q] = 1.0; wmax[q] = 1.0; Q[q] = 0.0;
-        Qprev[q] = __builtin_nan(""); relH[q] = 0.0;
-    }
 
     // ------------------------------------------------------------------
-    // shared evaluation pass for the four chains.
-    //   chain q scratch : u_q = V vec_q           (vec = v)
-    //   else            : u_q = u_q - V vec_q     (vec = delta)
-    // updates ui, wi, Hi in place; rho; returns per-chain sums.
-    // ------------------------------------------------------------------
-    auto eval_pass = [&](double (&oS)[MCC], double (&odH)[MCC], double (&oHn)[MCC],
-                         double (&owm)[MCC]) {
-        double pS[MCC], pdH[MCC], pHn[MCC], pwm[MCC];
-#pragma unroll
-        for (int q = 0; q < MCC; ++q) { pS[q] = 0.0; pdH[q] = 0.0; pHn[q] = 0.0; pwm[q] = 0.0; }
-        for (int i = 2 * tid; i < nwp; i += 2 * T) {
-            double a[MCC][2];
-#pragma unroll
-            for (int q = 0; q < MCC; ++q) { a[q][0] = 0.0; a[q][1] = 0.0; }
-            const double* col = Vt + i;
-#pragma unroll 4
-            for (int k = 0; k < ns; ++k) {
-                const double2 xv = *reinterpret_cast<const double2*>(col + (size_t)k * nwp);
-                const double2 d01 = *reinterpret_cast<const double2*>(vecI + k * MCC);
-                const double2 d23 = *reinterpret_cast<const double2*>(vecI + k * MCC + 2);
-                a[0][0] = fma(xv.x, d01.x, a[0][0]); a[0][1] = fma(xv.y, d01.x, a[0][1]);
-                a[1][0] = fma(xv.x, d01.y, a[1][0]); a[1][1] = fma(xv.y, d01.y, a[1][1]);
-                a[2][0] = fma(xv.x, d23.x, a[2][0]); a[2][1] = fma(xv.y, d23.x, a[2][1]);
-                a[3][0] = fma(xv.x, d23.y, a[3][0]); a[3][1] = fma(xv.y, d23.y, a[3][1]);
-            }
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int ii = i + r;
-                double un[MCC], wn[MCC], Hn_[MCC];
-#pragma unroll
-                for (int q = 0; q < MCC; ++q) {
-                    const double vd = a[q][r];
-                    double uq;
-                    if (scratch[q]) uq = vd;
-                    else {
-                        uq = ui[ii * MCC + q] - vd;
-                        const double t = wi[ii * MCC + q] * vd;
-                        pdH[q] = fma(t, t, pdH[q]);
-                    }
-                    const double Di = Dg[q][ii];
-                    double Hq, wq, Sq;
-                    if (kind[q] == 0) {
-                        const double e = exp(uq);
-                        Hq = Di * e; wq = Hq;
-                        Sq = Hq - Di - Hq * uq;
-                    } else {
-                        const double ep = exp(uq), em = exp(-uq);
-                        const double Hp = Di * ep, Hm = Di * em;
-                        Hq = Hp - Hm; wq = Hp + Hm;
-                        Sq = (Hp - Di - Hp * uq) + (Hm - Di + Hm * uq);
-                    }
-                    if (ii >= nw) { Hq = 0.0; wq = 0.0; Sq = 0.0; }
-                    un[q] = uq; wn[q] = wq; Hn_[q] = Hq;
-                    pS[q] += Sq;
-                    pHn[q] = fma(Hq, Hq, pHn[q]);
-                    pwm[q] = fmax(pwm[q], wq);
-                }
-#pragma unroll
-                for (int q = 0; q < MCC; ++q) {
-                    ui[ii * MCC + q] = un[q]; wi[ii * MCC + q] = wn[q]; Hi[ii * MCC + q] = Hn_[q];
-                }
-            }
-        }
-        // partial sums of the row pass: one wave reduction per value
-#pragma unroll
-        for (int q = 0; q < MCC; ++q) {
-            pS[q] = wave_sum(pS[q]); pdH[q] = wave_sum(pdH[q]); pHn[q] = wave_sum(pHn[q]);
-            pwm[q] = wave_max(pwm[q]);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int q = 0; q < MCC; ++q) {
-                red[wave * 32 + q * 4 + 0] = pS[q]; red[wave * 32 + q * 4 + 1] = pdH[q];
-                red[wave * 32 + q * 4 + 2] = pHn[q]; red[wave * 32 + q * 4 + 3] = pwm[q];
-            }
-        }
-        __syncthreads();                         // Hi, wi, ui and the partial sums complete
-#pragma unroll
-        for (int q = 0; q < MCC; ++q) {
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-            for (int wv = 0; wv < MCC; ++wv) {
-                a0 += red[wv * 32 + q * 4 + 0]; a1 += red[wv * 32 + q * 4 + 1];
-                a2 += red[wv * 32 + q * 4 + 2]; a3 = fmax(a3, red[wv * 32 + q * 4 + 3]);
-            }
-            oS[q] = a0; odH[q] = a1; oHn[q] = a2; owm[q] = a3;
-        }
-    };
-
-    // ------------------------------------------------------------------
-    // fused pass over V (row major), once per round, for the state the row
-    // pass just produced:  h_q = V^T H_q  (all columns, VALU) and the Gram
-    // matrices W_q = V_a^T diag(w_q) V_a of the NT leading 16-column tiles
-    // (matrix cores, see mxe_kernel.hip.h).  A lane holds
-    // V[i0 + (l>>4)][16 t + (l&15)] for the four tiles t of a 4-row group --
-    // the MFMA operand layout -- and uses the same registers for both.
-    // Partial Gram tiles go to Wm[chain] in four rotating phases; h is
-    // reduced over the lane groups and the waves; rho and |rho|^2 follow.
-    // ------------------------------------------------------------------
-    auto fused_pass = [&](auto NTTag, double (&or2)[MCC]) {
-        constexpr int NT = decltype(NTTag)::value;
-        constexpr int NPAIR = NT * (NT + 1) / 2;
-        constexpr int DEPTH = 2;
-        d4 acc[MCC][NPAIR];
-        double hp[MCC][4];
-#pragma unroll
-        for (int c = 0; c < MCC; ++c) {
-#pragma unroll
-            for (int pr = 0; pr < NPAIR; ++pr) acc[c][pr] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) hp[c][t] = 0.0;
-        }
-        const int kq = lane >> 4, cn = lane & 15;
-        const int n_groups = nwp >> 2;
-        const double* Vl = V + (size_t)kq * NP + cn;
-        double f[DEPTH][4];
-        double2 hw[DEPTH][4];                    // [0,1] = H of chains 01 / 23, [2,3] = w of chains 01 / 23
-        auto load_group = [&](int d, int gidx) {
-            const int i0 = 4 * gidx;
-            const double2* hptr = reinterpret_cast<const double2*>(Hi + (size_t)(i0 + kq) * MCC);
-            const double2* wptr = reinterpret_cast<const double2*>(wi + (size_t)(i0 + kq) * MCC);
-            hw[d][0] = hptr[0]; hw[d][1] = hptr[1]; hw[d][2] = wptr[0]; hw[d][3] = wptr[1];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) f[d][t] = Vl[(size_t)i0 * NP + 16 * t];
-        };
-        int gidx = wave;
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) if (gidx + d * MCC < n_groups) load_group(d, gidx + d * MCC);
-        for (; gidx < n_groups; gidx += DEPTH * MCC) {
-            double fc[DEPTH][4];
-            double2 hc[DEPTH][4];
-#pragma unroll
-            for (int d = 0; d < DEPTH; ++d) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { fc[d][t] = f[d][t]; hc[d][t] = hw[d][t]; }
-            }
-#pragma unroll
-            for (int d = 0; d < DEPTH; ++d) {
-                const int gn = gidx + (DEPTH + d) * MCC;
-                if (gn < n_groups) load_group(d, gn);
-            }
-#pragma unroll
-            for (int d = 0; d < DEPTH; ++d) {
-                if (gidx + d * MCC < n_groups) {
-                    const double Hq[MCC] = {hc[d][0].x, hc[d][0].y, hc[d][1].x, hc[d][1].y};
-                    const double wq[MCC] = {hc[d][2].x, hc[d][2].y, hc[d][3].x, hc[d][3].y};
-#pragma unroll
-                    for (int c = 0; c < MCC; ++c) {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) hp[c][t] = fma(fc[d][t], Hq[c], hp[c][t]);
-                        double a[NT];
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) a[t] = fc[d][t] * wq[c];
-                        int pr = 0;
-#pragma unroll
-                        for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-                            for (int nt = mt; nt < NT; ++nt) {
-                                acc[c][pr] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], fc[d][nt], acc[c][pr], 0, 0, 0);
-                                ++pr;
-                            }
-                    }
-                }
-            }
-        }
-        // h: sum the four row-residue lane groups, then the waves
-#pragma unroll
-        for (int c = 0; c < MCC; ++c)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                double v_ = hp[c][t];
-                v_ += __shfl_xor(v_, 16, WAVE);
-                v_ += __shfl_xor(v_, 32, WAVE);
-                if (kq == 0) hpart[(wave * MCC + c) * NP + 16 * t + cn] = v_;
-            }
-        // Gram tiles: four rotating phases (wave wv adds into chain (wv + phase) mod 4)
-        for (int ph = 0; ph < MCC; ++ph) {
-#pragma unroll
-            for (int c = 0; c < MCC; ++c) {
-                if (((c - wave) & (MCC - 1)) == ph) {
-                    double* Wq = Wm + (size_t)c * NA * LD;
-                    int pr = 0;
-#pragma unroll
-                    for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-                        for (int nt = mt; nt < NT; ++nt) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = 16 * mt + kq + 4 * r, col = 16 * nt + cn;
-                                if (row < NA && col < NA) {
-                                    if (ph == 0) Wq[row * LD + col] = acc[c][pr][r];
-                                    else Wq[row * LD + col] += acc[c][pr][r];
-                                }
-                            }
-                            ++pr;
-                        }
-                }
-            }
-            __syncthreads();
-        }
-        // rho of chain q on its home wave (hpart complete after the first phase barrier)
-        {
-            const int q = wave, k = lane;
-            double h = 0.0;
-#pragma unroll
-            for (int wv = 0; wv < MCC; ++wv) h += hpart[(wv * MCC + q) * NP + k];
-            const double r = (k < ns) ? cc[k] * h - gh[q * NP + k] : 0.0;
-            rho[q * NP + k] = r;
-            const double r2 = wave_sum(r * r);
-            if (lane == 0) red[wave * 32 + 16] = r2;       // slot 16 of wave q = |rho_q|^2
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < MCC; ++q) or2[q] = red[q * 32 + 16];
-        __syncthreads();                         // red / hpart free again
-    };
-
-    auto fused = [&](int n_cover, double (&or2)[MCC]) {
-        const int ntile = (n_cover + 15) >> 4;
-        if (ntile <= 1) fused_pass(std::integral_constant<int, 1>{}, or2);
-        else if (ntile == 2 || NA <= 32) fused_pass(std::integral_constant<int, 2>{}, or2);
-        else fused_pass(std::integral_constant<int, (NA > 32 ? 3 : 2)>{}, or2);
-    };
-
-    // ------------------------------------------------------------------
-    // home wave: register Cholesky of chain q's active block + solve
-    // (identical to chol_solve_reg of mxe_kernel.hip.h, wave local)
+    // home wave: register Cholesky of the slot's active block + solve
+    // (see chol_solve_reg in mxe_kernel.hip.h)
     // ------------------------------------------------------------------
     auto chol_home = [&](auto NTag, double a, int n_act) -> bool {
         constexpr int N = decltype(NTag)::value;
@@ -423,113 +204,46 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         return ok;
     };
 
-    // columns the next Newton block of chain q can need (alpha may advance to the next one)
-    auto cover_of = [&](int q, double wm) -> int {
-        const double an = (ia[q] + 1 < clen[q]) ? p.alpha[(size_t)prob0[q] + ia[q] + 1] : alpha[q];
-        const double thr = p.theta * fmin(an, alpha[q]) / fmax(wm, 1e-300);
-        int cnt = 0;
-        for (int k = 0; k < ns; ++k) cnt += (cc[k] * cc[k] > thr) ? 1 : 0;
-        if (p.theta <= 0.0) cnt = ns;
-        return min(cnt + 1, NA);
-    };
-
-    // ------------------------------------------------------------------
-    // round 0: evaluation from scratch for every chain
-    // ------------------------------------------------------------------
-    {
-        double oS[MCC], odH[MCC], oHn[MCC], or2[MCC], owm[MCC];
-        eval_pass(oS, odH, oHn, owm);
-        int cover = 1;
-#pragma unroll
-        for (int q = 0; q < MCC; ++q) if (active[q]) cover = max(cover, cover_of(q, owm[q]));
-        fused(cover, or2);
-#pragma unroll
-        for (int q = 0; q < MCC; ++q) {
-            chi2[q] = or2[q] + cperp[q]; S[q] = oS[q]; Hn2[q] = oHn[q]; wmax[q] = owm[q];
-            scratch[q] = false;
-            if (active[q]) { nevals[q] = 1; Q[q] = 0.5 * chi2[q] - alpha[q] * S[q]; }
-        }
-    }
-
+    bool okflag_prev = false;                    // home wave: did this round carry a real trial step
     long long guard = 0;
-    bool exhausted = !dynamic;
     const long long guard_max = (long long)(dynamic ? x.n_queue : 1) * p.n_alpha * (p.maxiter + 64) + 64;
-    while ((active[0] || active[1] || active[2] || active[3] || !exhausted) && guard++ < guard_max) {
-        // ---- 0. dynamic layout: idle slots take the next piece from the queue ----
-        if (dynamic && !exhausted && !(active[0] && active[1] && active[2] && active[3])) {
-            bool idle_q = false;
-#pragma unroll
-            for (int q = 0; q < MCC; ++q) if (q == wave) idle_q = !active[q];
-            if (lane == 0) {
-                int c = -2;                               // -2: slot busy
-                if (idle_q) { const int idx = atomicAdd(x.counter, 1); c = (idx < x.n_queue) ? x.queue[idx] : -1; }
-                s_claim[wave] = c;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < MCC; ++q) {
-                const int c = s_claim[q];
-                if (c == -1) exhausted = true;
-                if (c >= 0) {
-                    chain[q] = c;
-                    const int e = p.chain_elem[c];
-                    elem[q] = e; kind[q] = p.elem_kind[e]; cperp[q] = p.cperp[e];
-                    step_lim[q] = p.step_max * p.sumD[e]; Dg[q] = p.D + (size_t)e * nwp;
-                    active[q] = true; scratch[q] = true;
-                    ia[q] = 0; n_iter[q] = 0; nevals[q] = 0; it_alpha[q] = 0; nact_last[q] = 0;
-                    prob0[q] = p.chain_prob0[c]; clen[q] = p.chain_len[c];
-                    alpha[q] = p.alpha[(size_t)prob0[q]];
-                    mu[q] = 0.0; Qprev[q] = __builtin_nan("");
-                    if (wave == q) {
-                        gh[q * NP + lane] = p.ghat[(size_t)e * NP + lane];
-                        vv[q * NP + lane] = p.v0[(size_t)p.chain_v0[c] * NP + lane];
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        // ---- 1. right-hand sides and active blocks (home waves) ----
-        {
-            const int q = wave, k = lane;
-            const double a0 = alpha[0], a1 = alpha[1], a2 = alpha[2], a3 = alpha[3];
-            const double aq = (q == 0) ? a0 : (q == 1) ? a1 : (q == 2) ? a2 : a3;
-            const double w0 = wmax[0], w1 = wmax[1], w2 = wmax[2], w3 = wmax[3];
-            const double wq = (q == 0) ? w0 : (q == 1) ? w1 : (q == 2) ? w2 : w3;
-            rhs[q * NP + k] = (k < ns) ? fma(aq * vv[q * NP + k], ci[k], rho[q * NP + k]) : 0.0;
-            const double thr = p.theta * aq / fmax(wq, 1e-300);
-            int cnt = (k < ns && cc[k] * cc[k] > thr) ? 1 : 0;
-            int na = (int)wave_sum((double)cnt);
-            if (p.theta <= 0.0) na = ns;
-            na = max(1, min(na, NA));
-            if (lane == 0) s_nact[q] = na;
-        }
-        __syncthreads();
-        int nact[MCC], namax = 1;
-#pragma unroll
-        for (int q = 0; q < MCC; ++q) {
-            nact[q] = s_nact[q];
-            if (active[q] && !scratch[q]) namax = max(namax, nact[q]);
-        }
 
-        MXE_STAMP(0);
-        MXE_STAMP(1);
-        // ---- 3. home wave: factorise, solve, step, Bryan's bound ----
+    while (guard++ < guard_max) {
+        // ---- 0. idle slots take the next piece from the queue ----
+        if (dynamic && s_exh == 0) {
+            __syncthreads();                     // everybody has read s_exh / s_new
+            if (tid == 0) s_new = 0;
+            __syncthreads();
+            if (!my_active) {
+                int idx = 0;
+                if (lane == 0) idx = atomicAdd(x.counter, 1);
+                idx = __builtin_amdgcn_readfirstlane(idx);
+                if (idx < x.n_queue) start_piece(x.queue[idx]);
+                else if (lane == 0) s_exh = 1;
+            }
+            __syncthreads();
+            if (s_new) refresh_slots();          // uniform: written before the barrier
+        }
+        if (!(s_act[0] | s_act[1] | s_act[2] | s_act[3])) break;      // uniform: LDS flags behind a barrier
+
+        // ---- 1. home wave: right-hand side, active block, factorise, solve, step ----
         {
             const int q = wave, k = lane;
-            bool act_q = false, scr_q = false; double aq = 1.0, muq = 0.0, lim = 0.0; int na = 1;
-#pragma unroll
-            for (int c = 0; c < MCC; ++c) if (c == q) {
-                act_q = active[c]; scr_q = scratch[c]; aq = alpha[c]; muq = mu[c]; lim = step_lim[c]; na = nact[c];
-            }
             int okflag = 0;
             double dk = 0.0;
-            if (act_q && scr_q) {
-                dk = vv[q * NP + k];                 // evaluation from scratch: operand is v
-            } else if (act_q) {
-                // damping loop of the home wave: raise mu until the factorisation
-                // succeeds and Bryan's bound holds (no evaluation needed for that)
+            if (my_active && my_scratch) {
+                dk = vv[q * NP + k];                 // evaluation from scratch: the operand is v
+            } else if (my_active) {
+                rhs[q * NP + k] = (k < ns) ? fma(my_alpha * vv[q * NP + k], ci[k], rho[q * NP + k]) : 0.0;
+                const double thr = p.theta * my_alpha / fmax(my_wmax, 1e-300);
+                const unsigned long long m = __ballot(k < ns && cc[k] * cc[k] > thr);
+                int na = (p.theta > 0.0) ? __popcll(m) : ns;
+                na = max(1, min(na, NA));
+                my_nact = na;
+                wave_sync();
+                // damping loop: raise mu until the factorisation succeeds and Bryan's bound holds
                 while (true) {
-                    const double a = aq + muq;
+                    const double a = my_alpha + my_mu;
                     bool ok;
                     if (na <= 16) ok = chol_home(std::integral_constant<int, 16>{}, a, na);
                     else if (na <= 24) ok = chol_home(std::integral_constant<int, 24>{}, a, na);
@@ -540,100 +254,280 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         if (k < na) { z = zz[q * NP + k]; nrm = z * (rhs[q * NP + k] - a * z); }
                         else if (k < ns) z = rhs[q * NP + k] / a;
                         nrm = wave_sum(nrm);
-                        if (nrm <= lim) { okflag = 1; dk = (k < ns) ? cc[k] * z : 0.0; break; }
+                        if (nrm <= my_steplim) { okflag = 1; dk = (k < ns) ? cc[k] * z : 0.0; break; }
                     }
-                    muq = (muq == 0.0) ? p.mu_first * aq : muq * p.mu_grow;
-                    if (!(muq <= p.mu_max * aq)) break;
+                    my_mu = (my_mu == 0.0) ? p.mu_first * my_alpha : my_mu * p.mu_grow;
+                    if (!(my_mu <= p.mu_max * my_alpha)) break;
                 }
-                if (lane == 0) s_mu[q] = muq;
             }
             dlc[q * NP + k] = (okflag ? dk : 0.0);
             vecI[k * MCC + q] = dk;
-            if (lane == 0) s_ok[q] = okflag;
+            okflag_prev = okflag != 0;
         }
         __syncthreads();
-        bool okq[MCC];
-#pragma unroll
-        for (int q = 0; q < MCC; ++q) { okq[q] = s_ok[q] != 0; if (active[q] && !scratch[q]) mu[q] = s_mu[q]; }
-
         MXE_STAMP(2);
-        // ---- 4. shared evaluation pass ----
-        double oS[MCC], odH[MCC], oHn[MCC], or2[MCC], owm[MCC];
-        eval_pass(oS, odH, oHn, owm);
-        MXE_STAMP(3);
-        {
-            int cover = 1;
-#pragma unroll
-            for (int q = 0; q < MCC; ++q) if (active[q]) cover = max(cover, cover_of(q, owm[q]));
-            fused(cover, or2);
-        }
 
-        MXE_STAMP(4);
-        // ---- 5. accept / converge / advance (scalars in every thread, LDS by home wave) ----
+        // ---- 2. row pass (V^T once): u, w, H of the four trial points, in place ----
+        {
+            bool scr[MCC];
 #pragma unroll
-        for (int q = 0; q < MCC; ++q) {
-            if (!active[q]) continue;
-            const double chi2t = or2[q] + cperp[q], St = oS[q];
-            const double Qt = 0.5 * chi2t - alpha[q] * St;
-            const bool finite = fabs(Qt) <= 1.7e308;
-            bool finish_alpha = false; int conv = 0;
-            if (scratch[q]) {
-                // state restored from v (or first evaluation); keep the damping
-                if (finite) { scratch[q] = false; chi2[q] = chi2t; S[q] = St; Hn2[q] = oHn[q]; wmax[q] = owm[q]; Q[q] = Qt; }
-                else { finish_alpha = true; }                   // cannot even evaluate: give up on this alpha
-                ++nevals[q];
-            } else if (!okq[q]) {
-                // the damping loop ran out of range: give up on this alpha
-                finish_alpha = true;
-            } else if (!finite || (mu[q] > 0.0 && Qt > Q[q])) {
-                // not finite, or a damped step that made Q worse: more damping
-                ++nevals[q];
-                mu[q] = (mu[q] == 0.0) ? p.mu_first * alpha[q] : mu[q] * p.mu_grow;
-                scratch[q] = true;                              // u, w were overwritten: restore from v
-                if (!(mu[q] <= p.mu_max * alpha[q])) finish_alpha = true;
-            } else {
-                // accepted
-                ++nevals[q];
-                relH[q] = sqrt(odH[q] / Hn2[q]);
-                if (wave == q) vv[q * NP + lane] -= dlc[q * NP + lane];
-                chi2[q] = chi2t; S[q] = St; Hn2[q] = oHn[q]; wmax[q] = owm[q];
-                Qprev[q] = Q[q]; Q[q] = Qt; mu[q] = 0.0;
-                nact_last[q] = nact[q];
-                ++n_iter[q]; ++it_alpha[q];
-                if (p.tol_h > 0.0 && relH[q] < p.tol_h && n_iter[q] > p.miniter) { conv = 1; finish_alpha = true; }
-                else if (p.tol_relq > 0.0 && fabs(fabs(Qprev[q] - Q[q]) / Q[q]) < p.tol_relq && n_iter[q] > p.miniter) { conv = 1; finish_alpha = true; }
-                else if (n_iter[q] >= p.maxiter) finish_alpha = true;
+            for (int q = 0; q < MCC; ++q) scr[q] = s_scr[q] != 0;
+            double pS[MCC], pdH[MCC], pHn[MCC], pwm[MCC];
+#pragma unroll
+            for (int q = 0; q < MCC; ++q) { pS[q] = 0.0; pdH[q] = 0.0; pHn[q] = 0.0; pwm[q] = 0.0; }
+            for (int i = 2 * tid; i < nwp; i += 2 * T) {
+                double a[MCC][2];
+#pragma unroll
+                for (int q = 0; q < MCC; ++q) { a[q][0] = 0.0; a[q][1] = 0.0; }
+                const double* col = Vt + i;
+#pragma unroll 4
+                for (int k = 0; k < ns; ++k) {
+                    const double2 xv = *reinterpret_cast<const double2*>(col + (size_t)k * nwp);
+                    const double2 d01 = *reinterpret_cast<const double2*>(vecI + k * MCC);
+                    const double2 d23 = *reinterpret_cast<const double2*>(vecI + k * MCC + 2);
+                    a[0][0] = fma(xv.x, d01.x, a[0][0]); a[0][1] = fma(xv.y, d01.x, a[0][1]);
+                    a[1][0] = fma(xv.x, d01.y, a[1][0]); a[1][1] = fma(xv.y, d01.y, a[1][1]);
+                    a[2][0] = fma(xv.x, d23.x, a[2][0]); a[2][1] = fma(xv.y, d23.x, a[2][1]);
+                    a[3][0] = fma(xv.x, d23.y, a[3][0]); a[3][1] = fma(xv.y, d23.y, a[3][1]);
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int ii = i + r;
+                    double un[MCC], wn[MCC], Hn_[MCC];
+#pragma unroll
+                    for (int q = 0; q < MCC; ++q) {
+                        const double vd = a[q][r];
+                        double uq;
+                        if (scr[q]) uq = vd;
+                        else {
+                            uq = ui[ii * MCC + q] - vd;
+                            const double t = wi[ii * MCC + q] * vd;
+                            pdH[q] = fma(t, t, pdH[q]);
+                        }
+                        const double Di = Dg[q][ii];
+                        double Hq, wq, Sq;
+                        if (kind[q] == 0) {
+                            const double e = exp(uq);
+                            Hq = Di * e; wq = Hq;
+                            Sq = Hq - Di - Hq * uq;
+                        } else {
+                            const double ep = exp(uq), em = exp(-uq);
+                            const double Hp = Di * ep, Hm = Di * em;
+                            Hq = Hp - Hm; wq = Hp + Hm;
+                            Sq = (Hp - Di - Hp * uq) + (Hm - Di + Hm * uq);
+                        }
+                        if (ii >= nw) { Hq = 0.0; wq = 0.0; Sq = 0.0; }
+                        un[q] = uq; wn[q] = wq; Hn_[q] = Hq;
+                        pS[q] += Sq;
+                        pHn[q] = fma(Hq, Hq, pHn[q]);
+                        pwm[q] = fmax(pwm[q], wq);
+                    }
+#pragma unroll
+                    for (int q = 0; q < MCC; ++q) {
+                        ui[ii * MCC + q] = un[q]; wi[ii * MCC + q] = wn[q]; Hi[ii * MCC + q] = Hn_[q];
+                    }
+                }
             }
-            if (finish_alpha) {
-                const size_t prob = (size_t)prob0[q] + ia[q];
-                if (wave == q) {
+#pragma unroll
+            for (int q = 0; q < MCC; ++q) {
+                pS[q] = wave_sum(pS[q]); pdH[q] = wave_sum(pdH[q]); pHn[q] = wave_sum(pHn[q]);
+                pwm[q] = wave_max(pwm[q]);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < MCC; ++q) {
+                    red[wave * 32 + q * 4 + 0] = pS[q]; red[wave * 32 + q * 4 + 1] = pdH[q];
+                    red[wave * 32 + q * 4 + 2] = pHn[q]; red[wave * 32 + q * 4 + 3] = pwm[q];
+                }
+            }
+        }
+        __syncthreads();                         // Hi, wi, ui and the partial sums complete
+        MXE_STAMP(3);
+
+        // ---- 3. fused pass (V once): h = V^T H (VALU) and W = V_a^T diag(w) V_a (MFMA) ----
+        {
+            d4 acc[MCC][NPAIR];
+            double hp[MCC][4];
+#pragma unroll
+            for (int c = 0; c < MCC; ++c) {
+#pragma unroll
+                for (int pr = 0; pr < NPAIR; ++pr) acc[c][pr] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) hp[c][t] = 0.0;
+            }
+            const int kq = lane >> 4, cn = lane & 15;
+            const int n_groups = nwp >> 2;           // 4 omega rows per MFMA; multiple of 16
+            const double* Vl = V + (size_t)kq * NP + cn;
+            // four register sets, software pipelined without copies: the loads of
+            // the next three row groups are in flight while one is consumed
+            double fA[4], fB[4], fC[4], fD[4];
+            double2 hA[4], hB[4], hC[4], hD[4];      // [0,1] = H of chains 01 / 23, [2,3] = w of chains 01 / 23
+            auto load_group = [&](double (&f)[4], double2 (&hw)[4], int gidx) {
+                const int i0 = 4 * gidx;
+                const double2* hptr = reinterpret_cast<const double2*>(Hi + (size_t)(i0 + kq) * MCC);
+                const double2* wptr = reinterpret_cast<const double2*>(wi + (size_t)(i0 + kq) * MCC);
+                hw[0] = hptr[0]; hw[1] = hptr[1]; hw[2] = wptr[0]; hw[3] = wptr[1];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) f[t] = Vl[(size_t)i0 * NP + 16 * t];
+            };
+            auto consume = [&](const double (&f)[4], const double2 (&hw)[4]) {
+                const double Hq[MCC] = {hw[0].x, hw[0].y, hw[1].x, hw[1].y};
+                const double wq[MCC] = {hw[2].x, hw[2].y, hw[3].x, hw[3].y};
+                double a[MCC][NT];
+#pragma unroll
+                for (int c = 0; c < MCC; ++c)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) a[c][t] = f[t] * wq[c];
+#pragma unroll
+                for (int c = 0; c < MCC; ++c) {
+                    int pr = 0;
+#pragma unroll
+                    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                        for (int nt = mt; nt < NT; ++nt) {
+                            acc[c][pr] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c][mt], f[nt], acc[c][pr], 0, 0, 0);
+                            ++pr;
+                        }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) hp[c][t] = fma(f[t], Hq[c], hp[c][t]);
+                }
+                // issue order: the VALU work of a group rides in the shadow of its
+                // MFMAs (one matrix instruction, then up to two vector ones)
+#pragma unroll
+                for (int r = 0; r < MCC * NPAIR; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                }
+            };
+            // n_groups is a multiple of 16 and the waves take groups wave, wave+4, ...:
+            // every wave has a multiple of four groups
+            int g = wave;
+            load_group(fA, hA, g); load_group(fB, hB, g + MCC); load_group(fC, hC, g + 2 * MCC);
+            for (; g < n_groups; g += 4 * MCC) {
+                load_group(fD, hD, g + 3 * MCC);
+                consume(fA, hA);
+                if (g + 4 * MCC < n_groups) load_group(fA, hA, g + 4 * MCC);
+                consume(fB, hB);
+                if (g + 5 * MCC < n_groups) load_group(fB, hB, g + 5 * MCC);
+                consume(fC, hC);
+                if (g + 6 * MCC < n_groups) load_group(fC, hC, g + 6 * MCC);
+                consume(fD, hD);
+            }
+            // h: sum the four row-residue lane groups, then (in step 4) the waves
+#pragma unroll
+            for (int c = 0; c < MCC; ++c)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    double v_ = hp[c][t];
+                    v_ += __shfl_xor(v_, 16, WAVE);
+                    v_ += __shfl_xor(v_, 32, WAVE);
+                    if (kq == 0) hpart[(wave * MCC + c) * NP + 16 * t + cn] = v_;
+                }
+            // Gram tiles: four rotating phases (wave wv adds into chain (wv + phase) mod 4)
+            for (int ph = 0; ph < MCC; ++ph) {
+#pragma unroll
+                for (int c = 0; c < MCC; ++c) {
+                    if (((c - wave) & (MCC - 1)) == ph) {
+                        double* Wq = Wm + (size_t)c * NA * LD;
+                        int pr = 0;
+#pragma unroll
+                        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                            for (int nt = mt; nt < NT; ++nt) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int row = 16 * mt + kq + 4 * r, col = 16 * nt + cn;
+                                    if (ph == 0) Wq[row * LD + col] = acc[c][pr][r];
+                                    else Wq[row * LD + col] += acc[c][pr][r];
+                                }
+                                ++pr;
+                            }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        MXE_STAMP(4);
+
+        // ---- 4. home wave: rho, sums, accept / converge / advance, results ----
+        {
+            const int q = wave, k = lane;
+            double h = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < MCC; ++wv) h += hpart[(wv * MCC + q) * NP + k];
+            const double r = (k < ns) ? cc[k] * h - gh[q * NP + k] : 0.0;
+            const double r2 = wave_sum(r * r);
+            double sS = 0.0, sdH = 0.0, sHn = 0.0, swm = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < MCC; ++wv) {
+                sS += red[wv * 32 + q * 4 + 0]; sdH += red[wv * 32 + q * 4 + 1];
+                sHn += red[wv * 32 + q * 4 + 2]; swm = fmax(swm, red[wv * 32 + q * 4 + 3]);
+            }
+            if (my_active) {
+                rho[q * NP + k] = r;
+                const double chi2t = r2 + my_cperp, St = sS;
+                const double Qt = 0.5 * chi2t - my_alpha * St;
+                const bool finite = fabs(Qt) <= 1.7e308;
+                bool finish_alpha = false; int conv = 0;
+                if (my_scratch) {
+                    // state restored from v (or first evaluation of the piece); damping kept
+                    ++my_nevals;
+                    if (finite) { my_scratch = false; my_chi2 = chi2t; my_S = St; my_Hn2 = sHn; my_wmax = swm; my_Q = Qt; }
+                    else finish_alpha = true;                   // cannot even evaluate: give up on this alpha
+                } else if (!okflag_prev) {
+                    finish_alpha = true;                        // the damping loop ran out of range
+                } else if (!finite || (my_mu > 0.0 && Qt > my_Q)) {
+                    // not finite, or a damped step that made Q worse: more damping, restore from v
+                    ++my_nevals;
+                    my_mu = (my_mu == 0.0) ? p.mu_first * my_alpha : my_mu * p.mu_grow;
+                    my_scratch = true;
+                    if (!(my_mu <= p.mu_max * my_alpha)) finish_alpha = true;
+                } else {
+                    // accepted
+                    ++my_nevals;
+                    const double relH = sqrt(sdH / my_Hn2);
+                    vv[q * NP + k] -= dlc[q * NP + k];
+                    my_chi2 = chi2t; my_S = St; my_Hn2 = sHn; my_wmax = swm;
+                    my_Qprev = my_Q; my_Q = Qt; my_mu = 0.0;
+                    ++my_niter;
+                    if (p.tol_h > 0.0 && relH < p.tol_h && my_niter > p.miniter) { conv = 1; finish_alpha = true; }
+                    else if (p.tol_relq > 0.0 && fabs(fabs(my_Qprev - my_Q) / my_Q) < p.tol_relq && my_niter > p.miniter) { conv = 1; finish_alpha = true; }
+                    else if (my_niter >= p.maxiter) finish_alpha = true;
+                }
+                if (finish_alpha) {
+                    const size_t prob = (size_t)my_prob0 + my_ia;
                     if (p.out_H) {
                         double* Ho = p.out_H + prob * nw;
+                        const int kd = p.elem_kind[my_elem];
+                        const double* Dq = p.D + (size_t)my_elem * nwp;
                         for (int i = lane; i < nw; i += 64) {
-                            const double Di = Dg[q][i], uq = ui[i * MCC + q];
-                            Ho[i] = (kind[q] == 0) ? Di * exp(uq) : Di * exp(uq) - Di * exp(-uq);
+                            const double Di = Dq[i], uq = ui[i * MCC + q];
+                            Ho[i] = (kd == 0) ? Di * exp(uq) : Di * exp(uq) - Di * exp(-uq);
                         }
                     }
                     if (p.out_v) p.out_v[prob * NP + lane] = vv[q * NP + lane];
                     if (lane == 0) {
-                        p.out_chi2[prob] = chi2[q]; p.out_S[prob] = S[q]; p.out_Q[prob] = Q[q];
-                        p.out_niter[prob] = n_iter[q]; p.out_conv[prob] = conv;
-                        p.out_nevals[prob] = nevals[q]; p.out_nact[prob] = nact_last[q];
+                        p.out_chi2[prob] = my_chi2; p.out_S[prob] = my_S; p.out_Q[prob] = my_Q;
+                        p.out_niter[prob] = my_niter; p.out_conv[prob] = conv;
+                        p.out_nevals[prob] = my_nevals; p.out_nact[prob] = my_nact;
+                    }
+                    ++my_ia;
+                    my_niter = 0; my_nevals = 0; my_mu = 0.0;
+                    my_Qprev = __builtin_nan("");
+                    if (my_ia >= my_clen) my_active = false;
+                    else {
+                        my_alpha = p.alpha[(size_t)my_prob0 + my_ia];
+                        my_Q = 0.5 * my_chi2 - my_alpha * my_S;
                     }
                 }
-                ++ia[q];
-                n_iter[q] = 0; nevals[q] = 0; it_alpha[q] = 0; mu[q] = 0.0;
-                Qprev[q] = __builtin_nan("");
-                if (ia[q] >= clen[q]) active[q] = false;
-                else {
-                    alpha[q] = p.alpha[(size_t)prob0[q] + ia[q]];
-                    Q[q] = 0.5 * chi2[q] - alpha[q] * S[q];
-                }
+                if (lane == 0) { s_act[q] = my_active ? 1 : 0; s_scr[q] = my_scratch ? 1 : 0; }
             }
         }
-        __syncthreads();                         // vv updates visible before the next round
+        __syncthreads();                         // slot flags, v, rho visible to the next round
         MXE_STAMP(5);
-        if (tid == 0) prof_rounds_inc();
+#ifdef MXE_PROFILE
+        ++prof_rounds;
+#endif
     }
 #ifdef MXE_PROFILE
     if (tid == 0 && p.prof) { for (int r = 0; r < 7; ++r) p.prof[(size_t)blockIdx.x * 8 + r] = prof_acc[r]; p.prof[(size_t)blockIdx.x * 8 + 7] = prof_rounds; }
