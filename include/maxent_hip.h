@@ -147,7 +147,9 @@ int  mxe_solve_chains(mxe_ctx* ctx, int n_chain, int n_alpha,
  * mxe_result_device_ptrs exposes the device result buffers (for an RCCL
  * gather driven by the caller); layouts as above except v, which is in the
  * whitened basis with row stride mxe_ns_padded() (use mxe_chains_fetch for
- * caller-basis v). */
+ * caller-basis v).  H, chi2, S, Q are contiguous in that order in ONE
+ * allocation of P*n_omega + 3*P doubles starting at d_H, so that one
+ * collective moves all per-alpha results. */
 int  mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
                        const int32_t* elem_of_chain, const double* alpha_scaled,
                        const double* v0, const mxe_opts* opts);
@@ -161,6 +163,9 @@ int  mxe_result_device_ptrs(mxe_ctx* ctx, void** d_H, void** d_chi2,
                             void** d_S, void** d_Q, void** d_v,
                             void** d_niter, void** d_converged);
 int  mxe_ns_padded(mxe_ctx* ctx);
+/* two result allocations (0, 1): the next launches / fetches / pointer queries use
+ * `which`, so that a driver can gather buffer k while the solver fills buffer 1-k */
+int  mxe_set_result_buffer(mxe_ctx* ctx, int which);
 /* duration of the last mxe_chains_launch in ms (HIP events on the ctx stream) */
 int  mxe_last_kernel_ms(mxe_ctx* ctx, float* ms);
 /* kernel geometry of the last launch: waves per chain, workgroups, LDS bytes */

@@ -67,7 +67,11 @@ struct mxe_ctx {
     // device
     DevBuf<double> dV, dVt, dc, dcinv, dghat, dcperp, dD, dsumD, dalpha, dv0;
     DevBuf<int> delem_ds, delem_kind, dchain_elem, dsub_prob0, dsub_len, dsub_v0, dwg_chains;
-    DevBuf<double> dout_v, dout_H, dout_chi2, dout_S, dout_Q, dB, dA;
+    // H, chi2, S, Q live back to back in ONE allocation (dout_pack) so that a
+    // multi-GPU driver can move all per-alpha results with a single collective
+    DevBuf<double> dout_v, dout_pack, dout_pack2, dB, dA;
+    int result_buffer = 0;        // which of the two result allocations launches write to
+    struct View { double* p = nullptr; } dout_H, dout_chi2, dout_S, dout_Q;
     DevBuf<int> dout_niter, dout_conv, dout_nevals, dout_nact;
     DevBuf<long long> dprof;
     DevBuf<int> dqueue, dcounter;
@@ -303,8 +307,7 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
     ctx->dV.release(); ctx->dVt.release(); ctx->dc.release(); ctx->dcinv.release();
     ctx->dghat.release(); ctx->dcperp.release(); ctx->dD.release(); ctx->dsumD.release();
     ctx->dalpha.release(); ctx->dv0.release(); ctx->delem_ds.release(); ctx->delem_kind.release();
-    ctx->dchain_elem.release(); ctx->dsub_prob0.release(); ctx->dsub_len.release(); ctx->dsub_v0.release(); ctx->dwg_chains.release(); ctx->dqueue.release(); ctx->dcounter.release(); ctx->dout_v.release(); ctx->dout_H.release();
-    ctx->dout_chi2.release(); ctx->dout_S.release(); ctx->dout_Q.release();
+    ctx->dchain_elem.release(); ctx->dsub_prob0.release(); ctx->dsub_len.release(); ctx->dsub_v0.release(); ctx->dwg_chains.release(); ctx->dqueue.release(); ctx->dcounter.release(); ctx->dout_v.release(); ctx->dout_pack.release(); ctx->dout_pack2.release();
     ctx->dout_niter.release(); ctx->dout_conv.release(); ctx->dout_nevals.release(); ctx->dout_nact.release();
     ctx->dB.release(); ctx->dA.release();
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -526,10 +529,12 @@ int mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
     HIPCHK(ctx, ctx->dalpha.ensure(P));
     HIPCHK(ctx, ctx->dv0.ensure(hv0.size()));
     HIPCHK(ctx, ctx->dout_v.ensure(P * NP));
-    HIPCHK(ctx, ctx->dout_H.ensure(P * nw));
-    HIPCHK(ctx, ctx->dout_chi2.ensure(P));
-    HIPCHK(ctx, ctx->dout_S.ensure(P));
-    HIPCHK(ctx, ctx->dout_Q.ensure(P));
+    HIPCHK(ctx, ctx->dout_pack.ensure(P * nw + 3 * P));
+    ctx->result_buffer = 0;
+    ctx->dout_H.p = ctx->dout_pack.p;
+    ctx->dout_chi2.p = ctx->dout_pack.p + P * nw;
+    ctx->dout_S.p = ctx->dout_chi2.p + P;
+    ctx->dout_Q.p = ctx->dout_S.p + P;
     HIPCHK(ctx, ctx->dout_niter.ensure(P));
     HIPCHK(ctx, ctx->dout_conv.ensure(P));
     HIPCHK(ctx, ctx->dout_nevals.ensure(P));
@@ -697,6 +702,19 @@ int mxe_result_device_ptrs(mxe_ctx* ctx, void** d_H, void** d_chi2, void** d_S, 
 }
 
 int mxe_ns_padded(mxe_ctx* ctx) { return ctx ? ctx->NP : MXE_ERR_ARG; }
+
+int mxe_set_result_buffer(mxe_ctx* ctx, int which)
+{
+    if (!ctx || (which != 0 && which != 1)) return MXE_ERR_ARG;
+    if (!ctx->chains_ready) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)ctx->n_chain * ctx->n_alpha, nw = ctx->n_omega;
+    if (which == 1) HIPCHK(ctx, ctx->dout_pack2.ensure(P * nw + 3 * P));
+    double* base = which ? ctx->dout_pack2.p : ctx->dout_pack.p;
+    ctx->result_buffer = which;
+    ctx->dout_H.p = base; ctx->dout_chi2.p = base + P * nw; ctx->dout_S.p = ctx->dout_chi2.p + P; ctx->dout_Q.p = ctx->dout_S.p + P;
+    return MXE_OK;
+}
 
 int mxe_last_kernel_ms(mxe_ctx* ctx, float* ms)
 {

@@ -75,6 +75,7 @@ SYMBOLS = [
                                         _ip]),
     ('mxe_result_device_ptrs', ctypes.c_int, [_vp] + [ctypes.POINTER(_vp)] * 7),
     ('mxe_ns_padded', ctypes.c_int, [_vp]),
+    ('mxe_set_result_buffer', ctypes.c_int, [_vp, ctypes.c_int]),
     ('mxe_last_kernel_ms', ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     ('mxe_last_launch_info', ctypes.c_int, [_vp] +
      [ctypes.POINTER(ctypes.c_int)] * 3),
@@ -306,6 +307,10 @@ class DeviceContext(object):
                     'mxe_last_launch_info')
         return dict(waves_per_chain=a.value, n_workgroups=b.value,
                     lds_bytes=c.value)
+
+    def set_result_buffer(self, which):
+        self._check(self._lib.mxe_set_result_buffer(self._h, int(which)),
+                    'mxe_set_result_buffer')
 
     def result_device_ptrs(self):
         ptrs = [_vp(None) for _ in range(7)]
