@@ -1,0 +1,117 @@
+"""GPU tests at BASELINE.json's full sizes through size-independent properties
+(the oracle cannot run 25 600 alpha-solves in seconds): convergence of every
+problem, stationarity of the returned points, symmetry, invariance under the
+way the library cuts and schedules the alpha scans, and agreement with the
+extended-precision truth on a sample."""
+import numpy as np
+import pytest
+
+import bench
+from maxent_amd import device
+from oracle import sform as SF, hp_truth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def cfg4():
+    batch = bench.build_batch(16, 200, 500, 100, 0)
+    ctx = bench.stage(batch, 0)
+    out = ctx.solve_chains(np.arange(256, dtype=np.int32), batch['alphas'], batch['v0'])
+    info = ctx.last_launch_info()
+    yield batch, ctx, out, info
+    ctx.close()
+
+
+def test_cfg4_all_converged_and_finite(cfg4):
+    batch, ctx, out, info = cfg4
+    assert out['converged'].all() and out['converged'].shape == (256, 100)
+    for k in ('H', 'v', 'chi2', 'S', 'Q'):
+        assert np.all(np.isfinite(out[k])), k
+    assert info['waves_per_chain'] == 4 and info['n_workgroups'] == 256     # lock-step layout, persistent grid
+    assert out['n_iter'].max() < 60 and 2.5 < out['n_iter'].mean() < 5.0
+    # chi2 decreases and the entropy becomes more negative as alpha decreases
+    assert np.all(np.diff(out['chi2'], axis=1) < 1e-9 * out['chi2'][:, 1:])
+    assert np.all(np.diff(out['S'], axis=1) < 1e-12)
+    np.testing.assert_allclose(out['Q'], 0.5 * out['chi2'] - batch['alphas'][None, :] * out['S'], rtol=1e-12)
+
+
+def test_cfg4_symmetric_input_gives_symmetric_output(cfg4):
+    """G_ij = G_ji (symmetrised noise): chains (i,j) and (j,i) are solved by
+    different slots / pieces and must agree to the convergence level."""
+    batch, ctx, out, info = cfg4
+    H = out['H'].reshape(16, 16, 100, 500)
+    chi2 = out['chi2'].reshape(16, 16, 100)
+    num = np.linalg.norm(H - H.transpose(1, 0, 2, 3), axis=-1)
+    den = np.linalg.norm(H, axis=-1)
+    assert (num / den).max() < 1e-8
+    np.testing.assert_allclose(chi2, chi2.transpose(1, 0, 2), rtol=1e-9)
+
+
+def test_cfg4_stationarity_and_truth_on_a_sample(cfg4):
+    """at the returned v the singular-space gradient W g vanishes (oracle
+    S-form evaluation) and H equals the extended-precision fixed point."""
+    batch, ctx, out, info = cfg4
+    K = batch['K']
+    basis = SF.Basis(K.U, K.S, K.V, batch['err'])
+    rng = np.random.RandomState(7)
+    worst = 0.0
+    for c in [0, 1, 16, 17, 100, 255] + list(rng.randint(0, 256, 4)):
+        i, j = batch['elems'][c]
+        ent = 'normal' if batch['kinds'][c] == device.ENTROPY_NORMAL else 'plusminus'
+        el = SF.Element(basis, batch['Gmat'][i, j], batch['D'], ent)
+        for ia in (0, 37, 87, 99):
+            a, v = batch['alphas'][ia], out['v'][c, ia]
+            ev = SF.evaluate(basis, el, a, basis.from_v(v))
+            assert np.linalg.norm(ev['H'] - out['H'][c, ia]) / np.linalg.norm(ev['H']) < 1e-11
+            assert abs(ev['chi2'] - out['chi2'][c, ia]) / ev['chi2'] < 1e-10
+            g = basis.c * ev['rho'] + a * basis.from_v(v)
+            d = SF.gram(basis, ev['w']) @ g
+            scale = SF.gram(basis, ev['w']) @ (np.abs(basis.c * ev['rho']) + a * np.abs(basis.from_v(v)))
+            assert np.max(np.abs(d)) < 1e-6 * np.max(scale) + 1e-7
+            _, Ht = hp_truth.polish(np.array(K.K), batch['Gmat'][i, j], batch['err'], batch['D'], K.V, K.S,
+                                    a, v, ent, iters=4)
+            worst = max(worst, np.linalg.norm(out['H'][c, ia] - Ht) / np.linalg.norm(Ht))
+    assert worst < 1e-6, worst
+
+
+@pytest.mark.parametrize('opts', [dict(alpha_split=1, chains_per_wg=1), dict(alpha_split=4, chains_per_wg=1),
+                                  dict(alpha_split=3, chains_per_wg=4), dict(alpha_split=16, chains_per_wg=4)])
+def test_cfg4_invariant_under_scheduling(cfg4, opts):
+    """cutting the alpha scans into cold-started pieces and the workgroup
+    layout must not change the per-alpha answers."""
+    batch, ctx, out, info = cfg4
+    other = ctx.solve_chains(np.arange(256, dtype=np.int32), batch['alphas'], batch['v0'],
+                             device.default_opts(**opts), want_v=False)
+    assert other['converged'].all()
+    e = np.linalg.norm(other['H'] - out['H'], axis=-1) / np.linalg.norm(out['H'], axis=-1)
+    assert e.max() < 1e-8, e.max()
+    np.testing.assert_allclose(other['chi2'], out['chi2'], rtol=1e-9)
+    np.testing.assert_allclose(other['S'], out['S'], rtol=1e-8, atol=1e-12)
+
+
+def test_cfg3_elementwise_api_matches_direct_batch():
+    """cfg3 (4x4 elements x 100 alpha) through ElementwiseMaxEnt equals the same
+    problems handed to the C-ABI directly."""
+    import maxent_amd as mx
+    batch = bench.build_batch(4, 200, 500, 100, 0)
+    ctx = bench.stage(batch, 0)
+    direct = ctx.solve_chains(np.arange(16, dtype=np.int32), batch['alphas'], batch['v0'], want_v=False)
+    ctx.close()
+    ew = mx.ElementwiseMaxEnt(use_hermiticity=False)
+    ew.set_verbosity(mx.VerbosityFlags.Quiet)
+    ew.set_G_tau_data(batch['tau'], batch['Gmat'])
+    ew.omega = batch['omega']
+    ew.alpha_mesh = mx.LogAlphaMesh(alpha_min=1e-2, alpha_max=1e4, n_points=100)
+    ew.set_error(1e-4)
+    res = ew.run()
+    assert res.A.shape == (4, 4, 100, 500) and not np.any(np.isnan(res.A))
+    H = direct['H'].reshape(4, 4, 100, 500)
+    e = np.linalg.norm(res.H - H, axis=-1) / np.linalg.norm(H, axis=-1)
+    assert e.max() < 1e-8
+    np.testing.assert_allclose(res.A, res.H / batch['omega'].delta, rtol=1e-14)
+    assert res.A_out.shape == (4, 4, 500)
+    # diagonal spectra are normalised, off-diagonal ones integrate to ~0
+    w = np.asarray(batch['omega'])
+    for i in range(4):
+        assert abs(np.trapezoid(res.A_out[i, i], w) - 1) < 2e-2
