@@ -59,7 +59,7 @@ struct mxe_ctx {
     int n_chain = 0, n_alpha = 0;
     std::vector<int> chain_elem;      // per parent chain
     std::vector<int> sub_elem, sub_prob0, sub_len, sub_v0, wg_chains;   // per launched (sub-)chain
-    int n_sub = 0, n_wg = 0, mc_na = 0, n_queue = 0;
+    int n_sub = 0, n_wg = 0, mc_na = 0, mc_nwv = 4, n_queue = 0;
     std::vector<int> queue;
     mxe_opts opts;
     bool chains_ready = false, launched = false;
@@ -208,6 +208,12 @@ int upload_bases(mxe_ctx* ctx)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->ds_dirty = false;
     return MXE_OK;
+}
+
+size_t mc_lds_doubles(int NA, int nwp, int NWV)
+{
+    return (size_t)4 * NA * (NA + 1) + 6 * 4 * 64 + 2 * 64 + 64 * 4 + (size_t)NWV * 4 * 64 + (size_t)NWV * 32 +
+           (size_t)3 * nwp * 4;
 }
 
 size_t lds_doubles(int NP, int nwp, int NW)
@@ -476,9 +482,9 @@ int mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
         }
         if (worst32 <= 1e-2) ctx->mc_na = 32; else if (worst48 <= 1e-2) ctx->mc_na = 48; else layout = 1;
         if (layout == 4) {
-            const size_t doubles = (size_t)4 * ctx->mc_na * (ctx->mc_na + 1) + 6 * 4 * 64 + 2 * 64 + 64 * 4 + 4 * 4 * 64 + 4 * 32 +
-                                   (size_t)3 * ctx->nwp * 4;
-            if (doubles * sizeof(double) > 160 * 1024 - 256) { layout = 1; ctx->mc_na = 0; }
+            ctx->mc_nwv = (o.waves_per_chain == 8) ? 8 : 4;
+            if (mc_lds_doubles(ctx->mc_na, ctx->nwp, ctx->mc_nwv) * sizeof(double) > 160 * 1024 - 256) ctx->mc_nwv = 4;
+            if (mc_lds_doubles(ctx->mc_na, ctx->nwp, ctx->mc_nwv) * sizeof(double) > 160 * 1024 - 256) { layout = 1; ctx->mc_na = 0; }
         }
     }
     ctx->wg_chains.clear(); ctx->queue.clear(); ctx->n_queue = 0;
@@ -584,23 +590,22 @@ int mxe_chains_launch(mxe_ctx* ctx)
     hipError_t e;
     if (ctx->mc_na > 0) {
         // four chains per workgroup, lock-step (mxe_kernel_mc.hip.h)
-        const int NA = ctx->mc_na;
-        const size_t doubles = (size_t)4 * NA * (NA + 1) + 6 * 4 * 64 + 2 * 64 + 64 * 4 + 4 * 4 * 64 + 4 * 32 +
-                               (size_t)3 * ctx->nwp * 4;
-        const size_t lds = doubles * sizeof(double);
+        const int NA = ctx->mc_na, NWV = ctx->mc_nwv;
+        const size_t lds = mc_lds_doubles(NA, ctx->nwp, NWV) * sizeof(double);
         if (lds > 160 * 1024 - 256) return MXE_ERR_LIMIT;
         mxe::MCExtra ex; ex.wg_chains = ctx->dwg_chains.p; ex.n_wg = ctx->n_wg;
         ex.queue = ctx->dqueue.p; ex.n_queue = ctx->n_queue; ex.counter = ctx->dcounter.p;
         HIPCHK(ctx, hipMemsetAsync(ctx->dcounter.p, 0, sizeof(int), ctx->stream));
-        ctx->last_nw = 4; ctx->last_lds = (int)lds;
+        ctx->last_nw = NWV; ctx->last_lds = (int)lds;
         HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-        if (NA == 32) {
-            e = hipFuncSetAttribute((const void*)mxe::chain_kernel_mc<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<32>), dim3(ctx->n_wg), dim3(256), lds, ctx->stream, kp, ex); e = hipGetLastError(); }
-        } else {
-            e = hipFuncSetAttribute((const void*)mxe::chain_kernel_mc<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<48>), dim3(ctx->n_wg), dim3(256), lds, ctx->stream, kp, ex); e = hipGetLastError(); }
-        }
+#define MXE_LAUNCH_MC(NA_, NWV_) do { \
+        e = hipFuncSetAttribute((const void*)mxe::chain_kernel_mc<NA_, NWV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<NA_, NWV_>), dim3(ctx->n_wg), dim3(64 * NWV_), lds, ctx->stream, kp, ex); e = hipGetLastError(); } } while (0)
+        if (NA == 32 && NWV == 4) MXE_LAUNCH_MC(32, 4);
+        else if (NA == 32) MXE_LAUNCH_MC(32, 8);
+        else if (NWV == 4) MXE_LAUNCH_MC(48, 4);
+        else MXE_LAUNCH_MC(48, 8);
+#undef MXE_LAUNCH_MC
         HIPCHK(ctx, e);
     } else {
         int NW = o.waves_per_chain;

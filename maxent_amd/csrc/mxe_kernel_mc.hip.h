@@ -38,12 +38,16 @@ struct MCExtra {
     int* counter;                 //   next queue position (zeroed before every launch)
 };
 
-template <int NA>                 // capacity of the active block: 32 or 48
-__global__ __launch_bounds__(64 * MCC)
+// NA  capacity of the active block: 32 or 48
+// NWV wavefronts per workgroup: 4 (the home waves) or 8 (4 home + 4 helper waves that
+//     take half of the rows of the two streaming passes: two waves per SIMD there)
+template <int NA, int NWV>
+__global__ __launch_bounds__(64 * NWV)
 void chain_kernel_mc(const KParams p, const MCExtra x)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int T = 64 * MCC;
+    constexpr int T = 64 * NWV;
+    constexpr int RPT = (NWV == 4) ? 2 : 1;       // omega rows per thread in the row pass
     constexpr int NP = 64;
     constexpr int LD = NA + 1;
     constexpr int NT = NA / 16;                   // 16-column tiles of the Gram block
@@ -65,9 +69,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     double* cc   = dlc + MCC * NP;               // [NP]
     double* ci   = cc + NP;                      // [NP]
     double* vecI = ci + NP;                      // [NP][MCC]   step / v, chain minor (row-pass operand)
-    double* hpart = vecI + NP * MCC;             // [MCC waves][MCC chains][NP]
-    double* red  = hpart + MCC * MCC * NP;       // [MCC waves][32]
-    double* ui   = red + MCC * 32;               // [nwp][MCC]
+    double* hpart = vecI + NP * MCC;             // [NWV waves][MCC chains][NP]
+    double* red  = hpart + NWV * MCC * NP;       // [NWV waves][32]
+    double* ui   = red + NWV * 32;               // [nwp][MCC]
     double* wi   = ui + (size_t)nwp * MCC;       // [nwp][MCC]
     double* Hi   = wi + (size_t)nwp * MCC;       // [nwp][MCC]
     __shared__ int s_elem[MCC], s_act[MCC], s_scr[MCC], s_exh, s_new;
@@ -95,7 +99,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     // ---- first pieces ----
     if (tid == 0) { s_exh = dynamic ? 0 : 1; s_new = 0; }
     __syncthreads();
-    {
+    if (wave < MCC) {
         int c;
         if (dynamic) {
             int idx = 0;
@@ -111,8 +115,8 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             gh[wave * NP + lane] = 0.0; vv[wave * NP + lane] = 0.0;
             if (lane == 0) { s_elem[wave] = -1; s_act[wave] = 0; s_scr[wave] = 1; }
         }
+        dlc[wave * NP + lane] = 0.0;
     }
-    dlc[wave * NP + lane] = 0.0;
     __syncthreads();
     int any_elem = -1;
 #pragma unroll
@@ -214,7 +218,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             __syncthreads();                     // everybody has read s_exh / s_new
             if (tid == 0) s_new = 0;
             __syncthreads();
-            if (!my_active) {
+            if (wave < MCC && !my_active) {
                 int idx = 0;
                 if (lane == 0) idx = atomicAdd(x.counter, 1);
                 idx = __builtin_amdgcn_readfirstlane(idx);
@@ -227,7 +231,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         if (!(s_act[0] | s_act[1] | s_act[2] | s_act[3])) break;      // uniform: LDS flags behind a barrier
 
         // ---- 1. home wave: right-hand side, active block, factorise, solve, step ----
-        {
+        if (wave < MCC) {
             const int q = wave, k = lane;
             int okflag = 0;
             double dk = 0.0;
@@ -275,23 +279,32 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             double pS[MCC], pdH[MCC], pHn[MCC], pwm[MCC];
 #pragma unroll
             for (int q = 0; q < MCC; ++q) { pS[q] = 0.0; pdH[q] = 0.0; pHn[q] = 0.0; pwm[q] = 0.0; }
-            for (int i = 2 * tid; i < nwp; i += 2 * T) {
-                double a[MCC][2];
+            for (int i = RPT * tid; i < nwp; i += RPT * T) {
+                double a[MCC][RPT];
 #pragma unroll
-                for (int q = 0; q < MCC; ++q) { a[q][0] = 0.0; a[q][1] = 0.0; }
+                for (int q = 0; q < MCC; ++q)
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) a[q][r] = 0.0;
                 const double* col = Vt + i;
 #pragma unroll 4
                 for (int k = 0; k < ns; ++k) {
-                    const double2 xv = *reinterpret_cast<const double2*>(col + (size_t)k * nwp);
+                    double xr[RPT];
+                    if (RPT == 2) {
+                        const double2 xv = *reinterpret_cast<const double2*>(col + (size_t)k * nwp);
+                        xr[0] = xv.x; xr[RPT - 1] = xv.y;
+                    } else {
+                        xr[0] = col[(size_t)k * nwp];
+                    }
                     const double2 d01 = *reinterpret_cast<const double2*>(vecI + k * MCC);
                     const double2 d23 = *reinterpret_cast<const double2*>(vecI + k * MCC + 2);
-                    a[0][0] = fma(xv.x, d01.x, a[0][0]); a[0][1] = fma(xv.y, d01.x, a[0][1]);
-                    a[1][0] = fma(xv.x, d01.y, a[1][0]); a[1][1] = fma(xv.y, d01.y, a[1][1]);
-                    a[2][0] = fma(xv.x, d23.x, a[2][0]); a[2][1] = fma(xv.y, d23.x, a[2][1]);
-                    a[3][0] = fma(xv.x, d23.y, a[3][0]); a[3][1] = fma(xv.y, d23.y, a[3][1]);
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) {
+                        a[0][r] = fma(xr[r], d01.x, a[0][r]); a[1][r] = fma(xr[r], d01.y, a[1][r]);
+                        a[2][r] = fma(xr[r], d23.x, a[2][r]); a[3][r] = fma(xr[r], d23.y, a[3][r]);
+                    }
                 }
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
+                for (int r = 0; r < RPT; ++r) {
                     const int ii = i + r;
                     double un[MCC], wn[MCC], Hn_[MCC];
 #pragma unroll
@@ -399,19 +412,33 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                 }
             };
-            // n_groups is a multiple of 16 and the waves take groups wave, wave+4, ...:
-            // every wave has a multiple of four groups
+            // the waves take groups wave, wave + NWV, ...; the register sets rotate
+            // (four with one wave per SIMD; two with two waves per SIMD, where the
+            // other wave covers the latency and registers are halved)
+            constexpr int ST = NWV;
             int g = wave;
-            load_group(fA, hA, g); load_group(fB, hB, g + MCC); load_group(fC, hC, g + 2 * MCC);
-            for (; g < n_groups; g += 4 * MCC) {
-                load_group(fD, hD, g + 3 * MCC);
-                consume(fA, hA);
-                if (g + 4 * MCC < n_groups) load_group(fA, hA, g + 4 * MCC);
-                consume(fB, hB);
-                if (g + 5 * MCC < n_groups) load_group(fB, hB, g + 5 * MCC);
-                consume(fC, hC);
-                if (g + 6 * MCC < n_groups) load_group(fC, hC, g + 6 * MCC);
-                consume(fD, hD);
+            if (NWV == 4) {
+                if (g < n_groups) load_group(fA, hA, g);
+                if (g + ST < n_groups) load_group(fB, hB, g + ST);
+                if (g + 2 * ST < n_groups) load_group(fC, hC, g + 2 * ST);
+                for (; g < n_groups; g += 4 * ST) {
+                    if (g + 3 * ST < n_groups) load_group(fD, hD, g + 3 * ST);
+                    consume(fA, hA);
+                    if (g + 4 * ST < n_groups) load_group(fA, hA, g + 4 * ST);
+                    if (g + ST < n_groups) consume(fB, hB);
+                    if (g + 5 * ST < n_groups) load_group(fB, hB, g + 5 * ST);
+                    if (g + 2 * ST < n_groups) consume(fC, hC);
+                    if (g + 6 * ST < n_groups) load_group(fC, hC, g + 6 * ST);
+                    if (g + 3 * ST < n_groups) consume(fD, hD);
+                }
+            } else {
+                if (g < n_groups) load_group(fA, hA, g);
+                for (; g < n_groups; g += 2 * ST) {
+                    if (g + ST < n_groups) load_group(fB, hB, g + ST);
+                    consume(fA, hA);
+                    if (g + 2 * ST < n_groups) load_group(fA, hA, g + 2 * ST);
+                    if (g + ST < n_groups) consume(fB, hB);
+                }
             }
             // h: sum the four row-residue lane groups, then (in step 4) the waves
 #pragma unroll
@@ -423,11 +450,11 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     v_ += __shfl_xor(v_, 32, WAVE);
                     if (kq == 0) hpart[(wave * MCC + c) * NP + 16 * t + cn] = v_;
                 }
-            // Gram tiles: four rotating phases (wave wv adds into chain (wv + phase) mod 4)
-            for (int ph = 0; ph < MCC; ++ph) {
+            // Gram tiles: rotating phases (in phase ph wave w adds into chain (w + ph) mod NWV if < 4)
+            for (int ph = 0; ph < NWV; ++ph) {
 #pragma unroll
                 for (int c = 0; c < MCC; ++c) {
-                    if (((c - wave) & (MCC - 1)) == ph) {
+                    if (((c - wave) & (NWV - 1)) == ph) {
                         double* Wq = Wm + (size_t)c * NA * LD;
                         int pr = 0;
 #pragma unroll
@@ -450,16 +477,16 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         MXE_STAMP(4);
 
         // ---- 4. home wave: rho, sums, accept / converge / advance, results ----
-        {
+        if (wave < MCC) {
             const int q = wave, k = lane;
             double h = 0.0;
 #pragma unroll
-            for (int wv = 0; wv < MCC; ++wv) h += hpart[(wv * MCC + q) * NP + k];
+            for (int wv = 0; wv < NWV; ++wv) h += hpart[(wv * MCC + q) * NP + k];
             const double r = (k < ns) ? cc[k] * h - gh[q * NP + k] : 0.0;
             const double r2 = wave_sum(r * r);
             double sS = 0.0, sdH = 0.0, sHn = 0.0, swm = 0.0;
 #pragma unroll
-            for (int wv = 0; wv < MCC; ++wv) {
+            for (int wv = 0; wv < NWV; ++wv) {
                 sS += red[wv * 32 + q * 4 + 0]; sdH += red[wv * 32 + q * 4 + 1];
                 sHn += red[wv * 32 + q * 4 + 2]; swm = fmax(swm, red[wv * 32 + q * 4 + 3]);
             }

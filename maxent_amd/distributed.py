@@ -82,7 +82,7 @@ def solve_elements_sharded(K, specs, minimizer, solve_fn=None, device_id=None,
         block = parts[r].cpu().numpy()
         for n, i in enumerate(shard_indices(len(specs), world, r)):
             b = block[n]
-            out[i] = dict(alpha=np.asarray(specs[i]['alpha'], dtype=float),
+            out[i] = dict(alpha=np.asarray(specs[i]['alpha'], dtype=float), A=None,
                           H=b[:, :n_omega].copy(),
                           v=b[:, n_omega:n_omega + n_s].copy(),
                           chi2=b[:, n_omega + n_s + 0].copy(),

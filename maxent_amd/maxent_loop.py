@@ -81,11 +81,18 @@ def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0):
                                opts)
         info = dict(kernel_ms=ctx.last_kernel_ms())
         info.update(ctx.last_launch_info())
+        # output map A = B H on the device when every element shares it
+        # (PreblurA_of_H.f, reference functions.py:999-1001)
+        A_dev = None
+        B0 = specs[0].get('A_matrix')
+        if B0 is not None and all(s.get('A_matrix') is B0 for s in specs):
+            A_dev = ctx.apply_output_map(B0)
     finally:
         ctx.close()
     res = []
     for c, s in enumerate(specs):
         res.append(dict(alpha=np.asarray(s['alpha'], dtype=float),
+                        A=(None if A_dev is None else A_dev[c]),
                         v=out['v'][c], H=out['H'][c], chi2=out['chi2'][c],
                         S=out['S'][c], Q=out['Q'][c],
                         n_iter=out['n_iter'][c],
@@ -195,11 +202,14 @@ class MaxEntLoop(object):
                     scale_alpha=scale,
                     G_orig=np.array(self.cost_function.G_orig, dtype=float),
                     data_variable=np.array(self.data_variable, dtype=float),
+                    A_matrix=self.A_of_H.matrix(),
                     T=K._T)
 
     def make_record(self, spec, sol):
         """MaxEntResult arrays of one finished scan (maxent_result.py:835-967)."""
-        A = self.A_of_H.f(sol['H'])
+        A = sol.get('A')
+        if A is None:
+            A = self.A_of_H.f(sol['H'])
         rec = dict(sol)
         rec['A'] = A
         rec['G'] = spec['G']

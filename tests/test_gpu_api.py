@@ -251,3 +251,43 @@ def test_single_minimize_call_and_reference_stopping_rule():
     assert tm.minimizer.converged and tm.minimizer.n_iter_last >= 1
     H = cf.H_of_v.f(v)
     assert np.linalg.norm(H - g['H_truth'][3]) / np.linalg.norm(g['H_truth'][3]) < 1e-4
+
+
+def test_cfg5_matrix_with_preblurred_offdiagonals():
+    """BASELINE cfg5 (fp64 part): 8x8 matrix G, off-diagonal worker with
+    PreblurKernel + PreblurA_of_H (plus-minus entropy), diagonal worker plain.
+    Two elements are checked against the oracle port run on the host, the
+    rest through structural properties."""
+    from maxent_amd import synthetic
+    from oracle import ref_numpy as R, hp_truth
+    n_tau, n_w, n_alpha, b = 100, 200, 20, 0.1
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(8, n_tau, n_w)
+    ew = mx.ElementwiseMaxEnt(use_hermiticity=True)
+    ew.set_verbosity(mx.VerbosityFlags.Quiet)
+    ew.set_G_tau_data(tau, Gmat)
+    ew.omega = omega
+    ew.alpha_mesh = mx.LogAlphaMesh(alpha_min=1e-2, alpha_max=1e4, n_points=n_alpha)
+    ew.set_error(1e-4)
+    off = ew.maxent_offdiagonal
+    off.A_of_H = mx.PreblurA_of_H(b=b, omega=off.omega)
+    off.K = mx.PreblurKernel(K=off.K, b=b)
+    res = ew.run()
+    assert res.A.shape == (8, 8, n_alpha, n_w) and not np.any(np.isnan(res.A))
+    assert np.all(res.converged[~np.isnan(res.converged)] == 1)
+    np.testing.assert_array_equal(res.A[3, 1], res.A[1, 3])          # hermitian mirror
+    B = off.A_of_H.matrix()
+    np.testing.assert_allclose(res.A[0, 2], res.H[0, 2] @ B.T, rtol=1e-11, atol=1e-13)   # device output map
+    np.testing.assert_allclose(res.A[2, 2], res.H[2, 2] / omega.delta, rtol=1e-14)
+    mesh = np.asarray(ew.alpha_mesh)
+    for (i, j), ent in (((2, 2), 'normal'), ((0, 2), 'plusminus')):
+        p, delta, Bp, _ = R.make_tau_problem(tau, np.asarray(omega), Gmat[i, j], 1e-4, beta=synthetic.BETA,
+                                             entropy=ent, preblur_b=(b if i != j else None))
+        ref = R.alpha_loop(p, delta, mesh, A_of_H=Bp)
+        assert rel_l2(res.H[i, j], ref['H']).max() < REF_SPREAD
+        assert rel_l2(res.A[i, j], ref['A']).max() < REF_SPREAD
+        np.testing.assert_allclose(res.chi2[i, j], ref['chi2'], rtol=REF_SPREAD)
+        worst = 0.0
+        for ia in (0, n_alpha // 2, n_alpha - 1):
+            _, Ht = hp_truth.polish(p.K, p.G, p.err, p.D, p.V, p.S, ref['alpha'][ia], ref['v'][ia], ent, iters=5)
+            worst = max(worst, np.linalg.norm(res.H[i, j, ia] - Ht) / np.linalg.norm(Ht))
+        assert worst < GATE, worst
