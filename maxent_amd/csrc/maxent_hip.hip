@@ -583,8 +583,8 @@ int mxe_chains_launch(mxe_ctx* ctx)
     kp.theta = o.decouple_tol; kp.out_nact = ctx->dout_nact.p;
     kp.prof = nullptr;
 #ifdef MXE_PROFILE
-    HIPCHK(ctx, ctx->dprof.ensure((size_t)ctx->n_sub * 8));
-    HIPCHK(ctx, hipMemsetAsync(ctx->dprof.p, 0, (size_t)ctx->n_sub * 64, ctx->stream));
+    HIPCHK(ctx, ctx->dprof.ensure(((size_t)ctx->n_sub + 8 * 1024) * 8));   // rows: chain (v2) or workgroup*8 + wave (lock-step)
+    HIPCHK(ctx, hipMemsetAsync(ctx->dprof.p, 0, ((size_t)ctx->n_sub + 8 * 1024) * 64, ctx->stream));
     kp.prof = ctx->dprof.p;
 #endif
     hipError_t e;
@@ -744,11 +744,11 @@ int mxe_last_launch_info(mxe_ctx* ctx, int* waves_per_chain, int* n_workgroups, 
 
 #ifdef MXE_PROFILE
 // diagnostic build only: per-chain phase cycle counters of the last launch
-extern "C" int mxe_prof_fetch(mxe_ctx* ctx, long long* out /*[n_chain][8]*/)
+extern "C" int mxe_prof_fetch(mxe_ctx* ctx, long long* out /*[n_sub + 8192][8]*/)
 {
     if (!ctx || !out) return MXE_ERR_ARG;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipMemcpy(out, ctx->dprof.p, (size_t)ctx->n_sub * 64, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out, ctx->dprof.p, ((size_t)ctx->n_sub + 8 * 1024) * 64, hipMemcpyDeviceToHost));
     return MXE_OK;
 }
 #endif

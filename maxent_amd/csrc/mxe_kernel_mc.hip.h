@@ -74,32 +74,54 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     double* ui   = red + NWV * 32;               // [nwp][MCC]
     double* wi   = ui + (size_t)nwp * MCC;       // [nwp][MCC]
     double* Hi   = wi + (size_t)nwp * MCC;       // [nwp][MCC]
-    __shared__ int s_elem[MCC], s_act[MCC], s_scr[MCC], s_exh, s_new;
+    __shared__ int s_elem[MCC], s_kind[MCC], s_act[MCC], s_scr[MCC], s_exh;
 
-    // ---- slot state: lives in the registers of the home wave only ----
-    int my_elem = 0, my_prob0 = 0, my_clen = 0, my_ia = 0, my_niter = 0, my_nevals = 0, my_nact = 0;
-    double my_alpha = 1.0, my_mu = 0.0, my_chi2 = 0.0, my_S = 0.0, my_Hn2 = 1.0, my_wmax = 1.0, my_Q = 0.0;
-    double my_Qprev = __builtin_nan(""), my_cperp = 0.0, my_steplim = 0.0;
-    bool my_active = false, my_scratch = false;
-
-    auto start_piece = [&](int c) {              // home wave: take chain (piece) c into this slot
-        my_elem = p.chain_elem[c];
-        my_cperp = p.cperp[my_elem];
-        my_steplim = p.step_max * p.sumD[my_elem];
-        my_prob0 = p.chain_prob0[c]; my_clen = p.chain_len[c];
-        my_ia = 0; my_niter = 0; my_nevals = 0; my_nact = 0;
-        my_alpha = p.alpha[(size_t)my_prob0];
-        my_mu = 0.0; my_Qprev = __builtin_nan("");
-        my_active = true; my_scratch = true;
-        gh[wave * NP + lane] = p.ghat[(size_t)my_elem * NP + lane];
+    // ---- slot state.  It is owned by the home wave, which loads it from LDS at the
+    //      start of its two sections of a round and stores it back at their end, so
+    //      that no register is pinned by it during the two streaming passes. ----
+    struct Slot {
+        double alpha, mu, chi2, S, Hn2, wmax, Q, Qprev, cperp, steplim;
+        int elem, prob0, clen, ia, niter, nevals, nact, active, scratch, okprev;
+    };
+    __shared__ double s_sd[MCC][10];
+    __shared__ int s_si[MCC][10];
+    auto load_slot = [&](Slot& t) {
+        const double* d = s_sd[wave]; const int* n = s_si[wave];
+        t.alpha = d[0]; t.mu = d[1]; t.chi2 = d[2]; t.S = d[3]; t.Hn2 = d[4]; t.wmax = d[5];
+        t.Q = d[6]; t.Qprev = d[7]; t.cperp = d[8]; t.steplim = d[9];
+        t.elem = n[0]; t.prob0 = n[1]; t.clen = n[2]; t.ia = n[3]; t.niter = n[4]; t.nevals = n[5];
+        t.nact = n[6]; t.active = n[7]; t.scratch = n[8]; t.okprev = n[9];
+    };
+    auto store_slot = [&](const Slot& t) {
+        if (lane == 0) {
+            double* d = s_sd[wave]; int* n = s_si[wave];
+            d[0] = t.alpha; d[1] = t.mu; d[2] = t.chi2; d[3] = t.S; d[4] = t.Hn2; d[5] = t.wmax;
+            d[6] = t.Q; d[7] = t.Qprev; d[8] = t.cperp; d[9] = t.steplim;
+            n[0] = t.elem; n[1] = t.prob0; n[2] = t.clen; n[3] = t.ia; n[4] = t.niter; n[5] = t.nevals;
+            n[6] = t.nact; n[7] = t.active; n[8] = t.scratch; n[9] = t.okprev;
+            s_act[wave] = t.active; s_scr[wave] = t.scratch;
+        }
+        wave_sync();
+    };
+    auto start_piece = [&](Slot& t, int c) {     // home wave: take chain (piece) c into this slot
+        t.elem = p.chain_elem[c];
+        t.cperp = p.cperp[t.elem];
+        t.steplim = p.step_max * p.sumD[t.elem];
+        t.prob0 = p.chain_prob0[c]; t.clen = p.chain_len[c];
+        t.ia = 0; t.niter = 0; t.nevals = 0; t.nact = 0; t.okprev = 0;
+        t.alpha = p.alpha[(size_t)t.prob0];
+        t.mu = 0.0; t.Qprev = __builtin_nan("");
+        t.chi2 = 0.0; t.S = 0.0; t.Hn2 = 1.0; t.wmax = 1.0; t.Q = 0.0;
+        t.active = 1; t.scratch = 1;
+        gh[wave * NP + lane] = p.ghat[(size_t)t.elem * NP + lane];
         vv[wave * NP + lane] = p.v0[(size_t)p.chain_v0[c] * NP + lane];
-        if (lane == 0) { s_elem[wave] = my_elem; s_act[wave] = 1; s_scr[wave] = 1; s_new = 1; }
+        if (lane == 0) { s_elem[wave] = t.elem; s_kind[wave] = p.elem_kind[t.elem]; }
     };
 
     // ---- first pieces ----
-    if (tid == 0) { s_exh = dynamic ? 0 : 1; s_new = 0; }
-    __syncthreads();
+    if (tid == 0) s_exh = dynamic ? 0 : 1;
     if (wave < MCC) {
+        Slot t;
         int c;
         if (dynamic) {
             int idx = 0;
@@ -109,12 +131,14 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         } else {
             c = x.wg_chains[blockIdx.x * MCC + wave];
         }
-        if (c >= 0) start_piece(c);
+        if (c >= 0) start_piece(t, c);
         else {
             // empty slot: evaluates v = 0 of a neighbour's element every round (finite, never used)
+            t = Slot{1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0};
             gh[wave * NP + lane] = 0.0; vv[wave * NP + lane] = 0.0;
-            if (lane == 0) { s_elem[wave] = -1; s_act[wave] = 0; s_scr[wave] = 1; }
+            if (lane == 0) { s_elem[wave] = -1; s_kind[wave] = 0; }
         }
+        store_slot(t);
         dlc[wave * NP + lane] = 0.0;
     }
     __syncthreads();
@@ -126,23 +150,23 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     const double* __restrict__ V  = p.V  + (size_t)ds * nwp * NP;
     const double* __restrict__ Vt = p.Vt + (size_t)ds * NP * nwp;
     if (wave == 0) { cc[lane] = p.c[ds * NP + lane]; ci[lane] = p.cinv[ds * NP + lane]; }
-    int kind[MCC];
-    const double* Dg[MCC];
-    auto refresh_slots = [&]() {
-#pragma unroll
-        for (int q = 0; q < MCC; ++q) {
-            const int e = (s_elem[q] >= 0) ? s_elem[q] : any_elem;
-            kind[q] = p.elem_kind[e];
-            Dg[q] = p.D + (size_t)e * nwp;
-        }
-    };
-    refresh_slots();
     __syncthreads();
 
 #ifdef MXE_PROFILE
+    // per-wave stamps (diagnostic build only): row = workgroup * 8 + wave
     long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long prof_t = clock64();
     long long prof_rounds = 0;
+#ifdef MXE_PROFILE_HOME          // split the home phase instead: everything else goes to slot 5
+#define MXE_STAMPW(idx) do { const long long t__ = clock64(); prof_acc[(idx) == 2 ? 2 : 5] += t__ - prof_t; prof_t = t__; } while (0)
+#define MXE_STAMPH(idx) do { const long long t__ = clock64(); prof_acc[idx] += t__ - prof_t; prof_t = t__; } while (0)
+#else
+#define MXE_STAMPW(idx) do { const long long t__ = clock64(); prof_acc[idx] += t__ - prof_t; prof_t = t__; } while (0)
+#define MXE_STAMPH(idx) do {} while (0)
+#endif
+#else
+#define MXE_STAMPW(idx) do {} while (0)
+#define MXE_STAMPH(idx) do {} while (0)
 #endif
 
     // ------------------------------------------------------------------
@@ -158,15 +182,24 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         const bool live = i < n_act;
         const double ci_ = live ? cc[i] : 0.0;
         double A[N];
+        {
+            // all N loads are issued back to back (clamped lane index, selected afterwards):
+            // a load under a predicate costs one LDS round trip each
+            const int ic = min(i, N - 1);
+            double wr[N];
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            double xv = 0.0;
-            if (live && j <= i && j < n_act) xv = ci_ * Wq[j * LD + i] * cc[j];
-            if (j == i) xv = live ? xv + a : 1.0;
-            A[j] = xv;
+            for (int j = 0; j < N; ++j) wr[j] = Wq[j * LD + ic];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const double cj = wave_bcast(ci_, j);        // = c_j for j < n_act, else 0
+                double xv = (j <= i) ? ci_ * wr[j] * cj : 0.0;
+                if (j == i) xv = live ? xv + a : 1.0;
+                A[j] = xv;
+            }
         }
         double b = live ? rq[i] : 0.0;
         double dinv_i = 1.0;
+        MXE_STAMPH(1);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             const double piv = wave_bcast(A[j], j);
@@ -190,64 +223,72 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        MXE_STAMPH(3);
         if (ok) {
+            // transpose L through the strictly lower triangle of the slot's W (rows >= n_act
+            // of L are unit rows; lanes >= N write nothing), then solve L^T z = y from
+            // registers: lt[j] = L[j][i]
+            if (i < N) {
 #pragma unroll
-            for (int j = 0; j < N; ++j) if (j < i && i < n_act) Wq[i * LD + j] = A[j];
+                for (int j = 0; j < N - 1; ++j) if (j < i) Wq[i * LD + j] = A[j];
+            }
             wave_sync();
+            const int ic = min(i, N - 1);
+            double lt[N];
+#pragma unroll
+            for (int j = 1; j < N; ++j) lt[j] = Wq[j * LD + ic];
             double r = b;
-            double lnext = (i < n_act - 1) ? Wq[(n_act - 1) * LD + i] : 0.0;
-            for (int j = n_act - 1; j >= 0; --j) {
-                const double lcur = lnext;
-                lnext = (j > 0 && i < j - 1) ? Wq[(j - 1) * LD + i] : 0.0;
+#pragma unroll
+            for (int j = N - 1; j >= 0; --j) {
                 const double zj = wave_bcast(r * dinv_i, j);
                 if (i == j) r = zj;
-                else if (i < j) r = fma(-lcur, zj, r);
+                else if (i < j) r = fma(-lt[j], zj, r);
             }
             if (live) zz[q * NP + i] = r;
         }
+        MXE_STAMPH(4);
         return ok;
     };
 
-    bool okflag_prev = false;                    // home wave: did this round carry a real trial step
     long long guard = 0;
     const long long guard_max = (long long)(dynamic ? x.n_queue : 1) * p.n_alpha * (p.maxiter + 64) + 64;
 
     while (guard++ < guard_max) {
         // ---- 0. idle slots take the next piece from the queue ----
         if (dynamic && s_exh == 0) {
-            __syncthreads();                     // everybody has read s_exh / s_new
-            if (tid == 0) s_new = 0;
-            __syncthreads();
-            if (wave < MCC && !my_active) {
+            __syncthreads();                     // everybody has read s_exh
+            if (wave < MCC && s_act[wave] == 0) {
                 int idx = 0;
                 if (lane == 0) idx = atomicAdd(x.counter, 1);
                 idx = __builtin_amdgcn_readfirstlane(idx);
-                if (idx < x.n_queue) start_piece(x.queue[idx]);
+                if (idx < x.n_queue) { Slot t; start_piece(t, x.queue[idx]); store_slot(t); }
                 else if (lane == 0) s_exh = 1;
             }
             __syncthreads();
-            if (s_new) refresh_slots();          // uniform: written before the barrier
         }
         if (!(s_act[0] | s_act[1] | s_act[2] | s_act[3])) break;      // uniform: LDS flags behind a barrier
 
         // ---- 1. home wave: right-hand side, active block, factorise, solve, step ----
         if (wave < MCC) {
             const int q = wave, k = lane;
+            Slot t;
+            load_slot(t);
             int okflag = 0;
             double dk = 0.0;
-            if (my_active && my_scratch) {
+            if (t.active && t.scratch) {
                 dk = vv[q * NP + k];                 // evaluation from scratch: the operand is v
-            } else if (my_active) {
-                rhs[q * NP + k] = (k < ns) ? fma(my_alpha * vv[q * NP + k], ci[k], rho[q * NP + k]) : 0.0;
-                const double thr = p.theta * my_alpha / fmax(my_wmax, 1e-300);
+            } else if (t.active) {
+                rhs[q * NP + k] = (k < ns) ? fma(t.alpha * vv[q * NP + k], ci[k], rho[q * NP + k]) : 0.0;
+                const double thr = p.theta * t.alpha / fmax(t.wmax, 1e-300);
                 const unsigned long long m = __ballot(k < ns && cc[k] * cc[k] > thr);
                 int na = (p.theta > 0.0) ? __popcll(m) : ns;
                 na = max(1, min(na, NA));
-                my_nact = na;
+                t.nact = na;
                 wave_sync();
+                MXE_STAMPH(0);
                 // damping loop: raise mu until the factorisation succeeds and Bryan's bound holds
                 while (true) {
-                    const double a = my_alpha + my_mu;
+                    const double a = t.alpha + t.mu;
                     bool ok;
                     if (na <= 16) ok = chol_home(std::integral_constant<int, 16>{}, a, na);
                     else if (na <= 24) ok = chol_home(std::integral_constant<int, 24>{}, a, na);
@@ -258,24 +299,32 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         if (k < na) { z = zz[q * NP + k]; nrm = z * (rhs[q * NP + k] - a * z); }
                         else if (k < ns) z = rhs[q * NP + k] / a;
                         nrm = wave_sum(nrm);
-                        if (nrm <= my_steplim) { okflag = 1; dk = (k < ns) ? cc[k] * z : 0.0; break; }
+                        if (nrm <= t.steplim) { okflag = 1; dk = (k < ns) ? cc[k] * z : 0.0; break; }
                     }
-                    my_mu = (my_mu == 0.0) ? p.mu_first * my_alpha : my_mu * p.mu_grow;
-                    if (!(my_mu <= p.mu_max * my_alpha)) break;
+                    t.mu = (t.mu == 0.0) ? p.mu_first * t.alpha : t.mu * p.mu_grow;
+                    if (!(t.mu <= p.mu_max * t.alpha)) break;
                 }
             }
             dlc[q * NP + k] = (okflag ? dk : 0.0);
             vecI[k * MCC + q] = dk;
-            okflag_prev = okflag != 0;
+            t.okprev = okflag;
+            store_slot(t);
+            MXE_STAMPH(6);
         }
         __syncthreads();
-        MXE_STAMP(2);
+        MXE_STAMPW(2);
 
         // ---- 2. row pass (V^T once): u, w, H of the four trial points, in place ----
         {
             bool scr[MCC];
+            int kind[MCC];
+            const double* Dg[MCC];
 #pragma unroll
-            for (int q = 0; q < MCC; ++q) scr[q] = s_scr[q] != 0;
+            for (int q = 0; q < MCC; ++q) {
+                scr[q] = s_scr[q] != 0;
+                kind[q] = s_kind[q];
+                Dg[q] = p.D + (size_t)((s_elem[q] >= 0) ? s_elem[q] : any_elem) * nwp;
+            }
             double pS[MCC], pdH[MCC], pHn[MCC], pwm[MCC];
 #pragma unroll
             for (int q = 0; q < MCC; ++q) { pS[q] = 0.0; pdH[q] = 0.0; pHn[q] = 0.0; pwm[q] = 0.0; }
@@ -286,23 +335,51 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 #pragma unroll
                     for (int r = 0; r < RPT; ++r) a[q][r] = 0.0;
                 const double* col = Vt + i;
-#pragma unroll 4
-                for (int k = 0; k < ns; ++k) {
-                    double xr[RPT];
-                    if (RPT == 2) {
-                        const double2 xv = *reinterpret_cast<const double2*>(col + (size_t)k * nwp);
-                        xr[0] = xv.x; xr[RPT - 1] = xv.y;
-                    } else {
-                        xr[0] = col[(size_t)k * nwp];
-                    }
-                    const double2 d01 = *reinterpret_cast<const double2*>(vecI + k * MCC);
-                    const double2 d23 = *reinterpret_cast<const double2*>(vecI + k * MCC + 2);
+                // chunks of KC singular directions through a ring of four register
+                // buffers; loads unconditional (rows of Vt beyond n_s are zero and exist
+                // up to NP), so that three chunks stay in flight behind the one consumed
+                constexpr int KC = 8, NCH = NP / KC;
+                double xa[KC][RPT], xb[KC][RPT], xc[KC][RPT], xd[KC][RPT];
+                auto loadc = [&](double (&xr)[KC][RPT], int ch) {
+                    const double* src = col + (size_t)(ch * KC) * nwp;
 #pragma unroll
-                    for (int r = 0; r < RPT; ++r) {
-                        a[0][r] = fma(xr[r], d01.x, a[0][r]); a[1][r] = fma(xr[r], d01.y, a[1][r]);
-                        a[2][r] = fma(xr[r], d23.x, a[2][r]); a[3][r] = fma(xr[r], d23.y, a[3][r]);
+                    for (int j = 0; j < KC; ++j) {
+                        if (RPT == 2) {
+                            const double2 xv = *reinterpret_cast<const double2*>(src + (size_t)j * nwp);
+                            xr[j][0] = xv.x; xr[j][RPT - 1] = xv.y;
+                        } else {
+                            xr[j][0] = src[(size_t)j * nwp];
+                        }
                     }
+                };
+                auto fmac = [&](const double (&xr)[KC][RPT], int ch) {
+#pragma unroll
+                    for (int j = 0; j < KC; ++j) {
+                        const int k = ch * KC + j;
+                        const double2 d01 = *reinterpret_cast<const double2*>(vecI + k * MCC);
+                        const double2 d23 = *reinterpret_cast<const double2*>(vecI + k * MCC + 2);
+#pragma unroll
+                        for (int r = 0; r < RPT; ++r) {
+                            a[0][r] = fma(xr[j][r], d01.x, a[0][r]); a[1][r] = fma(xr[j][r], d01.y, a[1][r]);
+                            a[2][r] = fma(xr[j][r], d23.x, a[2][r]); a[3][r] = fma(xr[j][r], d23.y, a[3][r]);
+                        }
+                    }
+                };
+                const int nch = (ns + KC - 1) / KC;
+                loadc(xa, 0);
+                loadc(xb, 1);
+                loadc(xc, 2);
+                for (int ch = 0; ch < nch; ch += 4) {
+                    loadc(xd, min(ch + 3, NCH - 1));
+                    fmac(xa, ch);
+                    loadc(xa, min(ch + 4, NCH - 1));
+                    fmac(xb, min(ch + 1, NCH - 1));
+                    loadc(xb, min(ch + 5, NCH - 1));
+                    fmac(xc, min(ch + 2, NCH - 1));
+                    loadc(xc, min(ch + 6, NCH - 1));
+                    fmac(xd, min(ch + 3, NCH - 1));
                 }
+                MXE_STAMPW(0);
 #pragma unroll
                 for (int r = 0; r < RPT; ++r) {
                     const int ii = i + r;
@@ -354,8 +431,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 }
             }
         }
+        MXE_STAMPW(3);
         __syncthreads();                         // Hi, wi, ui and the partial sums complete
-        MXE_STAMP(3);
+        MXE_STAMPW(7);
 
         // ---- 3. fused pass (V once): h = V^T H (VALU) and W = V_a^T diag(w) V_a (MFMA) ----
         {
@@ -414,32 +492,38 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             };
             // the waves take groups wave, wave + NWV, ...; the register sets rotate
             // (four with one wave per SIMD; two with two waves per SIMD, where the
-            // other wave covers the latency and registers are halved)
+            // other wave covers the latency and registers are halved).  n_groups is a
+            // multiple of 16 = the groups of one trip of either loop, and every load is
+            // issued unconditionally (the look-ahead past the end re-reads the last
+            // group): a load under a branch would force s_waitcnt vmcnt(0) at the join
+            // and drain the whole pipeline before every consume.
             constexpr int ST = NWV;
+            const int g_last = n_groups - 1;
             int g = wave;
             if (NWV == 4) {
-                if (g < n_groups) load_group(fA, hA, g);
-                if (g + ST < n_groups) load_group(fB, hB, g + ST);
-                if (g + 2 * ST < n_groups) load_group(fC, hC, g + 2 * ST);
+                load_group(fA, hA, g);
+                load_group(fB, hB, g + ST);
+                load_group(fC, hC, g + 2 * ST);
                 for (; g < n_groups; g += 4 * ST) {
-                    if (g + 3 * ST < n_groups) load_group(fD, hD, g + 3 * ST);
+                    load_group(fD, hD, g + 3 * ST);
                     consume(fA, hA);
-                    if (g + 4 * ST < n_groups) load_group(fA, hA, g + 4 * ST);
-                    if (g + ST < n_groups) consume(fB, hB);
-                    if (g + 5 * ST < n_groups) load_group(fB, hB, g + 5 * ST);
-                    if (g + 2 * ST < n_groups) consume(fC, hC);
-                    if (g + 6 * ST < n_groups) load_group(fC, hC, g + 6 * ST);
-                    if (g + 3 * ST < n_groups) consume(fD, hD);
+                    load_group(fA, hA, min(g + 4 * ST, g_last));
+                    consume(fB, hB);
+                    load_group(fB, hB, min(g + 5 * ST, g_last));
+                    consume(fC, hC);
+                    load_group(fC, hC, min(g + 6 * ST, g_last));
+                    consume(fD, hD);
                 }
             } else {
-                if (g < n_groups) load_group(fA, hA, g);
+                load_group(fA, hA, g);
                 for (; g < n_groups; g += 2 * ST) {
-                    if (g + ST < n_groups) load_group(fB, hB, g + ST);
+                    load_group(fB, hB, g + ST);
                     consume(fA, hA);
-                    if (g + 2 * ST < n_groups) load_group(fA, hA, g + 2 * ST);
-                    if (g + ST < n_groups) consume(fB, hB);
+                    load_group(fA, hA, min(g + 2 * ST, g_last));
+                    consume(fB, hB);
                 }
             }
+            MXE_STAMPW(1);
             // h: sum the four row-residue lane groups, then (in step 4) the waves
 #pragma unroll
             for (int c = 0; c < MCC; ++c)
@@ -450,6 +534,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     v_ += __shfl_xor(v_, 32, WAVE);
                     if (kq == 0) hpart[(wave * MCC + c) * NP + 16 * t + cn] = v_;
                 }
+            MXE_STAMPW(6);
             // Gram tiles: rotating phases (in phase ph wave w adds into chain (w + ph) mod NWV if < 4)
             for (int ph = 0; ph < NWV; ++ph) {
 #pragma unroll
@@ -474,7 +559,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 __syncthreads();
             }
         }
-        MXE_STAMP(4);
+        MXE_STAMPW(4);
 
         // ---- 4. home wave: rho, sums, accept / converge / advance, results ----
         if (wave < MCC) {
@@ -490,43 +575,45 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 sS += red[wv * 32 + q * 4 + 0]; sdH += red[wv * 32 + q * 4 + 1];
                 sHn += red[wv * 32 + q * 4 + 2]; swm = fmax(swm, red[wv * 32 + q * 4 + 3]);
             }
-            if (my_active) {
+            Slot t;
+            load_slot(t);
+            if (t.active) {
                 rho[q * NP + k] = r;
-                const double chi2t = r2 + my_cperp, St = sS;
-                const double Qt = 0.5 * chi2t - my_alpha * St;
+                const double chi2t = r2 + t.cperp, St = sS;
+                const double Qt = 0.5 * chi2t - t.alpha * St;
                 const bool finite = fabs(Qt) <= 1.7e308;
                 bool finish_alpha = false; int conv = 0;
-                if (my_scratch) {
+                if (t.scratch) {
                     // state restored from v (or first evaluation of the piece); damping kept
-                    ++my_nevals;
-                    if (finite) { my_scratch = false; my_chi2 = chi2t; my_S = St; my_Hn2 = sHn; my_wmax = swm; my_Q = Qt; }
+                    ++t.nevals;
+                    if (finite) { t.scratch = 0; t.chi2 = chi2t; t.S = St; t.Hn2 = sHn; t.wmax = swm; t.Q = Qt; }
                     else finish_alpha = true;                   // cannot even evaluate: give up on this alpha
-                } else if (!okflag_prev) {
+                } else if (!t.okprev) {
                     finish_alpha = true;                        // the damping loop ran out of range
-                } else if (!finite || (my_mu > 0.0 && Qt > my_Q)) {
+                } else if (!finite || (t.mu > 0.0 && Qt > t.Q)) {
                     // not finite, or a damped step that made Q worse: more damping, restore from v
-                    ++my_nevals;
-                    my_mu = (my_mu == 0.0) ? p.mu_first * my_alpha : my_mu * p.mu_grow;
-                    my_scratch = true;
-                    if (!(my_mu <= p.mu_max * my_alpha)) finish_alpha = true;
+                    ++t.nevals;
+                    t.mu = (t.mu == 0.0) ? p.mu_first * t.alpha : t.mu * p.mu_grow;
+                    t.scratch = 1;
+                    if (!(t.mu <= p.mu_max * t.alpha)) finish_alpha = true;
                 } else {
                     // accepted
-                    ++my_nevals;
-                    const double relH = sqrt(sdH / my_Hn2);
+                    ++t.nevals;
+                    const double relH = sqrt(sdH / t.Hn2);
                     vv[q * NP + k] -= dlc[q * NP + k];
-                    my_chi2 = chi2t; my_S = St; my_Hn2 = sHn; my_wmax = swm;
-                    my_Qprev = my_Q; my_Q = Qt; my_mu = 0.0;
-                    ++my_niter;
-                    if (p.tol_h > 0.0 && relH < p.tol_h && my_niter > p.miniter) { conv = 1; finish_alpha = true; }
-                    else if (p.tol_relq > 0.0 && fabs(fabs(my_Qprev - my_Q) / my_Q) < p.tol_relq && my_niter > p.miniter) { conv = 1; finish_alpha = true; }
-                    else if (my_niter >= p.maxiter) finish_alpha = true;
+                    t.chi2 = chi2t; t.S = St; t.Hn2 = sHn; t.wmax = swm;
+                    t.Qprev = t.Q; t.Q = Qt; t.mu = 0.0;
+                    ++t.niter;
+                    if (p.tol_h > 0.0 && relH < p.tol_h && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
+                    else if (p.tol_relq > 0.0 && fabs(fabs(t.Qprev - t.Q) / t.Q) < p.tol_relq && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
+                    else if (t.niter >= p.maxiter) finish_alpha = true;
                 }
                 if (finish_alpha) {
-                    const size_t prob = (size_t)my_prob0 + my_ia;
+                    const size_t prob = (size_t)t.prob0 + t.ia;
                     if (p.out_H) {
                         double* Ho = p.out_H + prob * nw;
-                        const int kd = p.elem_kind[my_elem];
-                        const double* Dq = p.D + (size_t)my_elem * nwp;
+                        const int kd = s_kind[q];
+                        const double* Dq = p.D + (size_t)t.elem * nwp;
                         for (int i = lane; i < nw; i += 64) {
                             const double Di = Dq[i], uq = ui[i * MCC + q];
                             Ho[i] = (kd == 0) ? Di * exp(uq) : Di * exp(uq) - Di * exp(-uq);
@@ -534,30 +621,34 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     }
                     if (p.out_v) p.out_v[prob * NP + lane] = vv[q * NP + lane];
                     if (lane == 0) {
-                        p.out_chi2[prob] = my_chi2; p.out_S[prob] = my_S; p.out_Q[prob] = my_Q;
-                        p.out_niter[prob] = my_niter; p.out_conv[prob] = conv;
-                        p.out_nevals[prob] = my_nevals; p.out_nact[prob] = my_nact;
+                        p.out_chi2[prob] = t.chi2; p.out_S[prob] = t.S; p.out_Q[prob] = t.Q;
+                        p.out_niter[prob] = t.niter; p.out_conv[prob] = conv;
+                        p.out_nevals[prob] = t.nevals; p.out_nact[prob] = t.nact;
                     }
-                    ++my_ia;
-                    my_niter = 0; my_nevals = 0; my_mu = 0.0;
-                    my_Qprev = __builtin_nan("");
-                    if (my_ia >= my_clen) my_active = false;
+                    ++t.ia;
+                    t.niter = 0; t.nevals = 0; t.mu = 0.0;
+                    t.Qprev = __builtin_nan("");
+                    if (t.ia >= t.clen) t.active = 0;
                     else {
-                        my_alpha = p.alpha[(size_t)my_prob0 + my_ia];
-                        my_Q = 0.5 * my_chi2 - my_alpha * my_S;
+                        t.alpha = p.alpha[(size_t)t.prob0 + t.ia];
+                        t.Q = 0.5 * t.chi2 - t.alpha * t.S;
                     }
                 }
-                if (lane == 0) { s_act[q] = my_active ? 1 : 0; s_scr[q] = my_scratch ? 1 : 0; }
+                store_slot(t);
             }
         }
         __syncthreads();                         // slot flags, v, rho visible to the next round
-        MXE_STAMP(5);
+        MXE_STAMPW(5);
 #ifdef MXE_PROFILE
         ++prof_rounds;
 #endif
     }
 #ifdef MXE_PROFILE
-    if (tid == 0 && p.prof) { for (int r = 0; r < 7; ++r) p.prof[(size_t)blockIdx.x * 8 + r] = prof_acc[r]; p.prof[(size_t)blockIdx.x * 8 + 7] = prof_rounds; }
+    if (lane == 0 && p.prof && blockIdx.x < 1024) {
+        long long* pr = p.prof + ((size_t)blockIdx.x * 8 + wave) * 8;
+        for (int r = 0; r < 7; ++r) pr[r] = prof_acc[r];
+        pr[7] = (wave == 0) ? prof_rounds : prof_acc[7];     // wave 0: rounds; others: wait at the row-pass barrier
+    }
 #endif
 }
 

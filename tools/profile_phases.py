@@ -25,6 +25,7 @@ ap.add_argument('--n-orb', type=int, default=16)
 ap.add_argument('--theta', type=float, default=1e-6)
 ap.add_argument('--layout', type=int, default=1)
 ap.add_argument('--split', type=int, default=1)
+ap.add_argument('--home', action='store_true', help='library built with -DMXE_PROFILE_HOME: split the home phase')
 args = ap.parse_args()
 batch = bench.build_batch(args.n_orb, 200, 500, 100, 0)
 ctx = bench.stage(batch, 0)
@@ -36,23 +37,44 @@ for _ in range(2):
     ctx.launch(); ctx.sync()
 lib = device.load_library()
 lib.mxe_prof_fetch.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
+info = ctx.last_launch_info()
 n_sub = n_chain * max(args.split, 1)
-n_rows = ctx.last_launch_info()['n_workgroups'] if args.layout == 4 else n_sub
-prof = np.zeros((n_sub, 8), dtype=np.int64)
+prof = np.zeros((n_sub + 8192, 8), dtype=np.int64)
 rc = lib.mxe_prof_fetch(ctx._h, prof.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)))
 assert rc == 0
-prof = prof[:n_rows]
 out = ctx.fetch(want_v=False, want_H=False)
-names = ['prep', 'gram', 'chol+solve', 'step/norm', 'eval', 'accept', 'output', '-']
+print('kernel ms %.3f  info %s' % (ctx.last_kernel_ms(), info))
 if args.layout == 4:
-    rounds = prof[:, 7].copy(); prof[:, 7] = 0
-    iters = rounds          # per workgroup: rounds (one Newton iteration of up to 4 chains each)
+    # lock-step kernel: one row per (workgroup, wave); slot 7 of wave 0 = rounds, of the others = wait
+    n_wg, nwv = info['n_workgroups'], info['waves_per_chain']
+    pw = prof[:n_wg * 8].reshape(n_wg, 8, 8)[:, :nwv, :]
+    rounds = pw[:, 0, 7].astype(float)
+    names = ['row:matvec', 'fused:loop', 'home', 'row:exp+sums', 'fused:accum', 'accept', 'fused:shuffle', 'row:barrier']
+    order = (2, 0, 3, 7, 1, 6, 4, 5)
+    if args.home:
+        names = ['home:refill+rhs', 'home:load A', 'home:barrier', 'home:factor', 'home:solve', 'all passes', 'home:step+store', 'row:barrier']
+        order = (0, 1, 3, 4, 6, 2, 5)
+    print('workgroups %d, rounds per workgroup: mean %.1f' % (n_wg, rounds.mean()))
+    print('cycles per round, by wave (mean over workgroups):')
+    print('  %-16s' % 'phase' + ''.join('   wave%d' % w for w in range(nwv)))
+    tot = np.zeros(nwv)
+    for q in order:
+        per = pw[:, :, q].sum(axis=0) / rounds.sum()
+        if q == 7:
+            per[0] = np.nan
+        if q == 7 and not args.home:
+            pass
+        else:
+            tot += per
+        print('  %-16s' % names[q] + ''.join(' %7.0f' % x for x in per))
+    print('  %-16s' % 'total' + ''.join(' %7.0f' % x for x in tot))
 else:
-    iters = np.full(n_rows, out['n_iter'].sum() / n_rows)
-tot = prof.sum(axis=1)
-print('kernel ms %.3f  info %s' % (ctx.last_kernel_ms(), ctx.last_launch_info()))
-print('rows %d, newton iterations (rounds) per row: mean %.1f' % (n_rows, iters.mean()))
-print('cycles per chain: mean %.3e (max %.3e)' % (tot.mean(), tot.max()))
-for q, nme in enumerate(names[:7]):
-    print('  %-11s %6.2f %%   %8.0f cycles / newton iteration' % (nme, 100.0 * prof[:, q].sum() / tot.sum(),
-                                                                 prof[:, q].sum() / iters.sum()))
+    prof = prof[:n_sub]
+    names = ['prep', 'gram', 'chol+solve', 'step/norm', 'eval', 'accept', 'output', '-']
+    iters = np.full(n_sub, out['n_iter'].sum() / n_sub)
+    tot = prof.sum(axis=1)
+    print('rows %d, newton iterations per row: mean %.1f' % (n_sub, iters.mean()))
+    print('cycles per chain: mean %.3e (max %.3e)' % (tot.mean(), tot.max()))
+    for q, nme in enumerate(names[:7]):
+        print('  %-11s %6.2f %%   %8.0f cycles / newton iteration' % (nme, 100.0 * prof[:, q].sum() / tot.sum(),
+                                                                     prof[:, q].sum() / iters.sum()))
