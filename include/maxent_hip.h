@@ -62,7 +62,8 @@ typedef struct mxe_opts {
     int32_t maxiter;      /* max Newton iterations per alpha (reference: 1000)            */
     int32_t miniter;      /* reference: 0                                                 */
     double  tol_h;        /* converged when the Newton correction satisfies
-                             ||dH||_2 / ||H||_2 < tol_h   (default 1e-9; 0 = off)         */
+                             ||dH||_2 / ||H||_2 < tol_h   (0 = off); with stop_estimate
+                             the ESTIMATED next correction is tested as well             */
     double  tol_d;        /* MaxDerivativeConvergenceMethod: max|W g| < tol_d (0 = off;
                              reference default 1e-4)                                      */
     double  tol_relq;     /* RelativeFunctionChangeConvergenceMethod: |Q0-Q1|/|Q1| <
@@ -80,7 +81,12 @@ typedef struct mxe_opts {
     int32_t alpha_split;     /* cut every alpha scan into this many cold-started pieces
                                 (more chains to fill the GPU; results are path independent);
                                 0 = auto (only when fewer than 1024 chains), 1 = never      */
-    int32_t reserved;
+    int32_t stop_estimate;   /* 1 (default): after a full (undamped) Newton step the next
+                                correction is estimated as expm1(max|du|) * ||dH||/||H||
+                                (the relative change of the weights w bounds the relative
+                                change of the Jacobian) and tol_h is applied to it, which
+                                saves the last, verifying iteration; 0: tol_h is applied to
+                                the correction just taken only                              */
 } mxe_opts;
 
 /* ---- library / device ------------------------------------------------- */

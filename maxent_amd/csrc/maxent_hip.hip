@@ -276,7 +276,7 @@ void mxe_opts_default(mxe_opts* o)
     o->tol_h = 1e-9; o->tol_d = 0.0; o->tol_relq = 0.0;
     o->step_max = 0.2; o->mu_first = 1e-3; o->mu_grow = 4.0; o->mu_max = 1e20;
     o->decouple_tol = 1e-6;
-    o->waves_per_chain = 0; o->chains_per_wg = 0; o->alpha_split = 0; o->reserved = 0;
+    o->waves_per_chain = 0; o->chains_per_wg = 0; o->alpha_split = 0; o->stop_estimate = 1;
 }
 
 int mxe_ctx_create(int device, int n_tau, int n_omega, int n_s,
@@ -578,7 +578,7 @@ int mxe_chains_launch(mxe_ctx* ctx)
     kp.out_S = ctx->dout_S.p; kp.out_Q = ctx->dout_Q.p; kp.out_niter = ctx->dout_niter.p;
     kp.out_conv = ctx->dout_conv.p; kp.out_nevals = ctx->dout_nevals.p;
     kp.maxiter = o.maxiter; kp.miniter = o.miniter;
-    kp.tol_h = o.tol_h; kp.tol_d = o.tol_d; kp.tol_relq = o.tol_relq;
+    kp.tol_h = o.tol_h; kp.tol_d = o.tol_d; kp.tol_relq = o.tol_relq; kp.stop_estimate = o.stop_estimate != 0;
     kp.step_max = o.step_max; kp.mu_first = o.mu_first; kp.mu_grow = o.mu_grow; kp.mu_max = o.mu_max;
     kp.theta = o.decouple_tol; kp.out_nact = ctx->dout_nact.p;
     kp.prof = nullptr;

@@ -73,6 +73,7 @@ struct KParams {
     // options
     int maxiter, miniter;
     double tol_h, tol_d, tol_relq, step_max, mu_first, mu_grow, mu_max, theta;
+    int stop_estimate;  // tol_h also applies to the estimated next correction (see mxe_opts)
     long long* prof;    // [n_chain][8] phase cycle counters (diagnostic build only)
 };
 
@@ -145,6 +146,34 @@ __device__ __forceinline__ void block_reduce(double (&x)[NV], double& mx, double
     mx = m;
 }
 
+// same with two maxima (red: [NW*(NV+2)])
+template <int NW, int NV>
+__device__ __forceinline__ void block_reduce2(double (&x)[NV], double& mx, double& mx2, double* red) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) x[q] = wave_sum(x[q]);
+    mx = wave_max(mx); mx2 = wave_max(mx2);
+    if (NW == 1) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) red[wave * (NV + 2) + q] = x[q];
+        red[wave * (NV + 2) + NV] = mx; red[wave * (NV + 2) + NV + 1] = mx2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        double s = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) s += red[wv * (NV + 2) + q];
+        x[q] = s;
+    }
+    double m = red[NV], m2 = red[NV + 1];
+#pragma unroll
+    for (int wv = 1; wv < NW; ++wv) { m = fmax(m, red[wv * (NV + 2) + NV]); m2 = fmax(m2, red[wv * (NV + 2) + NV + 1]); }
+    mx = m; mx2 = m2;
+}
+
 // NW  wavefronts per chain
 // NAB padded singular dimension in units of 32 (2 -> NP = 64, 4 -> NP = 128)
 template <int NW, int NAB>
@@ -211,11 +240,11 @@ void chain_kernel(const KParams p)
     // ------------------------------------------------------------------
     // evaluation pass: trial u = u - V*vec (from_scratch: u = V*vec).
     // Fills ut, wt, Hs, rhot; returns chi2, S, |w_old o V vec|^2, |H_t|^2,
-    // max(w_t).  Each thread owns two adjacent omega rows (16-B loads of V^T).
+    // max(w_t), max|V vec|.  Each thread owns two adjacent omega rows (16-B loads of V^T).
     // ------------------------------------------------------------------
     auto eval_pass = [&](const double* vec, bool from_scratch,
-                         double& chi2, double& S, double& dH2, double& Hn2, double& wmax) {
-        double pS = 0.0, pdH = 0.0, pHn = 0.0, pwm = 0.0;
+                         double& chi2, double& S, double& dH2, double& Hn2, double& wmax, double& dumax) {
+        double pS = 0.0, pdH = 0.0, pHn = 0.0, pwm = 0.0, pdu = 0.0;
         for (int i = 2 * tid; i < nwp; i += 2 * T) {
             double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
             const double* col = Vt + i;
@@ -243,6 +272,7 @@ void chain_kernel(const KParams p)
                     ui = u[ii] - vd;
                     const double t = w[ii] * vd;
                     pdH = fma(t, t, pdH);
+                    pdu = fmax(pdu, fabs(vd));
                 }
                 const double Di = Dg[ii];
                 double Hi, wi, Si;
@@ -312,8 +342,8 @@ void chain_kernel(const KParams p)
             r2 = fma(r, r, r2);
         }
         double x4[4] = {pS, pdH, pHn, r2};
-        block_reduce<NW, 4>(x4, pwm, red);
-        S = x4[0]; dH2 = x4[1]; Hn2 = x4[2]; chi2 = x4[3] + cperp; wmax = pwm;
+        block_reduce2<NW, 4>(x4, pwm, pdu, red);
+        S = x4[0]; dH2 = x4[1]; Hn2 = x4[2]; chi2 = x4[3] + cperp; wmax = pwm; dumax = pdu;
         MXE_STAMP_E(5);
     };
 
@@ -743,8 +773,8 @@ void chain_kernel(const KParams p)
     // ------------------------------------------------------------------
     // initial state: u = V v0
     // ------------------------------------------------------------------
-    double chi2, S, dH2, Hn2, wmax;
-    eval_pass(v, true, chi2, S, dH2, Hn2, wmax);
+    double chi2, S, dH2, Hn2, wmax, dumax;
+    eval_pass(v, true, chi2, S, dH2, Hn2, wmax, dumax);
     accept_trial();                 // dl == 0: v unchanged
     int nevals_pending = 1;
 
@@ -798,7 +828,7 @@ void chain_kernel(const KParams p)
 
             // ---- damped Newton step with Bryan's step bound ----
             double mu = 0.0;
-            double chi2t = 0.0, St = 0.0, dH2t = 0.0, Hn2t = 0.0, wmaxt = 0.0;
+            double chi2t = 0.0, St = 0.0, dH2t = 0.0, Hn2t = 0.0, wmaxt = 0.0, dumaxt = 0.0;
             bool accepted = false;
             while (true) {
                 const double a = alpha + mu;
@@ -829,7 +859,7 @@ void chain_kernel(const KParams p)
                     if (!(x1[0] <= step_lim)) good = false;
                     MXE_STAMP(3);
                     if (good) {
-                        eval_pass(dl, false, chi2t, St, dH2t, Hn2t, wmaxt);
+                        eval_pass(dl, false, chi2t, St, dH2t, Hn2t, wmaxt, dumaxt);
                         MXE_STAMP(4);
                         ++nevals;
                         const double Qt = 0.5 * chi2t - alpha * St;
@@ -846,13 +876,15 @@ void chain_kernel(const KParams p)
             }
             if (!accepted) { failed = true; break; }
             const double relH = sqrt(dH2t / Hn2);
+            // estimate of the next Newton correction after a full step (see mxe_opts.stop_estimate)
+            const double relH_next = (p.stop_estimate && mu == 0.0) ? expm1(dumaxt) * relH : relH;
             accept_trial();
             MXE_STAMP(5);
             chi2 = chi2t; S = St; Hn2 = Hn2t; wmax = wmaxt;
             Qprev = Q;
             Q = 0.5 * chi2 - alpha * S;
             ++n_iter;
-            if (p.tol_h > 0.0 && relH < p.tol_h && n_iter > p.miniter) { conv = 1; break; }
+            if (p.tol_h > 0.0 && fmin(relH, relH_next) < p.tol_h && n_iter > p.miniter) { conv = 1; break; }
         }
 
         // ---- results of this alpha (MaxEntResult fields, maxent_result.py:835-967)

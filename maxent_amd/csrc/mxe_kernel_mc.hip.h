@@ -247,6 +247,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             if (live) zz[q * NP + i] = r;
         }
         MXE_STAMPH(4);
+#ifdef MXE_PROFILE_HOME
+        prof_acc[6] += 1;                        // factorisations (slot 6 is a count in this build)
+#endif
         return ok;
     };
 
@@ -309,7 +312,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             vecI[k * MCC + q] = dk;
             t.okprev = okflag;
             store_slot(t);
-            MXE_STAMPH(6);
+            MXE_STAMPH(0);
         }
         __syncthreads();
         MXE_STAMPW(2);
@@ -325,9 +328,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 kind[q] = s_kind[q];
                 Dg[q] = p.D + (size_t)((s_elem[q] >= 0) ? s_elem[q] : any_elem) * nwp;
             }
-            double pS[MCC], pdH[MCC], pHn[MCC], pwm[MCC];
+            double pS[MCC], pdH[MCC], pHn[MCC], pwm[MCC], pdu[MCC];
 #pragma unroll
-            for (int q = 0; q < MCC; ++q) { pS[q] = 0.0; pdH[q] = 0.0; pHn[q] = 0.0; pwm[q] = 0.0; }
+            for (int q = 0; q < MCC; ++q) { pS[q] = 0.0; pdH[q] = 0.0; pHn[q] = 0.0; pwm[q] = 0.0; pdu[q] = 0.0; }
             for (int i = RPT * tid; i < nwp; i += RPT * T) {
                 double a[MCC][RPT];
 #pragma unroll
@@ -393,6 +396,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                             uq = ui[ii * MCC + q] - vd;
                             const double t = wi[ii * MCC + q] * vd;
                             pdH[q] = fma(t, t, pdH[q]);
+                            pdu[q] = fmax(pdu[q], fabs(vd));     // padded rows of V^T are zero
                         }
                         const double Di = Dg[q][ii];
                         double Hq, wq, Sq;
@@ -421,13 +425,14 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 #pragma unroll
             for (int q = 0; q < MCC; ++q) {
                 pS[q] = wave_sum(pS[q]); pdH[q] = wave_sum(pdH[q]); pHn[q] = wave_sum(pHn[q]);
-                pwm[q] = wave_max(pwm[q]);
+                pwm[q] = wave_max(pwm[q]); pdu[q] = wave_max(pdu[q]);
             }
             if (lane == 0) {
 #pragma unroll
                 for (int q = 0; q < MCC; ++q) {
-                    red[wave * 32 + q * 4 + 0] = pS[q]; red[wave * 32 + q * 4 + 1] = pdH[q];
-                    red[wave * 32 + q * 4 + 2] = pHn[q]; red[wave * 32 + q * 4 + 3] = pwm[q];
+                    red[wave * 32 + q * 8 + 0] = pS[q]; red[wave * 32 + q * 8 + 1] = pdH[q];
+                    red[wave * 32 + q * 8 + 2] = pHn[q]; red[wave * 32 + q * 8 + 3] = pwm[q];
+                    red[wave * 32 + q * 8 + 4] = pdu[q];
                 }
             }
         }
@@ -569,11 +574,12 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             for (int wv = 0; wv < NWV; ++wv) h += hpart[(wv * MCC + q) * NP + k];
             const double r = (k < ns) ? cc[k] * h - gh[q * NP + k] : 0.0;
             const double r2 = wave_sum(r * r);
-            double sS = 0.0, sdH = 0.0, sHn = 0.0, swm = 0.0;
+            double sS = 0.0, sdH = 0.0, sHn = 0.0, swm = 0.0, sdu = 0.0;
 #pragma unroll
             for (int wv = 0; wv < NWV; ++wv) {
-                sS += red[wv * 32 + q * 4 + 0]; sdH += red[wv * 32 + q * 4 + 1];
-                sHn += red[wv * 32 + q * 4 + 2]; swm = fmax(swm, red[wv * 32 + q * 4 + 3]);
+                sS += red[wv * 32 + q * 8 + 0]; sdH += red[wv * 32 + q * 8 + 1];
+                sHn += red[wv * 32 + q * 8 + 2]; swm = fmax(swm, red[wv * 32 + q * 8 + 3]);
+                sdu = fmax(sdu, red[wv * 32 + q * 8 + 4]);
             }
             Slot t;
             load_slot(t);
@@ -600,11 +606,14 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     // accepted
                     ++t.nevals;
                     const double relH = sqrt(sdH / t.Hn2);
+                    // estimate of the NEXT Newton correction after a full step: the weights
+                    // change by at most expm1(max|du|) relatively, and so does the Jacobian
+                    const double relH_next = (p.stop_estimate && t.mu == 0.0) ? expm1(sdu) * relH : relH;
                     vv[q * NP + k] -= dlc[q * NP + k];
                     t.chi2 = chi2t; t.S = St; t.Hn2 = sHn; t.wmax = swm;
                     t.Qprev = t.Q; t.Q = Qt; t.mu = 0.0;
                     ++t.niter;
-                    if (p.tol_h > 0.0 && relH < p.tol_h && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
+                    if (p.tol_h > 0.0 && fmin(relH, relH_next) < p.tol_h && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                     else if (p.tol_relq > 0.0 && fabs(fabs(t.Qprev - t.Q) / t.Q) < p.tol_relq && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                     else if (t.niter >= p.maxiter) finish_alpha = true;
                 }

@@ -39,7 +39,7 @@ class MxeOpts(ctypes.Structure):
                 ('waves_per_chain', ctypes.c_int32),
                 ('chains_per_wg', ctypes.c_int32),
                 ('alpha_split', ctypes.c_int32),
-                ('reserved', ctypes.c_int32)]
+                ('stop_estimate', ctypes.c_int32)]
 
 
 _dp = ctypes.POINTER(ctypes.c_double)

@@ -76,13 +76,21 @@ class RelativeFunctionChangeConvergenceMethod(ConvergenceMethod):
 
 class NewtonStepConvergenceMethod(ConvergenceMethod):
     """||dH||_2 / ||H||_2 < criterion for the Newton correction dH = w o V delta
-    (scale free; not in the reference)."""
+    (scale free; not in the reference).
 
-    def __init__(self, convergence_criterion=1.e-9):
+    With ``estimate`` (default) the criterion is also applied to the estimated
+    NEXT correction after a full Newton step, expm1(max|du|) * ||dH||/||H||,
+    which is the error left in the accepted point: the iteration that would
+    only confirm convergence is not run.  ``estimate=False`` tests the
+    correction actually taken."""
+
+    def __init__(self, convergence_criterion=1.e-9, estimate=True):
         self.convergence_criterion = convergence_criterion
+        self.estimate = estimate
 
     def apply(self, opts):
         opts.tol_h = float(self.convergence_criterion)
+        opts.stop_estimate = 1 if self.estimate else 0
 
 
 class NullConvergenceMethod(ConvergenceMethod):

@@ -118,7 +118,7 @@ class KernelOptions(object):
 
     def __init__(self, maxiter=1000, miniter=0, tol_h=1e-9, tol_d=0.0,
                  tol_relq=0.0, step_max=0.2, mu_first=1e-3, mu_grow=4.0,
-                 mu_max=1e20):
+                 mu_max=1e20, stop_estimate=True):
         self.maxiter = maxiter
         self.miniter = miniter
         self.tol_h = tol_h            # |w o V delta| / |H| < tol_h
@@ -128,6 +128,7 @@ class KernelOptions(object):
         self.mu_first = mu_first
         self.mu_grow = mu_grow
         self.mu_max = mu_max
+        self.stop_estimate = stop_estimate   # tol_h also on expm1(max|du|) * relH
 
 
 def solve_alpha(basis, el, alpha, v, ev, opts, stats=None):
@@ -187,14 +188,19 @@ def solve_alpha(basis, el, alpha, v, ev, opts, stats=None):
                 break
         if not accepted:
             break
-        dH = ev['w'] * np.dot(basis.V, delta)
+        du = np.dot(basis.V, delta)
+        dH = ev['w'] * du
         relH = np.linalg.norm(dH) / np.linalg.norm(ev['H'])
+        relH_next = relH
+        if opts.stop_estimate and mu == 0.0:
+            relH_next = np.expm1(np.max(np.abs(du))) * relH
         v = v - delta
         ev = evt
         Qprev = Q
         Q = 0.5 * ev['chi2'] - alpha * ev['S']
         n_iter += 1
-        if opts.tol_h > 0 and relH < opts.tol_h and n_iter > opts.miniter:
+        if opts.tol_h > 0 and min(relH, relH_next) < opts.tol_h \
+                and n_iter > opts.miniter:
             converged = True
             break
     if stats is not None:

@@ -89,7 +89,7 @@ def test_four_chain_kernel_equals_single_chain_kernel():
     assert ctx.last_launch_info()['n_workgroups'] == 9      # 36 pieces, four per workgroup
     for o in (b, c):
         assert rel_l2(o['H'], a['H']).max() < 1e-8
-        np.testing.assert_allclose(o['chi2'], a['chi2'], rtol=1e-9)
+        np.testing.assert_allclose(o['chi2'], a['chi2'], rtol=1e-7)
         np.testing.assert_allclose(o['Q'], a['Q'], rtol=1e-10)
     np.testing.assert_array_equal(a['n_iter'], b['n_iter'])
     ctx.close()

@@ -52,7 +52,7 @@ if args.layout == 4:
     names = ['row:matvec', 'fused:loop', 'home', 'row:exp+sums', 'fused:accum', 'accept', 'fused:shuffle', 'row:barrier']
     order = (2, 0, 3, 7, 1, 6, 4, 5)
     if args.home:
-        names = ['home:refill+rhs', 'home:load A', 'home:barrier', 'home:factor', 'home:solve', 'all passes', 'home:step+store', 'row:barrier']
+        names = ['home:refill+rhs', 'home:load A', 'home:barrier', 'home:factor', 'home:solve', 'all passes', '#factorisations', 'row:barrier']
         order = (0, 1, 3, 4, 6, 2, 5)
     print('workgroups %d, rounds per workgroup: mean %.1f' % (n_wg, rounds.mean()))
     print('cycles per round, by wave (mean over workgroups):')
@@ -66,7 +66,7 @@ if args.layout == 4:
             pass
         else:
             tot += per
-        print('  %-16s' % names[q] + ''.join(' %7.0f' % x for x in per))
+        print('  %-16s' % names[q] + ''.join((' %7.2f' if names[q].startswith('#') else ' %7.0f') % x for x in per))
     print('  %-16s' % 'total' + ''.join(' %7.0f' % x for x in tot))
 else:
     prof = prof[:n_sub]
