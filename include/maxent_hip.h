@@ -165,6 +165,9 @@ int  mxe_chains_fetch(mxe_ctx* ctx, double* out_v, double* out_H,
                       double* out_chi2, double* out_S, double* out_Q,
                       int32_t* out_niter, int32_t* out_converged,
                       int32_t* out_nevals);
+/* diagnostic: size of the coupled (active) block of the last Newton iteration of
+ * every problem, [n_chain][n_alpha] (see mxe_opts.decouple_tol) */
+int  mxe_chains_fetch_nact(mxe_ctx* ctx, int32_t* out_nact);
 int  mxe_result_device_ptrs(mxe_ctx* ctx, void** d_H, void** d_chi2,
                             void** d_S, void** d_Q, void** d_v,
                             void** d_niter, void** d_converged);

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -510,7 +511,7 @@ int mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
             hipDeviceProp_t prop;
             HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
             const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            ctx->n_wg = std::min((ctx->n_sub + 3) / 4, n_cu);
+            ctx->n_wg = std::min((ctx->n_sub + 3) / 4, n_cu * MXE_X_WGPC);
         } else {
             // static layout: group by data set, four per workgroup, -1 pads
             std::vector<std::vector<int>> by_ds(ctx->ds.size());
@@ -600,6 +601,9 @@ int mxe_chains_launch(mxe_ctx* ctx)
         HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
 #define MXE_LAUNCH_MC(NA_, NWV_) do { \
         e = hipFuncSetAttribute((const void*)mxe::chain_kernel_mc<NA_, NWV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess && getenv("MXE_DEBUG_OCC")) { int nb__ = 0; \
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb__, (const void*)mxe::chain_kernel_mc<NA_, NWV_>, 64 * NWV_, lds); \
+            fprintf(stderr, "[mxe] lock-step kernel NA=%d NWV=%d lds=%zu: %d workgroup(s) per CU resident\n", NA_, NWV_, (size_t)lds, nb__); } \
         if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<NA_, NWV_>), dim3(ctx->n_wg), dim3(64 * NWV_), lds, ctx->stream, kp, ex); e = hipGetLastError(); } } while (0)
         if (NA == 32 && NWV == 4) MXE_LAUNCH_MC(32, 4);
         else if (NA == 32) MXE_LAUNCH_MC(32, 8);
@@ -674,6 +678,17 @@ int mxe_chains_fetch(mxe_ctx* ctx, double* out_v, double* out_H, double* out_chi
             }
         }
     }
+    return MXE_OK;
+}
+
+int mxe_chains_fetch_nact(mxe_ctx* ctx, int32_t* out_nact)
+{
+    if (!ctx || !out_nact) return MXE_ERR_ARG;
+    if (!ctx->launched) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t P = (size_t)ctx->n_chain * ctx->n_alpha;
+    HIPCHK(ctx, hipMemcpy(out_nact, ctx->dout_nact.p, P * 4, hipMemcpyDeviceToHost));
     return MXE_OK;
 }
 

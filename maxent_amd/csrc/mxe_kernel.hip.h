@@ -95,16 +95,53 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// exp(-u) from e = exp(u): v_rcp_f64 and two Newton steps (full precision; an
+// overflowed or underflowed e gives NaN / inf, which the callers treat like any
+// other non-finite trial point)
+__device__ __forceinline__ double recip_exp(double e) {
+    double y = __builtin_amdgcn_rcp(e);
+    y = fma(fma(-e, y, 1.0), y, y);
+    y = fma(fma(-e, y, 1.0), y, y);
+    return y;
+}
+
+// cross-lane move of a double inside every row of 16 lanes (two v_mov_b32_dpp)
+template <int CTRL> __device__ __forceinline__ double dpp_row(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;  // i <-> 7 - i   inside 8 lanes
+constexpr int DPP_MIRROR = 0x140;       // i <-> 15 - i  inside 16 lanes
+
+// wave-wide sum / max, result in every lane: four DPP steps inside the rows of 16
+// lanes, then the four row results through v_readlane (no LDS crossbar round trips)
 __device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, WAVE);
-    return x;
+    x += dpp_row<DPP_XOR1>(x);
+    x += dpp_row<DPP_XOR2>(x);
+    x += dpp_row<DPP_HALF_MIRROR>(x);
+    x += dpp_row<DPP_MIRROR>(x);
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 __device__ __forceinline__ double wave_max(double x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x = fmax(x, __shfl_xor(x, off, WAVE));
-    return x;
+    x = fmax(x, dpp_row<DPP_XOR1>(x));
+    x = fmax(x, dpp_row<DPP_XOR2>(x));
+    x = fmax(x, dpp_row<DPP_HALF_MIRROR>(x));
+    x = fmax(x, dpp_row<DPP_MIRROR>(x));
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return fmax(fmax(r0, r1), fmax(r2, r3));
 }
 
 // broadcast lane `src` (wave-uniform index) of x to all lanes via v_readlane
@@ -281,7 +318,7 @@ void chain_kernel(const KParams p)
                     Hi = Di * e; wi = Hi;
                     Si = Hi - Di - Hi * ui;
                 } else {
-                    const double ep = exp(ui), em = exp(-ui);
+                    const double ep = exp(ui), em = recip_exp(ep);
                     const double Hp = Di * ep, Hm = Di * em;
                     Hi = Hp - Hm; wi = Hp + Hm;
                     Si = (Hp - Di - Hp * ui) + (Hm - Di + Hm * ui);
@@ -893,7 +930,8 @@ void chain_kernel(const KParams p)
             double* Ho = p.out_H + prob * nw;
             for (int i = tid; i < nw; i += T) {
                 const double Di = Dg[i], ui = u[i];
-                Ho[i] = (kind == 0) ? Di * exp(ui) : Di * exp(ui) - Di * exp(-ui);
+                const double ep = exp(ui);
+                Ho[i] = (kind == 0) ? Di * ep : Di * ep - Di * recip_exp(ep);
             }
         }
         if (p.out_v) for (int k = tid; k < NP; k += T) p.out_v[prob * NP + k] = v[k];

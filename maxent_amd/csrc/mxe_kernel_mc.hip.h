@@ -42,7 +42,10 @@ struct MCExtra {
 // NWV wavefronts per workgroup: 4 (the home waves) or 8 (4 home + 4 helper waves that
 //     take half of the rows of the two streaming passes: two waves per SIMD there)
 template <int NA, int NWV>
-__global__ __launch_bounds__(64 * NWV)
+#ifndef MXE_X_WGPC
+#define MXE_X_WGPC 1        // experiment: workgroups per CU the register budget is sized for
+#endif
+__global__ __launch_bounds__(64 * NWV, MXE_X_WGPC)
 void chain_kernel_mc(const KParams p, const MCExtra x)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -337,11 +340,31 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 for (int q = 0; q < MCC; ++q)
 #pragma unroll
                     for (int r = 0; r < RPT; ++r) a[q][r] = 0.0;
+                // D and the current u, w of these rows: fetched now, used after the matvec
+                double Dv[MCC][RPT], uo[RPT][MCC], wo[RPT][MCC];
+#pragma unroll
+                for (int q = 0; q < MCC; ++q) {
+                    if (RPT == 2) {
+                        const double2 dd = *reinterpret_cast<const double2*>(Dg[q] + i);
+                        Dv[q][0] = dd.x; Dv[q][RPT - 1] = dd.y;
+                    } else {
+                        Dv[q][0] = Dg[q][i];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {
+                    const double2 u01 = *reinterpret_cast<const double2*>(ui + (size_t)(i + r) * MCC);
+                    const double2 u23 = *reinterpret_cast<const double2*>(ui + (size_t)(i + r) * MCC + 2);
+                    const double2 w01 = *reinterpret_cast<const double2*>(wi + (size_t)(i + r) * MCC);
+                    const double2 w23 = *reinterpret_cast<const double2*>(wi + (size_t)(i + r) * MCC + 2);
+                    uo[r][0] = u01.x; uo[r][1] = u01.y; uo[r][2] = u23.x; uo[r][3] = u23.y;
+                    wo[r][0] = w01.x; wo[r][1] = w01.y; wo[r][2] = w23.x; wo[r][3] = w23.y;
+                }
                 const double* col = Vt + i;
                 // chunks of KC singular directions through a ring of four register
                 // buffers; loads unconditional (rows of Vt beyond n_s are zero and exist
                 // up to NP), so that three chunks stay in flight behind the one consumed
-                constexpr int KC = 8, NCH = NP / KC;
+                constexpr int KC = (NWV == 4 && MXE_X_WGPC == 2) ? 4 : 8, NCH = NP / KC;
                 double xa[KC][RPT], xb[KC][RPT], xc[KC][RPT], xd[KC][RPT];
                 auto loadc = [&](double (&xr)[KC][RPT], int ch) {
                     const double* src = col + (size_t)(ch * KC) * nwp;
@@ -393,19 +416,19 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         double uq;
                         if (scr[q]) uq = vd;
                         else {
-                            uq = ui[ii * MCC + q] - vd;
-                            const double t = wi[ii * MCC + q] * vd;
+                            uq = uo[r][q] - vd;
+                            const double t = wo[r][q] * vd;
                             pdH[q] = fma(t, t, pdH[q]);
                             pdu[q] = fmax(pdu[q], fabs(vd));     // padded rows of V^T are zero
                         }
-                        const double Di = Dg[q][ii];
+                        const double Di = Dv[q][r];
                         double Hq, wq, Sq;
+                        const double ep = exp(uq);
                         if (kind[q] == 0) {
-                            const double e = exp(uq);
-                            Hq = Di * e; wq = Hq;
+                            Hq = Di * ep; wq = Hq;
                             Sq = Hq - Di - Hq * uq;
                         } else {
-                            const double ep = exp(uq), em = exp(-uq);
+                            const double em = recip_exp(ep);
                             const double Hp = Di * ep, Hm = Di * em;
                             Hq = Hp - Hm; wq = Hp + Hm;
                             Sq = (Hp - Di - Hp * uq) + (Hm - Di + Hm * uq);
@@ -505,7 +528,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             constexpr int ST = NWV;
             const int g_last = n_groups - 1;
             int g = wave;
-            if (NWV == 4) {
+            if (NWV == 4 && MXE_X_WGPC == 1) {
                 load_group(fA, hA, g);
                 load_group(fB, hB, g + ST);
                 load_group(fC, hC, g + 2 * ST);
@@ -620,13 +643,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 if (finish_alpha) {
                     const size_t prob = (size_t)t.prob0 + t.ia;
                     if (p.out_H) {
+                        // H of the point just evaluated (the accepted one unless the alpha failed)
                         double* Ho = p.out_H + prob * nw;
-                        const int kd = s_kind[q];
-                        const double* Dq = p.D + (size_t)t.elem * nwp;
-                        for (int i = lane; i < nw; i += 64) {
-                            const double Di = Dq[i], uq = ui[i * MCC + q];
-                            Ho[i] = (kd == 0) ? Di * exp(uq) : Di * exp(uq) - Di * exp(-uq);
-                        }
+                        for (int i = lane; i < nw; i += 64) Ho[i] = Hi[i * MCC + q];
                     }
                     if (p.out_v) p.out_v[prob * NP + lane] = vv[q * NP + lane];
                     if (lane == 0) {

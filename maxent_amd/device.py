@@ -71,6 +71,7 @@ SYMBOLS = [
                                          _dp, _dp, ctypes.POINTER(MxeOpts)]),
     ('mxe_chains_launch', ctypes.c_int, [_vp]),
     ('mxe_sync', ctypes.c_int, [_vp]),
+    ('mxe_chains_fetch_nact', ctypes.c_int, [_vp, _ip]),
     ('mxe_chains_fetch', ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _ip, _ip,
                                         _ip]),
     ('mxe_result_device_ptrs', ctypes.c_int, [_vp] + [ctypes.POINTER(_vp)] * 7),
@@ -277,6 +278,12 @@ class DeviceContext(object):
             'mxe_chains_fetch')
         out['v'] = v
         out['H'] = H
+        return out
+
+    def fetch_n_act(self):
+        """diagnostic: size of the coupled block per problem, [n_chain][n_alpha]."""
+        out = np.empty((self._n_chain, self._n_alpha), dtype=np.int32)
+        self._check(self._lib.mxe_chains_fetch_nact(self._h, _p(out)), 'mxe_chains_fetch_nact')
         return out
 
     def solve_chains(self, elem_of_chain, alpha_scaled, v0, opts=None,

@@ -25,9 +25,10 @@ ap.add_argument('--n-orb', type=int, default=16)
 ap.add_argument('--theta', type=float, default=1e-6)
 ap.add_argument('--layout', type=int, default=1)
 ap.add_argument('--split', type=int, default=1)
+ap.add_argument('--n-omega', type=int, default=500)
 ap.add_argument('--home', action='store_true', help='library built with -DMXE_PROFILE_HOME: split the home phase')
 args = ap.parse_args()
-batch = bench.build_batch(args.n_orb, 200, 500, 100, 0)
+batch = bench.build_batch(args.n_orb, 200, args.n_omega, 100, 0)
 ctx = bench.stage(batch, 0)
 n_chain = len(batch['elems'])
 ctx.upload_chains(np.arange(n_chain, dtype=np.int32), batch['alphas'], batch['v0'],
