@@ -165,6 +165,12 @@ int  mxe_chains_fetch(mxe_ctx* ctx, double* out_v, double* out_H,
                       double* out_chi2, double* out_S, double* out_Q,
                       int32_t* out_niter, int32_t* out_converged,
                       int32_t* out_nevals);
+/* log det(I + M W / alpha~) at the returned point of every problem of the last launch,
+ * [n_chain][n_alpha], over all n_s kept singular directions (M = S U^T diag(1/err^2) U S,
+ * W = V^T diag(w) V).  It is the only expensive term of NormalLogProbability
+ * (probabilities.py:60-85: two n_omega x n_omega slogdet per alpha in the reference):
+ * log p = -1/2 logdet - Q - log(alpha~) with the default norm and prior. */
+int  mxe_logdet(mxe_ctx* ctx, double* out_logdet);
 /* diagnostic: size of the coupled (active) block of the last Newton iteration of
  * every problem, [n_chain][n_alpha] (see mxe_opts.decouple_tol) */
 int  mxe_chains_fetch_nact(mxe_ctx* ctx, int32_t* out_nact);

@@ -70,7 +70,8 @@ struct mxe_ctx {
     DevBuf<int> delem_ds, delem_kind, dchain_elem, dsub_prob0, dsub_len, dsub_v0, dwg_chains;
     // H, chi2, S, Q live back to back in ONE allocation (dout_pack) so that a
     // multi-GPU driver can move all per-alpha results with a single collective
-    DevBuf<double> dout_v, dout_pack, dout_pack2, dB, dA;
+    DevBuf<double> dout_v, dout_pack, dout_pack2, dB, dA, dlogdet;
+    DevBuf<int> dparent_elem;
     int result_buffer = 0;        // which of the two result allocations launches write to
     struct View { double* p = nullptr; } dout_H, dout_chi2, dout_S, dout_Q;
     DevBuf<int> dout_niter, dout_conv, dout_nevals, dout_nact;
@@ -311,7 +312,7 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    ctx->dV.release(); ctx->dVt.release(); ctx->dc.release(); ctx->dcinv.release();
+    ctx->dlogdet.release(); ctx->dparent_elem.release(); ctx->dV.release(); ctx->dVt.release(); ctx->dc.release(); ctx->dcinv.release();
     ctx->dghat.release(); ctx->dcperp.release(); ctx->dD.release(); ctx->dsumD.release();
     ctx->dalpha.release(); ctx->dv0.release(); ctx->delem_ds.release(); ctx->delem_kind.release();
     ctx->dchain_elem.release(); ctx->dsub_prob0.release(); ctx->dsub_len.release(); ctx->dsub_v0.release(); ctx->dwg_chains.release(); ctx->dqueue.release(); ctx->dcounter.release(); ctx->dout_v.release(); ctx->dout_pack.release(); ctx->dout_pack2.release();
@@ -767,6 +768,138 @@ extern "C" int mxe_prof_fetch(mxe_ctx* ctx, long long* out /*[n_sub + 8192][8]*/
     return MXE_OK;
 }
 #endif
+
+// ---- log det(I + M W / alpha) of every problem of the last launch ------------
+namespace mxe {
+// One workgroup (4 waves) per problem.  In the whitened basis M = diag(c^2), so
+// det(I + M W / a) = det(c W c + a I) / a^n_s with W = V^T diag(w) V over ALL n_s
+// kept directions (no active-subspace cut here).  w is rebuilt from the stored H
+// (normal: w = H; plusminus: w = sqrt(H^2 + 4 D^2), free of cancellation).
+//   1. W by v_mfma_f64_16x16x4_f64, the omega rows split over the waves, the
+//      upper-triangular 16x16 tiles (mt <= nt) of one tile row per sweep of V;
+//   2. B = c W c + a I, Cholesky in LDS (right-looking, all threads);
+//   3. log det = 2 sum log L_jj - n_s log a.
+template <int NT>
+__global__ __launch_bounds__(256)
+void logdet_kernel(const double* __restrict__ Vall, const double* __restrict__ call,
+                   const int* __restrict__ elem_ds, const int* __restrict__ elem_kind,
+                   const double* __restrict__ Dall, const int* __restrict__ elem_of_chain,
+                   const double* __restrict__ alpha, const double* __restrict__ H,
+                   double* __restrict__ out, int n_alpha, int nw, int nwp, int ns)
+{
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    constexpr int NP = 16 * NT, LD = NP + 1;
+    extern __shared__ double sm[];
+    double* Bm = sm;                 // [NP][LD]
+    double* wsh = Bm + NP * LD;      // [nwp]
+    double* red = wsh + nwp;         // [4]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const size_t prob = blockIdx.x;
+    const int e = elem_of_chain[prob / n_alpha];
+    const int ds = elem_ds[e], kind = elem_kind[e];
+    const double a = alpha[prob];
+    const double* V = Vall + (size_t)ds * nwp * NP;
+    const double* cc = call + (size_t)ds * NP;
+    const double* Hp = H + prob * nw;
+    const double* Dp = Dall + (size_t)e * nwp;
+    for (int i = tid; i < nwp; i += 256) {
+        double w = 0.0;
+        if (i < nw) {
+            const double h = Hp[i];
+            if (kind == 0) w = h;
+            else { const double d2 = 2.0 * Dp[i]; w = sqrt(fma(h, h, d2 * d2)); }
+        }
+        wsh[i] = w;
+    }
+    for (int i = tid; i < NP * LD; i += 256) Bm[i] = 0.0;
+    __syncthreads();
+    const int kq = lane >> 4, cn = lane & 15;
+    const int n_groups = nwp >> 2;
+    const int ntile = (ns + 15) >> 4;            // tile rows / columns that hold data
+    for (int mt = 0; mt < ntile; ++mt) {
+        d4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int g = wave; g < n_groups; g += 4) {
+            const double* row = V + (size_t)(4 * g + kq) * NP + cn;
+            const double wq = wsh[4 * g + kq];
+            const double am = row[16 * mt] * wq;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (t >= mt && t < ntile) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(am, row[16 * t], acc[t], 0, 0, 0);
+        }
+        // the four waves add their partial tiles one after the other (fixed order)
+        for (int ph = 0; ph < 4; ++ph) {
+            if (wave == ph) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (t >= mt && t < ntile) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Bm[(16 * mt + kq + 4 * r) * LD + 16 * t + cn] += acc[t][r];
+                    }
+            }
+            __syncthreads();
+        }
+    }
+    // B = c W c + a I on the upper triangle (row <= col), mirrored to the lower one
+    for (int idx = tid; idx < ns * ns; idx += 256) {
+        const int i = idx / ns, j = idx % ns;
+        if (i <= j) {
+            double b = cc[i] * Bm[i * LD + j] * cc[j];
+            if (i == j) b += a;
+            Bm[j * LD + i] = b;          // lower triangle: row j >= col i
+        }
+    }
+    __syncthreads();
+    // right-looking Cholesky on the lower triangle
+    double logsum = 0.0;
+    bool ok = true;
+    for (int j = 0; j < ns; ++j) {
+        const double piv = Bm[j * LD + j];
+        if (!(piv > 0.0)) ok = false;
+        const double d = sqrt(piv);
+        logsum += log(d);
+        __syncthreads();                         // everybody has read the pivot
+        for (int i = j + 1 + tid; i < ns; i += 256) Bm[i * LD + j] /= d;
+        __syncthreads();
+        const int m = ns - j - 1;
+        for (int idx = tid; idx < m * m; idx += 256) {
+            const int i = j + 1 + idx / m, k = j + 1 + idx % m;
+            if (k <= i) Bm[i * LD + k] = fma(-Bm[i * LD + j], Bm[k * LD + j], Bm[i * LD + k]);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out[prob] = ok ? 2.0 * logsum - ns * log(a) : __builtin_nan("");
+    (void)red;
+}
+} // namespace mxe
+
+extern "C" int mxe_logdet(mxe_ctx* ctx, double* out_logdet)
+{
+    if (!ctx || !out_logdet) return MXE_ERR_ARG;
+    if (!ctx->launched) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)ctx->n_chain * ctx->n_alpha;
+    const int NP = ctx->NP;
+    HIPCHK(ctx, ctx->dlogdet.ensure(P));
+    HIPCHK(ctx, ctx->dparent_elem.ensure(ctx->chain_elem.size()));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dparent_elem.p, ctx->chain_elem.data(), ctx->chain_elem.size() * sizeof(int),
+                               hipMemcpyHostToDevice, ctx->stream));
+    const size_t lds = ((size_t)NP * (NP + 1) + ctx->nwp + 4) * sizeof(double);
+    if (lds > 160 * 1024) return MXE_ERR_LIMIT;
+    hipError_t e;
+#define MXE_LAUNCH_LOGDET(NT_) do { \
+        e = hipFuncSetAttribute((const void*)mxe::logdet_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) { hipLaunchKernelGGL((mxe::logdet_kernel<NT_>), dim3((unsigned)P), dim3(256), lds, ctx->stream, \
+            ctx->dV.p, ctx->dc.p, ctx->delem_ds.p, ctx->delem_kind.p, ctx->dD.p, ctx->dparent_elem.p, ctx->dalpha.p, \
+            ctx->dout_H.p, ctx->dlogdet.p, ctx->n_alpha, ctx->n_omega, ctx->nwp, ctx->n_s); e = hipGetLastError(); } } while (0)
+    if (NP == 64) MXE_LAUNCH_LOGDET(4); else MXE_LAUNCH_LOGDET(8);
+#undef MXE_LAUNCH_LOGDET
+    HIPCHK(ctx, e);
+    HIPCHK(ctx, hipMemcpyAsync(out_logdet, ctx->dlogdet.p, P * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MXE_OK;
+}
 
 // ---- output map A = B H ----------------------------------------------------
 namespace mxe {

@@ -71,6 +71,7 @@ SYMBOLS = [
                                          _dp, _dp, ctypes.POINTER(MxeOpts)]),
     ('mxe_chains_launch', ctypes.c_int, [_vp]),
     ('mxe_sync', ctypes.c_int, [_vp]),
+    ('mxe_logdet', ctypes.c_int, [_vp, _dp]),
     ('mxe_chains_fetch_nact', ctypes.c_int, [_vp, _ip]),
     ('mxe_chains_fetch', ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _ip, _ip,
                                         _ip]),
@@ -278,6 +279,12 @@ class DeviceContext(object):
             'mxe_chains_fetch')
         out['v'] = v
         out['H'] = H
+        return out
+
+    def logdet(self):
+        """log det(I + M W / alpha) per problem of the last launch, [n_chain][n_alpha]."""
+        out = np.empty((self._n_chain, self._n_alpha))
+        self._check(self._lib.mxe_logdet(self._h, _p(out)), 'mxe_logdet')
         return out
 
     def fetch_n_act(self):

@@ -150,7 +150,8 @@ class ElementwiseMaxEnt(object):
         for (element, cidx) in live:
             res.start_timing(element, cidx, time=t0)
         sols, info = solve_elements(loop.K, specs, loop.minimizer,
-                                    device_id=loop.device_id)
+                                    device_id=loop.device_id,
+                                    want_logdet=loop.probability is not None)
         self.last_launches.append(info)
         t1 = datetime.now()
         per_alpha = (t1 - t0) / max(1, len(specs) * len(specs[0]['alpha']))

@@ -32,7 +32,8 @@ from .probabilities import NormalLogProbability
 #  device batch
 # --------------------------------------------------------------------------
 
-def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0):
+def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0,
+                   want_logdet=False):
     """Solve the alpha scans of several elements in ONE kernel launch.
 
     ``K``: kernel whose singular space has been reduced (U, S, V staged once).
@@ -42,8 +43,10 @@ def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0):
         D (default model incl. delta), kind (device.ENTROPY_*),
         v0 (start vector), alpha (scaled alphas, in visiting order).
     All specs must have the same number of alphas.
+    ``want_logdet``: also return log det(I + M W/alpha) per alpha (device
+    kernel; the expensive term of NormalLogProbability).
     Returns (list of per-spec dicts(alpha, v, H, chi2, S, Q, n_iter,
-    converged, n_evals), info dict).
+    converged, n_evals[, logdet]), info dict).
     """
     if not specs:
         return [], dict(kernel_ms=0.0)
@@ -87,6 +90,7 @@ def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0):
         B0 = specs[0].get('A_matrix')
         if B0 is not None and all(s.get('A_matrix') is B0 for s in specs):
             A_dev = ctx.apply_output_map(B0)
+        logdet = ctx.logdet() if want_logdet else None
     finally:
         ctx.close()
     res = []
@@ -98,6 +102,8 @@ def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0):
                         n_iter=out['n_iter'][c],
                         converged=out['converged'][c].astype(bool),
                         n_evals=out['n_evals'][c]))
+        if logdet is not None:
+            res[-1]['logdet'] = logdet[c]
     return res, info
 
 
@@ -218,7 +224,11 @@ class MaxEntLoop(object):
         rec['G_rec'] = np.dot(A, self.K.K_delta.T)
         rec['omega'] = self.omega
         X = len(sol['alpha'])
-        if self.probability is not None:
+        if self.probability is not None and sol.get('logdet') is not None:
+            # the determinant came from the device (mxe_logdet)
+            rec['probability'] = self.probability.from_logdet(
+                sol['logdet'], sol['alpha'], sol['Q'], len(self.omega))
+        elif self.probability is not None:
             K = self.K
             u = np.dot(sol['v'], K.V.T)
             Dd = spec['D'][np.newaxis, :]
@@ -277,6 +287,7 @@ class MaxEntLoop(object):
         result.start_timing(matrix_element, complex_index)
         t0 = datetime.now()
         sols, info = solve_elements(self.K, [spec], self.minimizer,
+                                    want_logdet=self.probability is not None,
                                     device_id=self.device_id)
         self.last_launch = info
         sol = sols[0]

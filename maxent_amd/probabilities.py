@@ -29,6 +29,19 @@ class NormalLogProbability(object):
         self.log_norm_S = log_norm_S
         self.log_prior_alpha = log_prior_alpha
 
+    def from_logdet(self, logdet, alpha, Q, n_omega):
+        """log p from ``logdet`` = log det(I + M W/alpha) (``mxe_logdet``)."""
+        alpha = np.asarray(alpha, dtype=float)
+        lp = -0.5 * np.asarray(logdet, dtype=float) - np.asarray(Q, dtype=float)
+        if self.log_norm_S is not None:
+            lp = lp + np.array([self.log_norm_S(a, n_omega) - (n_omega / 2.0) * np.log(a)
+                                for a in alpha])
+        if self.log_prior_alpha is None:
+            lp = lp - np.log(alpha)
+        else:
+            lp = lp + np.array([self.log_prior_alpha(a) for a in alpha])
+        return lp
+
     def evaluate(self, U, S, V, err, alpha, w, Q):
         """vectorised over alpha: ``alpha`` (X,), ``w`` (X, n_omega), ``Q`` (X,)."""
         C = (U * S[np.newaxis, :]) / np.asarray(err)[:, np.newaxis]

@@ -245,3 +245,26 @@ def test_matrix_result_layout_and_hermiticity():
     cres.add_element_results(rec(3.0), (0, 1), 1)
     assert cres.A.shape == (2, 2, 2, X, W)
     np.testing.assert_array_equal(cres.A[1, 0, 1], -cres.A[0, 1, 1])   # conjugate
+
+
+def test_probability_from_device_logdet_equals_host_evaluation():
+    """NormalLogProbability.from_logdet (fed by mxe_logdet on the device) and the host
+    evaluation are the same formula."""
+    from maxent_amd.probabilities import NormalLogProbability
+    rng = np.random.RandomState(3)
+    n_tau, n_omega, n_s, X = 30, 50, 9, 4
+    U = np.linalg.qr(rng.randn(n_tau, n_s))[0]
+    V = np.linalg.qr(rng.randn(n_omega, n_s))[0]
+    S = 10.0 ** (-np.arange(n_s))
+    err = 1e-3 * (1 + rng.rand(n_tau))
+    alpha = np.array([50.0, 5.0, 0.5, 0.05])
+    w = rng.rand(X, n_omega) + 0.1
+    Q = rng.randn(X)
+    C = (U * S[None, :]) / err[:, None]
+    M = C.T @ C
+    logdet = np.array([np.linalg.slogdet(np.eye(n_s) + M @ ((V.T * w[i]) @ V) / alpha[i])[1] for i in range(X)])
+    for kw in (dict(), dict(log_prior_alpha=lambda a: -2 * np.log(a)),
+               dict(log_norm_S=lambda a, n: 0.25 * n * np.log(a))):
+        p = NormalLogProbability(**kw)
+        np.testing.assert_allclose(p.from_logdet(logdet, alpha, Q, n_omega),
+                                   p.evaluate(U, S, V, err, alpha, w, Q), rtol=1e-12, atol=1e-12)

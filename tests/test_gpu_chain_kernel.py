@@ -93,3 +93,35 @@ def test_four_chain_kernel_equals_single_chain_kernel():
         np.testing.assert_allclose(o['Q'], a['Q'], rtol=1e-10)
     np.testing.assert_array_equal(a['n_iter'], b['n_iter'])
     ctx.close()
+
+
+def test_logdet_kernel_matches_numpy_slogdet():
+    """mxe_logdet = log det(I + M W/alpha) over all kept singular directions, for both
+    entropies and a tau-dependent error (rotated whitened basis on the device)."""
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(2, 120, 300)
+    K.reduce_singular_space(1e-14)
+    D = synthetic.flat_D(omega)
+    rng = np.random.RandomState(5)
+    err = synthetic.SIGMA * (1.0 + rng.rand(120))
+    alphas = np.array(synthetic.alpha_mesh(12)) * 120
+    elems = [(0, 0), (0, 1)]
+    kinds = [device.ENTROPY_NORMAL, device.ENTROPY_PLUSMINUS]
+    from maxent_amd import hostprep
+    v0 = np.stack([hostprep.initial_v(K.V, D, omega.delta, k) for k in kinds])
+    ctx = device.DeviceContext(K.U, K.S, K.V)
+    ds = ctx.add_dataset(err)
+    ctx.set_elements([ds] * 2, [Gmat[i, j] for i, j in elems], np.tile(D, (2, 1)), kinds)
+    out = ctx.solve_chains(np.arange(2), alphas, v0)
+    ld = ctx.logdet()
+    ctx.close()
+    assert out['converged'].all()
+    C = (K.U * K.S[None, :]) / err[:, None]
+    M = C.T @ C
+    for c in range(2):
+        for ia, a in enumerate(alphas):
+            H = out['H'][c, ia]
+            w = H if kinds[c] == device.ENTROPY_NORMAL else np.sqrt(H * H + 4.0 * D * D)
+            W = (K.V.T * w[None, :]) @ K.V
+            sign, ref = np.linalg.slogdet(np.eye(len(K.S)) + M @ W / a)
+            assert sign > 0
+            assert abs(ld[c, ia] - ref) < 1e-8 * max(1.0, abs(ref)), (c, ia, ld[c, ia], ref)
