@@ -181,7 +181,8 @@ int build_dataset(mxe_ctx* ctx, int n_rows, const double* U_rot, const double* e
 int upload_bases(mxe_ctx* ctx)
 {
     const int nds = (int)ctx->ds.size(), ns = ctx->n_s, NP = ctx->NP, nw = ctx->n_omega, nwp = ctx->nwp;
-    std::vector<double> hV((size_t)nds * nwp * NP, 0.0), hVt((size_t)nds * NP * nwp, 0.0);
+    // V carries zero rows behind the last data set for the look-ahead of the fused pass
+    std::vector<double> hV(((size_t)nds * nwp + mxe::MC_LOOKAHEAD_ROWS) * NP, 0.0), hVt((size_t)nds * NP * nwp, 0.0);
     std::vector<double> hc((size_t)nds * NP, 1.0), hci((size_t)nds * NP, 1.0);
     for (int d = 0; d < nds; ++d) {
         const DataSet& D = ctx->ds[d];
@@ -215,7 +216,7 @@ int upload_bases(mxe_ctx* ctx)
 size_t mc_lds_doubles(int NA, int nwp, int NWV)
 {
     return (size_t)4 * NA * (NA + 1) + 6 * 4 * 64 + 2 * 64 + 64 * 4 + (size_t)NWV * 4 * 64 + (size_t)NWV * 32 +
-           (size_t)3 * nwp * 4;
+           (size_t)3 * nwp * 4 + mxe::MC_LOOKAHEAD_LDS;
 }
 
 size_t lds_doubles(int NP, int nwp, int NW)

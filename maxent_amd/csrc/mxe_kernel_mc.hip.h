@@ -41,7 +41,14 @@ struct MCExtra {
 // NA  capacity of the active block: 32 or 48
 // NWV wavefronts per workgroup: 4 (the home waves) or 8 (4 home + 4 helper waves that
 //     take half of the rows of the two streaming passes: two waves per SIMD there)
+// rows of V behind the last omega row (and LDS doubles behind H) that the look-ahead of the
+// fused pass may read without using them: 2 * DEPTH * 4 waves * 4 rows, rounded up
+constexpr int MC_LOOKAHEAD_ROWS = 512;
+constexpr int MC_LOOKAHEAD_LDS = (8 * 4 + 4) * 4 * 4 + 64;       // doubles
 template <int NA, int NWV>
+#ifndef MXE_X_SETS
+#define MXE_X_SETS 4        // experiment: register sets of the old fused loop
+#endif
 #ifndef MXE_X_WGPC
 #define MXE_X_WGPC 1        // experiment: workgroups per CU the register budget is sized for
 #endif
@@ -492,11 +499,20 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             auto consume = [&](const double (&f)[4], const double2 (&hw)[4]) {
                 const double Hq[MCC] = {hw[0].x, hw[0].y, hw[1].x, hw[1].y};
                 const double wq[MCC] = {hw[2].x, hw[2].y, hw[3].x, hw[3].y};
+                // An f64 MFMA and the FP64 VALU share one pipe on this part (an MFMA blocks
+                // v_fma_f64 of its SIMD for its 64 cycles), so nothing rides in the shadow of the
+                // MFMAs and a VALU product consumed by the next MFMA only adds its latency: all
+                // vector work of the group first, then the twelve MFMAs back to back.
                 double a[MCC][NT];
 #pragma unroll
                 for (int c = 0; c < MCC; ++c)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) a[c][t] = f[t] * wq[c];
+#pragma unroll
+                for (int c = 0; c < MCC; ++c)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) hp[c][t] = fma(f[t], Hq[c], hp[c][t]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int c = 0; c < MCC; ++c) {
                     int pr = 0;
@@ -507,16 +523,8 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                             acc[c][pr] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c][mt], f[nt], acc[c][pr], 0, 0, 0);
                             ++pr;
                         }
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) hp[c][t] = fma(f[t], Hq[c], hp[c][t]);
                 }
-                // issue order: the VALU work of a group rides in the shadow of its
-                // MFMAs (one matrix instruction, then up to two vector ones)
-#pragma unroll
-                for (int r = 0; r < MCC * NPAIR; ++r) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                }
+                __builtin_amdgcn_sched_barrier(0);
             };
             // the waves take groups wave, wave + NWV, ...; the register sets rotate
             // (four with one wave per SIMD; two with two waves per SIMD, where the
@@ -528,7 +536,44 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             constexpr int ST = NWV;
             const int g_last = n_groups - 1;
             int g = wave;
-            if (NWV == 4 && MXE_X_WGPC == 1) {
+#ifndef MXE_X_DEPTH
+#define MXE_X_DEPTH 8
+#endif
+            if (NWV == 4 && MXE_X_WGPC == 1 && MXE_X_SETS == 4 && MXE_X_DEPTH > 0) {
+                // V through a ring of DEPTH register sets (DEPTH - 1 row groups in flight: the
+                // L2 latency under load is several thousand cycles), H and w (LDS) one group ahead
+                constexpr int DEPTH = MXE_X_DEPTH > 0 ? MXE_X_DEPTH : 1;
+                double fr[DEPTH][4];
+                double2 hr[2][4];
+                // addresses advance by constants (V and the LDS arrays are padded for the
+                // look-ahead past the last group, see MC_LOOKAHEAD_ROWS): no index arithmetic
+                // in the loop besides one 64-bit add per trip
+                auto loadV = [&](double (&f)[4], const double* src) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) f[t] = src[16 * t];
+                };
+                auto loadHW = [&](double2 (&hw)[4], const double* hsrc, const double* wsrc) {
+                    const double2* hptr = reinterpret_cast<const double2*>(hsrc);
+                    const double2* wptr = reinterpret_cast<const double2*>(wsrc);
+                    hw[0] = hptr[0]; hw[1] = hptr[1]; hw[2] = wptr[0]; hw[3] = wptr[1];
+                };
+                constexpr size_t VSTEP = (size_t)4 * ST * NP;        // doubles per group step (V)
+                constexpr int HSTEP = 4 * ST * MCC;                  // ... (H, w in LDS)
+                const double* vp = Vl + (size_t)(4 * g) * NP;
+                const double* hb = Hi + (size_t)(4 * g + kq) * MCC;
+                const double* wb = wi + (size_t)(4 * g + kq) * MCC;
+#pragma unroll
+                for (int j = 0; j < DEPTH - 1; ++j) loadV(fr[j], vp + j * VSTEP);
+                loadHW(hr[0], hb, wb);
+                for (; g < n_groups; g += DEPTH * ST, vp += DEPTH * VSTEP, hb += DEPTH * HSTEP, wb += DEPTH * HSTEP) {
+#pragma unroll
+                    for (int j = 0; j < DEPTH; ++j) {
+                        loadV(fr[(j + DEPTH - 1) % DEPTH], vp + (j + DEPTH - 1) * VSTEP);
+                        loadHW(hr[(j + 1) & 1], hb + (j + 1) * HSTEP, wb + (j + 1) * HSTEP);
+                        if (g + j * ST < n_groups) consume(fr[j], hr[j & 1]);     // no memory operation inside
+                    }
+                }
+            } else if (NWV == 4 && MXE_X_WGPC == 1 && MXE_X_SETS == 4) {
                 load_group(fA, hA, g);
                 load_group(fB, hB, g + ST);
                 load_group(fC, hC, g + 2 * ST);
