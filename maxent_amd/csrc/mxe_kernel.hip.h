@@ -105,6 +105,22 @@ __device__ __forceinline__ double recip_exp(double e) {
     return y;
 }
 
+// x[l] + x[l ^ 32] and x[l] + x[l ^ 16] in every lane with the gfx950 lane-swap
+// instructions (v_permlane32_swap / v_permlane16_swap exchange half-waves / odd and
+// even rows of 16 lanes between two registers): no LDS crossbar round trip
+__device__ __forceinline__ double sum_xor32(double x) {
+    const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double sum_xor16(double x) {
+    const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
 // cross-lane move of a double inside every row of 16 lanes (two v_mov_b32_dpp)
 template <int CTRL> __device__ __forceinline__ double dpp_row(double x) {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);

@@ -603,8 +603,8 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     double v_ = hp[c][t];
-                    v_ += __shfl_xor(v_, 16, WAVE);
-                    v_ += __shfl_xor(v_, 32, WAVE);
+                    v_ = sum_xor16(v_);
+                    v_ = sum_xor32(v_);
                     if (kq == 0) hpart[(wave * MCC + c) * NP + 16 * t + cn] = v_;
                 }
             MXE_STAMPW(6);
