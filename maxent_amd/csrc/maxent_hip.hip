@@ -182,7 +182,7 @@ int upload_bases(mxe_ctx* ctx)
 {
     const int nds = (int)ctx->ds.size(), ns = ctx->n_s, NP = ctx->NP, nw = ctx->n_omega, nwp = ctx->nwp;
     // V carries zero rows behind the last data set for the look-ahead of the fused pass
-    std::vector<double> hV(((size_t)nds * nwp + mxe::MC_LOOKAHEAD_ROWS) * NP, 0.0), hVt((size_t)nds * NP * nwp, 0.0);
+    std::vector<double> hV(((size_t)nds * nwp + mxe::MC_LOOKAHEAD_ROWS) * NP, 0.0), hVt((size_t)nds * NP * nwp + 2 * mxe::MC_LOOKAHEAD_ROWS, 0.0);
     std::vector<double> hc((size_t)nds * NP, 1.0), hci((size_t)nds * NP, 1.0);
     for (int d = 0; d < nds; ++d) {
         const DataSet& D = ctx->ds[d];

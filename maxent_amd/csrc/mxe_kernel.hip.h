@@ -121,6 +121,19 @@ __device__ __forceinline__ double sum_xor16(double x) {
     return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
 
+__device__ __forceinline__ double max_xor32(double x) {
+    const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return fmax(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+}
+__device__ __forceinline__ double max_xor16(double x) {
+    const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return fmax(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+}
+
 // cross-lane move of a double inside every row of 16 lanes (two v_mov_b32_dpp)
 template <int CTRL> __device__ __forceinline__ double dpp_row(double x) {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
@@ -131,6 +144,21 @@ constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
 constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
 constexpr int DPP_HALF_MIRROR = 0x141;  // i <-> 7 - i   inside 8 lanes
 constexpr int DPP_MIRROR = 0x140;       // i <-> 15 - i  inside 16 lanes
+
+constexpr int DPP_ROR4 = 0x124;         // rotate right by 4 inside 16 lanes
+constexpr int DPP_ROR8 = 0x128;
+
+// sum / max over the 16 lanes of equal (lane & 3), result in all of them
+__device__ __forceinline__ double slot_sum(double x) {
+    x += dpp_row<DPP_ROR4>(x);
+    x += dpp_row<DPP_ROR8>(x);
+    return sum_xor32(sum_xor16(x));
+}
+__device__ __forceinline__ double slot_max(double x) {
+    x = fmax(x, dpp_row<DPP_ROR4>(x));
+    x = fmax(x, dpp_row<DPP_ROR8>(x));
+    return max_xor32(max_xor16(x));
+}
 
 // wave-wide sum / max, result in every lane: four DPP steps inside the rows of 16
 // lanes, then the four row results through v_readlane (no LDS crossbar round trips)

@@ -328,142 +328,97 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         MXE_STAMPW(2);
 
         // ---- 2. row pass (V^T once): u, w, H of the four trial points, in place ----
+        // du = V delta of the four slots as v_mfma_f64_4x4x4 (four independent 4x4x4 blocks per
+        // instruction): block b = omega rows 4b .. 4b+3 of a 16-row tile, columns = the four slots,
+        // K = four singular directions.  Operand / result lanes (probed, tools/mfma_4x4x4_layout.hip):
+        //   A[b][i][k] lane 16k + 4b + i,   B[b][k][j] lane 16k + 4b + j,   D[b][i][j] lane 16i + 4b + j
+        // so A is one 8-byte load of V^T per lane (four 128-B row segments per instruction), B one
+        // LDS read of the steps shared by every tile, and every lane ends up with ONE (row, slot)
+        // element per tile for the exp / entropy part (all 64 lanes busy, no per-slot loop).
         {
-            bool scr[MCC];
-            int kind[MCC];
-            const double* Dg[MCC];
+            const int j = lane & 3;                              // slot of this lane's results
+            const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4);      // result row inside the tile
+            const int ak = lane >> 4;                            // operand k inside the chunk
+            const bool scr_j = s_scr[j] != 0;
+            const bool pm_j = s_kind[j] != 0;
+            const double* Dj = p.D + (size_t)((s_elem[j] >= 0) ? s_elem[j] : any_elem) * nwp;
+            double pS = 0.0, pdH = 0.0, pHn = 0.0, pwm = 0.0, pdu = 0.0;
+            const int ntiles = nwp >> 4;
+            const int nchunk = (ns + 3) >> 2;                    // chunks of four singular directions
+            constexpr int TB = 8;                                // tiles per batch (accumulators)
+            constexpr int RD = 4;                                // ring depth in chunks
+            constexpr int NCHK = NP / 4;
+            for (int t0 = wave; t0 < ntiles; t0 += NWV * TB) {
+                // tile tt of the batch: t0 + NWV * tt; past the end: tile t0 again, results dropped
+                double acc[TB], Dv[TB], uo[TB], wo[TB];
 #pragma unroll
-            for (int q = 0; q < MCC; ++q) {
-                scr[q] = s_scr[q] != 0;
-                kind[q] = s_kind[q];
-                Dg[q] = p.D + (size_t)((s_elem[q] >= 0) ? s_elem[q] : any_elem) * nwp;
-            }
-            double pS[MCC], pdH[MCC], pHn[MCC], pwm[MCC], pdu[MCC];
-#pragma unroll
-            for (int q = 0; q < MCC; ++q) { pS[q] = 0.0; pdH[q] = 0.0; pHn[q] = 0.0; pwm[q] = 0.0; pdu[q] = 0.0; }
-            for (int i = RPT * tid; i < nwp; i += RPT * T) {
-                double a[MCC][RPT];
-#pragma unroll
-                for (int q = 0; q < MCC; ++q)
-#pragma unroll
-                    for (int r = 0; r < RPT; ++r) a[q][r] = 0.0;
-                // D and the current u, w of these rows: fetched now, used after the matvec
-                double Dv[MCC][RPT], uo[RPT][MCC], wo[RPT][MCC];
-#pragma unroll
-                for (int q = 0; q < MCC; ++q) {
-                    if (RPT == 2) {
-                        const double2 dd = *reinterpret_cast<const double2*>(Dg[q] + i);
-                        Dv[q][0] = dd.x; Dv[q][RPT - 1] = dd.y;
-                    } else {
-                        Dv[q][0] = Dg[q][i];
-                    }
+                for (int tt = 0; tt < TB; ++tt) {
+                    const int tile = (t0 + NWV * tt < ntiles) ? t0 + NWV * tt : t0;
+                    const int row = 16 * tile + drow;
+                    acc[tt] = 0.0;
+                    Dv[tt] = Dj[row];
+                    uo[tt] = ui[row * MCC + j];
+                    wo[tt] = wi[row * MCC + j];
                 }
+                // V^T operand: row 4 kc + ak of V^T, omega = 16 tile + (lane & 15); the tiles of a
+                // batch are 16 NWV rows apart (V^T is padded behind its last row for a partial batch)
+                const double* ap = Vt + (size_t)ak * nwp + 16 * t0 + (lane & 15);
+                const double* bp = vecI + ak * MCC + j;
+                double xr[RD][TB];
+                auto loadA = [&](double (&xv)[TB], int kc) {
+                    const double* src = ap + (size_t)(4 * kc) * nwp;
 #pragma unroll
-                for (int r = 0; r < RPT; ++r) {
-                    const double2 u01 = *reinterpret_cast<const double2*>(ui + (size_t)(i + r) * MCC);
-                    const double2 u23 = *reinterpret_cast<const double2*>(ui + (size_t)(i + r) * MCC + 2);
-                    const double2 w01 = *reinterpret_cast<const double2*>(wi + (size_t)(i + r) * MCC);
-                    const double2 w23 = *reinterpret_cast<const double2*>(wi + (size_t)(i + r) * MCC + 2);
-                    uo[r][0] = u01.x; uo[r][1] = u01.y; uo[r][2] = u23.x; uo[r][3] = u23.y;
-                    wo[r][0] = w01.x; wo[r][1] = w01.y; wo[r][2] = w23.x; wo[r][3] = w23.y;
-                }
-                const double* col = Vt + i;
-                // chunks of KC singular directions through a ring of four register
-                // buffers; loads unconditional (rows of Vt beyond n_s are zero and exist
-                // up to NP), so that three chunks stay in flight behind the one consumed
-                constexpr int KC = (NWV == 4 && MXE_X_WGPC == 2) ? 4 : 8, NCH = NP / KC;
-                double xa[KC][RPT], xb[KC][RPT], xc[KC][RPT], xd[KC][RPT];
-                auto loadc = [&](double (&xr)[KC][RPT], int ch) {
-                    const double* src = col + (size_t)(ch * KC) * nwp;
+                    for (int tt = 0; tt < TB; ++tt) xv[tt] = src[16 * NWV * tt];
+                };
 #pragma unroll
-                    for (int j = 0; j < KC; ++j) {
-                        if (RPT == 2) {
-                            const double2 xv = *reinterpret_cast<const double2*>(src + (size_t)j * nwp);
-                            xr[j][0] = xv.x; xr[j][RPT - 1] = xv.y;
-                        } else {
-                            xr[j][0] = src[(size_t)j * nwp];
+                for (int r = 0; r < RD - 1; ++r) loadA(xr[r], r);
+                for (int kc = 0; kc < nchunk; kc += RD) {
+#pragma unroll
+                    for (int r = 0; r < RD; ++r) {
+                        loadA(xr[(r + RD - 1) % RD], min(kc + r + RD - 1, NCHK - 1));
+                        const double bv = bp[min(kc + r, NCHK - 1) * 4 * MCC];
+                        if (kc + r < nchunk) {
+#pragma unroll
+                            for (int tt = 0; tt < TB; ++tt)
+                                acc[tt] = __builtin_amdgcn_mfma_f64_4x4x4f64(xr[r][tt], bv, acc[tt], 0, 0, 0);
                         }
                     }
-                };
-                auto fmac = [&](const double (&xr)[KC][RPT], int ch) {
-#pragma unroll
-                    for (int j = 0; j < KC; ++j) {
-                        const int k = ch * KC + j;
-                        const double2 d01 = *reinterpret_cast<const double2*>(vecI + k * MCC);
-                        const double2 d23 = *reinterpret_cast<const double2*>(vecI + k * MCC + 2);
-#pragma unroll
-                        for (int r = 0; r < RPT; ++r) {
-                            a[0][r] = fma(xr[j][r], d01.x, a[0][r]); a[1][r] = fma(xr[j][r], d01.y, a[1][r]);
-                            a[2][r] = fma(xr[j][r], d23.x, a[2][r]); a[3][r] = fma(xr[j][r], d23.y, a[3][r]);
-                        }
-                    }
-                };
-                const int nch = (ns + KC - 1) / KC;
-                loadc(xa, 0);
-                loadc(xb, 1);
-                loadc(xc, 2);
-                for (int ch = 0; ch < nch; ch += 4) {
-                    loadc(xd, min(ch + 3, NCH - 1));
-                    fmac(xa, ch);
-                    loadc(xa, min(ch + 4, NCH - 1));
-                    fmac(xb, min(ch + 1, NCH - 1));
-                    loadc(xb, min(ch + 5, NCH - 1));
-                    fmac(xc, min(ch + 2, NCH - 1));
-                    loadc(xc, min(ch + 6, NCH - 1));
-                    fmac(xd, min(ch + 3, NCH - 1));
                 }
                 MXE_STAMPW(0);
 #pragma unroll
-                for (int r = 0; r < RPT; ++r) {
-                    const int ii = i + r;
-                    double un[MCC], wn[MCC], Hn_[MCC];
-#pragma unroll
-                    for (int q = 0; q < MCC; ++q) {
-                        const double vd = a[q][r];
-                        double uq;
-                        if (scr[q]) uq = vd;
-                        else {
-                            uq = uo[r][q] - vd;
-                            const double t = wo[r][q] * vd;
-                            pdH[q] = fma(t, t, pdH[q]);
-                            pdu[q] = fmax(pdu[q], fabs(vd));     // padded rows of V^T are zero
-                        }
-                        const double Di = Dv[q][r];
-                        double Hq, wq, Sq;
+                for (int tt = 0; tt < TB; ++tt) {
+                    if (t0 + NWV * tt < ntiles) {                 // uniform
+                        const int row = 16 * (t0 + NWV * tt) + drow;
+                        const double vd = acc[tt];
+                        const double uq = scr_j ? vd : uo[tt] - vd;
+                        const double tq = scr_j ? 0.0 : wo[tt] * vd;
+                        pdH = fma(tq, tq, pdH);
+                        pdu = fmax(pdu, scr_j ? 0.0 : fabs(vd));  // padded rows of V^T are zero
+                        const double Di = Dv[tt];
                         const double ep = exp(uq);
-                        if (kind[q] == 0) {
-                            Hq = Di * ep; wq = Hq;
-                            Sq = Hq - Di - Hq * uq;
-                        } else {
-                            const double em = recip_exp(ep);
-                            const double Hp = Di * ep, Hm = Di * em;
+                        const double Hp = Di * ep;
+                        double Hq = Hp, wq = Hp, Sq = Hp - Di - Hp * uq;
+                        if (pm_j) {
+                            const double Hm = Di * recip_exp(ep);
                             Hq = Hp - Hm; wq = Hp + Hm;
-                            Sq = (Hp - Di - Hp * uq) + (Hm - Di + Hm * uq);
+                            Sq += Hm - Di + Hm * uq;
                         }
-                        if (ii >= nw) { Hq = 0.0; wq = 0.0; Sq = 0.0; }
-                        un[q] = uq; wn[q] = wq; Hn_[q] = Hq;
-                        pS[q] += Sq;
-                        pHn[q] = fma(Hq, Hq, pHn[q]);
-                        pwm[q] = fmax(pwm[q], wq);
-                    }
-#pragma unroll
-                    for (int q = 0; q < MCC; ++q) {
-                        ui[ii * MCC + q] = un[q]; wi[ii * MCC + q] = wn[q]; Hi[ii * MCC + q] = Hn_[q];
+                        if (row >= nw) { Hq = 0.0; wq = 0.0; Sq = 0.0; }
+                        ui[row * MCC + j] = uq; wi[row * MCC + j] = wq; Hi[row * MCC + j] = Hq;
+                        pS += Sq;
+                        pHn = fma(Hq, Hq, pHn);
+                        pwm = fmax(pwm, wq);                      // NaN-ignoring; non-finite states are caught through Q
                     }
                 }
             }
-#pragma unroll
-            for (int q = 0; q < MCC; ++q) {
-                pS[q] = wave_sum(pS[q]); pdH[q] = wave_sum(pdH[q]); pHn[q] = wave_sum(pHn[q]);
-                pwm[q] = wave_max(pwm[q]); pdu[q] = wave_max(pdu[q]);
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int q = 0; q < MCC; ++q) {
-                    red[wave * 32 + q * 8 + 0] = pS[q]; red[wave * 32 + q * 8 + 1] = pdH[q];
-                    red[wave * 32 + q * 8 + 2] = pHn[q]; red[wave * 32 + q * 8 + 3] = pwm[q];
-                    red[wave * 32 + q * 8 + 4] = pdu[q];
-                }
+            // sums over the lanes of equal slot (lane & 3): rotate by 4 and 8 inside the rows of
+            // 16 lanes, then across the rows
+            pS = slot_sum(pS); pdH = slot_sum(pdH); pHn = slot_sum(pHn);
+            pwm = slot_max(pwm); pdu = slot_max(pdu);
+            if (lane < MCC) {
+                red[wave * 32 + lane * 8 + 0] = pS; red[wave * 32 + lane * 8 + 1] = pdH;
+                red[wave * 32 + lane * 8 + 2] = pHn; red[wave * 32 + lane * 8 + 3] = pwm;
+                red[wave * 32 + lane * 8 + 4] = pdu;
             }
         }
         MXE_STAMPW(3);
