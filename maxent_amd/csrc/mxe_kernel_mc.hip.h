@@ -46,9 +46,6 @@ struct MCExtra {
 constexpr int MC_LOOKAHEAD_ROWS = 512;
 constexpr int MC_LOOKAHEAD_LDS = (8 * 4 + 4) * 4 * 4 + 64;       // doubles
 template <int NA, int NWV>
-#ifndef MXE_X_SETS
-#define MXE_X_SETS 4        // experiment: register sets of the old fused loop
-#endif
 #ifndef MXE_X_WGPC
 #define MXE_X_WGPC 1        // experiment: workgroups per CU the register budget is sized for
 #endif
@@ -439,10 +436,10 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             const int kq = lane >> 4, cn = lane & 15;
             const int n_groups = nwp >> 2;           // 4 omega rows per MFMA; multiple of 16
             const double* Vl = V + (size_t)kq * NP + cn;
-            // four register sets, software pipelined without copies: the loads of
-            // the next three row groups are in flight while one is consumed
-            double fA[4], fB[4], fC[4], fD[4];
-            double2 hA[4], hB[4], hC[4], hD[4];      // [0,1] = H of chains 01 / 23, [2,3] = w of chains 01 / 23
+            // register sets of the two-waves-per-SIMD variant (NWV = 8): two, the other wave
+            // of the SIMD covers the latency
+            double fA[4], fB[4];
+            double2 hA[4], hB[4];      // [0,1] = H of chains 01 / 23, [2,3] = w of chains 01 / 23
             auto load_group = [&](double (&f)[4], double2 (&hw)[4], int gidx) {
                 const int i0 = 4 * gidx;
                 const double2* hptr = reinterpret_cast<const double2*>(Hi + (size_t)(i0 + kq) * MCC);
@@ -491,13 +488,10 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             constexpr int ST = NWV;
             const int g_last = n_groups - 1;
             int g = wave;
-#ifndef MXE_X_DEPTH
-#define MXE_X_DEPTH 8
-#endif
-            if (NWV == 4 && MXE_X_WGPC == 1 && MXE_X_SETS == 4 && MXE_X_DEPTH > 0) {
+            if (NWV == 4 && MXE_X_WGPC == 1) {
                 // V through a ring of DEPTH register sets (DEPTH - 1 row groups in flight: the
                 // L2 latency under load is several thousand cycles), H and w (LDS) one group ahead
-                constexpr int DEPTH = MXE_X_DEPTH > 0 ? MXE_X_DEPTH : 1;
+                constexpr int DEPTH = 8;
                 double fr[DEPTH][4];
                 double2 hr[2][4];
                 // addresses advance by constants (V and the LDS arrays are padded for the
@@ -527,20 +521,6 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         loadHW(hr[(j + 1) & 1], hb + (j + 1) * HSTEP, wb + (j + 1) * HSTEP);
                         if (g + j * ST < n_groups) consume(fr[j], hr[j & 1]);     // no memory operation inside
                     }
-                }
-            } else if (NWV == 4 && MXE_X_WGPC == 1 && MXE_X_SETS == 4) {
-                load_group(fA, hA, g);
-                load_group(fB, hB, g + ST);
-                load_group(fC, hC, g + 2 * ST);
-                for (; g < n_groups; g += 4 * ST) {
-                    load_group(fD, hD, g + 3 * ST);
-                    consume(fA, hA);
-                    load_group(fA, hA, min(g + 4 * ST, g_last));
-                    consume(fB, hB);
-                    load_group(fB, hB, min(g + 5 * ST, g_last));
-                    consume(fC, hC);
-                    load_group(fC, hC, min(g + 6 * ST, g_last));
-                    consume(fD, hD);
                 }
             } else {
                 load_group(fA, hA, g);
