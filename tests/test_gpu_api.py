@@ -291,3 +291,24 @@ def test_cfg5_matrix_with_preblurred_offdiagonals():
             _, Ht = hp_truth.polish(p.K, p.G, p.err, p.D, p.V, p.S, ref['alpha'][ia], ref['v'][ia], ent, iters=5)
             worst = max(worst, np.linalg.norm(res.H[i, j, ia] - Ht) / np.linalg.norm(Ht))
         assert worst < GATE, worst
+
+
+def test_log_probability_with_more_than_64_singular_values():
+    """n_s = 100 (NP = 128 path of the chain kernel and of the log-determinant kernel): the
+    device log-probability equals the host evaluation of the same formula."""
+    from maxent_amd.probabilities import NormalLogProbability
+    g = load('kat_huge_alpha')
+    tm = mx.TauMaxEnt(probability='normal')
+    tm.set_verbosity(mx.VerbosityFlags.Quiet)
+    tm.set_G_tau_data(g['tau'], g['G'])
+    tm.alpha_mesh = mx.LogAlphaMesh(alpha_min=1e-1, alpha_max=1e3, n_points=6)
+    tm.set_error(5.e-4)
+    tm.reduce_singular_space = 1.e-16
+    res = tm.run()
+    assert np.all(res.converged)
+    K = tm.K
+    assert len(K.S) > 64
+    w = res.H                                  # normal entropy: w = H
+    host = NormalLogProbability().evaluate(K.U, K.S, K.V, tm.err * np.ones(len(g['G'])),
+                                           res.alpha, w, res.Q)
+    np.testing.assert_allclose(res.probability, host, rtol=1e-9, atol=1e-7)
