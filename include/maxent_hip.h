@@ -26,6 +26,9 @@
  *        BryanCostFunction.f/d/dd    bryan_cost_function.py:57-128
  *      Q_min = cost_function(v)      maxent_loop.py:246    | out_v/out_H/out_chi2/out_S/out_Q
  *      minimizer.n_iter_last/.converged  maxent_loop.py:254-256 | out_niter/out_converged
+ *      self.probability(Q_min)       maxent_loop.py:258-264 | mxe_logdet (the determinant of
+ *        NormalLogProbability        probabilities.py:60-85 |   the posterior curvature)
+ *   PreblurA_of_H.f  A = B H         functions.py:999-1001 | mxe_apply_output_map
  *
  * Conventions: plain C, no C++ types; every function returns 0 (MXE_OK) or a
  * negative error code and never throws or aborts; the caller owns every host
