@@ -444,11 +444,15 @@ int mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
     //      from the same v0 (the minimiser of each alpha does not depend on the path)
     int split = o.alpha_split;
     if (split <= 0) {
-        split = 1;
-        // enough pieces for two per chain slot of a full GPU (256 CUs x 4 slots),
-        // none shorter than 6 alphas (a cold start costs about as much as 2-3 alphas)
-        const int want = (2048 + n_chain - 1) / n_chain;
-        while (split * 2 <= want && split * 2 <= 16 && n_alpha / (split * 2) >= 6) split *= 2;
+        // about 3.5 pieces per chain slot of the GPU (CUs x 4 slots) so that the persistent
+        // grid balances (measured on cfg4: 8 pieces per scan 3.88 ms, 12: 3.59, 14: 3.37,
+        // 16: 3.43, 20: 3.60), none shorter than 6 alphas (a cold start costs about as much as
+        // 2 alphas: 0.025 Newton iterations per alpha and piece)
+        hipDeviceProp_t prop;
+        HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        const int n_slots = 4 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+        const int want = (7 * n_slots / 2 + n_chain - 1) / n_chain;
+        split = std::max(1, std::min(std::min(want, 16), n_alpha / 6));
     }
     if (split > n_alpha) split = n_alpha;
     ctx->sub_elem.clear(); ctx->sub_prob0.clear(); ctx->sub_len.clear(); ctx->sub_v0.clear();
