@@ -14,7 +14,8 @@
 //   g = c*rho + alpha v,  W = V^T diag(w) V
 //   Newton step (Bryan):  (c W c + (alpha+mu) I) z = rho + alpha v / c,
 //   delta = c*z, accepted when delta^T W delta <= step_max * sum(D) and the
-//   trial point is finite; converged when |w * V delta| / |H| < tol_h.
+//   trial point is finite; converged when r = |w * V delta| / |H| < tol_h, or,
+//   after a full step, when the estimated next correction expm1(max|du|) r is.
 //
 // Active subspace: the singular weights c_k decay exponentially.  For the
 // directions with c_k^2 max(w) <= theta (alpha+mu) the Newton matrix is

@@ -5,14 +5,15 @@
 //
 //  * a workgroup of 4 wavefronts owns 4 chain slots that share one data set
 //    (one V).  Every load of V feeds all four chains: the row pass streams
-//    V^T once (u = u - V delta for the four steps), the fused pass streams V
-//    once and produces both h = V^T H (VALU) and the Gram matrices
-//    W = V_a^T diag(w) V_a (f64 MFMA) of the four trial points from the same
-//    registers;
-//  * wave q is the "home" of slot q: it keeps the slot's scalars in its own
-//    registers, factorises the slot's Newton matrix (register Cholesky), takes
-//    the step, decides acceptance / convergence and writes the results --
-//    four factorisations run side by side on the four SIMDs;
+//    V^T once (du = V delta of the four steps, v_mfma_f64_4x4x4 with the four
+//    slots as the columns of every block), the fused pass streams V once and
+//    produces both h = V^T H (VALU) and the Gram matrices
+//    W = V_a^T diag(w) V_a (v_mfma_f64_16x16x4) of the four trial points from
+//    the same registers;
+//  * wave q is the "home" of slot q: it factorises the slot's Newton matrix
+//    (register Cholesky), takes the step, decides acceptance / convergence and
+//    writes the results -- four factorisations run side by side on the four
+//    SIMDs; the slot's scalars live in LDS between the home wave's sections;
 //  * per-chain state in LDS is interleaved [row][chain] so that one 16-byte
 //    LDS read serves two chains;
 //  * the grid is persistent: a slot that has finished its piece of an alpha
