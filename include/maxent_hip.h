@@ -76,7 +76,7 @@ typedef struct mxe_opts {
     double  mu_grow;      /* growth factor of the damping on a rejected step (4)          */
     double  mu_max;       /* give up on the alpha when mu/alpha exceeds this (1e20)       */
     double  decouple_tol; /* theta: singular directions with c_k^2 max(w) <= theta*alpha
-                             take the diagonal Newton step (1e-6; 0 = full n_s block)      */
+                             take the diagonal Newton step (1e-5; 0 = full n_s block)      */
     int32_t waves_per_chain; /* one-chain-per-workgroup layout: wavefronts per chain;
                                 0 = choose from the chain count; else 1,2,4,8             */
     int32_t chains_per_wg;   /* 0 = auto; 1 = one chain per workgroup; 4 = four chains of
@@ -86,7 +86,7 @@ typedef struct mxe_opts {
                                 0 = auto (about 3.5 pieces per chain slot of the GPU, at
                                 most 16, none shorter than 6 alphas), 1 = never             */
     int32_t stop_estimate;   /* 1 (default): after a full (undamped) Newton step the next
-                                correction is estimated as expm1(max|du|) * ||dH||/||H||
+                                correction is estimated as (expm1(max|du|) + decouple_tol) * ||dH||/||H||
                                 (the relative change of the weights w bounds the relative
                                 change of the Jacobian) and tol_h is applied to it, which
                                 saves the last, verifying iteration; 0: tol_h is applied to

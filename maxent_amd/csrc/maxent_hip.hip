@@ -278,7 +278,7 @@ void mxe_opts_default(mxe_opts* o)
     o->maxiter = 1000; o->miniter = 0;
     o->tol_h = 1e-9; o->tol_d = 0.0; o->tol_relq = 0.0;
     o->step_max = 0.2; o->mu_first = 1e-3; o->mu_grow = 4.0; o->mu_max = 1e20;
-    o->decouple_tol = 1e-6;
+    o->decouple_tol = 1e-5;
     o->waves_per_chain = 0; o->chains_per_wg = 0; o->alpha_split = 0; o->stop_estimate = 1;
 }
 

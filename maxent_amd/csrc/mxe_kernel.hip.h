@@ -959,7 +959,7 @@ void chain_kernel(const KParams p)
             if (!accepted) { failed = true; break; }
             const double relH = sqrt(dH2t / Hn2);
             // estimate of the next Newton correction after a full step (see mxe_opts.stop_estimate)
-            const double relH_next = (p.stop_estimate && mu == 0.0) ? expm1(dumaxt) * relH : relH;
+            const double relH_next = (p.stop_estimate && mu == 0.0) ? (expm1(dumaxt) + p.theta) * relH : relH;
             accept_trial();
             MXE_STAMP(5);
             chi2 = chi2t; S = St; Hn2 = Hn2t; wmax = wmaxt;

@@ -302,7 +302,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     const double a = t.alpha + t.mu;
                     bool ok;
                     if (na <= 16) ok = chol_home(std::integral_constant<int, 16>{}, a, na);
+                    else if (na <= 20) ok = chol_home(std::integral_constant<int, 20>{}, a, na);
                     else if (na <= 24) ok = chol_home(std::integral_constant<int, 24>{}, a, na);
+                    else if (na <= 28) ok = chol_home(std::integral_constant<int, 28>{}, a, na);
                     else if (NA <= 32 || na <= 32) ok = chol_home(std::integral_constant<int, 32>{}, a, na);
                     else ok = chol_home(std::integral_constant<int, (NA > 32 ? NA : 32)>{}, a, na);
                     if (ok) {
@@ -611,8 +613,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     ++t.nevals;
                     const double relH = sqrt(sdH / t.Hn2);
                     // estimate of the NEXT Newton correction after a full step: the weights
-                    // change by at most expm1(max|du|) relatively, and so does the Jacobian
-                    const double relH_next = (p.stop_estimate && t.mu == 0.0) ? expm1(sdu) * relH : relH;
+                    // change by at most expm1(max|du|) relatively, and so does the Jacobian;
+                    // the decoupled directions add the relative error theta of the Newton matrix
+                    const double relH_next = (p.stop_estimate && t.mu == 0.0) ? (expm1(sdu) + p.theta) * relH : relH;
                     vv[q * NP + k] -= dlc[q * NP + k];
                     t.chi2 = chi2t; t.S = St; t.Hn2 = sHn; t.wmax = swm;
                     t.Qprev = t.Q; t.Q = Qt; t.mu = 0.0;

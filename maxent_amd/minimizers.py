@@ -79,7 +79,8 @@ class NewtonStepConvergenceMethod(ConvergenceMethod):
     (scale free; not in the reference).
 
     With ``estimate`` (default) the criterion is also applied to the estimated
-    NEXT correction after a full Newton step, expm1(max|du|) * ||dH||/||H||,
+    NEXT correction after a full Newton step,
+    (expm1(max|du|) + decouple_tol) * ||dH||/||H||,
     which is the error left in the accepted point: the iteration that would
     only confirm convergence is not run.  ``estimate=False`` tests the
     correction actually taken."""

@@ -118,7 +118,7 @@ class KernelOptions(object):
 
     def __init__(self, maxiter=1000, miniter=0, tol_h=1e-9, tol_d=0.0,
                  tol_relq=0.0, step_max=0.2, mu_first=1e-3, mu_grow=4.0,
-                 mu_max=1e20, stop_estimate=True):
+                 mu_max=1e20, stop_estimate=True, decouple_tol=1e-5):
         self.maxiter = maxiter
         self.miniter = miniter
         self.tol_h = tol_h            # |w o V delta| / |H| < tol_h
@@ -128,7 +128,8 @@ class KernelOptions(object):
         self.mu_first = mu_first
         self.mu_grow = mu_grow
         self.mu_max = mu_max
-        self.stop_estimate = stop_estimate   # tol_h also on expm1(max|du|) * relH
+        self.stop_estimate = stop_estimate   # tol_h also on (expm1(max|du|) + decouple_tol) * relH
+        self.decouple_tol = decouple_tol     # only enters the estimate here (the model solves the full block)
 
 
 def solve_alpha(basis, el, alpha, v, ev, opts, stats=None):
@@ -193,7 +194,7 @@ def solve_alpha(basis, el, alpha, v, ev, opts, stats=None):
         relH = np.linalg.norm(dH) / np.linalg.norm(ev['H'])
         relH_next = relH
         if opts.stop_estimate and mu == 0.0:
-            relH_next = np.expm1(np.max(np.abs(du))) * relH
+            relH_next = (np.expm1(np.max(np.abs(du))) + opts.decouple_tol) * relH
         v = v - delta
         ev = evt
         Qprev = Q

@@ -40,7 +40,7 @@ def test_opts_defaults_and_struct_layout():
     o = device.default_opts()
     assert (o.maxiter, o.miniter) == (1000, 0)
     assert o.tol_h == 1e-9 and o.tol_d == 0.0 and o.tol_relq == 0.0
-    assert o.step_max == 0.2 and o.mu_grow == 4.0 and o.decouple_tol == 1e-6
+    assert o.step_max == 0.2 and o.mu_grow == 4.0 and o.decouple_tol == 1e-5
     assert (o.waves_per_chain, o.chains_per_wg, o.alpha_split) == (0, 0, 0)      # all automatic
     assert o.stop_estimate == 1
     with pytest.raises(TypeError):

@@ -9,8 +9,8 @@ batch = bench.build_batch(16, 200, 500, 100, 0)
 ctx = bench.stage(batch, 0)
 K = batch['K']
 truth = {}
-GRID = ((1e-6, 1e-9, 0), (1e-6, 1e-9, 1), (1e-6, 1e-8, 1), (1e-6, 1e-7, 1), (1e-6, 1e-6, 1), (1e-6, 1e-5, 1),
-        (1e-4, 1e-7, 1), (1e-6, 1e-6, 0), (1e-4, 1e-9, 0))
+GRID = ((1e-6, 1e-9, 0), (1e-6, 1e-9, 1), (1e-5, 1e-9, 1), (1e-4, 1e-9, 1), (3e-4, 1e-9, 1), (1e-3, 1e-9, 1),
+        (1e-6, 1e-8, 1), (1e-6, 1e-7, 1), (1e-6, 1e-6, 1), (1e-4, 1e-7, 1))
 for theta, tol, est in GRID:
     out = ctx.solve_chains(np.arange(256, dtype=np.int32), batch['alphas'], batch['v0'],
                            device.default_opts(tol_h=tol, decouple_tol=theta, stop_estimate=est))
