@@ -52,6 +52,7 @@ extern "C" {
 #define MXE_ERR_STATE       -4   /* call order (e.g. solve before elements)   */
 #define MXE_ERR_LIMIT       -5   /* n_s > 128 or LDS budget exceeded          */
 #define MXE_ERR_NUMERIC     -6   /* whitening failed (non-positive error bar) */
+#define MXE_ERR_NOMEM       -7   /* host allocation failed                     */
 
 #define MXE_ENTROPY_NORMAL     0 /* NormalEntropy + NormalH_of_v              */
 #define MXE_ENTROPY_PLUSMINUS  1 /* PlusMinusEntropy + PlusMinusH_of_v        */

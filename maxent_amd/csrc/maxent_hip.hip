@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -79,6 +80,11 @@ struct mxe_ctx {
     DevBuf<int> dqueue, dcounter;
     std::string hip_err;
 };
+
+// nothing may propagate through the C boundary: function-try-blocks of the entry points
+#define MXE_CATCH_ALL \
+    catch (const std::bad_alloc&) { return MXE_ERR_NOMEM; } \
+    catch (...) { return MXE_ERR_ARG; }
 
 #define HIPCHK(ctx, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { \
     (ctx)->hip_err = std::string(#call) + ": " + hipGetErrorString(e__); return MXE_ERR_HIP; } } while (0)
@@ -258,6 +264,7 @@ const char* mxe_strerror(int code)
         case MXE_ERR_STATE: return "call order violated";
         case MXE_ERR_LIMIT: return "problem exceeds kernel limits (n_s <= 128, 160 KB LDS per chain)";
         case MXE_ERR_NUMERIC: return "whitening failed (error bars must be finite and > 0)";
+        case MXE_ERR_NOMEM: return "out of host memory";
         default: return "unknown error";
     }
 }
@@ -284,14 +291,14 @@ void mxe_opts_default(mxe_opts* o)
 
 int mxe_ctx_create(int device, int n_tau, int n_omega, int n_s,
                    const double* U, const double* S, const double* V, mxe_ctx** out)
-{
+try {
     if (!out || !S || !V || n_tau < 1 || n_omega < 1 || n_s < 1) return MXE_ERR_ARG;
     if (n_s > 128) return MXE_ERR_LIMIT;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MXE_ERR_NODEVICE;
     if (device < 0 || device >= ndev) return MXE_ERR_ARG;
     mxe_ctx* ctx = new (std::nothrow) mxe_ctx();
-    if (!ctx) return MXE_ERR_ARG;
+    if (!ctx) return MXE_ERR_NOMEM;
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return MXE_ERR_NODEVICE; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -308,6 +315,7 @@ int mxe_ctx_create(int device, int n_tau, int n_omega, int n_s,
     *out = ctx;
     return MXE_OK;
 }
+MXE_CATCH_ALL
 
 void mxe_ctx_destroy(mxe_ctx* ctx)
 {
@@ -318,7 +326,7 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
     ctx->dalpha.release(); ctx->dv0.release(); ctx->delem_ds.release(); ctx->delem_kind.release();
     ctx->dchain_elem.release(); ctx->dsub_prob0.release(); ctx->dsub_len.release(); ctx->dsub_v0.release(); ctx->dwg_chains.release(); ctx->dqueue.release(); ctx->dcounter.release(); ctx->dout_v.release(); ctx->dout_pack.release(); ctx->dout_pack2.release();
     ctx->dout_niter.release(); ctx->dout_conv.release(); ctx->dout_nevals.release(); ctx->dout_nact.release();
-    ctx->dB.release(); ctx->dA.release();
+    ctx->dB.release(); ctx->dA.release(); ctx->dprof.release();
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -328,7 +336,7 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
 const char* mxe_last_hip_error(mxe_ctx* ctx) { return ctx ? ctx->hip_err.c_str() : ""; }
 
 int mxe_dataset_add(mxe_ctx* ctx, int n_rows, const double* U_rot, const double* err, int* id)
-{
+try {
     if (!ctx || !err || n_rows < 1) return MXE_ERR_ARG;
     if (!U_rot && (ctx->U.empty() || n_rows != ctx->n_tau)) return MXE_ERR_ARG;
     DataSet d;
@@ -340,6 +348,7 @@ int mxe_dataset_add(mxe_ctx* ctx, int n_rows, const double* U_rot, const double*
     if (id) *id = (int)ctx->ds.size() - 1;
     return MXE_OK;
 }
+MXE_CATCH_ALL
 
 int mxe_dataset_clear(mxe_ctx* ctx)
 {
@@ -351,7 +360,7 @@ int mxe_dataset_clear(mxe_ctx* ctx)
 int mxe_elements_set(mxe_ctx* ctx, int n_elem, const int32_t* dataset_of_elem,
                      const double* G, const int64_t* G_offset,
                      const double* D, const int32_t* entropy)
-{
+try {
     if (!ctx || n_elem < 1 || !dataset_of_elem || !G || !G_offset || !D || !entropy) return MXE_ERR_ARG;
     if (ctx->ds.empty()) return MXE_ERR_STATE;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -404,11 +413,12 @@ int mxe_elements_set(mxe_ctx* ctx, int n_elem, const int32_t* dataset_of_elem,
     ctx->chains_ready = false;
     return MXE_OK;
 }
+MXE_CATCH_ALL
 
 int mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
                       const int32_t* elem_of_chain, const double* alpha_scaled,
                       const double* v0, const mxe_opts* opts)
-{
+try {
     if (!ctx || n_chain < 1 || n_alpha < 1 || !elem_of_chain || !alpha_scaled || !v0) return MXE_ERR_ARG;
     if (ctx->n_elem < 1) return MXE_ERR_STATE;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -565,9 +575,10 @@ int mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
     ctx->chains_ready = true; ctx->launched = false;
     return MXE_OK;
 }
+MXE_CATCH_ALL
 
 int mxe_chains_launch(mxe_ctx* ctx)
-{
+try {
     if (!ctx) return MXE_ERR_ARG;
     if (!ctx->chains_ready) return MXE_ERR_STATE;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -641,6 +652,7 @@ int mxe_chains_launch(mxe_ctx* ctx)
     ctx->launched = true;
     return MXE_OK;
 }
+MXE_CATCH_ALL
 
 int mxe_sync(mxe_ctx* ctx)
 {
@@ -653,7 +665,7 @@ int mxe_sync(mxe_ctx* ctx)
 int mxe_chains_fetch(mxe_ctx* ctx, double* out_v, double* out_H, double* out_chi2,
                      double* out_S, double* out_Q, int32_t* out_niter,
                      int32_t* out_converged, int32_t* out_nevals)
-{
+try {
     if (!ctx) return MXE_ERR_ARG;
     if (!ctx->launched) return MXE_ERR_STATE;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -686,6 +698,7 @@ int mxe_chains_fetch(mxe_ctx* ctx, double* out_v, double* out_H, double* out_chi
     }
     return MXE_OK;
 }
+MXE_CATCH_ALL
 
 int mxe_chains_fetch_nact(mxe_ctx* ctx, int32_t* out_nact)
 {
@@ -880,7 +893,7 @@ void logdet_kernel(const double* __restrict__ Vall, const double* __restrict__ c
 } // namespace mxe
 
 extern "C" int mxe_logdet(mxe_ctx* ctx, double* out_logdet)
-{
+try {
     if (!ctx || !out_logdet) return MXE_ERR_ARG;
     if (!ctx->launched) return MXE_ERR_STATE;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -905,6 +918,7 @@ extern "C" int mxe_logdet(mxe_ctx* ctx, double* out_logdet)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return MXE_OK;
 }
+MXE_CATCH_ALL
 
 // ---- output map A = B H ----------------------------------------------------
 namespace mxe {
@@ -932,7 +946,7 @@ void output_map_kernel(const double* __restrict__ Bt, const double* __restrict__
 } // namespace mxe
 
 extern "C" int mxe_apply_output_map(mxe_ctx* ctx, const double* B, double* out_A)
-{
+try {
     if (!ctx || !B || !out_A) return MXE_ERR_ARG;
     if (!ctx->launched) return MXE_ERR_STATE;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -950,3 +964,4 @@ extern "C" int mxe_apply_output_map(mxe_ctx* ctx, const double* B, double* out_A
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return MXE_OK;
 }
+MXE_CATCH_ALL
