@@ -63,11 +63,12 @@ def fit_piecewise(logx, logy, p2_deg=0):
     p1 = [None] * n
     p2 = [None] * n
     ok = np.logical_not(np.isnan(logy))
-    for i in range(2, n - 2):
+
+    def exact(i):
         a, b = ok[:i], ok[i:]
         x1, y1, x2, y2 = logx[:i][a], logy[:i][a], logx[i:][b], logy[i:][b]
         if len(x1) < 1 or len(x2) < 1:
-            continue
+            return
         s1, c1, e1 = _linfit_sse(x1, y1)
         if p2_deg == 1:
             s2, c2, e2 = _linfit_sse(x2, y2)
@@ -78,6 +79,37 @@ def fit_piecewise(logx, logy, p2_deg=0):
             p2[i] = np.array([c2])
         p1[i] = np.array([s1, c1])
         misfit[i] = e1 + e2
+
+    # All break points at once from prefix sums (O(n) instead of O(n^2)); these values only
+    # select the candidates, which are then evaluated exactly as above, so the chosen index is
+    # that of the plain loop (a 16x16 run calls this 256 times with n = 100).
+    cands = range(2, n - 2)
+    if n > 8:
+        w = ok.astype(float)
+        x0 = logx - np.mean(logx)                      # centred: less cancellation
+        y0 = np.where(ok, logy, 0.0)
+        y0 = y0 - (np.sum(y0) / max(np.sum(w), 1.0)) * w
+        cs = [np.concatenate(([0.0], np.cumsum(v))) for v in
+              (w, w * x0, y0, w * x0 * x0, x0 * y0, y0 * y0)]
+
+        def sse(lo, hi, line):
+            m, sx, sy, sxx, sxy, syy = [c[hi] - c[lo] for c in cs]
+            with np.errstate(all='ignore'):
+                vyy = syy - sy * sy / m
+                if not line:
+                    return np.where(m >= 1, vyy, np.nan)
+                vxx = sxx - sx * sx / m
+                vxy = sxy - sx * sy / m
+                fit = np.where(vxx > 0, vyy - vxy * vxy / vxx, vyy)
+                return np.where(m >= 1, np.where(m >= 2, fit, vyy), np.nan)
+        idx = np.arange(2, n - 2)
+        approx = sse(np.zeros_like(idx), idx, True) + sse(idx, np.full_like(idx, n), p2_deg == 1)
+        if np.any(np.isfinite(approx)):
+            scale = np.nanmax(np.abs(cs[5][-1])) + 1e-300
+            best = np.nanmin(approx)
+            cands = idx[approx <= best + 1e-9 * scale + 1e-6 * abs(best)]
+    for i in cands:
+        exact(int(i))
     if np.all(np.isnan(misfit)):
         raise ValueError('chi2 is all NaN')
     i = int(np.nanargmin(misfit))
@@ -107,8 +139,10 @@ def curv(x, y):
     return der2 / (1 + der1 * der1) ** 1.5, der1, der2
 
 
-def _element(maxent_result, what, matrix_element):
-    return maxent_result._get_element(what, matrix_element)
+def _element(maxent_result, name, matrix_element):
+    """the arrays of ONE element, without assembling the (M, N, ...) array of all
+    elements first (``maxent_result.A`` of a 16x16 run is 100 MB)."""
+    return maxent_result.element_array(name, matrix_element)
 
 
 class LineFitAnalyzer(Analyzer):
@@ -121,15 +155,13 @@ class LineFitAnalyzer(Analyzer):
     def analyze(self, maxent_result, matrix_element=None):
         res = AnalyzerResult()
         alpha = np.asarray(maxent_result.alpha)
-        chi2 = np.asarray(_element(maxent_result, maxent_result.chi2,
-                                   matrix_element), dtype=float)
+        chi2 = np.asarray(_element(maxent_result, 'chi2', matrix_element), dtype=float)
         with np.errstate(all='ignore'):
             idx, params = fit_piecewise(np.log(alpha), np.log(chi2),
                                         self.linefit_deg)
         res['alpha_index'] = idx
         res['linefit_params'] = params
-        res['A_out'] = _element(maxent_result, maxent_result.A,
-                                matrix_element)[idx]
+        res['A_out'] = _element(maxent_result, 'A', matrix_element)[idx]
         res['linefit_deg'] = self.linefit_deg
         res['name'] = self.name
         res['info'] = 'Ideal alpha (linefit): {} (= index {} zero-based)' \
@@ -147,8 +179,7 @@ class Chi2CurvatureAnalyzer(Analyzer):
     def analyze(self, maxent_result, matrix_element=None):
         res = AnalyzerResult()
         alpha = np.asarray(maxent_result.alpha)
-        chi2 = np.asarray(_element(maxent_result, maxent_result.chi2,
-                                   matrix_element), dtype=float)
+        chi2 = np.asarray(_element(maxent_result, 'chi2', matrix_element), dtype=float)
         with np.errstate(all='ignore'):
             res['curvature'], _, _ = curv(self.gamma * np.log10(alpha),
                                           np.log10(chi2))
@@ -156,8 +187,7 @@ class Chi2CurvatureAnalyzer(Analyzer):
             raise ValueError('curvature is all NaN')
         idx = int(np.nanargmax(res['curvature']))
         res['alpha_index'] = idx
-        res['A_out'] = _element(maxent_result, maxent_result.A,
-                                matrix_element)[idx]
+        res['A_out'] = _element(maxent_result, 'A', matrix_element)[idx]
         res['gamma'] = self.gamma
         res['name'] = self.name
         res['info'] = 'Ideal alpha (curvature): {} (= index {} zero-based)' \
@@ -171,8 +201,7 @@ class EntropyAnalyzer(Analyzer):
     def analyze(self, maxent_result, matrix_element=None):
         res = AnalyzerResult()
         alpha = np.asarray(maxent_result.alpha)
-        S = np.asarray(_element(maxent_result, maxent_result.S,
-                                matrix_element), dtype=float)
+        S = np.asarray(_element(maxent_result, 'S', matrix_element), dtype=float)
         d = np.full(len(alpha), np.nan)
         d[1:-1] = (S[2:] - S[:-2]) / (np.log(alpha[2:]) - np.log(alpha[:-2]))
         res['dS_dalpha'] = d
@@ -180,8 +209,7 @@ class EntropyAnalyzer(Analyzer):
             raise ValueError('dS_dalpha is all NaN')
         idx = int(np.nanargmin(d ** 2))
         res['alpha_index'] = idx
-        res['A_out'] = _element(maxent_result, maxent_result.A,
-                                matrix_element)[idx]
+        res['A_out'] = _element(maxent_result, 'A', matrix_element)[idx]
         res['name'] = self.name
         res['info'] = 'Ideal alpha (entropy): {} (= index {} zero-based)' \
             .format(alpha[idx], idx)
@@ -206,13 +234,12 @@ class BryanAnalyzer(Analyzer):
     def analyze(self, maxent_result, matrix_element=None):
         res = AnalyzerResult()
         res['name'] = self.name
-        logp = np.asarray(_element(maxent_result, maxent_result.probability,
-                                   matrix_element), dtype=float)
+        logp = np.asarray(_element(maxent_result, 'probability', matrix_element), dtype=float)
         if np.all(np.isnan(logp)):
             res['info'] = 'Probability not calculated. Cannot use BryanAnalyzer.'
             return res
         alpha = np.asarray(maxent_result.alpha)
-        A = _element(maxent_result, maxent_result.A, matrix_element)
+        A = _element(maxent_result, 'A', matrix_element)
         good = np.logical_not(np.isnan(logp))
         p = np.exp(logp[good] - np.nanmax(logp))
         if self.average_by_integration:
@@ -231,15 +258,13 @@ class ClassicAnalyzer(Analyzer):
     def analyze(self, maxent_result, matrix_element=None):
         res = AnalyzerResult()
         res['name'] = self.name
-        logp = np.asarray(_element(maxent_result, maxent_result.probability,
-                                   matrix_element), dtype=float)
+        logp = np.asarray(_element(maxent_result, 'probability', matrix_element), dtype=float)
         if np.all(np.isnan(logp)):
             res['info'] = 'Probability not calculated. Cannot use ClassicAnalyzer.'
             return res
         idx = int(np.nanargmax(logp))
         res['alpha_index'] = idx
-        res['A_out'] = _element(maxent_result, maxent_result.A,
-                                matrix_element)[idx]
+        res['A_out'] = _element(maxent_result, 'A', matrix_element)[idx]
         res['info'] = 'Ideal alpha (classic): {} (= index {} zero-based)' \
             .format(np.asarray(maxent_result.alpha)[idx], idx)
         return res

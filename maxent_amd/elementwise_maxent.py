@@ -165,6 +165,9 @@ class ElementwiseMaxEnt(object):
             rec['run_times'] = [per_alpha] * len(sol['alpha'])
             res.add_element_results(rec, element, cidx)
             res.end_timing(element, cidx, time=t1)
+        # analyzers after every record of the batch is in (adding a record drops the
+        # assembled-array cache of the result)
+        for (element, cidx) in live:
             res.analyze(loop.analyzers, element, cidx)
         worker.logtaker.message(
             VerbosityFlags.Timing,

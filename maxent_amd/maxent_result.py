@@ -84,6 +84,10 @@ class MaxEntResultData(object):
             ret = ret[i]
         return ret
 
+    def element_array(self, name, matrix_element=None):
+        """field ``name`` of one element (all of it for a scalar result)."""
+        return self._get_element(getattr(self, name), matrix_element)
+
     # ---- field bookkeeping (h5 / pickle subset) -----------------------
     def include_only(self, fields):
         self._all_fields = []
@@ -291,6 +295,16 @@ class MaxEntResult(MaxEntResultData):
                 out[analyzer.name] = str(e)
         self._analysis[key] = out
         self._cache.pop('analyzer_results', None)
+
+    def element_array(self, name, matrix_element=None):
+        """field ``name`` of one element straight from its record (no assembly of the
+        array over all elements); mirrored / missing elements go the general way."""
+        if self.matrix_structure is None or not self.element_wise:
+            return np.asarray(self._records[None][name])
+        rec = self._records.get(tuple(matrix_element))
+        if rec is None or name not in rec:
+            return self._get_element(getattr(self, name), matrix_element)
+        return np.asarray(rec[name])
 
     # ---- assembling ------------------------------------------------------
     def _reference_record(self):

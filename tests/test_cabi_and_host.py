@@ -268,3 +268,40 @@ def test_probability_from_device_logdet_equals_host_evaluation():
         p = NormalLogProbability(**kw)
         np.testing.assert_allclose(p.from_logdet(logdet, alpha, Q, n_omega),
                                    p.evaluate(U, S, V, err, alpha, w, Q), rtol=1e-12, atol=1e-12)
+
+
+def test_fast_linefit_picks_the_index_of_the_plain_loop():
+    """fit_piecewise selects candidates from prefix sums and evaluates them exactly; the picked
+    break point and the returned polynomials are those of the O(n^2) loop."""
+    from maxent_amd import analyzers as an
+    rng = np.random.RandomState(11)
+
+    def plain(logx, logy, deg):
+        n = len(logx)
+        ok = ~np.isnan(logy)
+        best, bi, bp = np.inf, None, None
+        for i in range(2, n - 2):
+            x1, y1, x2, y2 = logx[:i][ok[:i]], logy[:i][ok[:i]], logx[i:][ok[i:]], logy[i:][ok[i:]]
+            if len(x1) < 1 or len(x2) < 1:
+                continue
+            s1, c1, e1 = an._linfit_sse(x1, y1)
+            if deg == 1:
+                s2, c2, e2 = an._linfit_sse(x2, y2)
+                q2 = np.array([s2, c2])
+            else:
+                c2 = float(np.mean(y2)); e2 = float(np.sum((y2 - c2) ** 2)); q2 = np.array([c2])
+            if e1 + e2 < best:
+                best, bi, bp = e1 + e2, i, (np.array([s1, c1]), q2)
+        return bi, bp
+    for trial in range(60):
+        n = rng.randint(9, 120)
+        logx = np.sort(rng.uniform(-5, 10, n))[::-1].copy()
+        k = rng.randint(3, n - 3)
+        logy = np.where(np.arange(n) < k, 2.0 + 0.8 * (logx - logx[k]), 2.0) + 0.05 * rng.randn(n)
+        if trial % 3 == 0:
+            logy[rng.randint(0, n, 3)] = np.nan
+        for deg in (0, 1):
+            bi, bp = plain(logx, logy, deg)
+            idx, (q1, q2) = an.fit_piecewise(logx, logy, deg)
+            np.testing.assert_array_equal(q1, bp[0])
+            np.testing.assert_array_equal(q2, bp[1])
