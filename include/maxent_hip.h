@@ -34,7 +34,8 @@
  * negative error code and never throws or aborts; the caller owns every host
  * buffer (C-contiguous, row-major); the library owns device memory inside
  * mxe_ctx.  Calls on one ctx are not re-entrant; different ctxs (devices) may
- * be driven from different threads.  All arithmetic is IEEE binary64.
+ * be driven from different threads.  All arithmetic is IEEE binary64 unless
+ * mxe_opts.precision asks for the binary32 streaming variant.
  */
 #ifndef MAXENT_HIP_H
 #define MAXENT_HIP_H
@@ -50,9 +51,12 @@ extern "C" {
 #define MXE_ERR_HIP         -2   /* a HIP runtime call failed (mxe_last_hip_error) */
 #define MXE_ERR_NODEVICE    -3   /* no usable gfx950 device                   */
 #define MXE_ERR_STATE       -4   /* call order (e.g. solve before elements)   */
-#define MXE_ERR_LIMIT       -5   /* n_s > 128 or LDS budget exceeded          */
+#define MXE_ERR_LIMIT       -5   /* n_s > 128 (fp32: > 64) or LDS budget exceeded */
 #define MXE_ERR_NUMERIC     -6   /* whitening failed (non-positive error bar) */
 #define MXE_ERR_NOMEM       -7   /* host allocation failed                     */
+
+#define MXE_PRECISION_F64      0 /* all arithmetic IEEE binary64 (default)      */
+#define MXE_PRECISION_F32      1 /* omega-space streaming arithmetic in binary32 */
 
 #define MXE_ENTROPY_NORMAL     0 /* NormalEntropy + NormalH_of_v              */
 #define MXE_ENTROPY_PLUSMINUS  1 /* PlusMinusEntropy + PlusMinusH_of_v        */
@@ -92,6 +96,14 @@ typedef struct mxe_opts {
                                 change of the Jacobian) and tol_h is applied to it, which
                                 saves the last, verifying iteration; 0: tol_h is applied to
                                 the correction just taken only                              */
+    int32_t precision;       /* MXE_PRECISION_F64 (default) or MXE_PRECISION_F32: V, u = V v, w, H,
+                                exp, h = V^T H and the Gram matrix in binary32 (fp32 MFMA); the
+                                n_act x n_act Newton system, the residual and all scalars stay
+                                binary64.  An alpha also stops when its Newton correction has
+                                reached the rounding floor (it no longer shrinks).  n_s <= 64,
+                                one chain per workgroup.  For the fp32-vs-fp64 tolerance sweep of
+                                BASELINE config 5 (tools/cfg5_tolerance_sweep.py)              */
+    int32_t reserved;        /* keep 0 */
 } mxe_opts;
 
 /* ---- library / device ------------------------------------------------- */

@@ -67,6 +67,7 @@ struct mxe_ctx {
     bool chains_ready = false, launched = false;
     int last_nw = 0, last_lds = 0;
     // device
+    DevBuf<float> dVf, dVtf;          // binary32 copies of dV / dVt (mxe_opts.precision = F32)
     DevBuf<double> dV, dVt, dc, dcinv, dghat, dcperp, dD, dsumD, dalpha, dv0;
     DevBuf<int> delem_ds, delem_kind, dchain_elem, dsub_prob0, dsub_len, dsub_v0, dwg_chains;
     // H, chi2, S, Q live back to back in ONE allocation (dout_pack) so that a
@@ -214,6 +215,11 @@ int upload_bases(mxe_ctx* ctx)
     HIPCHK(ctx, hipMemcpyAsync(ctx->dVt.p, hVt.data(), hVt.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dc.p, hc.data(), hc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dcinv.p, hci.data(), hci.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<float> hVf(hV.begin(), hV.end()), hVtf(hVt.begin(), hVt.end());
+    HIPCHK(ctx, ctx->dVf.ensure(hVf.size()));
+    HIPCHK(ctx, ctx->dVtf.ensure(hVtf.size()));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dVf.p, hVf.data(), hVf.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dVtf.p, hVtf.data(), hVtf.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->ds_dirty = false;
     return MXE_OK;
@@ -225,20 +231,24 @@ size_t mc_lds_doubles(int NA, int nwp, int NWV)
            (size_t)3 * nwp * 4 + mxe::MC_LOOKAHEAD_LDS;
 }
 
-size_t lds_doubles(int NP, int nwp, int NW)
+// LDS bytes of chain_kernel<NW, NAB, TS>: stream arrays (u, ut, w, wt, Hs, vecs) in the stream
+// type, the Gram staging area only in the binary64 build
+size_t lds_bytes(int NP, int nwp, int NW, bool f32)
 {
     const int SROW = (NP / 4) * mxe::GBLK;
-    return (size_t)NP * (NP + 1) + 11 * (size_t)NP + (size_t)NW * NP + (size_t)NW * 8 +
-           5 * (size_t)nwp + (size_t)NW * 2 * mxe::GRAM_R * SROW;
+    const size_t fixed = (size_t)NP * (NP + 1) + 11 * (size_t)NP + (size_t)NW * NP + (size_t)NW * 8;
+    const size_t stream = 5 * (size_t)nwp + NP;
+    const size_t stage = f32 ? 0 : (size_t)NW * 2 * mxe::GRAM_R * SROW;
+    return (fixed + stage) * 8 + stream * (f32 ? 4 : 8);
 }
 
-template <int NW, int NAB>
+template <int NW, int NAB, typename TS = double>
 hipError_t launch_t(const KParams& kp, size_t lds, hipStream_t s)
 {
-    hipError_t e = hipFuncSetAttribute((const void*)mxe::chain_kernel<NW, NAB>,
+    hipError_t e = hipFuncSetAttribute((const void*)mxe::chain_kernel<NW, NAB, TS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mxe::chain_kernel<NW, NAB>), dim3(kp.n_chain), dim3(64 * NW), lds, s, kp);
+    hipLaunchKernelGGL((mxe::chain_kernel<NW, NAB, TS>), dim3(kp.n_chain), dim3(64 * NW), lds, s, kp);
     return hipGetLastError();
 }
 
@@ -287,6 +297,7 @@ void mxe_opts_default(mxe_opts* o)
     o->step_max = 0.2; o->mu_first = 1e-3; o->mu_grow = 4.0; o->mu_max = 1e20;
     o->decouple_tol = 1e-5;
     o->waves_per_chain = 0; o->chains_per_wg = 0; o->alpha_split = 0; o->stop_estimate = 1;
+    o->precision = MXE_PRECISION_F64; o->reserved = 0;
 }
 
 int mxe_ctx_create(int device, int n_tau, int n_omega, int n_s,
@@ -321,7 +332,7 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    ctx->dlogdet.release(); ctx->dparent_elem.release(); ctx->dV.release(); ctx->dVt.release(); ctx->dc.release(); ctx->dcinv.release();
+    ctx->dlogdet.release(); ctx->dparent_elem.release(); ctx->dV.release(); ctx->dVt.release(); ctx->dVf.release(); ctx->dVtf.release(); ctx->dc.release(); ctx->dcinv.release();
     ctx->dghat.release(); ctx->dcperp.release(); ctx->dD.release(); ctx->dsumD.release();
     ctx->dalpha.release(); ctx->dv0.release(); ctx->delem_ds.release(); ctx->delem_kind.release();
     ctx->dchain_elem.release(); ctx->dsub_prob0.release(); ctx->dsub_len.release(); ctx->dsub_v0.release(); ctx->dwg_chains.release(); ctx->dqueue.release(); ctx->dcounter.release(); ctx->dout_v.release(); ctx->dout_pack.release(); ctx->dout_pack2.release();
@@ -431,6 +442,8 @@ try {
         o.waves_per_chain != 4 && o.waves_per_chain != 8) return MXE_ERR_ARG;
     if (o.chains_per_wg != 0 && o.chains_per_wg != 1 && o.chains_per_wg != 4) return MXE_ERR_ARG;
     if (o.alpha_split < 0) return MXE_ERR_ARG;
+    if (o.precision != MXE_PRECISION_F64 && o.precision != MXE_PRECISION_F32) return MXE_ERR_ARG;
+    if (o.precision == MXE_PRECISION_F32 && NP != 64) return MXE_ERR_LIMIT;
     ctx->chain_elem.assign(elem_of_chain, elem_of_chain + n_chain);
     std::vector<double> hv0((size_t)n_chain * NP, 0.0);
     for (int c = 0; c < n_chain; ++c) {
@@ -481,7 +494,7 @@ try {
     int layout = o.chains_per_wg;
     ctx->mc_na = 0;
     if (layout == 0) layout = (ctx->n_sub >= 768) ? 4 : 1;
-    if (layout == 4 && (NP != 64 || o.tol_d > 0.0 || o.decouple_tol <= 0.0)) layout = 1;
+    if (layout == 4 && (NP != 64 || o.tol_d > 0.0 || o.decouple_tol <= 0.0 || o.precision != MXE_PRECISION_F64)) layout = 1;
     if (layout == 4) {
         // capacity of the active block: the kernel clamps n_act to NA, and the
         // first neglected direction couples with relative strength
@@ -586,6 +599,7 @@ try {
     KParams kp;
     kp.n_omega = ctx->n_omega; kp.n_omega_pad = ctx->nwp; kp.n_s = ctx->n_s; kp.NP = ctx->NP;
     kp.n_alpha = ctx->n_alpha; kp.n_chain = ctx->n_chain;
+    kp.Vf = ctx->dVf.p; kp.Vtf = ctx->dVtf.p;
     kp.V = ctx->dV.p; kp.Vt = ctx->dVt.p; kp.c = ctx->dc.p; kp.cinv = ctx->dcinv.p;
     kp.elem_ds = ctx->delem_ds.p; kp.elem_kind = ctx->delem_kind.p;
     kp.ghat = ctx->dghat.p; kp.cperp = ctx->dcperp.p; kp.D = ctx->dD.p; kp.sumD = ctx->dsumD.p;
@@ -635,11 +649,20 @@ try {
             const int nc = ctx->n_sub;
             NW = (nc >= 2048) ? 1 : (nc >= 1024) ? 2 : (nc >= 256) ? 4 : 8;
         }
-        size_t lds = lds_doubles(ctx->NP, ctx->nwp, NW) * sizeof(double);
-        while (lds > 160 * 1024 && NW > 1) { NW /= 2; lds = lds_doubles(ctx->NP, ctx->nwp, NW) * sizeof(double); }
+        const bool f32 = (o.precision == MXE_PRECISION_F32);
+        size_t lds = lds_bytes(ctx->NP, ctx->nwp, NW, f32);
+        while (lds > 160 * 1024 && NW > 1) { NW /= 2; lds = lds_bytes(ctx->NP, ctx->nwp, NW, f32); }
         if (lds > 160 * 1024) return MXE_ERR_LIMIT;
         ctx->last_nw = NW; ctx->last_lds = (int)lds;
         HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        if (f32) {
+            switch (NW) {
+                case 1: e = launch_t<1, 2, float>(kp, lds, ctx->stream); break;
+                case 2: e = launch_t<2, 2, float>(kp, lds, ctx->stream); break;
+                case 4: e = launch_t<4, 2, float>(kp, lds, ctx->stream); break;
+                default: e = launch_t<8, 2, float>(kp, lds, ctx->stream); break;
+            }
+        } else
         switch (NW) {
             case 1: e = launch_nab<1>(ctx->NP, kp, lds, ctx->stream); break;
             case 2: e = launch_nab<2>(ctx->NP, kp, lds, ctx->stream); break;

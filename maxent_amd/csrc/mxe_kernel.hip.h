@@ -76,6 +76,9 @@ struct KParams {
     double tol_h, tol_d, tol_relq, step_max, mu_first, mu_grow, mu_max, theta;
     int stop_estimate;  // tol_h also applies to the estimated next correction (see mxe_opts)
     long long* prof;    // [n_chain][8] phase cycle counters (diagnostic build only)
+    // binary32 copies of V / Vt (same shapes) for the fp32 streaming variant (mxe_opts.precision)
+    const float* Vf;
+    const float* Vtf;
 };
 
 #if defined(MXE_PROFILE) && defined(MXE_PROFILE_EVAL)
@@ -105,6 +108,37 @@ __device__ __forceinline__ double recip_exp(double e) {
     y = fma(fma(-e, y, 1.0), y, y);
     return y;
 }
+
+__device__ __forceinline__ float recip_exp(float e) {
+    float y = __builtin_amdgcn_rcpf(e);
+    y = fmaf(fmaf(-e, y, 1.0f), y, y);
+    return y;
+}
+
+// stream type of the omega-space arithmetic: double (default) or float (mxe_opts.precision = F32:
+// V, u, w, H, exp, the two mat-vecs and the Gram matrix in binary32; the n_act x n_act Newton
+// system, the residual rho and every scalar of the iteration stay binary64)
+template <typename TS> struct Stream;
+template <> struct Stream<double> {
+    typedef double2 vec2;
+    typedef double acc4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ double exp_(double x) { return exp(x); }
+    static __device__ __forceinline__ const double* V(const KParams& p) { return p.V; }
+    static __device__ __forceinline__ const double* Vt(const KParams& p) { return p.Vt; }
+    static __device__ __forceinline__ acc4 mfma(double a, double b, acc4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = l & 15, row = (l >> 4) + 4 r
+    static __device__ __forceinline__ int crow(int kq, int r) { return kq + 4 * r; }
+};
+template <> struct Stream<float> {
+    typedef float2 vec2;
+    typedef float acc4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ float exp_(float x) { return expf(x); }
+    static __device__ __forceinline__ const float* V(const KParams& p) { return p.Vf; }
+    static __device__ __forceinline__ const float* Vt(const KParams& p) { return p.Vtf; }
+    static __device__ __forceinline__ acc4 mfma(float a, float b, acc4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    // C/D layout of v_mfma_f32_16x16x4_f32: col = l & 15, row = 4 (l >> 4) + r
+    static __device__ __forceinline__ int crow(int kq, int r) { return 4 * kq + r; }
+};
 
 // x[l] + x[l ^ 32] and x[l] + x[l ^ 16] in every lane with the gfx950 lane-swap
 // instructions (v_permlane32_swap / v_permlane16_swap exchange half-waves / odd and
@@ -258,10 +292,15 @@ __device__ __forceinline__ void block_reduce2(double (&x)[NV], double& mx, doubl
 
 // NW  wavefronts per chain
 // NAB padded singular dimension in units of 32 (2 -> NP = 64, 4 -> NP = 128)
-template <int NW, int NAB>
+// TS  stream type (double; float = the fp32 variant, NAB = 2 only)
+template <int NW, int NAB, typename TS = double>
 __global__ __launch_bounds__(64 * NW)
 void chain_kernel(const KParams p)
 {
+    typedef Stream<TS> ST;
+    typedef typename ST::vec2 TS2;
+    constexpr bool F64 = std::is_same<TS, double>::value;
+    static_assert(F64 || NAB == 2, "the fp32 variant is built for n_s <= 64");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int T = WAVE * NW;
     constexpr int NP = 32 * NAB;          // padded n_s == capacity of the active block
@@ -290,18 +329,19 @@ void chain_kernel(const KParams p)
     double* rhot = rho + NP;
     double* hpart = rhot + NP;               // [NW][NP]
     double* red  = hpart + NW * NP;          // [NW*8]
-    double* u    = red + NW * 8;             // [nwp]
-    double* ut   = u + nwp;
-    double* w    = ut + nwp;
-    double* wt   = w + nwp;
-    double* Hs   = wt + nwp;
-    double* stage = Hs + nwp;                // [NW][2 (x,y)][GRAM_R][SROW]
+    TS* u    = reinterpret_cast<TS*>(red + NW * 8);   // [nwp]
+    TS* ut   = u + nwp;
+    TS* w    = ut + nwp;
+    TS* wt   = w + nwp;
+    TS* Hs   = wt + nwp;
+    TS* vecs = Hs + nwp;                     // [NP] stream-type copy of the vector of a pass
+    double* stage = reinterpret_cast<double*>(vecs + NP);   // [NW][2 (x,y)][GRAM_R][SROW] (fp64 VALU Gram only)
 
     const int elem = p.chain_elem[chain];
     const int ds = p.elem_ds[elem];
     const int kind = p.elem_kind[elem];
-    const double* __restrict__ V  = p.V  + (size_t)ds * nwp * NP;
-    const double* __restrict__ Vt = p.Vt + (size_t)ds * NP * nwp;
+    const TS* __restrict__ V  = ST::V(p)  + (size_t)ds * nwp * NP;
+    const TS* __restrict__ Vt = ST::Vt(p) + (size_t)ds * NP * nwp;
     const double* __restrict__ Dg = p.D + (size_t)elem * nwp;
     const double cperp = p.cperp[elem];
     const double step_lim = p.step_max * p.sumD[elem];
@@ -327,52 +367,59 @@ void chain_kernel(const KParams p)
     auto eval_pass = [&](const double* vec, bool from_scratch,
                          double& chi2, double& S, double& dH2, double& Hn2, double& wmax, double& dumax) {
         double pS = 0.0, pdH = 0.0, pHn = 0.0, pwm = 0.0, pdu = 0.0;
+        const TS* vs;
+        if constexpr (F64) vs = vec;
+        else {
+            for (int k = tid; k < NP; k += T) vecs[k] = (TS)vec[k];
+            block_sync<NW>();
+            vs = vecs;
+        }
         for (int i = 2 * tid; i < nwp; i += 2 * T) {
-            double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-            const double* col = Vt + i;
+            TS a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+            const TS* col = Vt + i;
             int k = 0;
 #pragma unroll 8
             for (; k + 1 < ns; k += 2) {
-                const double2 x0 = *reinterpret_cast<const double2*>(col + (size_t)k * nwp);
-                const double2 x1 = *reinterpret_cast<const double2*>(col + (size_t)(k + 1) * nwp);
-                const double q0 = vec[k], q1 = vec[k + 1];
+                const TS2 x0 = *reinterpret_cast<const TS2*>(col + (size_t)k * nwp);
+                const TS2 x1 = *reinterpret_cast<const TS2*>(col + (size_t)(k + 1) * nwp);
+                const TS q0 = vs[k], q1 = vs[k + 1];
                 a0 = fma(x0.x, q0, a0); b0 = fma(x0.y, q0, b0);
                 a1 = fma(x1.x, q1, a1); b1 = fma(x1.y, q1, b1);
             }
             if (k < ns) {
-                const double2 x0 = *reinterpret_cast<const double2*>(col + (size_t)k * nwp);
-                a0 = fma(x0.x, vec[k], a0); b0 = fma(x0.y, vec[k], b0);
+                const TS2 x0 = *reinterpret_cast<const TS2*>(col + (size_t)k * nwp);
+                a0 = fma(x0.x, vs[k], a0); b0 = fma(x0.y, vs[k], b0);
             }
-            const double vd2[2] = {a0 + a1, b0 + b1};
+            const TS vd2[2] = {a0 + a1, b0 + b1};
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int ii = i + r;
-                const double vd = vd2[r];
-                double ui;
+                const TS vd = vd2[r];
+                TS ui;
                 if (from_scratch) ui = vd;
                 else {
                     ui = u[ii] - vd;
-                    const double t = w[ii] * vd;
-                    pdH = fma(t, t, pdH);
-                    pdu = fmax(pdu, fabs(vd));
+                    const TS t = w[ii] * vd;
+                    pdH += (double)(t * t);
+                    pdu = fmax(pdu, (double)fabs(vd));
                 }
-                const double Di = Dg[ii];
-                double Hi, wi, Si;
+                const TS Di = (TS)Dg[ii];
+                TS Hi, wi, Si;
                 if (kind == 0) {
-                    const double e = exp(ui);
+                    const TS e = ST::exp_(ui);
                     Hi = Di * e; wi = Hi;
                     Si = Hi - Di - Hi * ui;
                 } else {
-                    const double ep = exp(ui), em = recip_exp(ep);
-                    const double Hp = Di * ep, Hm = Di * em;
+                    const TS ep = ST::exp_(ui), em = recip_exp(ep);
+                    const TS Hp = Di * ep, Hm = Di * em;
                     Hi = Hp - Hm; wi = Hp + Hm;
                     Si = (Hp - Di - Hp * ui) + (Hm - Di + Hm * ui);
                 }
-                if (ii >= nw) { Hi = 0.0; wi = 0.0; Si = 0.0; }
+                if (ii >= nw) { Hi = 0; wi = 0; Si = 0; }
                 ut[ii] = ui; wt[ii] = wi; Hs[ii] = Hi;
-                pS += Si;
-                pHn = fma(Hi, Hi, pHn);
-                pwm = fmax(pwm, wi);     // NaN-ignoring; non-finite states are caught through Q
+                pS += (double)Si;
+                pHn += (double)(Hi * Hi);
+                pwm = fmax(pwm, (double)wi);     // NaN-ignoring; non-finite states are caught through Q
             }
         }
         block_sync<NW>();                    // Hs complete
@@ -387,20 +434,20 @@ void chain_kernel(const KParams p)
             const int half = lane >> 5, cl = lane & 31;
 #pragma unroll
             for (int cb = 0; cb < NP / 64; ++cb) {
-                double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
-                const double* Vc = V + 64 * cb + 2 * cl;
+                TS s0 = 0, s1 = 0, t0 = 0, t1 = 0;
+                const TS* Vc = V + 64 * cb + 2 * cl;
                 int i = r0 + half;
 #pragma unroll 4
                 for (; i + 2 < r1; i += 4) {
-                    const double2 x0 = *reinterpret_cast<const double2*>(Vc + (size_t)i * NP);
-                    const double2 x1 = *reinterpret_cast<const double2*>(Vc + (size_t)(i + 2) * NP);
-                    const double h0 = Hs[i], h1 = Hs[i + 2];
+                    const TS2 x0 = *reinterpret_cast<const TS2*>(Vc + (size_t)i * NP);
+                    const TS2 x1 = *reinterpret_cast<const TS2*>(Vc + (size_t)(i + 2) * NP);
+                    const TS h0 = Hs[i], h1 = Hs[i + 2];
                     s0 = fma(x0.x, h0, s0); s1 = fma(x0.y, h0, s1);
                     t0 = fma(x1.x, h1, t0); t1 = fma(x1.y, h1, t1);
                 }
                 for (; i < r1; i += 2) {
-                    const double2 x0 = *reinterpret_cast<const double2*>(Vc + (size_t)i * NP);
-                    const double h0 = Hs[i];
+                    const TS2 x0 = *reinterpret_cast<const TS2*>(Vc + (size_t)i * NP);
+                    const TS h0 = Hs[i];
                     s0 = fma(x0.x, h0, s0); s1 = fma(x0.y, h0, s1);
                 }
                 s0 += t0; s1 += t1;
@@ -536,14 +583,14 @@ void chain_kernel(const KParams p)
         constexpr int NT = decltype(NTTag)::value;       // 16-column tiles covering the active block
         constexpr int NPAIR = NT * (NT + 1) / 2;
         constexpr int DEPTH = 4;                         // row groups in flight
-        typedef double d4 __attribute__((ext_vector_type(4)));
+        typedef typename ST::acc4 d4;
         d4 acc[NPAIR];
 #pragma unroll
-        for (int q = 0; q < NPAIR; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < NPAIR; ++q) acc[q] = d4{0, 0, 0, 0};
         const int kq = lane >> 4, cn = lane & 15;
         const int n_groups = nwp >> 2;                   // 4 omega rows per MFMA (zero rows beyond n_omega)
-        const double* Vl = V + (size_t)kq * NP + cn;
-        double f[DEPTH][NT], wv_[DEPTH];
+        const TS* Vl = V + (size_t)kq * NP + cn;
+        TS f[DEPTH][NT], wv_[DEPTH];
         auto load_group = [&](int d, int gidx) {
             const int i0 = 4 * gidx;
             wv_[d] = w[i0 + kq];
@@ -554,7 +601,7 @@ void chain_kernel(const KParams p)
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) if (gidx + d * NW < n_groups) load_group(d, gidx + d * NW);
         for (; gidx < n_groups; gidx += DEPTH * NW) {
-            double fc[DEPTH][NT], wc[DEPTH];
+            TS fc[DEPTH][NT], wc[DEPTH];
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
                 wc[d] = wv_[d];
@@ -569,7 +616,7 @@ void chain_kernel(const KParams p)
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
                 if (gidx + d * NW < n_groups) {
-                    double a[NT];
+                    TS a[NT];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) a[t] = fc[d][t] * wc[d];
                     int q = 0;
@@ -577,7 +624,7 @@ void chain_kernel(const KParams p)
                     for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
                         for (int nt = mt; nt < NT; ++nt) {
-                            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], fc[d][nt], acc[q], 0, 0, 0);
+                            acc[q] = ST::mfma(a[mt], fc[d][nt], acc[q]);
                             ++q;
                         }
                 }
@@ -592,9 +639,9 @@ void chain_kernel(const KParams p)
                     for (int nt = mt; nt < NT; ++nt) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int row = 16 * mt + kq + 4 * r, col = 16 * nt + cn;
-                            if (wv == 0) Wm[row * LD + col] = acc[q][r];
-                            else Wm[row * LD + col] += acc[q][r];
+                            const int row = 16 * mt + ST::crow(kq, r), col = 16 * nt + cn;
+                            if (wv == 0) Wm[row * LD + col] = (double)acc[q][r];
+                            else Wm[row * LD + col] += (double)acc[q][r];
                         }
                         ++q;
                     }
@@ -604,7 +651,9 @@ void chain_kernel(const KParams p)
     };
 
     auto gram = [&](int n_act) {
-#ifndef MXE_GRAM_VALU
+#ifdef MXE_GRAM_VALU
+        if constexpr (!F64)
+#endif
         {
             const int ntile = (n_act + 15) >> 4;
             if (ntile <= 1) { gram_mfma(std::integral_constant<int, 1>{}); return; }
@@ -612,7 +661,7 @@ void chain_kernel(const KParams p)
             if (ntile == 3) { gram_mfma(std::integral_constant<int, 3>{}); return; }
             if (ntile == 4) { gram_mfma(std::integral_constant<int, 4>{}); return; }
         }
-#endif
+        if constexpr (F64) {
         const int nsb = (n_act + 31) >> 5;
         if (nsb == 1) {
             const int sr[1] = {0}, sc[1] = {0};
@@ -632,6 +681,7 @@ void chain_kernel(const KParams p)
                 const int s1[1] = {sr[q]}, s2[1] = {sc[q]};
                 gram_sweep(std::integral_constant<int, 1>{}, s1, s2);
             }
+        }
         }
     };
 
@@ -868,6 +918,7 @@ void chain_kernel(const KParams p)
         double Qprev = __builtin_nan("");
         double Q = 0.5 * chi2 - alpha * S;
         bool failed = false;
+        double relH_prev = 1e300;
 
         for (int it = 0; it < p.maxiter && !failed; ++it) {
             for (int k = tid; k < NP; k += T) {
@@ -967,6 +1018,12 @@ void chain_kernel(const KParams p)
             Q = 0.5 * chi2 - alpha * S;
             ++n_iter;
             if (p.tol_h > 0.0 && fmin(relH, relH_next) < p.tol_h && n_iter > p.miniter) { conv = 1; break; }
+            if constexpr (!F64) {
+                // binary32 noise floor: an undamped Newton correction that is already small and no
+                // longer shrinks is rounding noise of h = V^T H; the point cannot be improved
+                if (mu == 0.0 && relH < 1e-3 && relH > 0.5 * relH_prev && n_iter > p.miniter) { conv = 1; break; }
+                relH_prev = (mu == 0.0) ? relH : 1e300;
+            }
         }
 
         // ---- results of this alpha (MaxEntResult fields, maxent_result.py:835-967)
@@ -974,9 +1031,9 @@ void chain_kernel(const KParams p)
         if (p.out_H) {
             double* Ho = p.out_H + prob * nw;
             for (int i = tid; i < nw; i += T) {
-                const double Di = Dg[i], ui = u[i];
-                const double ep = exp(ui);
-                Ho[i] = (kind == 0) ? Di * ep : Di * ep - Di * recip_exp(ep);
+                const TS Di = (TS)Dg[i], ui = u[i];
+                const TS ep = ST::exp_(ui);
+                Ho[i] = (double)((kind == 0) ? Di * ep : Di * ep - Di * recip_exp(ep));
             }
         }
         if (p.out_v) for (int k = tid; k < NP; k += T) p.out_v[prob * NP + k] = v[k];

@@ -18,6 +18,8 @@ _LIB_PATH = os.environ.get(
 
 ENTROPY_NORMAL = 0
 ENTROPY_PLUSMINUS = 1
+PRECISION_F64 = 0
+PRECISION_F32 = 1
 
 
 class MaxEntDeviceError(RuntimeError):
@@ -39,7 +41,9 @@ class MxeOpts(ctypes.Structure):
                 ('waves_per_chain', ctypes.c_int32),
                 ('chains_per_wg', ctypes.c_int32),
                 ('alpha_split', ctypes.c_int32),
-                ('stop_estimate', ctypes.c_int32)]
+                ('stop_estimate', ctypes.c_int32),
+                ('precision', ctypes.c_int32),
+                ('reserved', ctypes.c_int32)]
 
 
 _dp = ctypes.POINTER(ctypes.c_double)

@@ -109,6 +109,11 @@ class Minimizer(object):
 class LevenbergMinimizer(Minimizer):
     """Parameters of the per-alpha damped Newton iteration.
 
+    ``precision='f32'`` selects the binary32 streaming variant of the chain
+    kernel (``mxe_opts.precision``; BASELINE config 5's fp32-vs-fp64 sweep):
+    V, u, H, exp, both mat-vecs and the Gram matrix in binary32, the Newton
+    system and all scalars in binary64.
+
     ``n_iter_last`` / ``n_iter`` / ``converged`` are filled after a run like
     in the reference (levenberg_minimizer.py:143,245-246); for a batched run
     they refer to the last alpha of the last chain, per-problem values are in
@@ -117,7 +122,11 @@ class LevenbergMinimizer(Minimizer):
 
     def __init__(self, convergence=None, maxiter=1000, miniter=0,
                  J_squared=False, marquardt=False, mu0=1.e-3, nu=4.0,
-                 max_mu=1.e20, step_max=0.2, verbose_callback=None):
+                 max_mu=1.e20, step_max=0.2, verbose_callback=None,
+                 precision='f64'):
+        if precision not in ('f64', 'f32'):
+            raise ValueError("precision must be 'f64' or 'f32'")
+        self.precision = precision
         if J_squared or marquardt:
             raise NotImplementedError('J_squared / marquardt variants are not '
                                       'part of the device solver')
@@ -145,7 +154,11 @@ class LevenbergMinimizer(Minimizer):
                                 step_max=float(self.step_max),
                                 mu_first=float(self.mu0),
                                 mu_grow=float(self.nu),
-                                mu_max=float(self.max_mu), **extra)
+                                mu_max=float(self.max_mu),
+                                precision=(device.PRECISION_F32
+                                           if self.precision == 'f32'
+                                           else device.PRECISION_F64),
+                                **extra)
         self.convergence.apply(o)
         return o
 

@@ -43,8 +43,20 @@ def test_opts_defaults_and_struct_layout():
     assert o.step_max == 0.2 and o.mu_grow == 4.0 and o.decouple_tol == 1e-5
     assert (o.waves_per_chain, o.chains_per_wg, o.alpha_split) == (0, 0, 0)      # all automatic
     assert o.stop_estimate == 1
+    assert o.precision == device.PRECISION_F64 and o.reserved == 0
+    # the struct of include/maxent_hip.h: 2 int32, 8 double, 6 int32, no padding holes
+    import ctypes
+    assert ctypes.sizeof(device.MxeOpts) == 2 * 4 + 8 * 8 + 6 * 4
+    assert device.MxeOpts.precision.offset == 2 * 4 + 8 * 8 + 4 * 4
     with pytest.raises(TypeError):
         device.default_opts(nonsense=1)
+
+
+def test_minimizer_precision_option_reaches_the_opts():
+    assert mx.LevenbergMinimizer().to_opts().precision == device.PRECISION_F64
+    assert mx.LevenbergMinimizer(precision='f32').to_opts().precision == device.PRECISION_F32
+    with pytest.raises(ValueError):
+        mx.LevenbergMinimizer(precision='f16')
 
 
 def test_no_gpu_fails_loudly_not_silently():

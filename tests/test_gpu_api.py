@@ -293,6 +293,56 @@ def test_cfg5_matrix_with_preblurred_offdiagonals():
         assert worst < GATE, worst
 
 
+def _cfg5_run(precision, n_tau=100, n_w=200, n_alpha=20, b=0.1):
+    from maxent_amd import synthetic
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(8, n_tau, n_w)
+    ew = mx.ElementwiseMaxEnt(use_hermiticity=True, minimizer=mx.LevenbergMinimizer(precision=precision))
+    ew.set_verbosity(mx.VerbosityFlags.Quiet)
+    ew.set_G_tau_data(tau, Gmat)
+    ew.omega = omega
+    ew.alpha_mesh = mx.LogAlphaMesh(alpha_min=1e-2, alpha_max=1e4, n_points=n_alpha)
+    ew.set_error(1e-4)
+    off = ew.maxent_offdiagonal
+    off.A_of_H = mx.PreblurA_of_H(b=b, omega=off.omega)
+    off.K = mx.PreblurKernel(K=off.K, b=b)
+    return ew.run()
+
+
+def test_cfg5_fp32_vs_fp64_tolerance_classes():
+    """BASELINE cfg5, the sweep: the binary32 streaming variant of the chain kernel
+    (mxe_opts.precision = F32) against the binary64 solver on the same 8x8 job.  Measured
+    (tools/cfg5_tolerance_sweep.py, profiles/r01_f_cfg5_fp32_sweep.txt): off-diagonal
+    (plus-minus + preblur) elements <= 4e-7, diagonal (normal entropy) elements <= 6.3e-6 at the
+    smallest alpha; tolerance written here: class 1e-6 for the off-diagonals, 1e-4 for everything."""
+    r64, r32 = _cfg5_run('f64'), _cfg5_run('f32')
+    iu = np.triu_indices(8)
+    assert np.all(r32.converged[iu] == 1)
+    e = rel_l2(r32.A[iu], r64.A[iu])                      # [36][n_alpha]
+    diag = iu[0] == iu[1]
+    assert e[~diag].max() < 1e-6, e[~diag].max()
+    assert e[diag].max() < 1e-4, e[diag].max()
+    assert 1e-9 < e.max()                                 # it really was a different arithmetic
+    np.testing.assert_allclose(r32.chi2[iu], r64.chi2[iu], rtol=1e-4)
+    # iteration counts stay those of the binary64 solver (the Gram matrix only preconditions)
+    assert r32.n_iter[iu].mean() < 1.1 * r64.n_iter[iu].mean()
+
+
+def test_fp32_single_scan_against_the_fixed_point():
+    """cfg2 golden (n_tau = 200, n_omega = 500, 100 alpha) in binary32 streaming arithmetic:
+    class 1e-4 against the extended-precision fixed point."""
+    g = load('cfg2_normal')
+    tm = mx.TauMaxEnt(cost_function='normal', minimizer=mx.LevenbergMinimizer(precision='f32'))
+    tm.set_verbosity(mx.VerbosityFlags.Quiet)
+    tm.omega = mx.DataOmegaMesh(g['omega'])
+    tm.set_G_tau_data(g['tau'], g['G'])
+    tm.set_error(g['err'])
+    tm.alpha_mesh = mx.DataAlphaMesh(g['alpha'] / len(g['tau']))
+    res = tm.run()
+    assert np.all(res.converged)
+    e = rel_l2(res.H[g['rows']], g['H_truth'])
+    assert 1e-9 < e.max() < 1e-4, e.max()
+
+
 def test_log_probability_with_more_than_64_singular_values():
     """n_s = 100 (NP = 128 path of the chain kernel and of the log-determinant kernel): the
     device log-probability equals the host evaluation of the same formula."""
