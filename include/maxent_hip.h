@@ -29,6 +29,8 @@
  *      self.probability(Q_min)       maxent_loop.py:258-264 | mxe_logdet (the determinant of
  *        NormalLogProbability        probabilities.py:60-85 |   the posterior curvature)
  *   PreblurA_of_H.f  A = B H         functions.py:999-1001 | mxe_apply_output_map
+ *   TauKernel / PreblurKernel fill + KernelSVD.svd         | mxe_kernel_svd (optional: the host
+ *     kernels.py:53-122,244-271,384-393                    |   numpy path stays the default)
  *
  * Conventions: plain C, no C++ types; every function returns 0 (MXE_OK) or a
  * negative error code and never throws or aborts; the caller owns every host
@@ -52,7 +54,7 @@ extern "C" {
 #define MXE_ERR_NODEVICE    -3   /* no usable gfx950 device                   */
 #define MXE_ERR_STATE       -4   /* call order (e.g. solve before elements)   */
 #define MXE_ERR_LIMIT       -5   /* n_s > 128 (fp32: > 64) or LDS budget exceeded */
-#define MXE_ERR_NUMERIC     -6   /* whitening failed (non-positive error bar) */
+#define MXE_ERR_NUMERIC     -6   /* whitening failed (non-positive error bar) / SVD sweeps exhausted */
 #define MXE_ERR_NOMEM       -7   /* host allocation failed                     */
 
 #define MXE_PRECISION_F64      0 /* all arithmetic IEEE binary64 (default)      */
@@ -208,6 +210,28 @@ int  mxe_last_launch_info(mxe_ctx* ctx, int* waves_per_chain, int* n_workgroups,
 /* B: n_omega x n_omega row-major.  Applies to the device-resident H of the
  * last solve; result n_problem x n_omega to host. */
 int  mxe_apply_output_map(mxe_ctx* ctx, const double* B, double* out_A);
+
+/* ---- kernel matrix staging on the device ------------- */
+/* TauKernel._fill_values (kernels.py:244-271), get_preblur (preblur.py:31-58),
+ * PreblurKernel._fill_values (kernels.py:384-393: K' = K diag(delta) B), KernelSVD.svd
+ * and reduce_singular_space (kernels.py:53-122) for a batch of n_b blur widths in one
+ * go (a b-scan; preblur_b[ib] <= 0: the plain TauKernel).  tau: n_tau, omega / delta:
+ * n_omega (delta = the trapezoid weights of the mesh, omega_meshes.py:54-62).
+ * The decomposition is a pivoted-QR preconditioned one-sided Jacobi SVD in binary64
+ * (one workgroup per blur width); singular values S >= threshold (ABSOLUTE, as in the
+ * reference) are kept, at most ns_max (<= 128).  Outputs, host, row-major, per item ib:
+ *   out_K [ib][n_tau][n_omega]   the (blurred) kernel matrix; may be NULL
+ *   out_U [ib][n_tau][ns_max], out_S [ib][ns_max], out_V [ib][n_omega][ns_max]
+ *         (columns >= out_ns[ib] are zero), out_ns [ib]
+ *   out_info [ib][3]: rank kept by the QR stage, Jacobi sweeps, status (may be NULL)
+ *   out_ms: device time of the whole batch (may be NULL)
+ * Returns MXE_ERR_LIMIT if more than ns_max singular values pass the threshold,
+ * MXE_ERR_NUMERIC if the Jacobi sweeps did not converge. */
+int  mxe_kernel_svd(int device, int n_tau, int n_omega, const double* tau,
+                    const double* omega, const double* delta, double beta,
+                    int n_b, const double* preblur_b, double threshold, int ns_max,
+                    double* out_K, double* out_U, double* out_S, double* out_V,
+                    int32_t* out_ns, int32_t* out_info, float* out_ms);
 
 #ifdef __cplusplus
 }

@@ -273,7 +273,7 @@ const char* mxe_strerror(int code)
         case MXE_ERR_NODEVICE: return "no usable HIP device";
         case MXE_ERR_STATE: return "call order violated";
         case MXE_ERR_LIMIT: return "problem exceeds kernel limits (n_s <= 128, 160 KB LDS per chain)";
-        case MXE_ERR_NUMERIC: return "whitening failed (error bars must be finite and > 0)";
+        case MXE_ERR_NUMERIC: return "numerical failure (whitening: error bars must be finite and > 0; device SVD: Jacobi sweeps exhausted)";
         case MXE_ERR_NOMEM: return "out of host memory";
         default: return "unknown error";
     }
@@ -986,5 +986,110 @@ try {
     HIPCHK(ctx, hipMemcpyAsync(out_A, ctx->dA.p, P * nw * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return MXE_OK;
+}
+MXE_CATCH_ALL
+
+// ---- kernel matrix staging on the device: fill, preblur product, truncated SVD -------------
+#include "mxe_svd.hip.h"
+
+namespace {
+struct SvdScratch {
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<void*> bufs;
+    template <typename T> hipError_t alloc(T** p, size_t count) {
+        hipError_t e = hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) bufs.push_back((void*)*p);
+        return e;
+    }
+    ~SvdScratch() {
+        for (void* b : bufs) hipFree(b);
+        if (e0) hipEventDestroy(e0);
+        if (e1) hipEventDestroy(e1);
+        if (stream) hipStreamDestroy(stream);
+    }
+};
+#define SVDCHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { \
+    fprintf(stderr, "[mxe] %s: %s\n", #call, hipGetErrorString(e__)); return MXE_ERR_HIP; } } while (0)
+} // namespace
+
+extern "C" int mxe_kernel_svd(int device, int n_tau, int n_omega, const double* tau, const double* omega,
+                              const double* delta, double beta, int n_b, const double* preblur_b,
+                              double threshold, int ns_max, double* out_K, double* out_U, double* out_S,
+                              double* out_V, int32_t* out_ns, int32_t* out_info, float* out_ms)
+try {
+    if (n_tau < 1 || n_omega < 1 || n_b < 1 || !tau || !omega || !delta || !preblur_b || !out_U || !out_S ||
+        !out_V || !out_ns || ns_max < 1 || ns_max > mxe::SVD_RCAP || !(threshold >= 0.0)) return MXE_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MXE_ERR_NODEVICE;
+    if (device < 0 || device >= ndev) return MXE_ERR_ARG;
+    const size_t lds = ((size_t)n_tau + 16 + 8 + mxe::SVD_RCAP + mxe::SVD_RCAP / 2) * sizeof(double);
+    if (lds > 60 * 1024) return MXE_ERR_LIMIT;
+    SVDCHK(hipSetDevice(device));
+    SvdScratch sc;
+    SVDCHK(hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking));
+    SVDCHK(hipEventCreate(&sc.e0));
+    SVDCHK(hipEventCreate(&sc.e1));
+    const size_t m = n_tau, n = n_omega, R = mxe::SVD_RCAP;
+    double *dtau, *dom, *ddel, *dKt0, *dr1, *ddc, *dB;
+    mxe::SvdParams sp;
+    sp.m = n_tau; sp.n = n_omega; sp.ns_max = ns_max; sp.threshold = threshold;
+    SVDCHK(sc.alloc(&dtau, m)); SVDCHK(sc.alloc(&dom, n)); SVDCHK(sc.alloc(&ddel, n));
+    SVDCHK(sc.alloc(&dKt0, n * m)); SVDCHK(sc.alloc(&dr1, n)); SVDCHK(sc.alloc(&ddc, n)); SVDCHK(sc.alloc(&dB, n * n));
+    SVDCHK(sc.alloc(&sp.A, (size_t)n_b * n * m)); SVDCHK(sc.alloc(&sp.Vh, (size_t)n_b * R * m));
+    SVDCHK(sc.alloc(&sp.Rm, (size_t)n_b * R * n)); SVDCHK(sc.alloc(&sp.Jt, (size_t)n_b * R * R));
+    SVDCHK(sc.alloc(&sp.Qc, (size_t)n_b * R * m)); SVDCHK(sc.alloc(&sp.cn2, (size_t)n_b * n));
+    SVDCHK(sc.alloc(&sp.perm, (size_t)n_b * n));
+    SVDCHK(sc.alloc(&sp.out_U, (size_t)n_b * m * ns_max)); SVDCHK(sc.alloc(&sp.out_S, (size_t)n_b * ns_max));
+    SVDCHK(sc.alloc(&sp.out_V, (size_t)n_b * n * ns_max)); SVDCHK(sc.alloc(&sp.out_info, (size_t)n_b * 4));
+    SVDCHK(hipMemcpyAsync(dtau, tau, m * 8, hipMemcpyHostToDevice, sc.stream));
+    SVDCHK(hipMemcpyAsync(dom, omega, n * 8, hipMemcpyHostToDevice, sc.stream));
+    SVDCHK(hipMemcpyAsync(ddel, delta, n * 8, hipMemcpyHostToDevice, sc.stream));
+    SVDCHK(hipEventRecord(sc.e0, sc.stream));
+    const int nel = n_tau * n_omega;
+    hipLaunchKernelGGL(mxe::tau_kernel_fill, dim3((nel + 255) / 256), dim3(256), 0, sc.stream, dtau, dom, beta, n_tau, n_omega, dKt0);
+    SVDCHK(hipGetLastError());
+    for (int ib = 0; ib < n_b; ++ib) {
+        double* Ai = sp.A + (size_t)ib * n * m;
+        const double b = preblur_b[ib];
+        if (b > 0.0) {
+            hipLaunchKernelGGL(mxe::preblur_rows, dim3(n_omega), dim3(256), 0, sc.stream, dom, ddel, b, n_omega, dr1);
+            hipLaunchKernelGGL(mxe::preblur_cols, dim3(n_omega), dim3(256), 0, sc.stream, dom, ddel, b, n_omega, dr1, ddc);
+            hipLaunchKernelGGL(mxe::preblur_matrix, dim3((n_omega * n_omega + 255) / 256), dim3(256), 0, sc.stream, dom, b, n_omega, dr1, ddc, dB);
+            hipLaunchKernelGGL(mxe::preblur_product, dim3(n_omega), dim3(256), n * 8, sc.stream, dKt0, ddel, dB, n_tau, n_omega, Ai);
+            SVDCHK(hipGetLastError());
+        } else {
+            SVDCHK(hipMemcpyAsync(Ai, dKt0, n * m * 8, hipMemcpyDeviceToDevice, sc.stream));
+        }
+    }
+    std::vector<double> hKt;
+    if (out_K) {
+        hKt.resize((size_t)n_b * n * m);
+        SVDCHK(hipMemcpyAsync(hKt.data(), sp.A, hKt.size() * 8, hipMemcpyDeviceToHost, sc.stream));
+    }
+    SVDCHK(hipFuncSetAttribute((const void*)mxe::svd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mxe::svd_kernel, dim3(n_b), dim3(mxe::SVD_T), lds, sc.stream, sp);
+    SVDCHK(hipGetLastError());
+    SVDCHK(hipEventRecord(sc.e1, sc.stream));
+    std::vector<int> hinfo((size_t)n_b * 4);
+    SVDCHK(hipMemcpyAsync(out_U, sp.out_U, (size_t)n_b * m * ns_max * 8, hipMemcpyDeviceToHost, sc.stream));
+    SVDCHK(hipMemcpyAsync(out_S, sp.out_S, (size_t)n_b * ns_max * 8, hipMemcpyDeviceToHost, sc.stream));
+    SVDCHK(hipMemcpyAsync(out_V, sp.out_V, (size_t)n_b * n * ns_max * 8, hipMemcpyDeviceToHost, sc.stream));
+    SVDCHK(hipMemcpyAsync(hinfo.data(), sp.out_info, hinfo.size() * 4, hipMemcpyDeviceToHost, sc.stream));
+    SVDCHK(hipStreamSynchronize(sc.stream));
+    if (out_ms) SVDCHK(hipEventElapsedTime(out_ms, sc.e0, sc.e1));
+    int rc = MXE_OK;
+    for (int ib = 0; ib < n_b; ++ib) {
+        out_ns[ib] = hinfo[(size_t)ib * 4];
+        if (out_info) { out_info[ib * 3] = hinfo[(size_t)ib * 4 + 1]; out_info[ib * 3 + 1] = hinfo[(size_t)ib * 4 + 2]; out_info[ib * 3 + 2] = hinfo[(size_t)ib * 4 + 3]; }
+        if (hinfo[(size_t)ib * 4 + 3] == 2) rc = MXE_ERR_LIMIT;
+        else if (hinfo[(size_t)ib * 4 + 3] == 1 && rc == MXE_OK) rc = MXE_ERR_NUMERIC;
+    }
+    if (out_K)
+        for (int ib = 0; ib < n_b; ++ib)
+            for (size_t j = 0; j < n; ++j)
+                for (size_t i = 0; i < m; ++i)
+                    out_K[((size_t)ib * m + i) * n + j] = hKt[((size_t)ib * n + j) * m + i];
+    return rc;
 }
 MXE_CATCH_ALL

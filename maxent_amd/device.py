@@ -86,6 +86,10 @@ SYMBOLS = [
     ('mxe_last_launch_info', ctypes.c_int, [_vp] +
      [ctypes.POINTER(ctypes.c_int)] * 3),
     ('mxe_apply_output_map', ctypes.c_int, [_vp, _dp, _dp]),
+    ('mxe_kernel_svd', ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp,
+                                      ctypes.c_double, ctypes.c_int, _dp, ctypes.c_double,
+                                      ctypes.c_int, _dp, _dp, _dp, _dp, _ip, _ip,
+                                      ctypes.POINTER(ctypes.c_float)]),
 ]
 
 
@@ -145,6 +149,39 @@ def _p(a):
     if a.dtype == np.int64:
         return a.ctypes.data_as(_lp)
     raise TypeError(a.dtype)
+
+
+def kernel_svd(tau, omega, delta, beta, preblur_b=(0.0,), threshold=1.e-14,
+               ns_max=128, want_K=False, device=0):
+    """``mxe_kernel_svd``: TauKernel (and PreblurKernel, one per entry of
+    ``preblur_b`` > 0) filled and decomposed on the device.  Returns a list of
+    dicts ``U, S, V`` (truncated at ``S >= threshold``), ``K`` (if wanted),
+    ``qr_rank``, ``sweeps`` and the device time ``ms`` of the whole batch."""
+    lib = load_library()
+    if device_count() < 1:
+        raise MaxEntDeviceError('no HIP device visible; the device SVD has no CPU fallback')
+    tau, omega, delta = _c(tau), _c(omega), _c(delta)
+    bs = _c(np.atleast_1d(np.asarray(preblur_b, dtype=float)))
+    n_tau, n_w, n_b = len(tau), len(omega), len(bs)
+    K = np.empty((n_b, n_tau, n_w)) if want_K else None
+    U = np.empty((n_b, n_tau, ns_max))
+    S = np.empty((n_b, ns_max))
+    V = np.empty((n_b, n_w, ns_max))
+    ns = np.zeros(n_b, dtype=np.int32)
+    info = np.zeros((n_b, 3), dtype=np.int32)
+    ms = ctypes.c_float(0)
+    rc = lib.mxe_kernel_svd(int(device), n_tau, n_w, _p(tau), _p(omega), _p(delta), float(beta),
+                            n_b, _p(bs), float(threshold), int(ns_max), _p(K), _p(U), _p(S), _p(V),
+                            _p(ns), _p(info), ctypes.byref(ms))
+    if rc != 0:
+        raise MaxEntDeviceError('mxe_kernel_svd failed: ' + lib.mxe_strerror(rc).decode())
+    out = []
+    for ib in range(n_b):
+        k = int(ns[ib])
+        out.append(dict(U=U[ib, :, :k].copy(), S=S[ib, :k].copy(), V=V[ib, :, :k].copy(),
+                        K=(K[ib] if want_K else None), qr_rank=int(info[ib, 0]),
+                        sweeps=int(info[ib, 1]), ms=float(ms.value)))
+    return out
 
 
 class DeviceContext(object):

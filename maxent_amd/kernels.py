@@ -19,6 +19,12 @@ class KernelSVD(object):
     ``V`` is stored as ``n_omega x n_s`` (reference kernels.py:53-64).
     """
 
+    #: 'host' (numpy / LAPACK, the reference's path) or 'device'
+    #: (``mxe_kernel_svd``: fill, preblur product and a preconditioned one-sided
+    #: Jacobi SVD on the GPU; kernels that know how they are filled -- TauKernel,
+    #: PreblurKernel of a TauKernel -- implement ``_device_svd``)
+    svd_backend = 'host'
+
     def __init__(self, K=None):
         self._U = self._S = self._V = None
         self._K = K
@@ -27,10 +33,19 @@ class KernelSVD(object):
     def _invalidate_svd(self):
         self._U = self._S = self._V = None
 
+    def _device_svd(self):
+        raise NotImplementedError('svd_backend="device" needs a kernel that can be '
+                                  'filled on the device (TauKernel, PreblurKernel)')
+
     def svd(self):
         if self._U is None:
-            U, S, Vh = np.linalg.svd(self.K, full_matrices=False)
-            self._U, self._S, self._V = U, S, Vh.transpose()
+            if self.svd_backend == 'device':
+                self._U, self._S, self._V = self._device_svd()
+            elif self.svd_backend == 'host':
+                U, S, Vh = np.linalg.svd(self.K, full_matrices=False)
+                self._U, self._S, self._V = U, S, Vh.transpose()
+            else:
+                raise ValueError("svd_backend must be 'host' or 'device'")
         return (self._U, self._S, self._V)
 
     @property
@@ -124,12 +139,27 @@ class TauKernel(Kernel):
     :math:`K(\tau,\omega) = -e^{-\tau\omega}/(1+e^{-\beta\omega})`
     (reference kernels.py:210-280).  ``beta`` defaults to ``tau[-1]``."""
 
-    def __init__(self, tau, omega, beta=None):
+    def __init__(self, tau, omega, beta=None, svd_backend='host'):
         super(TauKernel, self).__init__()
         self.tau = tau
         self.omega = omega
         self.beta = beta
+        self.svd_backend = svd_backend
         self._fill_values()
+
+    def _device_args(self):
+        tau = np.asarray(self.tau, dtype=float)
+        beta = tau[-1] if self.beta is None else self.beta
+        return tau, np.asarray(self.omega, dtype=float), self.omega.delta, beta
+
+    def _device_svd(self, preblur_b=0.0):
+        """U, S, V of the UNROTATED kernel from the device: everything the QR stage kept
+        (singular values down to eps * sigma_max; the reference's LAPACK values below
+        that are rounding noise), ``reduce_singular_space`` cuts as usual."""
+        from . import device
+        tau, w, delta, beta = self._device_args()
+        r = device.kernel_svd(tau, w, delta, beta, [preblur_b], threshold=0.0)[0]
+        return r['U'], r['S'], r['V']
 
     def _fill_values(self):
         self._invalidate_svd()
@@ -164,12 +194,37 @@ class PreblurKernel(Kernel):
     """``K' = K diag(delta) B`` for the preblur formalism; ``K_delta`` stays
     un-blurred (reference kernels.py:349-413)."""
 
-    def __init__(self, K, b):
+    def __init__(self, K, b, svd_backend=None):
         KernelSVD.__init__(self)
         self._T = None
         self.kernel = K
         self._b = b
+        self.svd_backend = K.svd_backend if svd_backend is None else svd_backend
         self._fill_values()
+
+    def _device_svd(self):
+        if not isinstance(self.kernel, TauKernel):
+            raise NotImplementedError('device SVD of a PreblurKernel needs a TauKernel inside')
+        U, S, V = self.kernel._device_svd(preblur_b=self._b)
+        T = self.kernel._T
+        return (U if T is None else np.dot(T, U)), S, V
+
+    @classmethod
+    def scan(cls, K, b_values, threshold=1.e-14):
+        """The kernels of a b-scan (reference doc/guide/preblur_example.py:49-56) with
+        their truncated SVDs from ONE batched device launch (``mxe_kernel_svd``)."""
+        from . import device
+        if not isinstance(K, TauKernel) or K._T is not None:
+            raise NotImplementedError('PreblurKernel.scan needs an unrotated TauKernel')
+        tau, w, delta, beta = K._device_args()
+        res = device.kernel_svd(tau, w, delta, beta, list(b_values), threshold=threshold)
+        out = []
+        for b, r in zip(b_values, res):
+            Kb = cls(K, b, svd_backend='device')
+            Kb._U, Kb._S, Kb._V = r['U'], r['S'], r['V']
+            Kb._last_threshold = threshold
+            out.append(Kb)
+        return out
 
     def parameter_change(self):
         self.kernel.parameter_change()

@@ -22,11 +22,12 @@ from .omega_meshes import HyperbolicOmegaMesh
 class TauMaxEnt(object):
     maxent_loop = None      # needed by the attribute shadowing below
 
-    def __init__(self, cov_threshold=1.e-14, **kwargs):
+    def __init__(self, cov_threshold=1.e-14, svd_backend='host', **kwargs):
         self.maxent_loop = MaxEntLoop(**kwargs)
         omega = HyperbolicOmegaMesh()
         self.D = FlatDefaultModel(omega)
-        self.K = TauKernel([0, 1], omega)      # placeholder tau grid
+        # svd_backend='device': kernel fill + SVD on the GPU (mxe_kernel_svd)
+        self.K = TauKernel([0, 1], omega, svd_backend=svd_backend)      # placeholder tau grid
         self.omega = omega
         self.cov_threshold = cov_threshold
 

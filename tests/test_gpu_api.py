@@ -362,3 +362,69 @@ def test_log_probability_with_more_than_64_singular_values():
     host = NormalLogProbability().evaluate(K.U, K.S, K.V, tm.err * np.ones(len(g['G'])),
                                            res.alpha, w, res.Q)
     np.testing.assert_allclose(res.probability, host, rtol=1e-9, atol=1e-7)
+
+
+# ---- kernel staging on the device --------------------------------------------
+def test_device_kernel_fill_preblur_and_svd_match_the_host_path():
+    """mxe_kernel_svd against numpy: K to a few ulp (reference tau_kernel.py:64-69 pins 1e-15),
+    the preblur product to 1e-14, singular values to 1e-13 absolute (LAPACK's own accuracy is
+    eps * sigma_max ~ 1e-15 * 10), same n_s at the 1e-14 cut, U S V^T = K to 1e-13 (the
+    reference's bound), orthonormal factors."""
+    from maxent_amd import synthetic, device
+    tau, omega = synthetic.grids(200, 500)
+    K = mx.TauKernel(tau=tau, omega=omega, beta=synthetic.BETA)
+    bs = [0.0, 0.1, 0.25]
+    res = device.kernel_svd(tau, np.asarray(omega), omega.delta, synthetic.BETA, bs, want_K=True)
+    for b, r in zip(bs, res):
+        Kh = np.array(K.K) if b <= 0 else np.array(mx.PreblurKernel(K=K, b=b).K)
+        assert np.abs(r['K'] - Kh).max() < (1e-15 if b <= 0 else 1e-14)
+        Sl = np.linalg.svd(Kh, compute_uv=False)
+        U, S, V = r['U'], r['S'], r['V']
+        ns = len(S)
+        assert ns == int((Sl >= 1e-14).sum())
+        assert np.all(np.diff(S) <= 0) and S[-1] >= 1e-14
+        assert np.abs(S - Sl[:ns]).max() < 1e-12
+        assert np.abs((U * S) @ V.T - Kh).max() < 1e-13
+        assert np.abs(U.T @ U - np.eye(ns)).max() < 1e-12
+        assert np.abs(V.T @ V - np.eye(ns)).max() < 1e-13
+        assert r['sweeps'] < 20 and ns <= r['qr_rank'] <= 128
+
+
+def test_tau_maxent_with_device_svd_matches_golden():
+    """cfg1 with the kernel filled and decomposed on the device: same gate as the host SVD path."""
+    g = load('cfg1_normal')
+    n_tau = len(g['tau'])
+    tm = mx.TauMaxEnt(cost_function='normal', svd_backend='device')
+    tm.set_verbosity(mx.VerbosityFlags.Quiet)
+    tm.omega = mx.DataOmegaMesh(g['omega'])
+    tm.set_G_tau_data(g['tau'], g['G'])
+    tm.set_error(g['err'])
+    tm.alpha_mesh = mx.DataAlphaMesh(g['alpha'] / n_tau)
+    res = tm.run()
+    assert tm.K.svd_backend == 'device' and np.all(res.converged)
+    e = rel_l2(res.H[g['rows']], g['H_truth'])
+    assert e.max() < GATE, e.max()
+    np.testing.assert_allclose(res.chi2, g['chi2_ref'], rtol=REF_SPREAD)
+
+
+def test_preblur_b_scan_from_one_batched_device_launch():
+    """PreblurKernel.scan: the kernels of a b-scan with their SVDs from one launch; a run with
+    such a kernel equals the run with the host-decomposed PreblurKernel."""
+    g = load('cfg5_preblur_pm')
+    b = float(g['preblur_b'])
+    outs = []
+    for backend in ('host', 'device'):
+        tm = make_tm(g, 'plusminus')
+        if backend == 'host':
+            tm.K = mx.PreblurKernel(K=tm.K, b=b)
+        else:
+            Ks = mx.PreblurKernel.scan(tm.K, [0.5 * b, b, 2 * b])
+            assert [k.b for k in Ks] == [0.5 * b, b, 2 * b]
+            assert len(Ks[0].S) >= len(Ks[1].S) >= len(Ks[2].S)
+            tm.K = Ks[1]
+        tm.A_of_H = mx.PreblurA_of_H(b=b, omega=tm.omega)
+        tm.alpha_mesh = mx.DataAlphaMesh(g['alpha'] / len(g['tau']))
+        outs.append(tm.run())
+    assert np.all(outs[1].converged)
+    assert rel_l2(outs[1].A, outs[0].A).max() < GATE
+    assert rel_l2(outs[1].H, g['H_truth']).max() < GATE
