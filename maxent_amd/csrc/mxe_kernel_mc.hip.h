@@ -44,6 +44,10 @@ struct MCExtra {
 //     take half of the rows of the two streaming passes: two waves per SIMD there)
 // rows of V behind the last omega row (and LDS doubles behind H) that the look-ahead of the
 // fused pass may read without using them: 2 * DEPTH * 4 waves * 4 rows, rounded up
+#ifndef MXE_MC_GRAM_F32
+#define MXE_MC_GRAM_F32 1   // Gram tiles of the fused pass as v_mfma_f32_16x16x4_f32 (see step 3)
+#endif
+constexpr double MC_GRAM_ERR = MXE_MC_GRAM_F32 ? 2e-5 : 0.0;   // relative error of the Newton matrix from the f32 tiles
 constexpr int MC_LOOKAHEAD_ROWS = 512;
 constexpr int MC_LOOKAHEAD_LDS = (8 * 4 + 4) * 4 * 4 + 64;       // doubles
 template <int NA, int NWV>
@@ -427,12 +431,22 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 
         // ---- 3. fused pass (V once): h = V^T H (VALU) and W = V_a^T diag(w) V_a (MFMA) ----
         {
-            d4 acc[MCC][NPAIR];
+#if MXE_MC_GRAM_F32
+            // The Gram matrix only preconditions the Newton step (the residual rho that defines
+            // the answer comes from h, binary64): its tiles are accumulated on the binary32 matrix
+            // pipe -- 32 cycles per 16x16x4 instead of 64, and no longer on the pipe the FP64
+            // vector work of h needs.  Relative error ~1e-6 of sqrt(W_ii W_jj), next to the
+            // decoupling threshold theta = 1e-5 that the Newton matrix carries anyway.
+            typedef float g4 __attribute__((ext_vector_type(4)));
+#else
+            typedef d4 g4;
+#endif
+            g4 acc[MCC][NPAIR];
             double hp[MCC][4];
 #pragma unroll
             for (int c = 0; c < MCC; ++c) {
 #pragma unroll
-                for (int pr = 0; pr < NPAIR; ++pr) acc[c][pr] = d4{0.0, 0.0, 0.0, 0.0};
+                for (int pr = 0; pr < NPAIR; ++pr) acc[c][pr] = g4{0, 0, 0, 0};
 #pragma unroll
                 for (int t = 0; t < 4; ++t) hp[c][t] = 0.0;
             }
@@ -458,6 +472,33 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 // v_fma_f64 of its SIMD for its 64 cycles), so nothing rides in the shadow of the
                 // MFMAs and a VALU product consumed by the next MFMA only adds its latency: all
                 // vector work of the group first, then the twelve MFMAs back to back.
+#if MXE_MC_GRAM_F32
+                float ff[NT], a[MCC][NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) ff[t] = (float)f[t];
+#pragma unroll
+                for (int c = 0; c < MCC; ++c) {
+                    const float wf = (float)wq[c];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) a[c][t] = ff[t] * wf;
+                }
+#pragma unroll
+                for (int c = 0; c < MCC; ++c) {
+                    int pr = 0;
+#pragma unroll
+                    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                        for (int nt = mt; nt < NT; ++nt) {
+                            acc[c][pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][mt], ff[nt], acc[c][pr], 0, 0, 0);
+                            ++pr;
+                        }
+                }
+                // the FP64 vector work of h rides next to the binary32 MFMAs
+#pragma unroll
+                for (int c = 0; c < MCC; ++c)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) hp[c][t] = fma(f[t], Hq[c], hp[c][t]);
+#else
                 double a[MCC][NT];
 #pragma unroll
                 for (int c = 0; c < MCC; ++c)
@@ -480,6 +521,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#endif
             };
             // the waves take groups wave, wave + NWV, ...; the register sets rotate
             // (four with one wave per SIMD; two with two waves per SIMD, where the
@@ -515,7 +557,14 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 const double* hb = Hi + (size_t)(4 * g + kq) * MCC;
                 const double* wb = wi + (size_t)(4 * g + kq) * MCC;
 #pragma unroll
-                for (int j = 0; j < DEPTH - 1; ++j) loadV(fr[j], vp + j * VSTEP);
+                for (int j = 0; j < DEPTH - 1; ++j) {
+                    // keep the issue order of the ring: if the scheduler issues the first set last,
+                    // the loop header needs s_waitcnt vmcnt(0) and drains the ring once per trip
+                    loadV(fr[j], vp + j * VSTEP);
+#ifdef MXE_X_ORDERED_RING
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
                 loadHW(hr[0], hb, wb);
                 for (; g < n_groups; g += DEPTH * ST, vp += DEPTH * VSTEP, hb += DEPTH * HSTEP, wb += DEPTH * HSTEP) {
 #pragma unroll
@@ -559,9 +608,10 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                             for (int nt = mt; nt < NT; ++nt) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
-                                    const int row = 16 * mt + kq + 4 * r, col = 16 * nt + cn;
-                                    if (ph == 0) Wq[row * LD + col] = acc[c][pr][r];
-                                    else Wq[row * LD + col] += acc[c][pr][r];
+                                    // C/D rows: f64 form kq + 4 r, f32 form 4 kq + r
+                                    const int row = 16 * mt + (MXE_MC_GRAM_F32 ? 4 * kq + r : kq + 4 * r), col = 16 * nt + cn;
+                                    if (ph == 0) Wq[row * LD + col] = (double)acc[c][pr][r];
+                                    else Wq[row * LD + col] += (double)acc[c][pr][r];
                                 }
                                 ++pr;
                             }
@@ -615,7 +665,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     // estimate of the NEXT Newton correction after a full step: the weights
                     // change by at most expm1(max|du|) relatively, and so does the Jacobian;
                     // the decoupled directions add the relative error theta of the Newton matrix
-                    const double relH_next = (p.stop_estimate && t.mu == 0.0) ? (expm1(sdu) + p.theta) * relH : relH;
+                    // ... and the binary32 Gram tiles theirs (MC_GRAM_ERR, measured: without it the
+                    // point is left 1.3e-9 from the fixed point at tol_h = 1e-9)
+                    const double relH_next = (p.stop_estimate && t.mu == 0.0) ? (expm1(sdu) + p.theta + MC_GRAM_ERR) * relH : relH;
                     vv[q * NP + k] -= dlc[q * NP + k];
                     t.chi2 = chi2t; t.S = St; t.Hn2 = sHn; t.wmax = swm;
                     t.Qprev = t.Q; t.Q = Qt; t.mu = 0.0;
