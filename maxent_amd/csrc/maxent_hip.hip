@@ -228,7 +228,7 @@ int upload_bases(mxe_ctx* ctx)
 size_t mc_lds_doubles(int NA, int nwp, int NWV)
 {
     return (size_t)4 * NA * (NA + 1) + 6 * 4 * 64 + 2 * 64 + 64 * 4 + (size_t)NWV * 4 * 64 + (size_t)NWV * 32 +
-           (size_t)3 * nwp * 4 + mxe::MC_LOOKAHEAD_LDS;
+           (size_t)3 * nwp * 4 + (size_t)nwp * 2 /* binary32 copy of w */ + mxe::MC_LOOKAHEAD_LDS;
 }
 
 // LDS bytes of chain_kernel<NW, NAB, TS>: stream arrays (u, ut, w, wt, Hs, vecs) in the stream

@@ -44,10 +44,7 @@ struct MCExtra {
 //     take half of the rows of the two streaming passes: two waves per SIMD there)
 // rows of V behind the last omega row (and LDS doubles behind H) that the look-ahead of the
 // fused pass may read without using them: 2 * DEPTH * 4 waves * 4 rows, rounded up
-#ifndef MXE_MC_GRAM_F32
-#define MXE_MC_GRAM_F32 1   // Gram tiles of the fused pass as v_mfma_f32_16x16x4_f32 (see step 3)
-#endif
-constexpr double MC_GRAM_ERR = MXE_MC_GRAM_F32 ? 2e-5 : 0.0;   // relative error of the Newton matrix from the f32 tiles
+constexpr double MC_GRAM_ERR = 2e-5;   // relative error of the Newton matrix from the binary32 Gram tiles (step 3)
 constexpr int MC_LOOKAHEAD_ROWS = 512;
 constexpr int MC_LOOKAHEAD_LDS = (8 * 4 + 4) * 4 * 4 + 64;       // doubles
 template <int NA, int NWV>
@@ -85,7 +82,8 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     double* red  = hpart + NWV * MCC * NP;       // [NWV waves][32]
     double* ui   = red + NWV * 32;               // [nwp][MCC]
     double* wi   = ui + (size_t)nwp * MCC;       // [nwp][MCC]
-    double* Hi   = wi + (size_t)nwp * MCC;       // [nwp][MCC]
+    float*  wiF  = reinterpret_cast<float*>(wi + (size_t)nwp * MCC);   // [nwp][MCC] binary32 copy of w (Gram operand)
+    double* Hi   = wi + (size_t)nwp * MCC + (size_t)nwp * MCC / 2;    // [nwp][MCC]
     __shared__ int s_elem[MCC], s_kind[MCC], s_act[MCC], s_scr[MCC], s_exh;
 
     // ---- slot state.  It is owned by the home wave, which loads it from LDS at the
@@ -409,6 +407,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         }
                         if (row >= nw) { Hq = 0.0; wq = 0.0; Sq = 0.0; }
                         ui[row * MCC + j] = uq; wi[row * MCC + j] = wq; Hi[row * MCC + j] = Hq;
+                        wiF[row * MCC + j] = (float)wq;
                         pS += Sq;
                         pHn = fma(Hq, Hq, pHn);
                         pwm = fmax(pwm, wq);                      // NaN-ignoring; non-finite states are caught through Q
@@ -429,59 +428,45 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         __syncthreads();                         // Hi, wi, ui and the partial sums complete
         MXE_STAMPW(7);
 
-        // ---- 3. fused pass (V once): h = V^T H (VALU) and W = V_a^T diag(w) V_a (MFMA) ----
+        // ---- 3. fused pass (V once): h = V^T H and W = V_a^T diag(w) V_a, both on the matrix pipes ----
         {
-#if MXE_MC_GRAM_F32
-            // The Gram matrix only preconditions the Newton step (the residual rho that defines
-            // the answer comes from h, binary64): its tiles are accumulated on the binary32 matrix
-            // pipe -- 32 cycles per 16x16x4 instead of 64, and no longer on the pipe the FP64
-            // vector work of h needs.  Relative error ~1e-6 of sqrt(W_ii W_jj), next to the
-            // decoupling threshold theta = 1e-5 that the Newton matrix carries anyway.
+            // The Gram matrix only preconditions the Newton step (the residual rho that defines the
+            // answer comes from h, binary64): its tiles are accumulated on the binary32 matrix pipe
+            // (v_mfma_f32_16x16x4_f32: 32 cycles per 16x16x4 instead of 64), operands converted from the
+            // same binary64 registers of V that feed h; w comes as the binary32 copy the row pass wrote.
+            // Relative error ~1e-6 of sqrt(W_ii W_jj), next to the decoupling threshold theta = 1e-5
+            // that the Newton matrix carries anyway (MC_GRAM_ERR in the stopping estimate).
+            // h_q = V^T H_q of the four slots is v_mfma_f64_4x4x4 (four blocks per instruction: block b =
+            // columns 16 t + 4 b .. + 3 of V, the four slots as columns, K = the 4 omega rows of the
+            // group) from the SAME operand registers: A[b][i][k] (lane 16 k + 4 b + i) = V[i0 + k][16 t + 4 b + i]
+            // is exactly f[t]; B[b][k][j] (lane 16 k + 4 b + j) = H[i0 + k][slot j] is one 8-byte LDS read;
+            // D[b][i][j] lands on lane 16 i + 4 b + j: one accumulator per tile and no cross-lane sum.
             typedef float g4 __attribute__((ext_vector_type(4)));
-#else
-            typedef d4 g4;
-#endif
             g4 acc[MCC][NPAIR];
-            double hp[MCC][4];
+            double hp[4];
 #pragma unroll
-            for (int c = 0; c < MCC; ++c) {
+            for (int c = 0; c < MCC; ++c)
 #pragma unroll
                 for (int pr = 0; pr < NPAIR; ++pr) acc[c][pr] = g4{0, 0, 0, 0};
 #pragma unroll
-                for (int t = 0; t < 4; ++t) hp[c][t] = 0.0;
-            }
+            for (int t = 0; t < 4; ++t) hp[t] = 0.0;
             const int kq = lane >> 4, cn = lane & 15;
             const int n_groups = nwp >> 2;           // 4 omega rows per MFMA; multiple of 16
             const double* Vl = V + (size_t)kq * NP + cn;
-            // register sets of the two-waves-per-SIMD variant (NWV = 8): two, the other wave
-            // of the SIMD covers the latency
-            double fA[4], fB[4];
-            double2 hA[4], hB[4];      // [0,1] = H of chains 01 / 23, [2,3] = w of chains 01 / 23
-            auto load_group = [&](double (&f)[4], double2 (&hw)[4], int gidx) {
-                const int i0 = 4 * gidx;
-                const double2* hptr = reinterpret_cast<const double2*>(Hi + (size_t)(i0 + kq) * MCC);
-                const double2* wptr = reinterpret_cast<const double2*>(wi + (size_t)(i0 + kq) * MCC);
-                hw[0] = hptr[0]; hw[1] = hptr[1]; hw[2] = wptr[0]; hw[3] = wptr[1];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) f[t] = Vl[(size_t)i0 * NP + 16 * t];
+            struct HW { double h; float4 w; };       // H of slot (lane & 3), w of the four slots, row i0 + kq
+            auto loadHW = [&](HW& hw, const double* hsrc, const float* wsrc) {
+                hw.h = hsrc[0];
+                hw.w = *reinterpret_cast<const float4*>(wsrc);
             };
-            auto consume = [&](const double (&f)[4], const double2 (&hw)[4]) {
-                const double Hq[MCC] = {hw[0].x, hw[0].y, hw[1].x, hw[1].y};
-                const double wq[MCC] = {hw[2].x, hw[2].y, hw[3].x, hw[3].y};
-                // An f64 MFMA and the FP64 VALU share one pipe on this part (an MFMA blocks
-                // v_fma_f64 of its SIMD for its 64 cycles), so nothing rides in the shadow of the
-                // MFMAs and a VALU product consumed by the next MFMA only adds its latency: all
-                // vector work of the group first, then the twelve MFMAs back to back.
-#if MXE_MC_GRAM_F32
+            auto consume = [&](const double (&f)[4], const HW& hw) {
+                const float wq[MCC] = {hw.w.x, hw.w.y, hw.w.z, hw.w.w};
                 float ff[NT], a[MCC][NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) ff[t] = (float)f[t];
 #pragma unroll
-                for (int c = 0; c < MCC; ++c) {
-                    const float wf = (float)wq[c];
+                for (int c = 0; c < MCC; ++c)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) a[c][t] = ff[t] * wf;
-                }
+                    for (int t = 0; t < NT; ++t) a[c][t] = ff[t] * wq[c];
 #pragma unroll
                 for (int c = 0; c < MCC; ++c) {
                     int pr = 0;
@@ -493,52 +478,19 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                             ++pr;
                         }
                 }
-                // the FP64 vector work of h rides next to the binary32 MFMAs
 #pragma unroll
-                for (int c = 0; c < MCC; ++c)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) hp[c][t] = fma(f[t], Hq[c], hp[c][t]);
-#else
-                double a[MCC][NT];
-#pragma unroll
-                for (int c = 0; c < MCC; ++c)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) a[c][t] = f[t] * wq[c];
-#pragma unroll
-                for (int c = 0; c < MCC; ++c)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) hp[c][t] = fma(f[t], Hq[c], hp[c][t]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c = 0; c < MCC; ++c) {
-                    int pr = 0;
-#pragma unroll
-                    for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-                        for (int nt = mt; nt < NT; ++nt) {
-                            acc[c][pr] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c][mt], f[nt], acc[c][pr], 0, 0, 0);
-                            ++pr;
-                        }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#endif
+                for (int t = 0; t < 4; ++t) hp[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(f[t], hw.h, hp[t], 0, 0, 0);
             };
-            // the waves take groups wave, wave + NWV, ...; the register sets rotate
-            // (four with one wave per SIMD; two with two waves per SIMD, where the
-            // other wave covers the latency and registers are halved).  n_groups is a
-            // multiple of 16 = the groups of one trip of either loop, and every load is
-            // issued unconditionally (the look-ahead past the end re-reads the last
-            // group): a load under a branch would force s_waitcnt vmcnt(0) at the join
-            // and drain the whole pipeline before every consume.
+            // the waves take groups wave, wave + NWV, ...; the register sets rotate.  n_groups is a
+            // multiple of 16 and every load is issued unconditionally (the look-ahead past the end reads
+            // the padding behind V and behind H in LDS): a load under a branch would force
+            // s_waitcnt vmcnt(0) at the join and drain the whole pipeline before every consume.
             constexpr int ST = NWV;
-            const int g_last = n_groups - 1;
+            constexpr int DEPTH = (NWV == 4 && MXE_X_WGPC == 1) ? 8 : 2;   // register sets of V (two waves per SIMD: the other wave covers the latency)
             int g = wave;
-            if (NWV == 4 && MXE_X_WGPC == 1) {
-                // V through a ring of DEPTH register sets (DEPTH - 1 row groups in flight: the
-                // L2 latency under load is several thousand cycles), H and w (LDS) one group ahead
-                constexpr int DEPTH = 8;
+            {
                 double fr[DEPTH][4];
-                double2 hr[2][4];
+                HW hr[2];
                 // addresses advance by constants (V and the LDS arrays are padded for the
                 // look-ahead past the last group, see MC_LOOKAHEAD_ROWS): no index arithmetic
                 // in the loop besides one 64-bit add per trip
@@ -546,20 +498,13 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) f[t] = src[16 * t];
                 };
-                auto loadHW = [&](double2 (&hw)[4], const double* hsrc, const double* wsrc) {
-                    const double2* hptr = reinterpret_cast<const double2*>(hsrc);
-                    const double2* wptr = reinterpret_cast<const double2*>(wsrc);
-                    hw[0] = hptr[0]; hw[1] = hptr[1]; hw[2] = wptr[0]; hw[3] = wptr[1];
-                };
                 constexpr size_t VSTEP = (size_t)4 * ST * NP;        // doubles per group step (V)
                 constexpr int HSTEP = 4 * ST * MCC;                  // ... (H, w in LDS)
                 const double* vp = Vl + (size_t)(4 * g) * NP;
-                const double* hb = Hi + (size_t)(4 * g + kq) * MCC;
-                const double* wb = wi + (size_t)(4 * g + kq) * MCC;
+                const double* hb = Hi + (size_t)(4 * g + kq) * MCC + (lane & 3);
+                const float* wb = wiF + (size_t)(4 * g + kq) * MCC;
 #pragma unroll
                 for (int j = 0; j < DEPTH - 1; ++j) {
-                    // keep the issue order of the ring: if the scheduler issues the first set last,
-                    // the loop header needs s_waitcnt vmcnt(0) and drains the ring once per trip
                     loadV(fr[j], vp + j * VSTEP);
 #ifdef MXE_X_ORDERED_RING
                     __builtin_amdgcn_sched_barrier(0);
@@ -574,26 +519,14 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         if (g + j * ST < n_groups) consume(fr[j], hr[j & 1]);     // no memory operation inside
                     }
                 }
-            } else {
-                load_group(fA, hA, g);
-                for (; g < n_groups; g += 2 * ST) {
-                    load_group(fB, hB, g + ST);
-                    consume(fA, hA);
-                    load_group(fA, hA, min(g + 2 * ST, g_last));
-                    consume(fB, hB);
-                }
             }
             MXE_STAMPW(1);
-            // h: sum the four row-residue lane groups, then (in step 4) the waves
+            // h: lane 16 i + 4 b + j holds column 16 t + 4 b + i of slot j; the waves are summed in step 4
+            {
+                const int hj = lane & 3, hcol = 4 * ((lane >> 2) & 3) + (lane >> 4);
 #pragma unroll
-            for (int c = 0; c < MCC; ++c)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    double v_ = hp[c][t];
-                    v_ = sum_xor16(v_);
-                    v_ = sum_xor32(v_);
-                    if (kq == 0) hpart[(wave * MCC + c) * NP + 16 * t + cn] = v_;
-                }
+                for (int t = 0; t < 4; ++t) hpart[(wave * MCC + hj) * NP + 16 * t + hcol] = hp[t];
+            }
             MXE_STAMPW(6);
             // Gram tiles: rotating phases (in phase ph wave w adds into chain (w + ph) mod NWV if < 4)
             for (int ph = 0; ph < NWV; ++ph) {
@@ -608,8 +541,8 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                             for (int nt = mt; nt < NT; ++nt) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
-                                    // C/D rows: f64 form kq + 4 r, f32 form 4 kq + r
-                                    const int row = 16 * mt + (MXE_MC_GRAM_F32 ? 4 * kq + r : kq + 4 * r), col = 16 * nt + cn;
+                                    // C/D layout of v_mfma_f32_16x16x4_f32: row 4 (l >> 4) + r, col l & 15
+                                    const int row = 16 * mt + 4 * kq + r, col = 16 * nt + cn;
                                     if (ph == 0) Wq[row * LD + col] = (double)acc[c][pr][r];
                                     else Wq[row * LD + col] += (double)acc[c][pr][r];
                                 }
