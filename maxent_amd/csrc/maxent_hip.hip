@@ -318,7 +318,7 @@ try {
     }
     ctx->n_tau = n_tau; ctx->n_omega = n_omega; ctx->n_s = n_s;
     ctx->NP = (n_s <= 64) ? 64 : 128;
-    ctx->nwp = ((n_omega + 63) / 64) * 64;
+    ctx->nwp = ((n_omega + 127) / 128) * 128;   // the lock-step kernel's fused pass runs whole trips of 128 rows
     if (U) ctx->U.assign(U, U + (size_t)n_tau * n_s);
     ctx->S.assign(S, S + n_s);
     ctx->V.assign(V, V + (size_t)n_omega * n_s);

@@ -454,19 +454,24 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             const int n_groups = nwp >> 2;           // 4 omega rows per MFMA; multiple of 16
             const double* Vl = V + (size_t)kq * NP + cn;
             struct HW { double h; float4 w; };       // H of slot (lane & 3), w of the four slots, row i0 + kq
+            struct OP { float ff[NT]; float a[MCC][NT]; };    // binary32 Gram operands of one row group
             auto loadHW = [&](HW& hw, const double* hsrc, const float* wsrc) {
                 hw.h = hsrc[0];
                 hw.w = *reinterpret_cast<const float4*>(wsrc);
             };
-            auto consume = [&](const double (&f)[4], const HW& hw) {
+            auto prep = [&](OP& o, const double (&f)[4], const HW& hw) {
                 const float wq[MCC] = {hw.w.x, hw.w.y, hw.w.z, hw.w.w};
-                float ff[NT], a[MCC][NT];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) ff[t] = (float)f[t];
+                for (int t = 0; t < NT; ++t) o.ff[t] = (float)f[t];
 #pragma unroll
                 for (int c = 0; c < MCC; ++c)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) a[c][t] = ff[t] * wq[c];
+                    for (int t = 0; t < NT; ++t) o.a[c][t] = o.ff[t] * wq[c];
+            };
+            auto mma = [&](const OP& o, const double (&f)[4], const HW& hw) {
+#ifdef MXE_X_NO_GRAM      // timing experiment only (results are wrong)
+                acc[0][0][0] += o.a[0][0] + o.a[1][1] + o.a[2][0] + o.a[3][1];
+#else
 #pragma unroll
                 for (int c = 0; c < MCC; ++c) {
                     int pr = 0;
@@ -474,26 +479,31 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
                         for (int nt = mt; nt < NT; ++nt) {
-                            acc[c][pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][mt], ff[nt], acc[c][pr], 0, 0, 0);
+                            acc[c][pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[c][mt], o.ff[nt], acc[c][pr], 0, 0, 0);
                             ++pr;
                         }
                 }
+#endif
 #pragma unroll
                 for (int t = 0; t < 4; ++t) hp[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(f[t], hw.h, hp[t], 0, 0, 0);
             };
-            // the waves take groups wave, wave + NWV, ...; the register sets rotate.  n_groups is a
-            // multiple of 16 and every load is issued unconditionally (the look-ahead past the end reads
-            // the padding behind V and behind H in LDS): a load under a branch would force
-            // s_waitcnt vmcnt(0) at the join and drain the whole pipeline before every consume.
+            // The waves take groups wave, wave + NWV, ...  Software pipeline, no branch inside: while the
+            // 12 + 4 MFMAs of group j occupy the matrix pipes, the vector instructions that build the
+            // binary32 operands of group j + 1 issue in their shadow (a wave issues in order: done the
+            // other way round, the pipe idles for the ~150 cycles of vector work per group -- measured
+            // 722 cycles per group against 472 of MFMA).  V comes through a ring of DEPTH register sets
+            // (DEPTH - 1 row groups in flight), H / w from LDS two groups ahead.  n_groups is a multiple
+            // of DEPTH * NWV (n_omega_pad is a multiple of 128) and every load is unconditional: the
+            // look-ahead past the end reads the zero rows behind V and the padding behind H in LDS, and
+            // what is prepared from them is never multiplied.
             constexpr int ST = NWV;
-            constexpr int DEPTH = (NWV == 4 && MXE_X_WGPC == 1) ? 8 : 2;   // register sets of V (two waves per SIMD: the other wave covers the latency)
+            constexpr int DEPTH = (NWV == 4 && MXE_X_WGPC == 1) ? 8 : 4;
+            static_assert(DEPTH % 4 == 0, "the H / w ring of four is indexed statically across trips");
             int g = wave;
             {
                 double fr[DEPTH][4];
-                HW hr[2];
-                // addresses advance by constants (V and the LDS arrays are padded for the
-                // look-ahead past the last group, see MC_LOOKAHEAD_ROWS): no index arithmetic
-                // in the loop besides one 64-bit add per trip
+                HW hr[4];
+                OP op[2];
                 auto loadV = [&](double (&f)[4], const double* src) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) f[t] = src[16 * t];
@@ -504,19 +514,29 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 const double* hb = Hi + (size_t)(4 * g + kq) * MCC + (lane & 3);
                 const float* wb = wiF + (size_t)(4 * g + kq) * MCC;
 #pragma unroll
-                for (int j = 0; j < DEPTH - 1; ++j) {
-                    loadV(fr[j], vp + j * VSTEP);
-#ifdef MXE_X_ORDERED_RING
-                    __builtin_amdgcn_sched_barrier(0);
-#endif
-                }
+                for (int j = 0; j < DEPTH - 1; ++j) loadV(fr[j], vp + j * VSTEP);
                 loadHW(hr[0], hb, wb);
+                loadHW(hr[1], hb + HSTEP, wb + HSTEP);
+                prep(op[0], fr[0], hr[0]);
                 for (; g < n_groups; g += DEPTH * ST, vp += DEPTH * VSTEP, hb += DEPTH * HSTEP, wb += DEPTH * HSTEP) {
 #pragma unroll
                     for (int j = 0; j < DEPTH; ++j) {
+#ifndef MXE_X_NO_VLOAD     // timing experiment only (results are wrong)
                         loadV(fr[(j + DEPTH - 1) % DEPTH], vp + (j + DEPTH - 1) * VSTEP);
-                        loadHW(hr[(j + 1) & 1], hb + (j + 1) * HSTEP, wb + (j + 1) * HSTEP);
-                        if (g + j * ST < n_groups) consume(fr[j], hr[j & 1]);     // no memory operation inside
+#endif
+                        loadHW(hr[(j + 2) & 3], hb + (j + 2) * HSTEP, wb + (j + 2) * HSTEP);
+                        mma(op[j & 1], fr[j], hr[j & 3]);
+                        prep(op[(j + 1) & 1], fr[(j + 1) % DEPTH], hr[(j + 1) & 3]);
+#ifndef MXE_X_NO_SGB
+                        // issue order: one MFMA, one vector instruction, ... (the operands of group j + 1
+                        // are NT conversions + MCC * NT products), then the remaining MFMAs
+#pragma unroll
+                        for (int q = 0; q < NT + MCC * NT; ++q) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, MCC * NPAIR + 4 - (NT + MCC * NT), 0);
+#endif
                     }
                 }
             }

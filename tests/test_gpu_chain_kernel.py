@@ -31,6 +31,8 @@ def _setup(n_tau, n_omega, entropy='normal', err=None):
     (200, 500, 100, 'normal', 0, 4, 1),       # four-chains-per-workgroup kernel, 1 chain (3 empty slots)
     (200, 500, 100, 'plusminus', 0, 4, 5),    # ... with the alpha scan cut into 5 cold-started pieces
     (200, 500, 100, 'normal', 8, 1, 8),
+    (200, 500, 100, 'plusminus', 8, 4, 3),    # lock-step kernel with four helper waves (NWV = 8)
+    (100, 200, 20, 'normal', 0, 4, 2),        # lock-step kernel, n_omega_pad = 256
 ])
 def test_chain_matches_kernel_model_and_truth(n_tau, n_omega, n_alpha, entropy, nw, layout, split):
     tau, omega, K, G, err, D, p = _setup(n_tau, n_omega, entropy)
