@@ -202,6 +202,9 @@ int  mxe_ns_padded(mxe_ctx* ctx);
 int  mxe_set_result_buffer(mxe_ctx* ctx, int which);
 /* duration of the last mxe_chains_launch in ms (HIP events on the ctx stream) */
 int  mxe_last_kernel_ms(mxe_ctx* ctx, float* ms);
+/* name of the kernel instantiation the last mxe_chains_launch ran, as a profiler shows it
+ * (e.g. "mxe::chain_kernel_mc<32, 4>"); owned by the ctx */
+const char* mxe_last_kernel_name(mxe_ctx* ctx);
 /* kernel geometry of the last launch: waves per chain, workgroups, LDS bytes */
 int  mxe_last_launch_info(mxe_ctx* ctx, int* waves_per_chain, int* n_workgroups,
                           int* lds_bytes);

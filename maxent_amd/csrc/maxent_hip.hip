@@ -66,6 +66,7 @@ struct mxe_ctx {
     mxe_opts opts;
     bool chains_ready = false, launched = false;
     int last_nw = 0, last_lds = 0;
+    std::string last_kernel;
     // device
     DevBuf<float> dVf, dVtf;          // binary32 copies of dV / dVt (mxe_opts.precision = F32)
     DevBuf<double> dV, dVt, dc, dcinv, dghat, dcperp, dD, dsumD, dalpha, dv0;
@@ -629,6 +630,7 @@ try {
         ex.queue = ctx->dqueue.p; ex.n_queue = ctx->n_queue; ex.counter = ctx->dcounter.p;
         HIPCHK(ctx, hipMemsetAsync(ctx->dcounter.p, 0, sizeof(int), ctx->stream));
         ctx->last_nw = NWV; ctx->last_lds = (int)lds;
+        ctx->last_kernel = "mxe::chain_kernel_mc<" + std::to_string(NA) + ", " + std::to_string(NWV) + ">";
         HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
 #define MXE_LAUNCH_MC(NA_, NWV_) do { \
         e = hipFuncSetAttribute((const void*)mxe::chain_kernel_mc<NA_, NWV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -654,6 +656,7 @@ try {
         while (lds > 160 * 1024 && NW > 1) { NW /= 2; lds = lds_bytes(ctx->NP, ctx->nwp, NW, f32); }
         if (lds > 160 * 1024) return MXE_ERR_LIMIT;
         ctx->last_nw = NW; ctx->last_lds = (int)lds;
+        ctx->last_kernel = "mxe::chain_kernel<" + std::to_string(NW) + ", " + std::to_string(ctx->NP / 32) + (f32 ? ", float>" : ", double>");
         HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         if (f32) {
             switch (NW) {
@@ -787,6 +790,8 @@ int mxe_last_kernel_ms(mxe_ctx* ctx, float* ms)
     HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
     return MXE_OK;
 }
+
+const char* mxe_last_kernel_name(mxe_ctx* ctx) { return ctx ? ctx->last_kernel.c_str() : ""; }
 
 int mxe_last_launch_info(mxe_ctx* ctx, int* waves_per_chain, int* n_workgroups, int* lds_bytes)
 {

@@ -487,11 +487,11 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) hp[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(f[t], hw.h, hp[t], 0, 0, 0);
             };
-            // The waves take groups wave, wave + NWV, ...  Software pipeline, no branch inside: while the
-            // 12 + 4 MFMAs of group j occupy the matrix pipes, the vector instructions that build the
-            // binary32 operands of group j + 1 issue in their shadow (a wave issues in order: done the
-            // other way round, the pipe idles for the ~150 cycles of vector work per group -- measured
-            // 722 cycles per group against 472 of MFMA).  V comes through a ring of DEPTH register sets
+            // The waves take groups wave, wave + NWV, ...  Software pipeline, no branch inside: the 12 + 4
+            // MFMAs of group j back to back, then the vector instructions that build the binary32
+            // operands of group j + 1 (on gfx950 a wave's vector instructions do not issue in the shadow
+            // of its own MFMAs, tools/mfma_shadow.hip; a row group costs 464 cycles of MFMA plus its
+            // vector and memory instructions, ~720 in all).  V comes through a ring of DEPTH register sets
             // (DEPTH - 1 row groups in flight), H / w from LDS two groups ahead.  n_groups is a multiple
             // of DEPTH * NWV (n_omega_pad is a multiple of 128) and every load is unconditional: the
             // look-ahead past the end reads the zero rows behind V and the padding behind H in LDS, and
@@ -525,18 +525,13 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         loadV(fr[(j + DEPTH - 1) % DEPTH], vp + (j + DEPTH - 1) * VSTEP);
 #endif
                         loadHW(hr[(j + 2) & 3], hb + (j + 2) * HSTEP, wb + (j + 2) * HSTEP);
-                        mma(op[j & 1], fr[j], hr[j & 3]);
+                        // blocks, not a mix (measured, tools/mfma_shadow.hip: a vector instruction placed
+                        // BETWEEN two MFMAs costs 14 cycles, behind the block 7): memory and vector
+                        // instructions of the step first, then the 16 MFMAs back to back
                         prep(op[(j + 1) & 1], fr[(j + 1) % DEPTH], hr[(j + 1) & 3]);
-#ifndef MXE_X_NO_SGB
-                        // issue order: one MFMA, one vector instruction, ... (the operands of group j + 1
-                        // are NT conversions + MCC * NT products), then the remaining MFMAs
-#pragma unroll
-                        for (int q = 0; q < NT + MCC * NT; ++q) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                        }
-                        __builtin_amdgcn_sched_group_barrier(0x008, MCC * NPAIR + 4 - (NT + MCC * NT), 0);
-#endif
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma(op[j & 1], fr[j], hr[j & 3]);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }

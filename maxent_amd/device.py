@@ -83,6 +83,7 @@ SYMBOLS = [
     ('mxe_ns_padded', ctypes.c_int, [_vp]),
     ('mxe_set_result_buffer', ctypes.c_int, [_vp, ctypes.c_int]),
     ('mxe_last_kernel_ms', ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    ('mxe_last_kernel_name', ctypes.c_char_p, [_vp]),
     ('mxe_last_launch_info', ctypes.c_int, [_vp] +
      [ctypes.POINTER(ctypes.c_int)] * 3),
     ('mxe_apply_output_map', ctypes.c_int, [_vp, _dp, _dp]),
@@ -361,7 +362,8 @@ class DeviceContext(object):
                                                    ctypes.byref(c)),
                     'mxe_last_launch_info')
         return dict(waves_per_chain=a.value, n_workgroups=b.value,
-                    lds_bytes=c.value)
+                    lds_bytes=c.value,
+                    kernel=self._lib.mxe_last_kernel_name(self._h).decode())
 
     def set_result_buffer(self, which):
         self._check(self._lib.mxe_set_result_buffer(self._h, int(which)),
