@@ -338,6 +338,14 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         // LDS read of the steps shared by every tile, and every lane ends up with ONE (row, slot)
         // element per tile for the exp / entropy part (all 64 lanes busy, no per-slot loop).
         {
+            // the home waves are done with W / L of the previous iteration: zero it for the tile sums of step 3
+            {
+                static_assert((MCC * NA * LD) % 2 == 0, "W is zeroed with 16-byte stores");
+                double2* Wz = reinterpret_cast<double2*>(Wm);
+#pragma unroll
+                for (int idx = 0; idx < (MCC * NA * LD / 2 + T - 1) / T; ++idx)
+                    if (tid + idx * T < MCC * NA * LD / 2) Wz[tid + idx * T] = double2{0.0, 0.0};
+            }
             const int j = lane & 3;                              // slot of this lane's results
             const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4);      // result row inside the tile
             const int ak = lane >> 4;                            // operand k inside the chunk
@@ -543,30 +551,30 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 for (int t = 0; t < 4; ++t) hpart[(wave * MCC + hj) * NP + 16 * t + hcol] = hp[t];
             }
             MXE_STAMPW(6);
-            // Gram tiles: rotating phases (in phase ph wave w adds into chain (w + ph) mod NWV if < 4)
-            for (int ph = 0; ph < NWV; ++ph) {
+            // Gram tiles: every wave adds its partial tiles into the slots' W with LDS atomics
+            // (ds_add_f64; W was zeroed at the start of the row pass), one barrier instead of four
+            // rotating read-modify-write phases
+            {
+                typedef __attribute__((address_space(3))) double lds_double;
 #pragma unroll
                 for (int c = 0; c < MCC; ++c) {
-                    if (((c - wave) & (NWV - 1)) == ph) {
-                        double* Wq = Wm + (size_t)c * NA * LD;
-                        int pr = 0;
+                    double* Wq = Wm + (size_t)c * NA * LD;
+                    int pr = 0;
 #pragma unroll
-                        for (int mt = 0; mt < NT; ++mt)
+                    for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
-                            for (int nt = mt; nt < NT; ++nt) {
+                        for (int nt = mt; nt < NT; ++nt) {
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    // C/D layout of v_mfma_f32_16x16x4_f32: row 4 (l >> 4) + r, col l & 15
-                                    const int row = 16 * mt + 4 * kq + r, col = 16 * nt + cn;
-                                    if (ph == 0) Wq[row * LD + col] = (double)acc[c][pr][r];
-                                    else Wq[row * LD + col] += (double)acc[c][pr][r];
-                                }
-                                ++pr;
+                            for (int r = 0; r < 4; ++r) {
+                                // C/D layout of v_mfma_f32_16x16x4_f32: row 4 (l >> 4) + r, col l & 15
+                                const int row = 16 * mt + 4 * kq + r, col = 16 * nt + cn;
+                                __builtin_amdgcn_ds_atomic_fadd_f64((lds_double*)(Wq + row * LD + col), (double)acc[c][pr][r]);
                             }
-                    }
+                            ++pr;
+                        }
                 }
-                __syncthreads();
             }
+            __syncthreads();
         }
         MXE_STAMPW(4);
 
