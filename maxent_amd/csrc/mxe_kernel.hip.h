@@ -962,7 +962,7 @@ void chain_kernel(const KParams p)
             // ---- damped Newton step with Bryan's step bound ----
             double mu = 0.0;
             double chi2t = 0.0, St = 0.0, dH2t = 0.0, Hn2t = 0.0, wmaxt = 0.0, dumaxt = 0.0;
-            bool accepted = false;
+            bool accepted = false, scaled = false;
             while (true) {
                 const double a = alpha + mu;
                 bool okc;
@@ -989,7 +989,18 @@ void chain_kernel(const KParams p)
                     double dummy = 0.0;
                     block_reduce<NW, 1>(x1, dummy, red);
                     block_sync<NW>();
-                    if (!(x1[0] <= step_lim)) good = false;
+                    scaled = false;
+                    if (!(x1[0] <= step_lim)) {
+                        // an undamped Newton step beyond Bryan's bound is shortened onto it (same
+                        // direction) instead of being recomputed with damping; it is then accepted
+                        // like a damped step (Q must not increase), else the damped path takes over
+                        if (mu == 0.0 && x1[0] < 1e300) {
+                            const double sc = sqrt(step_lim / x1[0]);
+                            for (int k = tid; k < NP; k += T) dl[k] *= sc;
+                            block_sync<NW>();
+                            scaled = true;
+                        } else good = false;
+                    }
                     MXE_STAMP(3);
                     if (good) {
                         eval_pass(dl, false, chi2t, St, dH2t, Hn2t, wmaxt, dumaxt);
@@ -1000,7 +1011,7 @@ void chain_kernel(const KParams p)
                         // an undamped Newton step may overshoot (it recovers
                         // quadratically); a step that needed damping must not
                         // make Q worse, or a cold start can land far out
-                        else if (mu > 0.0 && Qt > Q) good = false;
+                        else if ((mu > 0.0 || scaled) && Qt > Q) good = false;
                     }
                 }
                 if (good) { accepted = true; break; }
@@ -1010,7 +1021,7 @@ void chain_kernel(const KParams p)
             if (!accepted) { failed = true; break; }
             const double relH = sqrt(dH2t / Hn2);
             // estimate of the next Newton correction after a full step (see mxe_opts.stop_estimate)
-            const double relH_next = (p.stop_estimate && mu == 0.0) ? (expm1(dumaxt) + p.theta) * relH : relH;
+            const double relH_next = (p.stop_estimate && mu == 0.0 && !scaled) ? (expm1(dumaxt) + p.theta) * relH : relH;
             accept_trial();
             MXE_STAMP(5);
             chi2 = chi2t; S = St; Hn2 = Hn2t; wmax = wmaxt;

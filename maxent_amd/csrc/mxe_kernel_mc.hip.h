@@ -315,6 +315,17 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         else if (k < ns) z = rhs[q * NP + k] / a;
                         nrm = wave_sum(nrm);
                         if (nrm <= t.steplim) { okflag = 1; dk = (k < ns) ? cc[k] * z : 0.0; break; }
+#ifndef MXE_X_NO_STEP_SCALE
+                        // An undamped Newton step that violates Bryan's bound is shortened onto it
+                        // (same direction, a descent direction of Q) instead of being recomputed with
+                        // damping: a second factorisation in this round would keep the other three
+                        // slots of the workgroup waiting.  It is accepted like a damped step (Q must
+                        // not increase); if it is not, the damped path below takes over.
+                        if (t.mu == 0.0 && nrm < 1e300) {
+                            const double sc = sqrt(t.steplim / nrm);
+                            okflag = 2; dk = (k < ns) ? cc[k] * z * sc : 0.0; break;
+                        }
+#endif
                     }
                     t.mu = (t.mu == 0.0) ? p.mu_first * t.alpha : t.mu * p.mu_grow;
                     if (!(t.mu <= p.mu_max * t.alpha)) break;
@@ -608,7 +619,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     else finish_alpha = true;                   // cannot even evaluate: give up on this alpha
                 } else if (!t.okprev) {
                     finish_alpha = true;                        // the damping loop ran out of range
-                } else if (!finite || (t.mu > 0.0 && Qt > t.Q)) {
+                } else if (!finite || ((t.mu > 0.0 || t.okprev == 2) && Qt > t.Q)) {
                     // not finite, or a damped step that made Q worse: more damping, restore from v
                     ++t.nevals;
                     t.mu = (t.mu == 0.0) ? p.mu_first * t.alpha : t.mu * p.mu_grow;
@@ -623,7 +634,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     // the decoupled directions add the relative error theta of the Newton matrix
                     // ... and the binary32 Gram tiles theirs (MC_GRAM_ERR, measured: without it the
                     // point is left 1.3e-9 from the fixed point at tol_h = 1e-9)
-                    const double relH_next = (p.stop_estimate && t.mu == 0.0) ? (expm1(sdu) + p.theta + MC_GRAM_ERR) * relH : relH;
+                    const double relH_next = (p.stop_estimate && t.mu == 0.0 && t.okprev == 1) ? (expm1(sdu) + p.theta + MC_GRAM_ERR) * relH : relH;
                     vv[q * NP + k] -= dlc[q * NP + k];
                     t.chi2 = chi2t; t.S = St; t.Hn2 = sHn; t.wmax = swm;
                     t.Qprev = t.Q; t.Q = Qt; t.mu = 0.0;
