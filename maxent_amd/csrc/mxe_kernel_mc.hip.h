@@ -91,16 +91,16 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     //      that no register is pinned by it during the two streaming passes. ----
     struct Slot {
         double alpha, mu, chi2, S, Hn2, wmax, Q, Qprev, cperp, steplim;
-        int elem, prob0, clen, ia, niter, nevals, nact, active, scratch, okprev;
+        int elem, prob0, clen, ia, niter, nevals, nact, active, scratch, okprev, bt;
     };
     __shared__ double s_sd[MCC][10];
-    __shared__ int s_si[MCC][10];
+    __shared__ int s_si[MCC][12];
     auto load_slot = [&](Slot& t) {
         const double* d = s_sd[wave]; const int* n = s_si[wave];
         t.alpha = d[0]; t.mu = d[1]; t.chi2 = d[2]; t.S = d[3]; t.Hn2 = d[4]; t.wmax = d[5];
         t.Q = d[6]; t.Qprev = d[7]; t.cperp = d[8]; t.steplim = d[9];
         t.elem = n[0]; t.prob0 = n[1]; t.clen = n[2]; t.ia = n[3]; t.niter = n[4]; t.nevals = n[5];
-        t.nact = n[6]; t.active = n[7]; t.scratch = n[8]; t.okprev = n[9];
+        t.nact = n[6]; t.active = n[7]; t.scratch = n[8]; t.okprev = n[9]; t.bt = n[10];
     };
     auto store_slot = [&](const Slot& t) {
         if (lane == 0) {
@@ -108,7 +108,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             d[0] = t.alpha; d[1] = t.mu; d[2] = t.chi2; d[3] = t.S; d[4] = t.Hn2; d[5] = t.wmax;
             d[6] = t.Q; d[7] = t.Qprev; d[8] = t.cperp; d[9] = t.steplim;
             n[0] = t.elem; n[1] = t.prob0; n[2] = t.clen; n[3] = t.ia; n[4] = t.niter; n[5] = t.nevals;
-            n[6] = t.nact; n[7] = t.active; n[8] = t.scratch; n[9] = t.okprev;
+            n[6] = t.nact; n[7] = t.active; n[8] = t.scratch; n[9] = t.okprev; n[10] = t.bt;
             s_act[wave] = t.active; s_scr[wave] = t.scratch;
         }
         wave_sync();
@@ -118,7 +118,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         t.cperp = p.cperp[t.elem];
         t.steplim = p.step_max * p.sumD[t.elem];
         t.prob0 = p.chain_prob0[c]; t.clen = p.chain_len[c];
-        t.ia = 0; t.niter = 0; t.nevals = 0; t.nact = 0; t.okprev = 0;
+        t.ia = 0; t.niter = 0; t.nevals = 0; t.nact = 0; t.okprev = 0; t.bt = 0;
         t.alpha = p.alpha[(size_t)t.prob0];
         t.mu = 0.0; t.Qprev = __builtin_nan("");
         t.chi2 = 0.0; t.S = 0.0; t.Hn2 = 1.0; t.wmax = 1.0; t.Q = 0.0;
@@ -144,7 +144,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         if (c >= 0) start_piece(t, c);
         else {
             // empty slot: evaluates v = 0 of a neighbour's element every round (finite, never used)
-            t = Slot{1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0};
+            t = Slot{1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0};
             gh[wave * NP + lane] = 0.0; vv[wave * NP + lane] = 0.0;
             if (lane == 0) { s_elem[wave] = -1; s_kind[wave] = 0; }
         }
@@ -288,8 +288,16 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             load_slot(t);
             int okflag = 0;
             double dk = 0.0;
+            double dtot = 0.0;                       // total step from v of the trial point (dk: operand of the row pass)
             if (t.active && t.scratch) {
                 dk = vv[q * NP + k];                 // evaluation from scratch: the operand is v
+            } else if (t.active && t.okprev == 3) {
+                // backtracking: the last trial v - delta made Q worse; the next one is v - delta / 2,
+                // reached from the trial state in LDS by the step -delta / 2.  No factorisation, and
+                // no round spent on restoring the state from v.
+                dtot = 0.5 * dlc[q * NP + k];
+                dk = -dtot;
+                okflag = 4;
             } else if (t.active) {
                 rhs[q * NP + k] = (k < ns) ? fma(t.alpha * vv[q * NP + k], ci[k], rho[q * NP + k]) : 0.0;
                 const double thr = p.theta * t.alpha / fmax(t.wmax, 1e-300);
@@ -331,7 +339,8 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     if (!(t.mu <= p.mu_max * t.alpha)) break;
                 }
             }
-            dlc[q * NP + k] = (okflag ? dk : 0.0);
+            if (okflag != 4) dtot = okflag ? dk : 0.0;
+            dlc[q * NP + k] = dtot;
             vecI[k * MCC + q] = dk;
             t.okprev = okflag;
             store_slot(t);
@@ -619,12 +628,18 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     else finish_alpha = true;                   // cannot even evaluate: give up on this alpha
                 } else if (!t.okprev) {
                     finish_alpha = true;                        // the damping loop ran out of range
-                } else if (!finite || ((t.mu > 0.0 || t.okprev == 2) && Qt > t.Q)) {
-                    // not finite, or a damped step that made Q worse: more damping, restore from v
+                } else if (!finite || ((t.mu > 0.0 || t.okprev >= 2) && Qt > t.Q)) {
                     ++t.nevals;
-                    t.mu = (t.mu == 0.0) ? p.mu_first * t.alpha : t.mu * p.mu_grow;
-                    t.scratch = 1;
-                    if (!(t.mu <= p.mu_max * t.alpha)) finish_alpha = true;
+                    if (finite && t.bt < 3) {
+                        // a shortened / damped / halved step that made Q worse: halve it (step 1)
+                        ++t.bt;
+                        t.okprev = 3;
+                    } else {
+                        // not finite, or still worse after three halvings: more damping, restore from v
+                        t.mu = (t.mu == 0.0) ? p.mu_first * t.alpha : t.mu * p.mu_grow;
+                        t.scratch = 1; t.bt = 0;
+                        if (!(t.mu <= p.mu_max * t.alpha)) finish_alpha = true;
+                    }
                 } else {
                     // accepted
                     ++t.nevals;
@@ -639,7 +654,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     t.chi2 = chi2t; t.S = St; t.Hn2 = sHn; t.wmax = swm;
                     t.Qprev = t.Q; t.Q = Qt; t.mu = 0.0;
                     ++t.niter;
-                    if (p.tol_h > 0.0 && fmin(relH, relH_next) < p.tol_h && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
+                    const bool newton_step = t.okprev != 4;       // a halved step says nothing about convergence
+                    t.bt = 0;
+                    if (newton_step && p.tol_h > 0.0 && fmin(relH, relH_next) < p.tol_h && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                     else if (p.tol_relq > 0.0 && fabs(fabs(t.Qprev - t.Q) / t.Q) < p.tol_relq && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                     else if (t.niter >= p.maxiter) finish_alpha = true;
                 }
@@ -657,7 +674,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         p.out_nevals[prob] = t.nevals; p.out_nact[prob] = t.nact;
                     }
                     ++t.ia;
-                    t.niter = 0; t.nevals = 0; t.mu = 0.0;
+                    t.niter = 0; t.nevals = 0; t.mu = 0.0; t.bt = 0;
                     t.Qprev = __builtin_nan("");
                     if (t.ia >= t.clen) t.active = 0;
                     else {

@@ -1,0 +1,7 @@
+# kernel time of the cfg4 batch against alpha_split (pieces per alpha scan)
+for s in 0 12 14 16 0 15 16; do
+  timeout -k 10 100 python bench.py --no-cpu-baseline --steps 30 --alpha-split $s 2>/dev/null > /tmp/ss.json
+  python -c "
+import json
+d=json.load(open('/tmp/ss.json')); print($s, d['roofline']['kernel_ms'], d['roofline']['newton_iters_per_solve'], d['config']['converged'])"
+done
