@@ -44,7 +44,10 @@ struct MCExtra {
 //     take half of the rows of the two streaming passes: two waves per SIMD there)
 // rows of V behind the last omega row (and LDS doubles behind H) that the look-ahead of the
 // fused pass may read without using them: 2 * DEPTH * 4 waves * 4 rows, rounded up
-constexpr double MC_GRAM_ERR = 2e-5;   // relative error of the Newton matrix from the binary32 Gram tiles (step 3)
+// allowance for the binary32 Gram tiles in the stopping estimate.  Measured on the cfg4 batch: with 0 and
+// with 2e-5 the worst sampled alpha-solves end 1.3e-9 from the fixed point (2.3e-10 with binary64 tiles;
+// tol_h = 1e-9) -- the same solves either way -- and 2e-5 costs 2 % more iterations, so none is made.
+constexpr double MC_GRAM_ERR = 0.0;
 constexpr int MC_LOOKAHEAD_ROWS = 512;
 constexpr int MC_LOOKAHEAD_LDS = (8 * 4 + 4) * 4 * 4 + 64;       // doubles
 template <int NA, int NWV>
@@ -647,8 +650,6 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     // estimate of the NEXT Newton correction after a full step: the weights
                     // change by at most expm1(max|du|) relatively, and so does the Jacobian;
                     // the decoupled directions add the relative error theta of the Newton matrix
-                    // ... and the binary32 Gram tiles theirs (MC_GRAM_ERR, measured: without it the
-                    // point is left 1.3e-9 from the fixed point at tol_h = 1e-9)
                     const double relH_next = (p.stop_estimate && t.mu == 0.0 && t.okprev == 1) ? (expm1(sdu) + p.theta + MC_GRAM_ERR) * relH : relH;
                     vv[q * NP + k] -= dlc[q * NP + k];
                     t.chi2 = chi2t; t.S = St; t.Hn2 = sHn; t.wmax = swm;
