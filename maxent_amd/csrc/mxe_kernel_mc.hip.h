@@ -48,6 +48,11 @@ struct MCExtra {
 // with 2e-5 the worst sampled alpha-solves end 1.3e-9 from the fixed point (2.3e-10 with binary64 tiles;
 // tol_h = 1e-9) -- the same solves either way -- and 2e-5 costs 2 % more iterations, so none is made.
 constexpr double MC_GRAM_ERR = 0.0;
+#ifndef MXE_MC_PREFETCH_CHUNKS
+#define MXE_MC_PREFETCH_CHUNKS 0    // experiment: chunks (of 4 singular directions x 8 tiles) of V^T requested before the
+                                    // home phase and held in registers across it.  Measured: 8 chunks take 2.0 k cycles off
+                                    // the row pass and add 3.8 k to the home phase (register parking, load issue); 4: -1.2 k / +1.6 k
+#endif
 constexpr int MC_LOOKAHEAD_ROWS = 512;
 constexpr int MC_LOOKAHEAD_LDS = (8 * 4 + 4) * 4 * 4 + 64;       // doubles
 template <int NA, int NWV>
@@ -284,6 +289,18 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         }
         if (!(s_act[0] | s_act[1] | s_act[2] | s_act[3])) break;      // uniform: LDS flags behind a barrier
 
+        // ---- V^T of the first chunks of this wave's row pass, requested now and consumed after the
+        //      home phase (off by default, see MXE_MC_PREFETCH_CHUNKS) ----
+        constexpr int PRE = (NWV == 4) ? MXE_MC_PREFETCH_CHUNKS : 0;
+        double pre[PRE > 0 ? PRE : 1][8];
+        if (PRE > 0) {
+            const double* ap0 = Vt + (size_t)(lane >> 4) * nwp + 16 * wave + (lane & 15);
+#pragma unroll
+            for (int c = 0; c < PRE; ++c)
+#pragma unroll
+                for (int tt = 0; tt < 8; ++tt) pre[c][tt] = ap0[(size_t)(4 * c) * nwp + 16 * NWV * tt];
+        }
+
         // ---- 1. home wave: right-hand side, active block, factorise, solve, step ----
         if (wave < MCC) {
             const int q = wave, k = lane;
@@ -403,9 +420,22 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 #pragma unroll
                     for (int tt = 0; tt < TB; ++tt) xv[tt] = src[16 * NWV * tt];
                 };
+                // the first batch of a wave starts with the chunks that were requested before the home phase
+                const int kstart = (PRE > 0 && t0 == wave) ? PRE : 0;
 #pragma unroll
-                for (int r = 0; r < RD - 1; ++r) loadA(xr[r], r);
-                for (int kc = 0; kc < nchunk; kc += RD) {
+                for (int r = 0; r < RD - 1; ++r) loadA(xr[r], min(kstart + r, NCHK - 1));
+                if (PRE > 0 && t0 == wave) {
+#pragma unroll
+                    for (int c = 0; c < PRE; ++c) {
+                        const double bv = bp[c * 4 * MCC];
+                        if (c < nchunk) {
+#pragma unroll
+                            for (int tt = 0; tt < TB; ++tt)
+                                acc[tt] = __builtin_amdgcn_mfma_f64_4x4x4f64(pre[c][tt], bv, acc[tt], 0, 0, 0);
+                        }
+                    }
+                }
+                for (int kc = kstart; kc < nchunk; kc += RD) {
 #pragma unroll
                     for (int r = 0; r < RD; ++r) {
                         loadA(xr[(r + RD - 1) % RD], min(kc + r + RD - 1, NCHK - 1));
