@@ -92,7 +92,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     double* wi   = ui + (size_t)nwp * MCC;       // [nwp][MCC]
     float*  wiF  = reinterpret_cast<float*>(wi + (size_t)nwp * MCC);   // [nwp][MCC] binary32 copy of w (Gram operand)
     double* Hi   = wi + (size_t)nwp * MCC + (size_t)nwp * MCC / 2;    // [nwp][MCC]
-    __shared__ int s_elem[MCC], s_kind[MCC], s_act[MCC], s_scr[MCC], s_exh;
+    __shared__ int s_elem[MCC], s_kind[MCC], s_act[MCC], s_scr[MCC];
 
     // ---- slot state.  It is owned by the home wave, which loads it from LDS at the
     //      start of its two sections of a round and stores it back at their end, so
@@ -137,7 +137,6 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     };
 
     // ---- first pieces ----
-    if (tid == 0) s_exh = dynamic ? 0 : 1;
     if (wave < MCC) {
         Slot t;
         int c;
@@ -275,18 +274,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     const long long guard_max = (long long)(dynamic ? x.n_queue : 1) * p.n_alpha * (p.maxiter + 64) + 64;
 
     while (guard++ < guard_max) {
-        // ---- 0. idle slots take the next piece from the queue ----
-        if (dynamic && s_exh == 0) {
-            __syncthreads();                     // everybody has read s_exh
-            if (wave < MCC && s_act[wave] == 0) {
-                int idx = 0;
-                if (lane == 0) idx = atomicAdd(x.counter, 1);
-                idx = __builtin_amdgcn_readfirstlane(idx);
-                if (idx < x.n_queue) { Slot t; start_piece(t, x.queue[idx]); store_slot(t); }
-                else if (lane == 0) s_exh = 1;
-            }
-            __syncthreads();
-        }
+        // (a slot that finishes its piece takes the next one from the queue right away, in step 4)
         if (!(s_act[0] | s_act[1] | s_act[2] | s_act[3])) break;      // uniform: LDS flags behind a barrier
 
         // ---- V^T of the first chunks of this wave's row pass, requested now and consumed after the
@@ -707,8 +695,15 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     ++t.ia;
                     t.niter = 0; t.nevals = 0; t.mu = 0.0; t.bt = 0;
                     t.Qprev = __builtin_nan("");
-                    if (t.ia >= t.clen) t.active = 0;
-                    else {
+                    if (t.ia >= t.clen) {
+                        t.active = 0;
+                        if (dynamic) {           // next piece from the queue (most expensive first)
+                            int idx = 0;
+                            if (lane == 0) idx = atomicAdd(x.counter, 1);
+                            idx = __builtin_amdgcn_readfirstlane(idx);
+                            if (idx < x.n_queue) start_piece(t, x.queue[idx]);
+                        }
+                    } else {
                         t.alpha = p.alpha[(size_t)t.prob0 + t.ia];
                         t.Q = 0.5 * t.chi2 - t.alpha * t.S;
                     }
