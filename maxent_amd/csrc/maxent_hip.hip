@@ -228,7 +228,7 @@ int upload_bases(mxe_ctx* ctx)
 
 size_t mc_lds_doubles(int NA, int nwp, int NWV)
 {
-    return (size_t)4 * NA * (NA + 1) + 6 * 4 * 64 + 2 * 64 + 64 * 4 + (size_t)NWV * 4 * 64 + (size_t)NWV * 32 +
+    return (size_t)4 * NA * (NA + 1) + 8 * 4 * 64 + 2 * 64 + 64 * 4 + (size_t)NWV * 4 * 64 + (size_t)NWV * 32 +
            (size_t)3 * nwp * 4 + (size_t)nwp * 2 /* binary32 copy of w */ + mxe::MC_LOOKAHEAD_LDS;
 }
 
@@ -237,7 +237,7 @@ size_t mc_lds_doubles(int NA, int nwp, int NWV)
 size_t lds_bytes(int NP, int nwp, int NW, bool f32)
 {
     const int SROW = (NP / 4) * mxe::GBLK;
-    const size_t fixed = (size_t)NP * (NP + 1) + 11 * (size_t)NP + (size_t)NW * NP + (size_t)NW * 8;
+    const size_t fixed = (size_t)NP * (NP + 1) + (NP == 64 ? 13 : 11) * (size_t)NP + (size_t)NW * NP + (size_t)NW * 8;
     const size_t stream = 5 * (size_t)nwp + NP;
     const size_t stage = f32 ? 0 : (size_t)NW * 2 * mxe::GRAM_R * SROW;
     return (fixed + stage) * 8 + stream * (f32 ? 4 : 8);

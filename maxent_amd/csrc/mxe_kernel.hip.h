@@ -327,7 +327,12 @@ void chain_kernel(const KParams p)
     double* gh   = ci + NP;
     double* rho  = gh + NP;
     double* rhot = rho + NP;
-    double* hpart = rhot + NP;               // [NW][NP]
+    // the alpha-path predictor keeps two more vectors; not in the NP = 128 build, whose 132 KB of W
+    // leave no room for them
+    constexpr bool PRED = (NAB == 2);
+    double* ecor = rhot + NP;                // [NP] defect of the first Newton iterate of the previous alpha (predictor)
+    double* eacc = ecor + (PRED ? NP : 0);   // [NP] ... of this alpha, being accumulated
+    double* hpart = eacc + (PRED ? NP : 0);  // [NW][NP]
     double* red  = hpart + NW * NP;          // [NW*8]
     TS* u    = reinterpret_cast<TS*>(red + NW * 8);   // [nwp]
     TS* ut   = u + nwp;
@@ -356,6 +361,7 @@ void chain_kernel(const KParams p)
         gh[k] = p.ghat[(size_t)elem * NP + k];
         v[k]  = p.v0[(size_t)p.chain_v0[chain] * NP + k];
         dl[k] = 0.0;
+        if (PRED) { ecor[k] = 0.0; eacc[k] = 0.0; }
     }
     block_sync<NW>();
 
@@ -913,7 +919,7 @@ void chain_kernel(const KParams p)
     const int prob0 = p.chain_prob0[chain], clen = p.chain_len[chain];
     for (int ia = 0; ia < clen; ++ia) {
         const double alpha = p.alpha[(size_t)prob0 + ia];
-        int n_iter = 0, conv = 0, nevals = nevals_pending, n_act_last = 0;
+        int n_iter = 0, conv = 0, nevals = nevals_pending, n_act_last = 0, capp = 0;
         nevals_pending = 0;
         double Qprev = __builtin_nan("");
         double Q = 0.5 * chi2 - alpha * S;
@@ -962,7 +968,7 @@ void chain_kernel(const KParams p)
             // ---- damped Newton step with Bryan's step bound ----
             double mu = 0.0;
             double chi2t = 0.0, St = 0.0, dH2t = 0.0, Hn2t = 0.0, wmaxt = 0.0, dumaxt = 0.0;
-            bool accepted = false, scaled = false;
+            bool accepted = false, scaled = false, predicted = false;
             while (true) {
                 const double a = alpha + mu;
                 bool okc;
@@ -1002,6 +1008,24 @@ void chain_kernel(const KParams p)
                         } else good = false;
                     }
                     MXE_STAMP(3);
+                    predicted = false;
+                    if (PRED && good && !scaled && mu == 0.0 && n_iter == 0 && ia > 0) {
+                        // predictor along the alpha path: the defect of the previous alpha's first Newton
+                        // iterate (what its later iterations added) is added to this alpha's first step
+                        // (see the lock-step kernel, step 1)
+                        // safeguards: only a correction smaller than half the Newton step is used, and the
+                        // corrected step must not increase Q (else the damped path takes over)
+                        double n2[2] = {0.0, 0.0};
+                        for (int k = tid; k < NP; k += T) { n2[0] = fma(ecor[k], ecor[k], n2[0]); n2[1] = fma(dl[k], dl[k], n2[1]); }
+                        double dummy2 = 0.0;
+                        block_reduce<NW, 2>(n2, dummy2, red);
+                        block_sync<NW>();
+                        if (n2[0] > 0.0 && n2[0] <= 0.25 * n2[1]) {
+                            for (int k = tid; k < NP; k += T) dl[k] -= ecor[k];
+                            block_sync<NW>();
+                            predicted = true;
+                        }
+                    }
                     if (good) {
                         eval_pass(dl, false, chi2t, St, dH2t, Hn2t, wmaxt, dumaxt);
                         MXE_STAMP(4);
@@ -1011,7 +1035,10 @@ void chain_kernel(const KParams p)
                         // an undamped Newton step may overshoot (it recovers
                         // quadratically); a step that needed damping must not
                         // make Q worse, or a cold start can land far out
-                        else if ((mu > 0.0 || scaled) && Qt > Q) good = false;
+                        else if ((mu > 0.0 || scaled) && Qt > Q + 1e-12 * fabs(Q)) good = false;   // (margin: rounding of Q)
+                        // a predicted step may overshoot like any undamped Newton step; only a gross
+                        // increase of Q (an extrapolation gone wrong on a coarse alpha mesh) rejects it
+                        else if (predicted && Qt > 4.0 * fabs(Q) + 1.0) good = false;
                     }
                 }
                 if (good) { accepted = true; break; }
@@ -1021,7 +1048,9 @@ void chain_kernel(const KParams p)
             if (!accepted) { failed = true; break; }
             const double relH = sqrt(dH2t / Hn2);
             // estimate of the next Newton correction after a full step (see mxe_opts.stop_estimate)
-            const double relH_next = (p.stop_estimate && mu == 0.0 && !scaled) ? (expm1(dumaxt) + p.theta) * relH : relH;
+            const double relH_next = (p.stop_estimate && mu == 0.0 && !scaled && !predicted) ? (expm1(dumaxt) + p.theta) * relH : relH;
+            if (n_iter == 0) capp = predicted ? 2 : (mu == 0.0 && !scaled) ? 1 : 0;
+            else if (PRED) for (int k = tid; k < NP; k += T) eacc[k] -= dl[k];
             accept_trial();
             MXE_STAMP(5);
             chi2 = chi2t; S = St; Hn2 = Hn2t; wmax = wmaxt;
@@ -1037,6 +1066,22 @@ void chain_kernel(const KParams p)
             }
         }
 
+        if (PRED) {
+            // defect of this alpha's first Newton iterate -> predictor of the next alpha, scaled with
+            // the square of the ratio of the steps in log alpha
+            double rr2 = 0.0;
+            if (conv && capp > 0 && ia > 0 && ia + 1 < clen) {
+                const double a0 = p.alpha[(size_t)prob0 + ia - 1], a2 = p.alpha[(size_t)prob0 + ia + 1];
+                const double rr = log(a2 / alpha) / log(alpha / a0);
+                rr2 = rr * rr;
+            }
+            for (int k = tid; k < NP; k += T) {
+                double e = ((capp == 2 ? ecor[k] : 0.0) + eacc[k]) * rr2;
+                if (!(fabs(e) < 1e300)) e = 0.0;
+                ecor[k] = e; eacc[k] = 0.0;
+            }
+            block_sync<NW>();
+        }
         // ---- results of this alpha (MaxEntResult fields, maxent_result.py:835-967)
         const size_t prob = (size_t)prob0 + ia;
         if (p.out_H) {

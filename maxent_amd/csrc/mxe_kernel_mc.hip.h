@@ -83,7 +83,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     double* gh   = zz + MCC * NP;                // [MCC][NP]
     double* rho  = gh + MCC * NP;                // [MCC][NP]
     double* dlc  = rho + MCC * NP;               // [MCC][NP]   step per chain (chain major)
-    double* cc   = dlc + MCC * NP;               // [NP]
+    double* ecor = dlc + MCC * NP;               // [MCC][NP]   defect of the first Newton iterate of the previous alpha (predictor)
+    double* eacc = ecor + MCC * NP;              // [MCC][NP]   ... of this alpha, being accumulated
+    double* cc   = eacc + MCC * NP;              // [NP]
     double* ci   = cc + NP;                      // [NP]
     double* vecI = ci + NP;                      // [NP][MCC]   step / v, chain minor (row-pass operand)
     double* hpart = vecI + NP * MCC;             // [NWV waves][MCC chains][NP]
@@ -99,7 +101,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     //      that no register is pinned by it during the two streaming passes. ----
     struct Slot {
         double alpha, mu, chi2, S, Hn2, wmax, Q, Qprev, cperp, steplim;
-        int elem, prob0, clen, ia, niter, nevals, nact, active, scratch, okprev, bt;
+        int elem, prob0, clen, ia, niter, nevals, nact, active, scratch, okprev, bt, capp;
     };
     __shared__ double s_sd[MCC][10];
     __shared__ int s_si[MCC][12];
@@ -108,7 +110,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         t.alpha = d[0]; t.mu = d[1]; t.chi2 = d[2]; t.S = d[3]; t.Hn2 = d[4]; t.wmax = d[5];
         t.Q = d[6]; t.Qprev = d[7]; t.cperp = d[8]; t.steplim = d[9];
         t.elem = n[0]; t.prob0 = n[1]; t.clen = n[2]; t.ia = n[3]; t.niter = n[4]; t.nevals = n[5];
-        t.nact = n[6]; t.active = n[7]; t.scratch = n[8]; t.okprev = n[9]; t.bt = n[10];
+        t.nact = n[6]; t.active = n[7]; t.scratch = n[8]; t.okprev = n[9]; t.bt = n[10]; t.capp = n[11];
     };
     auto store_slot = [&](const Slot& t) {
         if (lane == 0) {
@@ -116,7 +118,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             d[0] = t.alpha; d[1] = t.mu; d[2] = t.chi2; d[3] = t.S; d[4] = t.Hn2; d[5] = t.wmax;
             d[6] = t.Q; d[7] = t.Qprev; d[8] = t.cperp; d[9] = t.steplim;
             n[0] = t.elem; n[1] = t.prob0; n[2] = t.clen; n[3] = t.ia; n[4] = t.niter; n[5] = t.nevals;
-            n[6] = t.nact; n[7] = t.active; n[8] = t.scratch; n[9] = t.okprev; n[10] = t.bt;
+            n[6] = t.nact; n[7] = t.active; n[8] = t.scratch; n[9] = t.okprev; n[10] = t.bt; n[11] = t.capp;
             s_act[wave] = t.active; s_scr[wave] = t.scratch;
         }
         wave_sync();
@@ -126,13 +128,14 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         t.cperp = p.cperp[t.elem];
         t.steplim = p.step_max * p.sumD[t.elem];
         t.prob0 = p.chain_prob0[c]; t.clen = p.chain_len[c];
-        t.ia = 0; t.niter = 0; t.nevals = 0; t.nact = 0; t.okprev = 0; t.bt = 0;
+        t.ia = 0; t.niter = 0; t.nevals = 0; t.nact = 0; t.okprev = 0; t.bt = 0; t.capp = 0;
         t.alpha = p.alpha[(size_t)t.prob0];
         t.mu = 0.0; t.Qprev = __builtin_nan("");
         t.chi2 = 0.0; t.S = 0.0; t.Hn2 = 1.0; t.wmax = 1.0; t.Q = 0.0;
         t.active = 1; t.scratch = 1;
         gh[wave * NP + lane] = p.ghat[(size_t)t.elem * NP + lane];
         vv[wave * NP + lane] = p.v0[(size_t)p.chain_v0[c] * NP + lane];
+        ecor[wave * NP + lane] = 0.0; eacc[wave * NP + lane] = 0.0;
         if (lane == 0) { s_elem[wave] = t.elem; s_kind[wave] = p.elem_kind[t.elem]; }
     };
 
@@ -151,7 +154,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         if (c >= 0) start_piece(t, c);
         else {
             // empty slot: evaluates v = 0 of a neighbour's element every round (finite, never used)
-            t = Slot{1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0};
+            t = Slot{1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0};
             gh[wave * NP + lane] = 0.0; vv[wave * NP + lane] = 0.0;
             if (lane == 0) { s_elem[wave] = -1; s_kind[wave] = 0; }
         }
@@ -330,7 +333,25 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         if (k < na) { z = zz[q * NP + k]; nrm = z * (rhs[q * NP + k] - a * z); }
                         else if (k < ns) z = rhs[q * NP + k] / a;
                         nrm = wave_sum(nrm);
-                        if (nrm <= t.steplim) { okflag = 1; dk = (k < ns) ? cc[k] * z : 0.0; break; }
+                        if (nrm <= t.steplim) {
+                            okflag = 1; dk = (k < ns) ? cc[k] * z : 0.0;
+#ifndef MXE_X_NO_PREDICTOR
+                            // Predictor along the alpha path.  The first Newton iterate of an alpha, started
+                            // from the solution of the previous one, misses the new solution by a defect
+                            // e = O(h^2) (h = the step in log alpha) whose coefficient changes slowly along
+                            // the path, and the defect of the PREVIOUS alpha is known exactly: it is what the
+                            // later iterations of that alpha added.  Adding it to the first step leaves
+                            // O(h^3): most alphas then need two iterations instead of three.
+                            // Safeguards: only a correction smaller than half the Newton step is used, and
+                            // the corrected step must not increase Q (else it is halved like a shortened one).
+                            if (t.niter == 0 && t.ia > 0 && t.mu == 0.0) {
+                                const double ek = ecor[q * NP + k];
+                                const double ne = wave_sum(ek * ek), nd = wave_sum(dk * dk);
+                                if (ne > 0.0 && ne <= 0.25 * nd) { dk -= ek; okflag = 5; }
+                            }
+#endif
+                            break;
+                        }
 #ifndef MXE_X_NO_STEP_SCALE
                         // An undamped Newton step that violates Bryan's bound is shortened onto it
                         // (same direction, a descent direction of Q) instead of being recomputed with
@@ -649,7 +670,11 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     else finish_alpha = true;                   // cannot even evaluate: give up on this alpha
                 } else if (!t.okprev) {
                     finish_alpha = true;                        // the damping loop ran out of range
-                } else if (!finite || ((t.mu > 0.0 || t.okprev >= 2) && Qt > t.Q)) {
+                } else if (!finite || ((t.mu > 0.0 || (t.okprev >= 2 && t.okprev <= 4)) && Qt > t.Q + 1e-12 * fabs(t.Q)) ||   // (margin: rounding of Q)
+                           // a predicted step may overshoot like any undamped Newton step (measured: a strict test
+                           // rejects 20 % of them and costs more than the predictor gains); only a gross increase
+                           // of Q -- an extrapolation gone wrong on a coarse alpha mesh -- rejects it
+                           (t.okprev == 5 && Qt > 4.0 * fabs(t.Q) + 1.0)) {
                     ++t.nevals;
                     if (finite && t.bt < 3) {
                         // a shortened / damped / halved step that made Q worse: halve it (step 1)
@@ -670,6 +695,8 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     // the decoupled directions add the relative error theta of the Newton matrix
                     const double relH_next = (p.stop_estimate && t.mu == 0.0 && t.okprev == 1) ? (expm1(sdu) + p.theta + MC_GRAM_ERR) * relH : relH;
                     vv[q * NP + k] -= dlc[q * NP + k];
+                    if (t.niter == 0) t.capp = (t.okprev == 5) ? 2 : (t.okprev == 1 && t.mu == 0.0) ? 1 : 0;
+                    else eacc[q * NP + k] -= dlc[q * NP + k];     // what the later iterations add to the first iterate
                     t.chi2 = chi2t; t.S = St; t.Hn2 = sHn; t.wmax = swm;
                     t.Qprev = t.Q; t.Q = Qt; t.mu = 0.0;
                     ++t.niter;
@@ -692,8 +719,20 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         p.out_niter[prob] = t.niter; p.out_conv[prob] = conv;
                         p.out_nevals[prob] = t.nevals; p.out_nact[prob] = t.nact;
                     }
+                    {
+                        // defect of this alpha's first Newton iterate -> predictor of the next alpha, scaled
+                        // with the square of the ratio of the steps in log alpha
+                        double e = 0.0;
+                        if (conv && t.capp > 0 && t.ia > 0 && t.ia + 1 < t.clen) {
+                            const double a0 = p.alpha[(size_t)t.prob0 + t.ia - 1], a1 = t.alpha, a2 = p.alpha[(size_t)t.prob0 + t.ia + 1];
+                            const double rr = log(a2 / a1) / log(a1 / a0);
+                            e = ((t.capp == 2 ? ecor[q * NP + k] : 0.0) + eacc[q * NP + k]) * rr * rr;
+                            if (!(fabs(e) < 1e300)) e = 0.0;
+                        }
+                        ecor[q * NP + k] = e; eacc[q * NP + k] = 0.0;
+                    }
                     ++t.ia;
-                    t.niter = 0; t.nevals = 0; t.mu = 0.0; t.bt = 0;
+                    t.niter = 0; t.nevals = 0; t.mu = 0.0; t.bt = 0; t.capp = 0;
                     t.Qprev = __builtin_nan("");
                     if (t.ia >= t.clen) {
                         t.active = 0;
