@@ -725,7 +725,8 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         double e = 0.0;
                         if (conv && t.capp > 0 && t.ia > 0 && t.ia + 1 < t.clen) {
                             const double a0 = p.alpha[(size_t)t.prob0 + t.ia - 1], a1 = t.alpha, a2 = p.alpha[(size_t)t.prob0 + t.ia + 1];
-                            const double rr = log(a2 / a1) / log(a1 / a0);
+                            const double q0 = a1 / a0, q1 = a2 / a1;       // a logarithmic mesh: equal ratios, no log
+                            const double rr = (fabs(q1 - q0) < 1e-9 * q0) ? 1.0 : log(q1) / log(q0);
                             e = ((t.capp == 2 ? ecor[q * NP + k] : 0.0) + eacc[q * NP + k]) * rr * rr;
                             if (!(fabs(e) < 1e300)) e = 0.0;
                         }
