@@ -90,7 +90,7 @@ typedef struct mxe_opts {
                                 one data set per workgroup in lock-step (shared V loads)   */
     int32_t alpha_split;     /* cut every alpha scan into this many cold-started pieces
                                 (more chains to fill the GPU; results are path independent);
-                                0 = auto (about 3.5 pieces per chain slot of the GPU, at
+                                0 = auto (about 2.5 pieces per chain slot of the GPU, at
                                 most 16, none shorter than 6 alphas), 1 = never             */
     int32_t stop_estimate;   /* 1 (default): after a full (undamped) Newton step the next
                                 correction is estimated as (expm1(max|du|) + decouple_tol) * ||dH||/||H||

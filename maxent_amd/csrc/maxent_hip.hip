@@ -468,14 +468,15 @@ try {
     //      from the same v0 (the minimiser of each alpha does not depend on the path)
     int split = o.alpha_split;
     if (split <= 0) {
-        // about 3.5 pieces per chain slot of the GPU (CUs x 4 slots) so that the persistent
-        // grid balances (measured on cfg4: 8 pieces per scan 3.88 ms, 12: 3.59, 14: 3.37,
-        // 16: 3.43, 20: 3.60), none shorter than 6 alphas (a cold start costs about as much as
-        // 2 alphas: 0.025 Newton iterations per alpha and piece)
+        // about 2.5 pieces per chain slot of the GPU (CUs x 4 slots) so that the persistent grid
+        // balances (pieces have unequal costs and are handed out most expensive first; measured on
+        // cfg4 with the alpha-path predictor: 7 pieces per scan 2.07 ms, 8: 2.21, 9: 2.08, 10: 1.98,
+        // 11: 2.06, 12: 2.13, 14: 2.04, 16: 2.14), none shorter than 6 alphas (a cold start costs
+        // about as much as 3 warm alphas)
         hipDeviceProp_t prop;
         HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
         const int n_slots = 4 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
-        const int want = (7 * n_slots / 2 + n_chain - 1) / n_chain;
+        const int want = (5 * n_slots / 2 + n_chain - 1) / n_chain;
         split = std::max(1, std::min(std::min(want, 16), n_alpha / 6));
     }
     if (split > n_alpha) split = n_alpha;

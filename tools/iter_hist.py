@@ -8,7 +8,7 @@ batch = bench.build_batch(16, 200, 500, 100, 0)
 ctx = bench.stage(batch, 0)
 out = ctx.solve_chains(np.arange(256, dtype=np.int32), batch['alphas'], batch['v0'])
 it = out['n_iter']
-split = 14
+split = 10
 starts = [int(100 * s / split) for s in range(split)] + [100]
 pos = np.zeros(100, dtype=int)
 for a, b in zip(starts[:-1], starts[1:]):

@@ -11,7 +11,7 @@ ctx = bench.stage(batch, 0)
 K = batch['K']
 out = ctx.solve_chains(np.arange(256, dtype=np.int32), batch['alphas'], batch['v0'])
 print('iters/solve %.3f, max iters %d, converged %d' % (out['n_iter'].mean(), out['n_iter'].max(), out['converged'].sum()))
-split = 14
+split = 10
 firsts = sorted(set(int(100 * s / split) for s in range(split)))
 worst = 0.0
 for c in (0, 1, 17, 100, 255):

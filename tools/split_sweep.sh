@@ -1,5 +1,5 @@
 # kernel time of the cfg4 batch against alpha_split (pieces per alpha scan)
-for s in 0 12 14 16 0 15 16; do
+for s in 5 6 9 10 11 18 10; do
   timeout -k 10 100 python bench.py --no-cpu-baseline --steps 30 --alpha-split $s 2>/dev/null > /tmp/ss.json
   python -c "
 import json
