@@ -478,6 +478,13 @@ try {
         const int n_slots = 4 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
         const int want = (5 * n_slots / 2 + n_chain - 1) / n_chain;
         split = std::max(1, std::min(std::min(want, 16), n_alpha / 6));
+        // a small batch that cannot fill the lock-step layout (>= 768 pieces) with pieces of six alphas,
+        // but can with shorter ones, takes those: the lock-step kernel serves four pieces with the loads
+        // and the time the one-chain kernel spends on one (cfg3, 16 scans: 1.9 ms with 256 pieces in the
+        // one-chain layout, 0.7 ms with 768 pieces of two alphas in the lock-step layout)
+        if ((long long)n_chain * split < 768 && n_alpha >= 4 && (long long)n_chain * (n_alpha / 2) >= 768 &&
+            NP == 64 && o.chains_per_wg != 1 && o.tol_d <= 0.0 && o.decouple_tol > 0.0 && o.precision == MXE_PRECISION_F64)
+            split = (768 + n_chain - 1) / n_chain;
     }
     if (split > n_alpha) split = n_alpha;
     ctx->sub_elem.clear(); ctx->sub_prob0.clear(); ctx->sub_len.clear(); ctx->sub_v0.clear();
