@@ -32,6 +32,20 @@ from .probabilities import NormalLogProbability
 #  device batch
 # --------------------------------------------------------------------------
 
+class _LazyProduct(object):
+    """``A @ K_delta.T`` (MaxEntResult.G_rec, reference maxent_result.py:908) evaluated on first use:
+    a 10 MFLOP product per matrix element that most jobs never look at."""
+
+    def __init__(self, A, K_delta):
+        self._A, self._K, self._val = A, K_delta, None
+
+    def __array__(self, dtype=None, copy=None):
+        if self._val is None:
+            self._val = np.dot(self._A, self._K.T)
+            self._A = self._K = None
+        return self._val if dtype is None else self._val.astype(dtype, copy=False)
+
+
 def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0,
                    want_logdet=False):
     """Solve the alpha scans of several elements in ONE kernel launch.
@@ -186,6 +200,8 @@ class MaxEntLoop(object):
                 self.scale_alpha))
         return float(self.scale_alpha)
 
+    _v0_cache = {}
+
     def below_threshold(self):
         return np.max(np.abs(self.G)) < self.G_threshold
 
@@ -195,7 +211,16 @@ class MaxEntLoop(object):
         self.K.reduce_singular_space(self.reduce_singular_space)
         start = (self.D.D if self.A_init is None else
                  np.asarray(self.A_init)) * self.omega.delta
-        v0 = self.H_of_v.inv(np.array(start, dtype=float))
+        start = np.array(start, dtype=float)
+        # the start vector depends on (V, D, start image, entropy kind) only: the element-wise drivers ask
+        # for it once per matrix element with the same arguments
+        key = (id(self.K.V), self.H_of_v.kind, start.tobytes(), np.asarray(self.D.D, dtype=float).tobytes())
+        cache = MaxEntLoop._v0_cache
+        if cache.get('key') != key:
+            cache['key'] = key
+            cache['K_V'] = self.K.V          # keeps id() valid
+            cache['v0'] = self.H_of_v.inv(start)
+        v0 = cache['v0'].copy()
         scale = self._alpha_scale()
         K = self.K
         return dict(G=np.array(self.G, dtype=float),
@@ -221,7 +246,7 @@ class MaxEntLoop(object):
         rec['G'] = spec['G']
         rec['G_orig'] = spec['G_orig']
         rec['data_variable'] = spec['data_variable']
-        rec['G_rec'] = np.dot(A, self.K.K_delta.T)
+        rec['G_rec'] = _LazyProduct(A, self.K.K_delta)      # K_delta A, formed when it is looked at
         rec['omega'] = self.omega
         X = len(sol['alpha'])
         if self.probability is not None and sol.get('logdet') is not None:
