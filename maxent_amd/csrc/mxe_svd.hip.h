@@ -27,7 +27,10 @@ namespace mxe {
 constexpr int SVD_T = 1024;          // threads of the decomposition workgroup
 constexpr int SVD_NWAVE = SVD_T / 64;
 constexpr int SVD_RCAP = 128;        // most rows of R kept (= the solver's n_s limit)
-constexpr int SVD_MAX_SWEEPS = 40;
+#ifndef MXE_X_SVD_SWEEPS
+#define MXE_X_SVD_SWEEPS 40
+#endif
+constexpr int SVD_MAX_SWEEPS = MXE_X_SVD_SWEEPS;
 
 // K^T[j][i] = K(tau_i, omega_j)  (column-major K: one column = one contiguous run of n_tau values)
 __global__ __launch_bounds__(256)
@@ -232,20 +235,41 @@ void svd_kernel(const SvdParams p)
             for (int i = k + lane; i < m; i += 64) A[(size_t)k * m + i] = (i == k) ? alpha : 0.0;
         }
         __syncthreads();
-        // apply H_k = I - 2 v v^T to the columns j > k, one wavefront per column; new remaining norms
-        for (int j = k + 1 + wave; j < n; j += SVD_NWAVE) {
-            double* col = A + (size_t)j * m;
-            double s = 0.0;
-            for (int i = k + lane; i < m; i += 64) s = fma(vk[i], col[i], s);
-            s = 2.0 * svd_wave_sum(s);
-            double rem = 0.0;
-            for (int i = k + lane; i < m; i += 64) {
-                const double x = fma(-s, vk[i], col[i]);
-                col[i] = x;
-                if (i > k) rem = fma(x, x, rem);
+        // apply H_k = I - 2 v v^T to the columns j > k, one wavefront per column, four columns in
+        // flight per wavefront (the loads of a column come from L2: latency, not bandwidth);
+        // new remaining norms
+        for (int j0 = k + 1 + wave; j0 < n; j0 += 4 * SVD_NWAVE) {
+            constexpr int MR = 16;                       // rows per lane held in registers: m <= 64 * MR
+            double s[4], rem[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s[q] = 0.0;
+                const int j = min(j0 + q * SVD_NWAVE, n - 1);
+                const double* col = A + (size_t)j * m;
+                for (int i = k + lane; i < m; i += 64) s[q] = fma(vk[i], col[i], s[q]);
             }
-            rem = svd_wave_sum(rem);
-            if (lane == 0) cn2[j] = rem;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[q] = 2.0 * svd_wave_sum(s[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                rem[q] = 0.0;
+                const int j = j0 + q * SVD_NWAVE;
+                if (j < n) {
+                    double* col = A + (size_t)j * m;
+                    for (int i = k + lane; i < m; i += 64) {
+                        const double x = fma(-s[q], vk[i], col[i]);
+                        col[i] = x;
+                        if (i > k) rem[q] = fma(x, x, rem[q]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                rem[q] = svd_wave_sum(rem[q]);
+                const int j = j0 + q * SVD_NWAVE;
+                if (lane == 0 && j < n) cn2[j] = rem[q];
+            }
+            (void)MR;
         }
         __syncthreads();
         r = k + 1;
