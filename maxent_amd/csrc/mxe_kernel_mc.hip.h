@@ -103,6 +103,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         double alpha, mu, chi2, S, Hn2, wmax, Q, Qprev, cperp, steplim;
         int elem, prob0, clen, ia, niter, nevals, nact, active, scratch, okprev, bt, capp;
     };
+    // the alphas of a slot's piece (a dependent global load in the accept step costs its full latency)
+    constexpr int ACAP = 128;
+    __shared__ double s_alpha[MCC][ACAP];
     __shared__ double s_sd[MCC][10];
     __shared__ int s_si[MCC][12];
     auto load_slot = [&](Slot& t) {
@@ -129,6 +132,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         t.steplim = p.step_max * p.sumD[t.elem];
         t.prob0 = p.chain_prob0[c]; t.clen = p.chain_len[c];
         t.ia = 0; t.niter = 0; t.nevals = 0; t.nact = 0; t.okprev = 0; t.bt = 0; t.capp = 0;
+        for (int i = lane; i < min(t.clen, ACAP); i += 64) s_alpha[wave][i] = p.alpha[(size_t)t.prob0 + i];
         t.alpha = p.alpha[(size_t)t.prob0];
         t.mu = 0.0; t.Qprev = __builtin_nan("");
         t.chi2 = 0.0; t.S = 0.0; t.Hn2 = 1.0; t.wmax = 1.0; t.Q = 0.0;
@@ -137,6 +141,10 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         vv[wave * NP + lane] = p.v0[(size_t)p.chain_v0[c] * NP + lane];
         ecor[wave * NP + lane] = 0.0; eacc[wave * NP + lane] = 0.0;
         if (lane == 0) { s_elem[wave] = t.elem; s_kind[wave] = p.elem_kind[t.elem]; }
+    };
+
+    auto alpha_at = [&](const Slot& t, int i) -> double {
+        return (t.clen <= ACAP) ? s_alpha[wave][i] : p.alpha[(size_t)t.prob0 + i];
     };
 
     // ---- first pieces ----
@@ -724,7 +732,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         // with the square of the ratio of the steps in log alpha
                         double e = 0.0;
                         if (conv && t.capp > 0 && t.ia > 0 && t.ia + 1 < t.clen) {
-                            const double a0 = p.alpha[(size_t)t.prob0 + t.ia - 1], a1 = t.alpha, a2 = p.alpha[(size_t)t.prob0 + t.ia + 1];
+                            const double a0 = alpha_at(t, t.ia - 1), a1 = t.alpha, a2 = alpha_at(t, t.ia + 1);
                             const double q0 = a1 / a0, q1 = a2 / a1;       // a logarithmic mesh: equal ratios, no log
                             const double rr = (fabs(q1 - q0) < 1e-9 * q0) ? 1.0 : log(q1) / log(q0);
                             e = ((t.capp == 2 ? ecor[q * NP + k] : 0.0) + eacc[q * NP + k]) * rr * rr;
@@ -744,7 +752,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                             if (idx < x.n_queue) start_piece(t, x.queue[idx]);
                         }
                     } else {
-                        t.alpha = p.alpha[(size_t)t.prob0 + t.ia];
+                        t.alpha = alpha_at(t, t.ia);
                         t.Q = 0.5 * t.chi2 - t.alpha * t.S;
                     }
                 }
