@@ -1039,6 +1039,9 @@ void chain_kernel(const KParams p)
                         // a predicted step may overshoot like any undamped Newton step; only a gross
                         // increase of Q (an extrapolation gone wrong on a coarse alpha mesh) rejects it
                         else if (predicted && Qt > 4.0 * fabs(Q) + 1.0) good = false;
+                        // a full Newton step may overshoot (a cold start does, and recovers quadratically); one
+                        // that multiplies Q by a million (alpha meshes with steps of a decade) does not come back
+                        else if (Qt > 1e6 * (fabs(Q) + 1.0)) good = false;
                     }
                 }
                 if (good) { accepted = true; break; }
@@ -1072,8 +1075,10 @@ void chain_kernel(const KParams p)
             double rr2 = 0.0;
             if (conv && capp > 0 && ia > 0 && ia + 1 < clen) {
                 const double a0 = p.alpha[(size_t)prob0 + ia - 1], a2 = p.alpha[(size_t)prob0 + ia + 1];
-                const double rr = log(a2 / alpha) / log(alpha / a0);
-                rr2 = rr * rr;
+                const double q0 = alpha / a0, q1 = a2 / alpha;
+                const double rr = log(q1) / log(q0);
+                // the extrapolation is an expansion in the step of log alpha: fine meshes only
+                if (q0 > 0.74 && q0 < 1.35 && q1 > 0.74 && q1 < 1.35) rr2 = rr * rr;
             }
             for (int k = tid; k < NP; k += T) {
                 double e = ((capp == 2 ? ecor[k] : 0.0) + eacc[k]) * rr2;

@@ -682,7 +682,11 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                            // a predicted step may overshoot like any undamped Newton step (measured: a strict test
                            // rejects 20 % of them and costs more than the predictor gains); only a gross increase
                            // of Q -- an extrapolation gone wrong on a coarse alpha mesh -- rejects it
-                           (t.okprev == 5 && Qt > 4.0 * fabs(t.Q) + 1.0)) {
+                           (t.okprev == 5 && Qt > 4.0 * fabs(t.Q) + 1.0) ||
+                           // a full Newton step may overshoot (a cold start does, by factors of hundreds in Q, and
+                           // recovers quadratically); one that multiplies Q by a million (alpha meshes with steps of
+                           // a decade) does not come back
+                           (t.okprev == 1 && Qt > 1e6 * (fabs(t.Q) + 1.0))) {
                     ++t.nevals;
                     if (finite && t.bt < 3) {
                         // a shortened / damped / halved step that made Q worse: halve it (step 1)
@@ -735,6 +739,10 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                             const double a0 = alpha_at(t, t.ia - 1), a1 = t.alpha, a2 = alpha_at(t, t.ia + 1);
                             const double q0 = a1 / a0, q1 = a2 / a1;       // a logarithmic mesh: equal ratios, no log
                             const double rr = (fabs(q1 - q0) < 1e-9 * q0) ? 1.0 : log(q1) / log(q0);
+                            // the extrapolation is an expansion in the step h of log alpha: fine meshes only
+                            // (|h| <= MC_PRED_HMAX, i.e. alpha ratios between 0.74 and 1.35)
+                            const bool fine = q0 > 0.74 && q0 < 1.35 && q1 > 0.74 && q1 < 1.35;
+                            if (fine)
                             e = ((t.capp == 2 ? ecor[q * NP + k] : 0.0) + eacc[q * NP + k]) * rr * rr;
                             if (!(fabs(e) < 1e300)) e = 0.0;
                         }

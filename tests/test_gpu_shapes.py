@@ -1,0 +1,56 @@
+"""Odd problem shapes through both kernel layouts: n_omega not a multiple of 16 / 64 / 128, few and
+many singular values, short alpha scans, mixed entropies, pieces of one or two alphas.  The two
+layouts must agree with each other and with the extended-precision fixed point."""
+import numpy as np
+import pytest
+
+from maxent_amd import device, synthetic, hostprep
+from oracle import hp_truth
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    return np.linalg.norm(a - b, axis=-1) / np.linalg.norm(b, axis=-1)
+
+
+@pytest.mark.parametrize('n_orb,n_tau,n_omega,n_alpha,split', [
+    (2, 50, 64, 7, 0),
+    (3, 60, 100, 12, 3),
+    (2, 120, 130, 30, 0),
+    (3, 80, 257, 9, 9),          # one alpha per piece
+    (2, 200, 640, 16, 4),
+    (4, 40, 33, 5, 0),
+])
+def test_layouts_agree_on_odd_shapes(n_orb, n_tau, n_omega, n_alpha, split):
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(n_orb, n_tau, n_omega)
+    K.reduce_singular_space(1e-14)
+    assert len(K.S) <= 64
+    D = synthetic.flat_D(omega)
+    err = synthetic.SIGMA * np.ones(n_tau)
+    alphas = np.array(synthetic.alpha_mesh(n_alpha)) * n_tau
+    elems = [(i, j) for i in range(n_orb) for j in range(n_orb)]
+    kinds = [device.ENTROPY_NORMAL if i == j else device.ENTROPY_PLUSMINUS for i, j in elems]
+    v0 = np.stack([hostprep.initial_v(K.V, D, omega.delta, k) for k in kinds])
+    ctx = device.DeviceContext(K.U, K.S, K.V)
+    ds = ctx.add_dataset(err)
+    n = len(elems)
+    ctx.set_elements([ds] * n, [Gmat[i, j] for i, j in elems], np.tile(D, (n, 1)), kinds)
+    a = ctx.solve_chains(np.arange(n), alphas, v0, device.default_opts(chains_per_wg=1, alpha_split=max(split, 1)))
+    assert ctx.last_launch_info()['kernel'].startswith('mxe::chain_kernel<')
+    b = ctx.solve_chains(np.arange(n), alphas, v0, device.default_opts(chains_per_wg=4, alpha_split=split))
+    assert ctx.last_launch_info()['kernel'].startswith('mxe::chain_kernel_mc<')
+    for o in (a, b):
+        assert o['converged'].all()
+        assert np.all(np.isfinite(o['H']))
+    assert rel_l2(b['H'], a['H']).max() < 1e-7
+    np.testing.assert_allclose(b['chi2'], a['chi2'], rtol=1e-6)
+    np.testing.assert_allclose(b['S'], a['S'], rtol=1e-6, atol=1e-10)
+    # the fixed point itself, at the two ends of one diagonal and one off-diagonal scan
+    for c in (0, 1):
+        i, j = elems[c]
+        ent = 'normal' if kinds[c] == device.ENTROPY_NORMAL else 'plusminus'
+        for ia in (0, n_alpha - 1):
+            _, Ht = hp_truth.polish(np.array(K.K), Gmat[i, j], err, D, K.V, K.S, alphas[ia], b['v'][c, ia], ent, iters=4)
+            assert np.linalg.norm(b['H'][c, ia] - Ht) / np.linalg.norm(Ht) < 1e-6
+    ctx.close()
