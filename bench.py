@@ -88,6 +88,11 @@ def cpu_baseline(batch, out_gpu, n_chains=2):
     Also reports how far the GPU result is from it and from the
     extended-precision truth on that sample."""
     from oracle import ref_numpy as R, hp_truth
+    try:                                  # really one core: no BLAS worker threads for the 56 x 500 products
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
     K = batch['K']
     n_alpha = len(batch['alphas'])
     n_tau = len(batch['tau'])
@@ -122,6 +127,49 @@ def cpu_baseline(batch, out_gpu, n_chains=2):
                 gpu_vs_extended_precision_truth_max_rel_l2=err_truth)
 
 
+def _pool_worker(c):
+    """one alpha scan of element c with the oracle port (forked worker: inherits _POOL_BATCH)"""
+    try:                                  # one BLAS thread per worker (the pool is the parallelism)
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
+    from oracle import ref_numpy as R
+    batch = _POOL_BATCH
+    K = batch['K']
+    i, j = batch['elems'][c]
+    ent = 'normal' if batch['kinds'][c] == device.ENTROPY_NORMAL else 'plusminus'
+    p = R.Problem(np.array(K.K), K.U, K.S, K.V, batch['Gmat'][i, j], batch['err'], batch['D'], entropy=ent)
+    timing = []
+    R.alpha_loop(p, batch['omega'].delta, batch['alphas'] / len(batch['tau']), timing=timing)
+    return timing[0]
+
+
+_POOL_BATCH = None
+
+
+def cpu_pool_baseline(batch):
+    """the same oracle port on all host cores, one process per core, one matrix element
+    (100 alpha) per process.  Runs BEFORE this process touches the GPU (workers are forked)."""
+    global _POOL_BATCH
+    import multiprocessing as mp
+    n = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 16,
+                   len(batch['elems'])))
+    _POOL_BATCH = batch
+    try:
+        ctx = mp.get_context('fork')
+        t0 = time.perf_counter()
+        with ctx.Pool(processes=n) as pool:
+            pool.map(_pool_worker, list(range(n)))
+        wall = time.perf_counter() - t0
+    except Exception as exc:              # a baseline must not break the bench
+        return dict(error=repr(exc))
+    finally:
+        _POOL_BATCH = None
+    return dict(value=n * len(batch['alphas']) / wall, cores=n,
+                sample='%d matrix elements x %d alpha, one process each, %.1f s wall' % (n, len(batch['alphas']), wall))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -149,6 +197,11 @@ def main():
                   % (args.gpus, world, args.gpus), file=sys.stderr)
         if args.gpus > 1:
             sys.exit(2)
+
+    pool_baseline = None
+    if world == 1 and not args.force_dist and not args.no_cpu_baseline:
+        # host cores first, before anything initialises the GPU in this process (forked workers)
+        pool_baseline = cpu_pool_baseline(build_batch(args.n_orb, args.n_tau, args.n_omega, args.n_alpha, rank))
 
     dist = None
     use_dist = world > 1 or args.force_dist
@@ -326,6 +379,7 @@ def main():
                 roofline=roofline)
     if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(batch, out)
+        line['cpu_baseline']['all_cores'] = pool_baseline
     else:
         line['cpu_baseline'] = None
     if use_dist:
