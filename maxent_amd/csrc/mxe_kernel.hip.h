@@ -925,6 +925,7 @@ void chain_kernel(const KParams p)
         double Q = 0.5 * chi2 - alpha * S;
         bool failed = false;
         double relH_prev = 1e300;
+        double mu_hint = 0.0;       // damping the last damped step of this alpha needed
 
         for (int it = 0; it < p.maxiter && !failed; ++it) {
             for (int k = tid; k < NP; k += T) {
@@ -1045,7 +1046,7 @@ void chain_kernel(const KParams p)
                     }
                 }
                 if (good) { accepted = true; break; }
-                mu = (mu == 0.0) ? p.mu_first * alpha : mu * p.mu_grow;
+                mu = (mu == 0.0) ? fmax(p.mu_first * alpha, mu_hint / p.mu_grow) : mu * p.mu_grow;
                 if (!(mu <= p.mu_max * alpha)) break;
             }
             if (!accepted) { failed = true; break; }
@@ -1058,6 +1059,7 @@ void chain_kernel(const KParams p)
             MXE_STAMP(5);
             chi2 = chi2t; S = St; Hn2 = Hn2t; wmax = wmaxt;
             Qprev = Q;
+            mu_hint = mu;
             Q = 0.5 * chi2 - alpha * S;
             ++n_iter;
             if (p.tol_h > 0.0 && fmin(relH, relH_next) < p.tol_h && n_iter > p.miniter) { conv = 1; break; }

@@ -100,18 +100,18 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     //      start of its two sections of a round and stores it back at their end, so
     //      that no register is pinned by it during the two streaming passes. ----
     struct Slot {
-        double alpha, mu, chi2, S, Hn2, wmax, Q, Qprev, cperp, steplim;
+        double alpha, mu, chi2, S, Hn2, wmax, Q, Qprev, cperp, steplim, muh;    // muh: damping the last damped step of this piece needed
         int elem, prob0, clen, ia, niter, nevals, nact, active, scratch, okprev, bt, capp;
     };
     // the alphas of a slot's piece (a dependent global load in the accept step costs its full latency)
     constexpr int ACAP = 128;
     __shared__ double s_alpha[MCC][ACAP];
-    __shared__ double s_sd[MCC][10];
+    __shared__ double s_sd[MCC][12];
     __shared__ int s_si[MCC][12];
     auto load_slot = [&](Slot& t) {
         const double* d = s_sd[wave]; const int* n = s_si[wave];
         t.alpha = d[0]; t.mu = d[1]; t.chi2 = d[2]; t.S = d[3]; t.Hn2 = d[4]; t.wmax = d[5];
-        t.Q = d[6]; t.Qprev = d[7]; t.cperp = d[8]; t.steplim = d[9];
+        t.Q = d[6]; t.Qprev = d[7]; t.cperp = d[8]; t.steplim = d[9]; t.muh = d[10];
         t.elem = n[0]; t.prob0 = n[1]; t.clen = n[2]; t.ia = n[3]; t.niter = n[4]; t.nevals = n[5];
         t.nact = n[6]; t.active = n[7]; t.scratch = n[8]; t.okprev = n[9]; t.bt = n[10]; t.capp = n[11];
     };
@@ -119,7 +119,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         if (lane == 0) {
             double* d = s_sd[wave]; int* n = s_si[wave];
             d[0] = t.alpha; d[1] = t.mu; d[2] = t.chi2; d[3] = t.S; d[4] = t.Hn2; d[5] = t.wmax;
-            d[6] = t.Q; d[7] = t.Qprev; d[8] = t.cperp; d[9] = t.steplim;
+            d[6] = t.Q; d[7] = t.Qprev; d[8] = t.cperp; d[9] = t.steplim; d[10] = t.muh;
             n[0] = t.elem; n[1] = t.prob0; n[2] = t.clen; n[3] = t.ia; n[4] = t.niter; n[5] = t.nevals;
             n[6] = t.nact; n[7] = t.active; n[8] = t.scratch; n[9] = t.okprev; n[10] = t.bt; n[11] = t.capp;
             s_act[wave] = t.active; s_scr[wave] = t.scratch;
@@ -134,7 +134,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         t.ia = 0; t.niter = 0; t.nevals = 0; t.nact = 0; t.okprev = 0; t.bt = 0; t.capp = 0;
         for (int i = lane; i < min(t.clen, ACAP); i += 64) s_alpha[wave][i] = p.alpha[(size_t)t.prob0 + i];
         t.alpha = p.alpha[(size_t)t.prob0];
-        t.mu = 0.0; t.Qprev = __builtin_nan("");
+        t.mu = 0.0; t.muh = 0.0; t.Qprev = __builtin_nan("");
         t.chi2 = 0.0; t.S = 0.0; t.Hn2 = 1.0; t.wmax = 1.0; t.Q = 0.0;
         t.active = 1; t.scratch = 1;
         gh[wave * NP + lane] = p.ghat[(size_t)t.elem * NP + lane];
@@ -162,7 +162,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         if (c >= 0) start_piece(t, c);
         else {
             // empty slot: evaluates v = 0 of a neighbour's element every round (finite, never used)
-            t = Slot{1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0};
+            t = Slot{1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0};
             gh[wave * NP + lane] = 0.0; vv[wave * NP + lane] = 0.0;
             if (lane == 0) { s_elem[wave] = -1; s_kind[wave] = 0; }
         }
@@ -688,13 +688,16 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                            // a decade) does not come back
                            (t.okprev == 1 && Qt > 1e6 * (fabs(t.Q) + 1.0))) {
                     ++t.nevals;
-                    if (finite && t.bt < 3) {
+                    if (finite && t.bt < 3 && !(t.mu == 0.0 && t.muh > 0.0)) {
                         // a shortened / damped / halved step that made Q worse: halve it (step 1)
                         ++t.bt;
                         t.okprev = 3;
                     } else {
-                        // not finite, or still worse after three halvings: more damping, restore from v
-                        t.mu = (t.mu == 0.0) ? p.mu_first * t.alpha : t.mu * p.mu_grow;
+                        // not finite, or still worse after three halvings: more damping, restore from v.  Where
+                        // an earlier iteration of this piece needed damping, the search starts one notch below
+                        // that level instead of climbing from mu_first again (alphas far below the physical range
+                        // need it at every iteration)
+                        t.mu = (t.mu == 0.0) ? fmax(p.mu_first * t.alpha, t.muh / p.mu_grow) : t.mu * p.mu_grow;
                         t.scratch = 1; t.bt = 0;
                         if (!(t.mu <= p.mu_max * t.alpha)) finish_alpha = true;
                     }
@@ -710,7 +713,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     if (t.niter == 0) t.capp = (t.okprev == 5) ? 2 : (t.okprev == 1 && t.mu == 0.0) ? 1 : 0;
                     else eacc[q * NP + k] -= dlc[q * NP + k];     // what the later iterations add to the first iterate
                     t.chi2 = chi2t; t.S = St; t.Hn2 = sHn; t.wmax = swm;
-                    t.Qprev = t.Q; t.Q = Qt; t.mu = 0.0;
+                    t.Qprev = t.Q; t.Q = Qt; t.muh = t.mu; t.mu = 0.0;
                     ++t.niter;
                     const bool newton_step = t.okprev != 4;       // a halved step says nothing about convergence
                     t.bt = 0;
