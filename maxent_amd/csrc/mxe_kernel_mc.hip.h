@@ -48,11 +48,6 @@ struct MCExtra {
 // with 2e-5 the worst sampled alpha-solves end 1.3e-9 from the fixed point (2.3e-10 with binary64 tiles;
 // tol_h = 1e-9) -- the same solves either way -- and 2e-5 costs 2 % more iterations, so none is made.
 constexpr double MC_GRAM_ERR = 0.0;
-#ifndef MXE_MC_PREFETCH_CHUNKS
-#define MXE_MC_PREFETCH_CHUNKS 0    // experiment: chunks (of 4 singular directions x 8 tiles) of V^T requested before the
-                                    // home phase and held in registers across it.  Measured: 8 chunks take 2.0 k cycles off
-                                    // the row pass and add 3.8 k to the home phase (register parking, load issue); 4: -1.2 k / +1.6 k
-#endif
 constexpr int MC_LOOKAHEAD_ROWS = 512;
 constexpr int MC_LOOKAHEAD_LDS = (8 * 4 + 4) * 4 * 4 + 64;       // doubles
 template <int NA, int NWV>
@@ -288,18 +283,6 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         // (a slot that finishes its piece takes the next one from the queue right away, in step 4)
         if (!(s_act[0] | s_act[1] | s_act[2] | s_act[3])) break;      // uniform: LDS flags behind a barrier
 
-        // ---- V^T of the first chunks of this wave's row pass, requested now and consumed after the
-        //      home phase (off by default, see MXE_MC_PREFETCH_CHUNKS) ----
-        constexpr int PRE = (NWV == 4) ? MXE_MC_PREFETCH_CHUNKS : 0;
-        double pre[PRE > 0 ? PRE : 1][8];
-        if (PRE > 0) {
-            const double* ap0 = Vt + (size_t)(lane >> 4) * nwp + 16 * wave + (lane & 15);
-#pragma unroll
-            for (int c = 0; c < PRE; ++c)
-#pragma unroll
-                for (int tt = 0; tt < 8; ++tt) pre[c][tt] = ap0[(size_t)(4 * c) * nwp + 16 * NWV * tt];
-        }
-
         // ---- 1. home wave: right-hand side, active block, factorise, solve, step ----
         if (wave < MCC) {
             const int q = wave, k = lane;
@@ -410,49 +393,45 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             const bool pm_j = s_kind[j] != 0;
             const double* Dj = p.D + (size_t)((s_elem[j] >= 0) ? s_elem[j] : any_elem) * nwp;
             double pS = 0.0, pdH = 0.0, pHn = 0.0, pwm = 0.0, pdu = 0.0;
-            const int ntiles = nwp >> 4;
+            const int nblk = nwp >> 5;                           // blocks of 32 omega rows = two 16-row tiles
             const int nchunk = (ns + 3) >> 2;                    // chunks of four singular directions
             constexpr int TB = 8;                                // tiles per batch (accumulators)
             constexpr int RD = 4;                                // ring depth in chunks
             constexpr int NCHK = NP / 4;
-            for (int t0 = wave; t0 < ntiles; t0 += NWV * TB) {
-                // tile tt of the batch: t0 + NWV * tt; past the end: tile t0 again, results dropped
+            // The two tiles of a block interleave: tile parity = omega parity, so that a lane's operands of
+            // both come from ONE 16-byte load (V^T[4 kc + ak][32 blk + 2 (lane & 15) .. + 1]).  The loads of
+            // this pass wait for L2 latency with a bounded number in flight (vmcnt): wider loads, not more.
+            for (int b0 = wave; b0 < nblk; b0 += NWV * (TB / 2)) {
+                // tile tt of the batch: block b0 + NWV (tt >> 1), parity tt & 1; past the end: block b0 again,
+                // results dropped
                 double acc[TB], Dv[TB], uo[TB], wo[TB];
+                int rowt[TB];
 #pragma unroll
                 for (int tt = 0; tt < TB; ++tt) {
-                    const int tile = (t0 + NWV * tt < ntiles) ? t0 + NWV * tt : t0;
-                    const int row = 16 * tile + drow;
+                    const int blk = (b0 + NWV * (tt >> 1) < nblk) ? b0 + NWV * (tt >> 1) : b0;
+                    const int row = 32 * blk + 2 * drow + (tt & 1);
+                    rowt[tt] = row;
                     acc[tt] = 0.0;
                     Dv[tt] = Dj[row];
                     uo[tt] = ui[row * MCC + j];
                     wo[tt] = wi[row * MCC + j];
                 }
-                // V^T operand: row 4 kc + ak of V^T, omega = 16 tile + (lane & 15); the tiles of a
-                // batch are 16 NWV rows apart (V^T is padded behind its last row for a partial batch)
-                const double* ap = Vt + (size_t)ak * nwp + 16 * t0 + (lane & 15);
+                // V^T operand: row 4 kc + ak of V^T; the blocks of a batch are 32 NWV rows apart (V^T is
+                // padded behind its last row for a partial batch)
+                const double* ap = Vt + (size_t)ak * nwp + 32 * b0 + 2 * (lane & 15);
                 const double* bp = vecI + ak * MCC + j;
                 double xr[RD][TB];
                 auto loadA = [&](double (&xv)[TB], int kc) {
                     const double* src = ap + (size_t)(4 * kc) * nwp;
 #pragma unroll
-                    for (int tt = 0; tt < TB; ++tt) xv[tt] = src[16 * NWV * tt];
-                };
-                // the first batch of a wave starts with the chunks that were requested before the home phase
-                const int kstart = (PRE > 0 && t0 == wave) ? PRE : 0;
-#pragma unroll
-                for (int r = 0; r < RD - 1; ++r) loadA(xr[r], min(kstart + r, NCHK - 1));
-                if (PRE > 0 && t0 == wave) {
-#pragma unroll
-                    for (int c = 0; c < PRE; ++c) {
-                        const double bv = bp[c * 4 * MCC];
-                        if (c < nchunk) {
-#pragma unroll
-                            for (int tt = 0; tt < TB; ++tt)
-                                acc[tt] = __builtin_amdgcn_mfma_f64_4x4x4f64(pre[c][tt], bv, acc[tt], 0, 0, 0);
-                        }
+                    for (int pp = 0; pp < TB / 2; ++pp) {
+                        const double2 x2 = *reinterpret_cast<const double2*>(src + 32 * NWV * pp);
+                        xv[2 * pp] = x2.x; xv[2 * pp + 1] = x2.y;
                     }
-                }
-                for (int kc = kstart; kc < nchunk; kc += RD) {
+                };
+#pragma unroll
+                for (int r = 0; r < RD - 1; ++r) loadA(xr[r], min(r, NCHK - 1));
+                for (int kc = 0; kc < nchunk; kc += RD) {
 #pragma unroll
                     for (int r = 0; r < RD; ++r) {
                         loadA(xr[(r + RD - 1) % RD], min(kc + r + RD - 1, NCHK - 1));
@@ -467,8 +446,8 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 MXE_STAMPW(0);
 #pragma unroll
                 for (int tt = 0; tt < TB; ++tt) {
-                    if (t0 + NWV * tt < ntiles) {                 // uniform
-                        const int row = 16 * (t0 + NWV * tt) + drow;
+                    if (b0 + NWV * (tt >> 1) < nblk) {            // uniform
+                        const int row = rowt[tt];
                         const double vd = acc[tt];
                         const double uq = scr_j ? vd : uo[tt] - vd;
                         const double tq = scr_j ? 0.0 : wo[tt] * vd;
