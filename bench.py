@@ -340,16 +340,21 @@ def main():
     # more), and SURVEY 8d's nominal figure that prices the kernel's time
     # against the reference's 160/84 passes per alpha-solve.
     achieved = bytes_actual / (k_ms * 1e-3) / 1e9
-    # profiles/r01_f_pmc_hbm_traffic.csv: FETCH_SIZE 8 345 KB (x2, gfx950
-    # correction) + WRITE_SIZE 116 780 KB per launch of the default workload
-    traffic = (2 * 8345.0e3 + 116780.0e3) if (args.n_orb, args.n_tau, args.n_omega, args.n_alpha) == (16, 200, 500, 100) else None
+    # profiles/r01_f_pmc_hbm_traffic.csv: FETCH_SIZE 8 359 KB (x2, gfx950
+    # correction) + WRITE_SIZE 116 655 KB per launch of the default workload
+    traffic = (2 * 8359.0e3 + 116655.0e3) if (args.n_orb, args.n_tau, args.n_omega, args.n_alpha) == (16, 200, 500, 100) else None
     roofline = dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS,
                     unit='GB/s', frac=achieved / HBM_PEAK_GBS,
                     traffic=traffic,
                     kernel=info['kernel'], kernel_ms=k_ms,
                     definition='evaluation passes executed (kernel counter) x '
-                               'B_eval = %d B / kernel time (HIP events); V is '
-                               'L2 resident, see DESIGN.md section 4' % b_eval,
+                               'B_eval = %d B / kernel time (HIP events).  V (224 KB) is '
+                               'L2 resident: the algorithmic rate may exceed the HBM peak '
+                               '(frac > 1), the HBM traffic measured with PMC counters is '
+                               'the `traffic` bytes per launch (`hbm_measured`); the kernel '
+                               'is bound by the matrix / vector pipes, see DESIGN.md '
+                               'section 4' % b_eval,
+                    hbm_measured=(None if traffic is None else traffic / (k_ms * 1e-3) / 1e9),
                     algorithmic_bytes_per_launch=bytes_actual,
                     achieved_incl_gram_passes=bytes_streamed / (k_ms * 1e-3) / 1e9,
                     achieved_survey_nominal_reference_work=bytes_nominal / (k_ms * 1e-3) / 1e9,
