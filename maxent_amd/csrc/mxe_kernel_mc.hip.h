@@ -683,11 +683,21 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 } else {
                     // accepted
                     ++t.nevals;
-                    const double relH = sqrt(sdH / t.Hn2);
+                    // convergence in squares (no division, no square root in this serial section):
+                    // relH^2 = sdH / Hn2 against tol_h^2.
                     // estimate of the NEXT Newton correction after a full step: the weights
                     // change by at most expm1(max|du|) relatively, and so does the Jacobian;
-                    // the decoupled directions add the relative error theta of the Newton matrix
-                    const double relH_next = (p.stop_estimate && t.mu == 0.0 && t.okprev == 1) ? (expm1(sdu) + p.theta + MC_GRAM_ERR) * relH : relH;
+                    // the decoupled directions add the relative error theta of the Newton matrix.
+                    // expm1 by its series up to x^4 for x <= 1 (relative error < 1e-2, an estimate), no
+                    // estimate beyond
+                    double fac2 = 1.0;
+                    if (p.stop_estimate && t.mu == 0.0 && t.okprev == 1 && sdu <= 1.0) {
+                        const double em1 = sdu * fma(sdu, fma(sdu, fma(sdu, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0);
+                        const double fac = em1 + p.theta + MC_GRAM_ERR;
+                        fac2 = fmin(1.0, fac * fac);
+                    }
+                    const double relH2_min = fac2 * sdH;            // min(relH, relH_next)^2 * Hn2
+                    const double tol2Hn = p.tol_h * p.tol_h * t.Hn2;
                     vv[q * NP + k] -= dlc[q * NP + k];
                     if (t.niter == 0) t.capp = (t.okprev == 5) ? 2 : (t.okprev == 1 && t.mu == 0.0) ? 1 : 0;
                     else eacc[q * NP + k] -= dlc[q * NP + k];     // what the later iterations add to the first iterate
@@ -696,7 +706,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     ++t.niter;
                     const bool newton_step = t.okprev != 4;       // a halved step says nothing about convergence
                     t.bt = 0;
-                    if (newton_step && p.tol_h > 0.0 && fmin(relH, relH_next) < p.tol_h && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
+                    if (newton_step && p.tol_h > 0.0 && relH2_min < tol2Hn && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                     else if (p.tol_relq > 0.0 && fabs(fabs(t.Qprev - t.Q) / t.Q) < p.tol_relq && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                     else if (t.niter >= p.maxiter) finish_alpha = true;
                 }
