@@ -193,29 +193,37 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 #endif
 
     // ------------------------------------------------------------------
-    // home wave: register Cholesky of the slot's active block + solve
-    // (see chol_solve_reg in mxe_kernel.hip.h)
+    // home wave: the slot's Newton system  (c W c + a I) z = rhs  on the active block, in registers.
+    // Lane i holds the FULL row i of the symmetric matrix (N doubles, static indices: the j and k
+    // loops are fully unrolled) and its right-hand side.  Gauss-Jordan elimination without pivoting
+    // (the matrix is positive definite): for pivot j every other lane subtracts f = A_ij / A_jj times
+    // row j -- broadcast from lane j with v_readlane, eight entries at a time -- from the columns
+    // k > j of its row and from its right-hand side.  A wave issues the same instructions for the
+    // lanes above the pivot as a Cholesky factorisation does for the lanes below it alone, so the
+    // elimination costs what the factorisation cost, and when it ends z_i = b_i / A_ii: no transposed
+    // factor through LDS, no back substitution (they were 4-5.6 k cycles of the 10-16 k per slot).
+    // The solve only preconditions the (inexact) Newton step; rows >= n_act are identity rows.
     // ------------------------------------------------------------------
     auto chol_home = [&](auto NTag, double a, int n_act) -> bool {
         constexpr int N = decltype(NTag)::value;
         const int q = wave, i = lane;
-        double* Wq = Wm + (size_t)q * NA * LD;
+        const double* Wq = Wm + (size_t)q * NA * LD;
         const double* rq = rhs + q * NP;
         bool ok = true;
         const bool live = i < n_act;
         const double ci_ = live ? cc[i] : 0.0;
         double A[N];
         {
-            // all N loads are issued back to back (clamped lane index, selected afterwards):
-            // a load under a predicate costs one LDS round trip each
+            // W is kept as upper triangle + diagonal: entry (i, j) sits at [min][max].  All N loads are
+            // issued back to back (clamped lane index, selected afterwards)
             const int ic = min(i, N - 1);
             double wr[N];
 #pragma unroll
-            for (int j = 0; j < N; ++j) wr[j] = Wq[j * LD + ic];
+            for (int j = 0; j < N; ++j) wr[j] = Wq[min(j, ic) * LD + max(j, ic)];
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 const double cj = wave_bcast(ci_, j);        // = c_j for j < n_act, else 0
-                double xv = (j <= i) ? ci_ * wr[j] * cj : 0.0;
+                double xv = ci_ * wr[j] * cj;                // 0 in the rows and columns >= n_act
                 if (j == i) xv = live ? xv + a : 1.0;
                 A[j] = xv;
             }
@@ -227,51 +235,27 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         for (int j = 0; j < N; ++j) {
             const double piv = wave_bcast(A[j], j);
             if (!(piv > 0.0)) ok = false;
-            double inv = __builtin_amdgcn_rsq(piv);
-            inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+            double inv = __builtin_amdgcn_rcp(piv);
+            inv = fma(fma(-piv, inv, 1.0), inv, inv);
             if (i == j) dinv_i = inv;
-            const double lij = (i > j) ? A[j] * inv : 0.0;
-            A[j] = lij;
-            const double yj = wave_bcast(b, j) * inv;
-            if (i == j) b = yj;
-            b = fma(-lij, yj, b);
+            const double f = (i != j) ? A[j] * inv : 0.0;    // multiplier of row j for this lane's row
+            b = fma(-f, wave_bcast(b, j), b);
 #pragma unroll
             for (int k0 = j + 1; k0 < N; k0 += 8) {
-                double lk[8];
+                double rk[8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) if (k0 + r < N) lk[r] = wave_bcast(lij, k0 + r);
+                for (int r = 0; r < 8; ++r) if (k0 + r < N) rk[r] = wave_bcast(A[k0 + r], j);     // row j, column k
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < 8; ++r) if (k0 + r < N) A[k0 + r] = fma(-lij, lk[r], A[k0 + r]);
+                for (int r = 0; r < 8; ++r) if (k0 + r < N) A[k0 + r] = fma(-f, rk[r], A[k0 + r]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         MXE_STAMPH(3);
-        if (ok) {
-            // transpose L through the strictly lower triangle of the slot's W (rows >= n_act
-            // of L are unit rows; lanes >= N write nothing), then solve L^T z = y from
-            // registers: lt[j] = L[j][i]
-            if (i < N) {
-#pragma unroll
-                for (int j = 0; j < N - 1; ++j) if (j < i) Wq[i * LD + j] = A[j];
-            }
-            wave_sync();
-            const int ic = min(i, N - 1);
-            double lt[N];
-#pragma unroll
-            for (int j = 1; j < N; ++j) lt[j] = Wq[j * LD + ic];
-            double r = b;
-#pragma unroll
-            for (int j = N - 1; j >= 0; --j) {
-                const double zj = wave_bcast(r * dinv_i, j);
-                if (i == j) r = zj;
-                else if (i < j) r = fma(-lt[j], zj, r);
-            }
-            if (live) zz[q * NP + i] = r;
-        }
+        if (ok && live) zz[q * NP + i] = b * dinv_i;
         MXE_STAMPH(4);
 #ifdef MXE_PROFILE_HOME
-        prof_acc[6] += 1;                        // factorisations (slot 6 is a count in this build)
+        prof_acc[6] += 1;                        // solves (slot 6 is a count in this build)
 #endif
         return ok;
     };
