@@ -827,17 +827,24 @@ void chain_kernel(const KParams p)
         constexpr int N = decltype(NTag)::value;
         bool ok = true;
         if (wave == 0) {
+            // Gauss-Jordan elimination of the full symmetric rows (lane i = row i) instead of a Cholesky
+            // factorisation with a transposed solve: the wave issues the same instructions for the lanes
+            // above the pivot as the factorisation does for the lanes below it, and the solution falls out
+            // of the right-hand-side column (see the lock-step kernel, home phase)
             const int i = lane;
             const bool live = i < n_act;
             const double ci_ = live ? cc[i] : 0.0;
             double A[N];
+            {
+                const int ic = min(i, N - 1);
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                // lower triangle of row i: A_ij = c_i W_ji c_j (j < i), stored as W[j][i]
-                double x = 0.0;
-                if (live && j <= i && j < n_act) x = ci_ * Wm[j * LD + i] * cc[j];
-                if (j == i) x = live ? x + a : 1.0;
-                A[j] = x;
+                for (int j = 0; j < N; ++j) {
+                    // W is kept as upper triangle + diagonal: entry (i, j) sits at [min][max]
+                    double x = 0.0;
+                    if (live && j < n_act) x = ci_ * Wm[min(j, ic) * LD + max(j, ic)] * cc[j];
+                    if (j == i) x = live ? x + a : 1.0;
+                    A[j] = x;
+                }
             }
             double b = live ? rhs[i] : 0.0;
             double dinv_i = 1.0;
@@ -845,45 +852,25 @@ void chain_kernel(const KParams p)
             for (int j = 0; j < N; ++j) {
                 const double piv = wave_bcast(A[j], j);
                 if (!(piv > 0.0)) ok = false;
-                // the factor only preconditions the (inexact) Newton step: the
-                // hardware 1/sqrt estimate plus one Newton-Raphson step is plenty
-                double inv = __builtin_amdgcn_rsq(piv);
-                inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+                double inv = __builtin_amdgcn_rcp(piv);
+                inv = fma(fma(-piv, inv, 1.0), inv, inv);
                 if (i == j) dinv_i = inv;
-                const double lij = (i > j) ? A[j] * inv : 0.0;    // column j of L (rows > j)
-                A[j] = lij;
-                const double yj = wave_bcast(b, j) * inv;          // y_j = (b_j - ...)/L_jj
-                if (i == j) b = yj;
-                b = fma(-lij, yj, b);
-                // trailing update, broadcasts batched eight at a time so that the
-                // v_readlane -> v_fma SGPR hazard slots are filled with work
+                const double f = (i != j) ? A[j] * inv : 0.0;     // multiplier of row j for this lane's row
+                b = fma(-f, wave_bcast(b, j), b);
+                // broadcasts batched eight at a time so that the v_readlane -> v_fma SGPR hazard
+                // slots are filled with work
 #pragma unroll
                 for (int k0 = j + 1; k0 < N; k0 += 8) {
-                    double lk[8];
+                    double rk[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) if (k0 + q < N) lk[q] = wave_bcast(lij, k0 + q);
+                    for (int q = 0; q < 8; ++q) if (k0 + q < N) rk[q] = wave_bcast(A[k0 + q], j);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) if (k0 + q < N) A[k0 + q] = fma(-lij, lk[q], A[k0 + q]);
+                    for (int q = 0; q < 8; ++q) if (k0 + q < N) A[k0 + q] = fma(-f, rk[q], A[k0 + q]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (ok) {
-                // park L for the transposed solve: L[i][j], j < i
-#pragma unroll
-                for (int j = 0; j < N; ++j) if (j < i && i < n_act) Wm[i * LD + j] = A[j];
-                wave_sync();
-                double r = b;                                       // y_i
-                double lnext = (i < n_act - 1) ? Wm[(n_act - 1) * LD + i] : 0.0;
-                for (int j = n_act - 1; j >= 0; --j) {
-                    const double lcur = lnext;
-                    lnext = (j > 0 && i < j - 1) ? Wm[(j - 1) * LD + i] : 0.0;
-                    const double zj = wave_bcast(r * dinv_i, j);
-                    if (i == j) r = zj;
-                    else if (i < j) r = fma(-lcur, zj, r);
-                }
-                if (live) zz[i] = r;
-            }
+            if (ok && live) zz[i] = b * dinv_i;
         }
         if (NW > 1) {
             if (tid == 0) red[0] = ok ? 1.0 : 0.0;
