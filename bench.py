@@ -241,35 +241,37 @@ def main():
             assert t.data_ptr() == ptrs['H'], 'zero-copy view of the result buffer failed'
             packs.append(t)
             gathered.append([torch.empty_like(t) for _ in range(world)] if rank == 0 else None)
-        gather_bufs = dict(packs=packs, gathered=gathered, pending=[None, None], k=0)
+        gather_bufs = dict(packs=packs, gathered=gathered, pending=[None, None], k=0,
+                           ext=torch.cuda.ExternalStream(ctx.stream_handle(), device=torch.device('cuda', local_rank)))
 
     def one_step():
         """one pass of the solver; with several ranks the ONE RCCL gather of the
         packed per-alpha results of pass k runs while pass k+1 computes into the
         other result buffer (the gather of pass k-1 is waited for first)."""
         if not use_dist:
-            ctx.launch()
-            ctx.sync()
+            ctx.launch()        # enqueued back to back: no host synchronisation inside the timed region
             return
         g = gather_bufs
         b = g['k'] % 2
         g['k'] += 1
-        ta = time.perf_counter()
+        cur = torch.cuda.current_stream()
         if g['pending'][b] is not None:
+            # buffer b is free again once its gather has run: the wait is a dependency of the current
+            # stream, passed on to the library's stream with an event -- no host synchronisation
             g['pending'][b].wait()
-            torch.cuda.current_stream().synchronize()     # buffer b is free again
-        tb = time.perf_counter()
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            g['ext'].wait_event(ev)
         ctx.set_result_buffer(b)
         ctx.launch()
-        ctx.sync()
-        tc = time.perf_counter()
+        done = torch.cuda.Event()
+        done.record(g['ext'])
+        cur.wait_event(done)                  # the gather is enqueued behind the pass that fills its source
         g['pending'][b] = dist.gather(g['packs'][b], g['gathered'][b], dst=0, async_op=True)
-        td = time.perf_counter()
-        if os.environ.get('MXE_BENCH_DEBUG'):
-            sys.stderr.write('step %d: wait %.2f ms, solve %.2f ms, issue gather %.2f ms\n'
-                             % (g['k'], 1e3 * (tb - ta), 1e3 * (tc - tb), 1e3 * (td - tc)))
 
     def drain():
+        if not use_dist:
+            ctx.sync()
         if use_dist:
             for w in gather_bufs['pending']:
                 if w is not None:
@@ -298,11 +300,19 @@ def main():
         drain()
     kernel_ms = []
     barrier()
+    if not use_dist:
+        ctx.sync()
+        ctx.timing_mark()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
-        kernel_ms.append(ctx.last_kernel_ms())
     drain()                     # every gather has landed on rank 0 inside the timed region
+    if use_dist:
+        kernel_ms = [ctx.last_kernel_ms()]      # the last pass of the region (HIP events on the library's stream)
+    if not use_dist:
+        # device time from the first launch of the region to the end of the last one / steps (HIP events
+        # on the library's stream; includes the few microseconds between consecutive launches)
+        kernel_ms = [ctx.ms_since_mark() / args.steps]
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -340,9 +350,9 @@ def main():
     # more), and SURVEY 8d's nominal figure that prices the kernel's time
     # against the reference's 160/84 passes per alpha-solve.
     achieved = bytes_actual / (k_ms * 1e-3) / 1e9
-    # profiles/r01_f_pmc_hbm_traffic.csv: FETCH_SIZE 8 359 KB (x2, gfx950
-    # correction) + WRITE_SIZE 116 655 KB per launch of the default workload
-    traffic = (2 * 8359.0e3 + 116655.0e3) if (args.n_orb, args.n_tau, args.n_omega, args.n_alpha) == (16, 200, 500, 100) else None
+    # profiles/r01_f_pmc_hbm_traffic.csv: FETCH_SIZE 8 077 KB (x2, gfx950
+    # correction) + WRITE_SIZE 116 662 KB per launch of the default workload
+    traffic = (2 * 8077.0e3 + 116662.0e3) if (args.n_orb, args.n_tau, args.n_omega, args.n_alpha) == (16, 200, 500, 100) else None
     roofline = dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS,
                     unit='GB/s', frac=achieved / HBM_PEAK_GBS,
                     traffic=traffic,

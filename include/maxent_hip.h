@@ -202,6 +202,14 @@ int  mxe_ns_padded(mxe_ctx* ctx);
 int  mxe_set_result_buffer(mxe_ctx* ctx, int which);
 /* duration of the last mxe_chains_launch in ms (HIP events on the ctx stream) */
 int  mxe_last_kernel_ms(mxe_ctx* ctx, float* ms);
+/* mxe_timing_mark records an event on the ctx stream; mxe_ms_since_mark waits for the end of the
+ * last launch and returns the device time from the mark to it: the duration of a run of launches
+ * that were enqueued back to back, without a host synchronisation in between */
+int  mxe_timing_mark(mxe_ctx* ctx);
+int  mxe_ms_since_mark(mxe_ctx* ctx, float* ms);
+/* the HIP stream (hipStream_t) the ctx launches on, for callers that order their own device work
+ * (an RCCL gather of the result buffers) against it with events instead of host synchronisation */
+void* mxe_stream(mxe_ctx* ctx);
 /* name of the kernel instantiation the last mxe_chains_launch ran, as a profiler shows it
  * (e.g. "mxe::chain_kernel_mc<32, 4>"); owned by the ctx */
 const char* mxe_last_kernel_name(mxe_ctx* ctx);

@@ -48,7 +48,7 @@ template <typename T> struct DevBuf {
 struct mxe_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mark = nullptr;
     int n_tau = 0, n_omega = 0, n_s = 0, NP = 64, nwp = 0;
     std::vector<double> U, S, V;
     std::vector<DataSet> ds;
@@ -314,7 +314,8 @@ try {
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return MXE_ERR_NODEVICE; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipEventCreate(&ctx->ev_mark) != hipSuccess) {
         delete ctx; return MXE_ERR_HIP;
     }
     ctx->n_tau = n_tau; ctx->n_omega = n_omega; ctx->n_s = n_s;
@@ -341,6 +342,7 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
     ctx->dB.release(); ctx->dA.release(); ctx->dprof.release();
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->ev_mark) hipEventDestroy(ctx->ev_mark);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -800,6 +802,26 @@ int mxe_last_kernel_ms(mxe_ctx* ctx, float* ms)
 }
 
 const char* mxe_last_kernel_name(mxe_ctx* ctx) { return ctx ? ctx->last_kernel.c_str() : ""; }
+
+void* mxe_stream(mxe_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int mxe_timing_mark(mxe_ctx* ctx)
+{
+    if (!ctx) return MXE_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_mark, ctx->stream));
+    return MXE_OK;
+}
+
+int mxe_ms_since_mark(mxe_ctx* ctx, float* ms)
+{
+    if (!ctx || !ms) return MXE_ERR_ARG;
+    if (!ctx->launched) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev_mark, ctx->ev1));
+    return MXE_OK;
+}
 
 int mxe_last_launch_info(mxe_ctx* ctx, int* waves_per_chain, int* n_workgroups, int* lds_bytes)
 {

@@ -84,6 +84,9 @@ SYMBOLS = [
     ('mxe_set_result_buffer', ctypes.c_int, [_vp, ctypes.c_int]),
     ('mxe_last_kernel_ms', ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     ('mxe_last_kernel_name', ctypes.c_char_p, [_vp]),
+    ('mxe_timing_mark', ctypes.c_int, [_vp]),
+    ('mxe_ms_since_mark', ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    ('mxe_stream', ctypes.c_void_p, [_vp]),
     ('mxe_last_launch_info', ctypes.c_int, [_vp] +
      [ctypes.POINTER(ctypes.c_int)] * 3),
     ('mxe_apply_output_map', ctypes.c_int, [_vp, _dp, _dp]),
@@ -354,6 +357,17 @@ class DeviceContext(object):
         self._check(self._lib.mxe_last_kernel_ms(self._h, ctypes.byref(ms)),
                     'mxe_last_kernel_ms')
         return float(ms.value)
+
+    def timing_mark(self):
+        self._check(self._lib.mxe_timing_mark(self._h), 'mxe_timing_mark')
+
+    def ms_since_mark(self):
+        ms = ctypes.c_float(0)
+        self._check(self._lib.mxe_ms_since_mark(self._h, ctypes.byref(ms)), 'mxe_ms_since_mark')
+        return float(ms.value)
+
+    def stream_handle(self):
+        return int(self._lib.mxe_stream(self._h) or 0)
 
     def last_launch_info(self):
         a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
