@@ -815,15 +815,14 @@ void chain_kernel(const KParams p)
     };
 
     // ------------------------------------------------------------------
-    // wave 0, active block of at most N <= 64 rows: Cholesky entirely in
-    // registers.  Lane i holds row i of A = c W c + a I (N doubles, static
-    // indices: the j and k loops are fully unrolled); right-looking
-    // elimination with the pivot column broadcast through v_readlane, the
-    // right-hand side carried as one more column (forward substitution for
-    // free).  L is then parked in the strict lower triangle of Wm for the
-    // back substitution.  Rows >= n_act are padded with the identity.
+    // wave 0, active block of at most N <= 32 rows: the Newton system solved
+    // entirely in registers.  Lane i holds the full row i of A = c W c + a I
+    // (N doubles, static indices: the j and k loops are fully unrolled) and its
+    // right-hand side; Gauss-Jordan elimination with the pivot row broadcast
+    // through v_readlane; z falls out of the right-hand-side column.  Rows >=
+    // n_act are padded with the identity.  (n_act > 32: chol_solve, in LDS.)
     // ------------------------------------------------------------------
-    auto chol_solve_reg = [&](auto NTag, double a, int n_act) -> bool {
+    auto gj_solve_reg = [&](auto NTag, double a, int n_act) -> bool {
         constexpr int N = decltype(NTag)::value;
         bool ok = true;
         if (wave == 0) {
@@ -960,9 +959,9 @@ void chain_kernel(const KParams p)
             while (true) {
                 const double a = alpha + mu;
                 bool okc;
-                if (n_act0 <= 16) okc = chol_solve_reg(std::integral_constant<int, 16>{}, a, n_act0);
-                else if (n_act0 <= 24) okc = chol_solve_reg(std::integral_constant<int, 24>{}, a, n_act0);
-                else if (n_act0 <= 32) okc = chol_solve_reg(std::integral_constant<int, 32>{}, a, n_act0);
+                if (n_act0 <= 16) okc = gj_solve_reg(std::integral_constant<int, 16>{}, a, n_act0);
+                else if (n_act0 <= 24) okc = gj_solve_reg(std::integral_constant<int, 24>{}, a, n_act0);
+                else if (n_act0 <= 32) okc = gj_solve_reg(std::integral_constant<int, 32>{}, a, n_act0);
                 else okc = chol_solve(a, n_act0);
                 MXE_STAMP(2);
                 bool good = okc;

@@ -7,13 +7,13 @@
 //    (one V).  Every load of V feeds all four chains: the row pass streams
 //    V^T once (du = V delta of the four steps, v_mfma_f64_4x4x4 with the four
 //    slots as the columns of every block), the fused pass streams V once and
-//    produces both h = V^T H (VALU) and the Gram matrices
-//    W = V_a^T diag(w) V_a (v_mfma_f64_16x16x4) of the four trial points from
-//    the same registers;
-//  * wave q is the "home" of slot q: it factorises the slot's Newton matrix
-//    (register Cholesky), takes the step, decides acceptance / convergence and
-//    writes the results -- four factorisations run side by side on the four
-//    SIMDs; the slot's scalars live in LDS between the home wave's sections;
+//    produces both h = V^T H (v_mfma_f64_4x4x4) and the Gram matrices
+//    W = V_a^T diag(w) V_a (v_mfma_f32_16x16x4: they only precondition the step)
+//    of the four trial points from the same registers;
+//  * wave q is the "home" of slot q: it solves the slot's Newton system
+//    (Gauss-Jordan elimination in registers), takes the step, decides acceptance
+//    / convergence and writes the results -- four solves run side by side on the
+//    four SIMDs; the slot's scalars live in LDS between the home wave's sections;
 //  * per-chain state in LDS is interleaved [row][chain] so that one 16-byte
 //    LDS read serves two chains;
 //  * the grid is persistent: a slot that has finished its piece of an alpha
@@ -204,7 +204,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     // factor through LDS, no back substitution (they were 4-5.6 k cycles of the 10-16 k per slot).
     // The solve only preconditions the (inexact) Newton step; rows >= n_act are identity rows.
     // ------------------------------------------------------------------
-    auto chol_home = [&](auto NTag, double a, int n_act) -> bool {
+    auto gj_home = [&](auto NTag, double a, int n_act) -> bool {
         constexpr int N = decltype(NTag)::value;
         const int q = wave, i = lane;
         const double* Wq = Wm + (size_t)q * NA * LD;
@@ -297,12 +297,12 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 while (true) {
                     const double a = t.alpha + t.mu;
                     bool ok;
-                    if (na <= 16) ok = chol_home(std::integral_constant<int, 16>{}, a, na);
-                    else if (na <= 20) ok = chol_home(std::integral_constant<int, 20>{}, a, na);
-                    else if (na <= 24) ok = chol_home(std::integral_constant<int, 24>{}, a, na);
-                    else if (na <= 28) ok = chol_home(std::integral_constant<int, 28>{}, a, na);
-                    else if (NA <= 32 || na <= 32) ok = chol_home(std::integral_constant<int, 32>{}, a, na);
-                    else ok = chol_home(std::integral_constant<int, (NA > 32 ? NA : 32)>{}, a, na);
+                    if (na <= 16) ok = gj_home(std::integral_constant<int, 16>{}, a, na);
+                    else if (na <= 20) ok = gj_home(std::integral_constant<int, 20>{}, a, na);
+                    else if (na <= 24) ok = gj_home(std::integral_constant<int, 24>{}, a, na);
+                    else if (na <= 28) ok = gj_home(std::integral_constant<int, 28>{}, a, na);
+                    else if (NA <= 32 || na <= 32) ok = gj_home(std::integral_constant<int, 32>{}, a, na);
+                    else ok = gj_home(std::integral_constant<int, (NA > 32 ? NA : 32)>{}, a, na);
                     if (ok) {
                         double z = 0.0, nrm = 0.0;
                         if (k < na) { z = zz[q * NP + k]; nrm = z * (rhs[q * NP + k] - a * z); }
