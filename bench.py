@@ -173,8 +173,11 @@ def cpu_pool_baseline(batch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    # a step is 1.7 ms: 200 of them keep the timed region long enough (0.33 s) for the tens of
+    # milliseconds by which a fresh submission is sometimes picked up late on the MI355X boxes (seen in a
+    # quarter of the processes: device time of the region unchanged, host-side wait 33-47 ms longer)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--n-orb', type=int, default=16)
     ap.add_argument('--n-tau', type=int, default=200)
     ap.add_argument('--n-omega', type=int, default=500)
@@ -306,6 +309,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    t_enq = time.perf_counter()
     drain()                     # every gather has landed on rank 0 inside the timed region
     if use_dist:
         kernel_ms = [ctx.last_kernel_ms()]      # the last pass of the region (HIP events on the library's stream)
@@ -313,8 +317,10 @@ def main():
         # device time from the first launch of the region to the end of the last one / steps (HIP events
         # on the library's stream; includes the few microseconds between consecutive launches)
         kernel_ms = [ctx.ms_since_mark() / args.steps]
+    t_drained = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    host_split = dict(enqueue_ms=1e3 * (t_enq - t0), wait_ms=1e3 * (t_drained - t_enq))
     if use_dist:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
@@ -390,7 +396,7 @@ def main():
                             gather='one torch.distributed nccl (RCCL) gather per step of the packed H, chi2, S, Q '
                                    '(%.1f MB per rank) to rank 0, double buffered against the next pass, inside the timed region' % ((P * args.n_omega + 3 * P) * 8 / 1e6)
                             if use_dist else 'none (1 GPU)',
-                            svd_seconds_host=batch['t_svd']),
+                            svd_seconds_host=batch['t_svd'], host_split=host_split),
                 roofline=roofline)
     if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(batch, out)

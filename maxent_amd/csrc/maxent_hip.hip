@@ -10,6 +10,7 @@
 #include "mxe_kernel_mc.hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -690,11 +691,25 @@ try {
 }
 MXE_CATCH_ALL
 
+// Wait for the ctx stream by polling: a blocking hipStreamSynchronize was seen to return tens of
+// milliseconds after the work had finished in a quarter of the processes on the MI355X boxes (the
+// device time of 20 launches 33 ms, the host-side wait 67 ms); the launches last 1-20 ms, so the host
+// thread spins on hipStreamQuery for up to two seconds and only then blocks.
+static hipError_t stream_wait(hipStream_t s)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return hipStreamSynchronize(s);
+    }
+}
+
 int mxe_sync(mxe_ctx* ctx)
 {
     if (!ctx) return MXE_ERR_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));
     return MXE_OK;
 }
 
@@ -705,7 +720,7 @@ try {
     if (!ctx) return MXE_ERR_ARG;
     if (!ctx->launched) return MXE_ERR_STATE;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));
     const size_t P = (size_t)ctx->n_chain * ctx->n_alpha;
     const int ns = ctx->n_s, NP = ctx->NP, nw = ctx->n_omega;
     if (out_H) HIPCHK(ctx, hipMemcpy(out_H, ctx->dout_H.p, P * nw * 8, hipMemcpyDeviceToHost));
