@@ -295,12 +295,17 @@ def main():
     # the first collectives of a process group finish initialising in the background
     # (measured with one rank: a single 75 ms stall of one launch, 20-40 ms after the
     # first barrier); take the barrier here and let that settle outside the timed region
+    # ... and without a process group: with only a few warm-up passes, the first submission after the
+    # synchronisation that opens the timed region was picked up 30-50 ms late in a quarter of the
+    # processes on the MI355X boxes (12 of 12 clean with ten warm-up passes).  Both settle in untimed
+    # passes: half a second of them with a process group, a quarter of a second without.
     barrier()
-    if use_dist:
-        t_settle = time.perf_counter()
-        while time.perf_counter() - t_settle < 0.5:
-            one_step()
-        drain()
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < (0.5 if use_dist else 0.25):
+        one_step()
+        if not use_dist:
+            ctx.sync()
+    drain()
     kernel_ms = []
     barrier()
     if not use_dist:
