@@ -169,7 +169,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 #pragma unroll
     for (int q = 0; q < MCC; ++q) if (s_elem[q] >= 0 && any_elem < 0) any_elem = s_elem[q];
     if (any_elem < 0) return;                    // nothing for this workgroup
-    const int ds = p.elem_ds[any_elem];
+    const int ds = __builtin_amdgcn_readfirstlane(p.elem_ds[__builtin_amdgcn_readfirstlane(any_elem)]);     // wave-uniform: V, Vt become scalar base pointers
     const double* __restrict__ V  = p.V  + (size_t)ds * nwp * NP;
     const double* __restrict__ Vt = p.Vt + (size_t)ds * NP * nwp;
     if (wave == 0) { cc[lane] = p.c[ds * NP + lane]; ci[lane] = p.cinv[ds * NP + lane]; }
@@ -545,25 +545,35 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 double fr[DEPTH][4];
                 HW hr[4];
                 OP op[2];
-                auto loadV = [&](double (&f)[4], const double* src) {
+                // V through buffer loads: one resource descriptor for the data set's V (wave-uniform), one
+                // 32-bit lane offset, the position of the row group as a SCALAR offset -- the loop carries
+                // no 64-bit vector address arithmetic (it was four v_add_co / v_addc pairs with their
+                // hazard slots per row group)
+                typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, 0x7fffffff, 0x00020000);
+                const int loff = (kq * NP + cn) * 8;                  // bytes
+                auto loadV = [&](double (&f)[4], int soff_bytes) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) f[t] = src[16 * t];
+                    for (int t = 0; t < 4; ++t) {
+                        const u2v v2 = __builtin_amdgcn_raw_buffer_load_b64(vrsrc, loff + 128 * t, soff_bytes, 0);
+                        f[t] = __hiloint2double((int)v2.y, (int)v2.x);
+                    }
                 };
                 constexpr size_t VSTEP = (size_t)4 * ST * NP;        // doubles per group step (V)
                 constexpr int HSTEP = 4 * ST * MCC;                  // ... (H, w in LDS)
-                const double* vp = Vl + (size_t)(4 * g) * NP;
+                int vp = 4 * __builtin_amdgcn_readfirstlane(g) * NP * 8;          // byte offset of the wave's first row group (uniform)
                 const double* hb = Hi + (size_t)(4 * g + kq) * MCC + (lane & 3);
                 const float* wb = wiF + (size_t)(4 * g + kq) * MCC;
 #pragma unroll
-                for (int j = 0; j < DEPTH - 1; ++j) loadV(fr[j], vp + j * VSTEP);
+                for (int j = 0; j < DEPTH - 1; ++j) loadV(fr[j], vp + j * (int)(VSTEP * 8));
                 loadHW(hr[0], hb, wb);
                 loadHW(hr[1], hb + HSTEP, wb + HSTEP);
                 prep(op[0], fr[0], hr[0]);
-                for (; g < n_groups; g += DEPTH * ST, vp += DEPTH * VSTEP, hb += DEPTH * HSTEP, wb += DEPTH * HSTEP) {
+                for (; g < n_groups; g += DEPTH * ST, vp += DEPTH * (int)(VSTEP * 8), hb += DEPTH * HSTEP, wb += DEPTH * HSTEP) {
 #pragma unroll
                     for (int j = 0; j < DEPTH; ++j) {
 #ifndef MXE_X_NO_VLOAD     // timing experiment only (results are wrong)
-                        loadV(fr[(j + DEPTH - 1) % DEPTH], vp + (j + DEPTH - 1) * VSTEP);
+                        loadV(fr[(j + DEPTH - 1) % DEPTH], vp + (j + DEPTH - 1) * (int)(VSTEP * 8));
 #endif
                         loadHW(hr[(j + 2) & 3], hb + (j + 2) * HSTEP, wb + (j + 2) * HSTEP);
                         // blocks, not a mix (measured, tools/mfma_shadow.hip: a vector instruction placed
