@@ -361,9 +361,9 @@ def main():
     # more), and SURVEY 8d's nominal figure that prices the kernel's time
     # against the reference's 160/84 passes per alpha-solve.
     achieved = bytes_actual / (k_ms * 1e-3) / 1e9
-    # profiles/r01_f_pmc_hbm_traffic.csv: FETCH_SIZE 8 062 KB (x2, gfx950
-    # correction) + WRITE_SIZE 116 602 KB per launch of the default workload
-    traffic = (2 * 8062.0e3 + 116602.0e3) if (args.n_orb, args.n_tau, args.n_omega, args.n_alpha) == (16, 200, 500, 100) else None
+    # profiles/r01_f_pmc_hbm_traffic.csv: FETCH_SIZE 8 063 KB (x2, gfx950
+    # correction) + WRITE_SIZE 116 548 KB per launch of the default workload
+    traffic = (2 * 8063.0e3 + 116548.0e3) if (args.n_orb, args.n_tau, args.n_omega, args.n_alpha) == (16, 200, 500, 100) else None
     roofline = dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS,
                     unit='GB/s', frac=achieved / HBM_PEAK_GBS,
                     traffic=traffic,
