@@ -109,6 +109,33 @@ __device__ __forceinline__ double recip_exp(double e) {
     return y;
 }
 
+// exp(x) in binary64 for the row pass of the lock-step kernel: k = rint(x log2 e), r = x - k ln 2 (two
+// steps), Taylor polynomial of degree 12 in Horner form as plain 3-operand FMAs, result ldexp(p, k).
+// |r| <= 0.347: truncation 1.7e-16 relative; overflow / underflow / NaN come out of ldexp and the
+// arithmetic as inf / 0 / NaN, which is what the callers test for.  (The library exp spends a register
+// move per coefficient and five instructions on range checks: 35 instructions against 19.)
+__device__ __forceinline__ double fast_exp(double x) {
+    const double k = __builtin_rint(x * 1.4426950408889634);
+    double r = fma(k, -6.93147180369123816490e-01, x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = 1.0 / 479001600.0;
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    // k beyond the int range of ldexp only for |x| > 1e9: clamp (the result is inf / 0 either way)
+    const int ki = (int)fmin(fmax(k, -4000.0), 4000.0);
+    return ldexp(p, ki);
+}
+
 __device__ __forceinline__ float recip_exp(float e) {
     float y = __builtin_amdgcn_rcpf(e);
     y = fmaf(fmaf(-e, y, 1.0f), y, y);

@@ -438,7 +438,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         pdH = fma(tq, tq, pdH);
                         pdu = fmax(pdu, scr_j ? 0.0 : fabs(vd));  // padded rows of V^T are zero
                         const double Di = Dv[tt];
-                        const double ep = exp(uq);
+                        const double ep = fast_exp(uq);
                         const double Hp = Di * ep;
                         double Hq = Hp, wq = Hp, Sq = Hp - Di - Hp * uq;
                         if (pm_j) {
