@@ -2,7 +2,7 @@
 of the default scan split (cfg4 batch, default options)"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from maxent_amd import device
 from oracle import hp_truth

@@ -1,7 +1,7 @@
 """cost / accuracy of the active-subspace threshold theta (decouple_tol), tol_h and the stopping rule"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from maxent_amd import device
 from oracle import hp_truth

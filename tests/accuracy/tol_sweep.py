@@ -1,7 +1,7 @@
 """accuracy (vs extended-precision truth on sampled chains) and cost of the stopping tolerance tol_h"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from maxent_amd import device
 from oracle import ref_numpy as R, hp_truth
