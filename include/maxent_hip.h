@@ -106,6 +106,8 @@ typedef struct mxe_opts {
                                 one chain per workgroup.  For the fp32-vs-fp64 tolerance sweep of
                                 BASELINE config 5 (tools/cfg5_tolerance_sweep.py)              */
     int32_t reserved;        /* keep 0 */
+    double  chi2_factor;     /* eta in Q = eta chi2 / 2 - alpha S (CostFunction(chi2_factor=...),
+                                cost_function.py:60, bryan_cost_function.py:71); default 1       */
 } mxe_opts;
 
 /* ---- library / device ------------------------------------------------- */

@@ -8,6 +8,7 @@
 #include "../../include/maxent_hip.h"
 #include "mxe_kernel.hip.h"
 #include "mxe_kernel_mc.hip.h"
+#include "mxe_eval.hip.h"
 
 #include <algorithm>
 #include <chrono>
@@ -81,6 +82,10 @@ struct mxe_ctx {
     DevBuf<int> dout_niter, dout_conv, dout_nevals, dout_nact;
     DevBuf<long long> dprof;
     DevBuf<int> dqueue, dcounter;
+    // mxe_eval_batch / mxe_audit scratch
+    DevBuf<double> ev_x, ev_alpha, ev_scal, ev_vecw, ev_vecs, ev_mat;
+    DevBuf<int> ev_elem;
+    double chi2_factor = 1.0;     // of the staged chains (mxe_opts.chi2_factor)
     std::string hip_err;
 };
 
@@ -227,10 +232,14 @@ int upload_bases(mxe_ctx* ctx)
     return MXE_OK;
 }
 
-size_t mc_lds_doubles(int NA, int nwp, int NWV)
+// dynamic LDS of chain_kernel_mc<NA, 4> in bytes (the carve at the top of the kernel)
+size_t mc_lds_bytes(int NA, int nwp)
 {
-    return (size_t)4 * NA * (NA + 1) + 8 * 4 * 64 + 2 * 64 + 64 * 4 + (size_t)NWV * 4 * 64 + (size_t)NWV * 32 +
-           (size_t)3 * nwp * 4 + (size_t)nwp * 2 /* binary32 copy of w */ + mxe::MC_LOOKAHEAD_LDS;
+    const int NT = NA / 16, NPAIR = NT * (NT + 1) / 2;
+    const size_t doubles = 8 * 4 * 64 + 2 * 64 + 64 * 4 + 4 * 4 * 64 + 4 * 32 +        // vectors, c, 1/c, step, h parts, sums
+                           (size_t)2 * nwp * 4 + (size_t)4 * NPAIR * 256;               // u, H, Gram tiles
+    const size_t floats = (size_t)nwp * 4;                                              // sw
+    return doubles * 8 + floats * 4;
 }
 
 // LDS bytes of chain_kernel<NW, NAB, TS>: stream arrays (u, ut, w, wt, Hs, vecs) in the stream
@@ -300,6 +309,7 @@ void mxe_opts_default(mxe_opts* o)
     o->decouple_tol = 1e-5;
     o->waves_per_chain = 0; o->chains_per_wg = 0; o->alpha_split = 0; o->stop_estimate = 1;
     o->precision = MXE_PRECISION_F64; o->reserved = 0;
+    o->chi2_factor = 1.0;
 }
 
 int mxe_ctx_create(int device, int n_tau, int n_omega, int n_s,
@@ -341,6 +351,8 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
     ctx->dchain_elem.release(); ctx->dsub_prob0.release(); ctx->dsub_len.release(); ctx->dsub_v0.release(); ctx->dwg_chains.release(); ctx->dqueue.release(); ctx->dcounter.release(); ctx->dout_v.release(); ctx->dout_pack.release(); ctx->dout_pack2.release();
     ctx->dout_niter.release(); ctx->dout_conv.release(); ctx->dout_nevals.release(); ctx->dout_nact.release();
     ctx->dB.release(); ctx->dA.release(); ctx->dprof.release();
+    ctx->ev_x.release(); ctx->ev_alpha.release(); ctx->ev_scal.release(); ctx->ev_vecw.release(); ctx->ev_vecs.release();
+    ctx->ev_mat.release(); ctx->ev_elem.release();
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->ev_mark) hipEventDestroy(ctx->ev_mark);
@@ -448,6 +460,12 @@ try {
     if (o.alpha_split < 0) return MXE_ERR_ARG;
     if (o.precision != MXE_PRECISION_F64 && o.precision != MXE_PRECISION_F32) return MXE_ERR_ARG;
     if (o.precision == MXE_PRECISION_F32 && NP != 64) return MXE_ERR_LIMIT;
+    if (!(o.chi2_factor > 0.0) || !std::isfinite(o.chi2_factor)) return MXE_ERR_ARG;
+    // Q = eta chi2 / 2 - alpha S has the minimiser of chi2 / 2 - (alpha / eta) S: the device iterates on
+    // alpha / eta and the fetch multiplies Q by eta (cost_function.py:60, bryan_cost_function.py:71)
+    ctx->chi2_factor = o.chi2_factor;
+    std::vector<double> alpha_dev(alpha_scaled, alpha_scaled + (size_t)n_chain * n_alpha);
+    if (o.chi2_factor != 1.0) for (double& a : alpha_dev) a /= o.chi2_factor;
     ctx->chain_elem.assign(elem_of_chain, elem_of_chain + n_chain);
     std::vector<double> hv0((size_t)n_chain * NP, 0.0);
     for (int c = 0; c < n_chain; ++c) {
@@ -517,16 +535,15 @@ try {
             const int e = ctx->sub_elem[sc];
             const DataSet& DS = ctx->ds[ctx->elem_ds[e]];
             double amin = 1e300;
-            for (int i = 0; i < ctx->sub_len[sc]; ++i) amin = std::min(amin, alpha_scaled[ctx->sub_prob0[sc] + i]);
+            for (int i = 0; i < ctx->sub_len[sc]; ++i) amin = std::min(amin, alpha_dev[ctx->sub_prob0[sc] + i]);
             const double wbound = std::max(1.0, ctx->h_sumD[e]);
             if (ns > 32) worst32 = std::max(worst32, DS.c[32] * DS.c[32] * wbound / amin);
             if (ns > 48) worst48 = std::max(worst48, DS.c[48] * DS.c[48] * wbound / amin);
         }
         if (worst32 <= 1e-2) ctx->mc_na = 32; else if (worst48 <= 1e-2) ctx->mc_na = 48; else layout = 1;
         if (layout == 4) {
-            ctx->mc_nwv = (o.waves_per_chain == 8) ? 8 : 4;
-            if (mc_lds_doubles(ctx->mc_na, ctx->nwp, ctx->mc_nwv) * sizeof(double) > 160 * 1024 - 256) ctx->mc_nwv = 4;
-            if (mc_lds_doubles(ctx->mc_na, ctx->nwp, ctx->mc_nwv) * sizeof(double) > 160 * 1024 - 256) { layout = 1; ctx->mc_na = 0; }
+            ctx->mc_nwv = 4;
+            if (mc_lds_bytes(ctx->mc_na, ctx->nwp) > 160 * 1024 - 2048) { layout = 1; ctx->mc_na = 0; }
         }
     }
     ctx->wg_chains.clear(); ctx->queue.clear(); ctx->n_queue = 0;
@@ -541,7 +558,7 @@ try {
             for (int sc = 0; sc < ctx->n_sub; ++sc) {
                 const int e = ctx->sub_elem[sc];
                 double amin = 1e300;
-                for (int i = 0; i < ctx->sub_len[sc]; ++i) amin = std::min(amin, alpha_scaled[ctx->sub_prob0[sc] + i]);
+                for (int i = 0; i < ctx->sub_len[sc]; ++i) amin = std::min(amin, alpha_dev[ctx->sub_prob0[sc] + i]);
                 cost[sc] = ctx->sub_len[sc] * (ctx->elem_kind[e] == MXE_ENTROPY_NORMAL ? 4.0 : 3.0) +
                            (ctx->elem_kind[e] == MXE_ENTROPY_NORMAL ? 16.0 : 6.0) - 1e-3 * std::log10(amin);
             }
@@ -593,7 +610,7 @@ try {
     HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_v0.p, ctx->sub_v0.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
     if (!ctx->wg_chains.empty())
         HIPCHK(ctx, hipMemcpyAsync(ctx->dwg_chains.p, ctx->wg_chains.data(), ctx->wg_chains.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->dalpha.p, alpha_scaled, P * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dalpha.p, alpha_dev.data(), P * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dv0.p, hv0.data(), hv0.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_chain = n_chain; ctx->n_alpha = n_alpha;
@@ -635,8 +652,8 @@ try {
     if (ctx->mc_na > 0) {
         // four chains per workgroup, lock-step (mxe_kernel_mc.hip.h)
         const int NA = ctx->mc_na, NWV = ctx->mc_nwv;
-        const size_t lds = mc_lds_doubles(NA, ctx->nwp, NWV) * sizeof(double);
-        if (lds > 160 * 1024 - 256) return MXE_ERR_LIMIT;
+        const size_t lds = mc_lds_bytes(NA, ctx->nwp);
+        if (lds > 160 * 1024 - 2048) return MXE_ERR_LIMIT;
         mxe::MCExtra ex; ex.wg_chains = ctx->dwg_chains.p; ex.n_wg = ctx->n_wg;
         ex.queue = ctx->dqueue.p; ex.n_queue = ctx->n_queue; ex.counter = ctx->dcounter.p;
         HIPCHK(ctx, hipMemsetAsync(ctx->dcounter.p, 0, sizeof(int), ctx->stream));
@@ -649,10 +666,8 @@ try {
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb__, (const void*)mxe::chain_kernel_mc<NA_, NWV_>, 64 * NWV_, lds); \
             fprintf(stderr, "[mxe] lock-step kernel NA=%d NWV=%d lds=%zu: %d workgroup(s) per CU resident\n", NA_, NWV_, (size_t)lds, nb__); } \
         if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<NA_, NWV_>), dim3(ctx->n_wg), dim3(64 * NWV_), lds, ctx->stream, kp, ex); e = hipGetLastError(); } } while (0)
-        if (NA == 32 && NWV == 4) MXE_LAUNCH_MC(32, 4);
-        else if (NA == 32) MXE_LAUNCH_MC(32, 8);
-        else if (NWV == 4) MXE_LAUNCH_MC(48, 4);
-        else MXE_LAUNCH_MC(48, 8);
+        if (NA == 32) MXE_LAUNCH_MC(32, 4);
+        else MXE_LAUNCH_MC(48, 4);
 #undef MXE_LAUNCH_MC
         HIPCHK(ctx, e);
     } else {
@@ -726,7 +741,10 @@ try {
     if (out_H) HIPCHK(ctx, hipMemcpy(out_H, ctx->dout_H.p, P * nw * 8, hipMemcpyDeviceToHost));
     if (out_chi2) HIPCHK(ctx, hipMemcpy(out_chi2, ctx->dout_chi2.p, P * 8, hipMemcpyDeviceToHost));
     if (out_S) HIPCHK(ctx, hipMemcpy(out_S, ctx->dout_S.p, P * 8, hipMemcpyDeviceToHost));
-    if (out_Q) HIPCHK(ctx, hipMemcpy(out_Q, ctx->dout_Q.p, P * 8, hipMemcpyDeviceToHost));
+    if (out_Q) {
+        HIPCHK(ctx, hipMemcpy(out_Q, ctx->dout_Q.p, P * 8, hipMemcpyDeviceToHost));
+        if (ctx->chi2_factor != 1.0) for (size_t i = 0; i < P; ++i) out_Q[i] *= ctx->chi2_factor;
+    }
     if (out_niter) HIPCHK(ctx, hipMemcpy(out_niter, ctx->dout_niter.p, P * 4, hipMemcpyDeviceToHost));
     if (out_converged) HIPCHK(ctx, hipMemcpy(out_converged, ctx->dout_conv.p, P * 4, hipMemcpyDeviceToHost));
     if (out_nevals) HIPCHK(ctx, hipMemcpy(out_nevals, ctx->dout_nevals.p, P * 4, hipMemcpyDeviceToHost));

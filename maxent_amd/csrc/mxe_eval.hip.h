@@ -1,0 +1,311 @@
+// mxe_eval.hip.h -- the cost function and its derivatives at caller-supplied points
+//
+// One workgroup (4 wavefronts) per problem, everything binary64.  This is the device side of
+//     CostFunction.__call__ / f / d / dd          cost_functions/cost_function.py:73-85
+//     MaxEntCostFunction.f / dH / d / ddH / dd    cost_functions/maxent_cost_function.py:68-165
+//     BryanCostFunction.f / d / dd                cost_functions/bryan_cost_function.py:57-128
+//     NormalChi2, NormalEntropy, PlusMinusEntropy, NormalH_of_v, PlusMinusH_of_v   functions.py:336-796
+// in the singular-space form of SURVEY.md section 8 (whitened basis):
+//     u = V v,  H = D e^u | D (e^u - e^-u),  w = H | D (e^u + e^-u),  h = V^T H,
+//     rho = c h - ghat,  chi2 = |rho|^2 + c_perp,  S,  Q = eta chi2 / 2 - alpha S,
+//     g = eta c rho + alpha v            (= dQ/dv "without the factor W": Bryan's d, d with dA_projection = 1)
+//     W  = V^T diag(w) V                 (every derivative of the reference is built from g, W and M = diag(c^2):
+//                                          d = W g, dd = W M W + alpha W (default); d = g, dd = M W (Bryan))
+//     W2 = V^T diag((V g) H) V           (the d^2 H / dv dv term of d_dv = True)
+// It is also the checker of the solver itself (MODE_AUDIT): at the v the chain kernel returned, the
+// exact Newton correction  (eta c W c + alpha I) z = eta rho + alpha v / c,  delta = c z, over ALL n_s
+// directions, and its size in the metric of the stopping rule,  ||w * V delta||_2 / ||H||_2  -- to first
+// order the distance of the returned H from the minimiser.
+#pragma once
+#include "mxe_kernel.hip.h"
+
+namespace mxe {
+
+struct EvalParams {
+    int nw, nwp, ns, NP;
+    const double* V;        // [n_ds][nwp][NP]
+    const double* Vt;       // [n_ds][NP][nwp]
+    const double* c;        // [n_ds][NP]
+    const int* elem_ds;
+    const int* elem_kind;
+    const double* ghat;     // [n_elem][NP]
+    const double* cperp;    // [n_elem]
+    const double* D;        // [n_elem][nwp]
+    const int* elem;        // [P / elem_div] element of the problem
+    int elem_div;           // problems per entry of elem[] (n_alpha for the audit of a launch, else 1)
+    const double* alpha;    // [P]
+    const double* x;        // input: v (whitened basis) [P][x_stride] or H [P][x_stride]
+    int x_stride;
+    int input_is_H;         // 1: x is the hidden image H itself (u = H_of_v.inv(H)); g then has no alpha v term
+    double eta;             // chi2_factor
+    int want_gram, want_gram2, want_audit;
+    // outputs (device; any may be null)
+    double* Q; double* chi2; double* S;         // [P]
+    double* H; double* u; double* w;            // [P][nw]
+    double* h; double* g;                       // [P][NP]  whitened basis
+    double* W; double* W2;                      // [P][NP][NP] whitened basis, full symmetric
+    double* corr; double* gmax;                 // [P] audit: ||w * V delta|| / ||H||, max |g_k| / (|eta c rho|_k + |alpha v|_k)
+};
+
+// block-wide sum of NV values through LDS (256 threads); result in every thread
+template <int NV>
+__device__ __forceinline__ void eval_block_sum(double (&x)[NV], double* red /*[4 * NV]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) x[q] = wave_sum(x[q]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) red[wave * NV + q] = x[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) x[q] = (red[q] + red[NV + q]) + (red[2 * NV + q] + red[3 * NV + q]);
+}
+
+// W = V^T diag(wsh) V into Bm (full, symmetric) with v_mfma_f64_16x16x4_f64: the omega rows split over
+// the four waves, the upper-triangular tiles of one tile row per sweep of V (as in logdet_kernel)
+template <int NT>
+__device__ __forceinline__ void eval_gram(const double* __restrict__ V, const double* wsh, double* Bm,
+                                          int nwp, int ns)
+{
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    constexpr int NP = 16 * NT, LD = NP + 1;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int kq = lane >> 4, cn = lane & 15;
+    const int n_groups = nwp >> 2;
+    const int ntile = (ns + 15) >> 4;
+    for (int i = tid; i < NP * LD; i += 256) Bm[i] = 0.0;
+    __syncthreads();
+    for (int mt = 0; mt < ntile; ++mt) {
+        d4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int g = wave; g < n_groups; g += 4) {
+            const double* row = V + (size_t)(4 * g + kq) * NP + cn;
+            const double am = row[16 * mt] * wsh[4 * g + kq];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (t >= mt && t < ntile) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(am, row[16 * t], acc[t], 0, 0, 0);
+        }
+        for (int ph = 0; ph < 4; ++ph) {         // fixed order: the result does not depend on timing
+            if (wave == ph) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (t >= mt && t < ntile) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Bm[(16 * mt + kq + 4 * r) * LD + 16 * t + cn] += acc[t][r];
+                    }
+            }
+            __syncthreads();
+        }
+    }
+    // mirror: the tiles hold rows <= columns (tile-wise); make the matrix full
+    for (int idx = tid; idx < NP * NP; idx += 256) {
+        const int i = idx / NP, j = idx % NP;
+        if ((i >> 4) > (j >> 4)) Bm[i * LD + j] = Bm[j * LD + i];
+    }
+    __syncthreads();
+}
+
+template <int NT>
+__global__ __launch_bounds__(256)
+void eval_kernel(const EvalParams ep)
+{
+    constexpr int NP = 16 * NT, LD = NP + 1;
+    extern __shared__ double sm[];
+    double* Bm  = sm;                    // [NP][LD]
+    double* wsh = Bm + NP * LD;          // [nwp]  w (then the weights of W2)
+    double* Hsh = wsh + ep.nwp;          // [nwp]
+    double* vsh = Hsh + ep.nwp;          // [NP]   v
+    double* gsh = vsh + NP;              // [NP]   g
+    double* zsh = gsh + NP;              // [NP]   rhs / z / delta
+    double* hp  = zsh + NP;              // [4][NP] partial h
+    double* red = hp + 4 * NP;           // [16]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const size_t prob = blockIdx.x;
+    const int nw = ep.nw, nwp = ep.nwp, ns = ep.ns;
+    const int e = ep.elem[prob / ep.elem_div];
+    const int ds = ep.elem_ds[e], kind = ep.elem_kind[e];
+    const double a = ep.alpha[prob], eta = ep.eta;
+    const double* V  = ep.V + (size_t)ds * nwp * NP;
+    const double* Vt = ep.Vt + (size_t)ds * NP * nwp;
+    const double* cc = ep.c + (size_t)ds * NP;
+    const double* Dp = ep.D + (size_t)e * nwp;
+    const double* xp = ep.x + prob * ep.x_stride;
+
+    for (int k = tid; k < NP; k += 256) vsh[k] = (!ep.input_is_H && k < ns) ? xp[k] : 0.0;
+    __syncthreads();
+    // ---- u, H, w, S ----
+    double sums[2] = {0.0, 0.0};         // S, sum H^2
+    for (int i = tid; i < nwp; i += 256) {
+        double Hq = 0.0, wq = 0.0, uq = 0.0;
+        if (i < nw) {
+            const double Di = Dp[i];
+            if (ep.input_is_H) {
+                // H_of_v.inv (functions.py:749-755, 790-796) with its safelog (functions.py:53-56)
+                Hq = xp[i];
+                if (kind == 0) { wq = Hq; const double r = Hq / Di; uq = log(fabs(r) > 1e-100 ? r : 1e-100); }
+                else {
+                    const double d2 = 2.0 * Di; wq = sqrt(fma(Hq, Hq, d2 * d2));
+                    const double r = (Hq + wq) / d2; uq = log(fabs(r) > 1e-100 ? r : 1e-100);
+                }
+                if (kind == 0) sums[0] += Hq - Di - Hq * uq;
+                else {
+                    const double Hp = 0.5 * (wq + Hq), Hm = 0.5 * (wq - Hq);
+                    sums[0] += (Hp - Di - Hp * uq) + (Hm - Di + Hm * uq);
+                }
+            } else {
+                double acc0 = 0.0, acc1 = 0.0;
+                int k = 0;
+                for (; k + 1 < ns; k += 2) {
+                    acc0 = fma(Vt[(size_t)k * nwp + i], vsh[k], acc0);
+                    acc1 = fma(Vt[(size_t)(k + 1) * nwp + i], vsh[k + 1], acc1);
+                }
+                if (k < ns) acc0 = fma(Vt[(size_t)k * nwp + i], vsh[k], acc0);
+                uq = acc0 + acc1;
+                const double ep_ = exp(uq);
+                const double Hp = Di * ep_;
+                if (kind == 0) { Hq = Hp; wq = Hp; sums[0] += Hp - Di - Hp * uq; }
+                else {
+                    const double Hm = Di * exp(-uq);
+                    Hq = Hp - Hm; wq = Hp + Hm;
+                    sums[0] += (Hp - Di - Hp * uq) + (Hm - Di + Hm * uq);
+                }
+            }
+            sums[1] = fma(Hq, Hq, sums[1]);
+            if (ep.H) ep.H[prob * nw + i] = Hq;
+            if (ep.u) ep.u[prob * nw + i] = uq;
+            if (ep.w) ep.w[prob * nw + i] = wq;
+        }
+        Hsh[i] = Hq; wsh[i] = wq;
+    }
+    eval_block_sum<2>(sums, red);
+    const double Sval = sums[0], Hn2 = sums[1];
+    // ---- h = V^T H (row-major V: lane = column) ----
+    for (int k0 = 0; k0 < NP; k0 += 64) {
+        const int k = k0 + lane;
+        double acc = 0.0;
+        for (int i = wave; i < nw; i += 4) acc = fma(V[(size_t)i * NP + k], Hsh[i], acc);
+        hp[wave * NP + k] = acc;
+    }
+    __syncthreads();
+    double part[1] = {0.0};              // |rho|^2
+    double gm = 0.0;
+    for (int k = tid; k < NP; k += 256) {
+        double hk = 0.0, rk = 0.0, gk = 0.0;
+        if (k < ns) {
+            hk = (hp[k] + hp[NP + k]) + (hp[2 * NP + k] + hp[3 * NP + k]);
+            rk = cc[k] * hk - ep.ghat[(size_t)e * NP + k];
+            const double t1 = eta * cc[k] * rk, t2 = a * vsh[k];
+            gk = t1 + t2;
+            const double sc = fabs(t1) + fabs(t2);
+            gm = (sc > 0.0) ? fabs(gk) / sc : 0.0;
+            part[0] = rk * rk;
+            // right-hand side of the Newton system in the z variable (delta = c z)
+            zsh[k] = eta * rk + a * vsh[k] / cc[k];
+        } else {
+            zsh[k] = 0.0;
+        }
+        gsh[k] = gk;
+        if (ep.h) ep.h[prob * NP + k] = hk;
+        if (ep.g) ep.g[prob * NP + k] = gk;
+    }
+    eval_block_sum<1>(part, red);
+    gm = wave_max(gm);
+    __syncthreads();
+    if (lane == 0) red[wave] = gm;
+    __syncthreads();
+    gm = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    __syncthreads();
+    const double chi2 = part[0] + ep.cperp[e];
+    if (tid == 0) {
+        if (ep.chi2) ep.chi2[prob] = chi2;
+        if (ep.S) ep.S[prob] = Sval;
+        if (ep.Q) ep.Q[prob] = 0.5 * eta * chi2 - a * Sval;
+        if (ep.gmax) ep.gmax[prob] = gm;
+    }
+    if (!(ep.want_gram || ep.want_gram2 || ep.want_audit)) return;
+    // ---- W ----
+    if (ep.want_gram || ep.want_audit) {
+        eval_gram<NT>(V, wsh, Bm, nwp, ns);
+        if (ep.W)
+            for (int idx = tid; idx < NP * NP; idx += 256) {
+                const int i = idx / NP, j = idx % NP;
+                ep.W[prob * NP * NP + idx] = (i < ns && j < ns) ? Bm[i * LD + j] : 0.0;
+            }
+    }
+    // ---- audit: exact Newton correction over all n_s directions ----
+    if (ep.want_audit) {
+        __syncthreads();
+        for (int idx = tid; idx < ns * ns; idx += 256) {
+            const int i = idx / ns, j = idx % ns;
+            if (i >= j) {
+                double b = eta * cc[i] * Bm[i * LD + j] * cc[j];
+                if (i == j) b += a;
+                Bm[i * LD + j] = b;          // lower triangle
+            }
+        }
+        __syncthreads();
+        bool ok = true;
+        for (int j = 0; j < ns; ++j) {           // right-looking Cholesky
+            const double piv = Bm[j * LD + j];
+            if (!(piv > 0.0)) ok = false;
+            const double d = sqrt(piv);
+            __syncthreads();
+            for (int i = j + tid; i < ns; i += 256) Bm[i * LD + j] /= d;
+            __syncthreads();
+            const int m = ns - j - 1;
+            for (int idx = tid; idx < m * m; idx += 256) {
+                const int i = j + 1 + idx / m, k = j + 1 + idx % m;
+                if (k <= i) Bm[i * LD + k] = fma(-Bm[i * LD + j], Bm[k * LD + j], Bm[i * LD + k]);
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {                         // two triangular solves, column oriented, one wave
+            for (int j = 0; j < ns; ++j) {
+                if (lane == (j & 63)) zsh[j] /= Bm[j * LD + j];
+                wave_sync();
+                const double zj = zsh[j];
+                for (int i = lane; i < ns; i += 64) if (i > j) zsh[i] = fma(-Bm[i * LD + j], zj, zsh[i]);
+                wave_sync();
+            }
+            for (int j = ns - 1; j >= 0; --j) {
+                if (lane == (j & 63)) zsh[j] /= Bm[j * LD + j];
+                wave_sync();
+                const double zj = zsh[j];
+                for (int i = lane; i < j; i += 64) zsh[i] = fma(-Bm[j * LD + i], zj, zsh[i]);
+                wave_sync();
+            }
+            for (int i = lane; i < ns; i += 64) zsh[i] *= cc[i];       // delta = c z
+        }
+        __syncthreads();
+        double s2[1] = {0.0};
+        for (int i = tid; i < nw; i += 256) {
+            double du = 0.0;
+            for (int k = 0; k < ns; ++k) du = fma(Vt[(size_t)k * nwp + i], zsh[k], du);
+            const double t = wsh[i] * du;
+            s2[0] = fma(t, t, s2[0]);
+        }
+        eval_block_sum<1>(s2, red);
+        if (tid == 0 && ep.corr) ep.corr[prob] = ok ? sqrt(s2[0] / Hn2) : __builtin_nan("");
+    }
+    // ---- W2 = V^T diag((V g) H'') V,  H'' = d^2 H / du^2 = H for both entropies ----
+    if (ep.want_gram2 && ep.W2) {
+        __syncthreads();
+        for (int i = tid; i < nwp; i += 256) {
+            double q = 0.0;
+            if (i < nw) for (int k = 0; k < ns; ++k) q = fma(Vt[(size_t)k * nwp + i], gsh[k], q);
+            wsh[i] = q * Hsh[i];
+        }
+        __syncthreads();
+        eval_gram<NT>(V, wsh, Bm, nwp, ns);
+        for (int idx = tid; idx < NP * NP; idx += 256) {
+            const int i = idx / NP, j = idx % NP;
+            ep.W2[prob * NP * NP + idx] = (i < ns && j < ns) ? Bm[i * LD + j] : 0.0;
+        }
+    }
+}
+
+} // namespace mxe

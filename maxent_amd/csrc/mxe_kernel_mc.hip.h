@@ -40,28 +40,24 @@ struct MCExtra {
 };
 
 // NA  capacity of the active block: 32 or 48
-// NWV wavefronts per workgroup: 4 (the home waves) or 8 (4 home + 4 helper waves that
-//     take half of the rows of the two streaming passes: two waves per SIMD there)
-// rows of V behind the last omega row (and LDS doubles behind H) that the look-ahead of the
-// fused pass may read without using them: 2 * DEPTH * 4 waves * 4 rows, rounded up
-// allowance for the binary32 Gram tiles in the stopping estimate.  Measured on the cfg4 batch: with 0 and
-// with 2e-5 the worst sampled alpha-solves end 1.3e-9 from the fixed point (2.3e-10 with binary64 tiles;
-// tol_h = 1e-9) -- the same solves either way -- and 2e-5 costs 2 % more iterations, so none is made.
-constexpr double MC_GRAM_ERR = 0.0;
+// NWV wavefronts per workgroup: 4 (the home waves)
+// rows of V behind the last omega row (and LDS entries behind H / sw) that the look-ahead of the
+// fused pass may read without using them: (DEPTH + 2) groups * 4 waves * 4 rows, rounded up
+constexpr double MC_GRAM_ERR = 0.0;              // allowance for the inexact Gram tiles in the stopping estimate
 constexpr int MC_LOOKAHEAD_ROWS = 512;
-constexpr int MC_LOOKAHEAD_LDS = (8 * 4 + 4) * 4 * 4 + 64;       // doubles
-template <int NA, int NWV>
 #ifndef MXE_X_WGPC
-#define MXE_X_WGPC 1        // experiment: workgroups per CU the register budget is sized for
+#define MXE_X_WGPC 1        // workgroups per CU the register budget is sized for
 #endif
+constexpr int MC_FUSED_DEPTH = (MXE_X_WGPC == 1) ? 8 : 4;
+constexpr int MC_LOOKAHEAD_LDS = (MC_FUSED_DEPTH + 2) * 4 * 4 * 4 + 64;       // entries
+template <int NA, int NWV>
 __global__ __launch_bounds__(64 * NWV, MXE_X_WGPC)
 void chain_kernel_mc(const KParams p, const MCExtra x)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int T = 64 * NWV;
-    constexpr int RPT = (NWV == 4) ? 2 : 1;       // omega rows per thread in the row pass
+    static_assert(NWV == 4, "one wavefront per chain slot");
     constexpr int NP = 64;
-    constexpr int LD = NA + 1;
     constexpr int NT = NA / 16;                   // 16-column tiles of the Gram block
     constexpr int NPAIR = NT * (NT + 1) / 2;
     typedef double d4 __attribute__((ext_vector_type(4)));
@@ -71,8 +67,14 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     const bool dynamic = x.n_queue > 0;
 
     // ---- LDS carve ----
-    double* Wm   = lds;                          // [MCC][NA][LD]
-    double* vv   = Wm + MCC * NA * LD;           // [MCC][NP]   v
+    // Per-chain omega state [row][chain]: u (binary64), H (binary64) and sw = sqrt(w * sc2) as binary32
+    // (sc2: a power of two per slot that puts the Gram operand sw * V into the binary16 range, see
+    // step 3); w itself is not kept -- the row pass gets the old w back as sw^2 / sc2, good to
+    // binary32, for the norm of the step that the stopping rule looks at.  The Gram tiles of the four
+    // slots are kept in the accumulator layout of the MFMA ([slot][tile pair][register][lane]) as
+    // binary64: the four waves add their binary32 partial tiles with ds_add_f64 -- ds_add_f32 takes
+    // 770 cycles per instruction on gfx950 against 34 (tools/lds_atomic_rate.hip).
+    double* vv   = lds;                          // [MCC][NP]   v
     double* rhs  = vv + MCC * NP;                // [MCC][NP]
     double* zz   = rhs + MCC * NP;               // [MCC][NP]
     double* gh   = zz + MCC * NP;                // [MCC][NP]
@@ -86,9 +88,12 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     double* hpart = vecI + NP * MCC;             // [NWV waves][MCC chains][NP]
     double* red  = hpart + NWV * MCC * NP;       // [NWV waves][32]
     double* ui   = red + NWV * 32;               // [nwp][MCC]
-    double* wi   = ui + (size_t)nwp * MCC;       // [nwp][MCC]
-    float*  wiF  = reinterpret_cast<float*>(wi + (size_t)nwp * MCC);   // [nwp][MCC] binary32 copy of w (Gram operand)
-    double* Hi   = wi + (size_t)nwp * MCC + (size_t)nwp * MCC / 2;    // [nwp][MCC]
+    // (the look-ahead of the fused pass reads up to MC_LOOKAHEAD_LDS entries past the end of Hi and of swF:
+    //  they land in swF and Wt, are never used, and need no padding)
+    double* Hi   = ui + (size_t)nwp * MCC;       // [nwp][MCC]
+    float*  swF  = reinterpret_cast<float*>(Hi + (size_t)nwp * MCC);    // [nwp][MCC]
+    double* Wt   = reinterpret_cast<double*>(swF + (size_t)nwp * MCC);  // [MCC][NPAIR][4][64]
+    static_assert(MCC * NPAIR * 256 * 2 >= MC_LOOKAHEAD_LDS, "the look-ahead stays inside the allocation");
     __shared__ int s_elem[MCC], s_kind[MCC], s_act[MCC], s_scr[MCC];
 
     // ---- slot state.  It is owned by the home wave, which loads it from LDS at the
@@ -96,17 +101,19 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     //      that no register is pinned by it during the two streaming passes. ----
     struct Slot {
         double alpha, mu, chi2, S, Hn2, wmax, Q, Qprev, cperp, steplim, muh;    // muh: damping the last damped step of this piece needed
+        double sc2;        // the power of two the sw in LDS (and the Gram tiles computed from it) carry
         int elem, prob0, clen, ia, niter, nevals, nact, active, scratch, okprev, bt, capp;
     };
     // the alphas of a slot's piece (a dependent global load in the accept step costs its full latency)
     constexpr int ACAP = 128;
     __shared__ double s_alpha[MCC][ACAP];
     __shared__ double s_sd[MCC][12];
+    __shared__ double s_scw[MCC][2];             // row pass: 1 / sc2 of the sw it reads, sc2 of the sw it writes
     __shared__ int s_si[MCC][12];
     auto load_slot = [&](Slot& t) {
         const double* d = s_sd[wave]; const int* n = s_si[wave];
         t.alpha = d[0]; t.mu = d[1]; t.chi2 = d[2]; t.S = d[3]; t.Hn2 = d[4]; t.wmax = d[5];
-        t.Q = d[6]; t.Qprev = d[7]; t.cperp = d[8]; t.steplim = d[9]; t.muh = d[10];
+        t.Q = d[6]; t.Qprev = d[7]; t.cperp = d[8]; t.steplim = d[9]; t.muh = d[10]; t.sc2 = d[11];
         t.elem = n[0]; t.prob0 = n[1]; t.clen = n[2]; t.ia = n[3]; t.niter = n[4]; t.nevals = n[5];
         t.nact = n[6]; t.active = n[7]; t.scratch = n[8]; t.okprev = n[9]; t.bt = n[10]; t.capp = n[11];
     };
@@ -114,7 +121,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         if (lane == 0) {
             double* d = s_sd[wave]; int* n = s_si[wave];
             d[0] = t.alpha; d[1] = t.mu; d[2] = t.chi2; d[3] = t.S; d[4] = t.Hn2; d[5] = t.wmax;
-            d[6] = t.Q; d[7] = t.Qprev; d[8] = t.cperp; d[9] = t.steplim; d[10] = t.muh;
+            d[6] = t.Q; d[7] = t.Qprev; d[8] = t.cperp; d[9] = t.steplim; d[10] = t.muh; d[11] = t.sc2;
             n[0] = t.elem; n[1] = t.prob0; n[2] = t.clen; n[3] = t.ia; n[4] = t.niter; n[5] = t.nevals;
             n[6] = t.nact; n[7] = t.active; n[8] = t.scratch; n[9] = t.okprev; n[10] = t.bt; n[11] = t.capp;
             s_act[wave] = t.active; s_scr[wave] = t.scratch;
@@ -130,7 +137,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         for (int i = lane; i < min(t.clen, ACAP); i += 64) s_alpha[wave][i] = p.alpha[(size_t)t.prob0 + i];
         t.alpha = p.alpha[(size_t)t.prob0];
         t.mu = 0.0; t.muh = 0.0; t.Qprev = __builtin_nan("");
-        t.chi2 = 0.0; t.S = 0.0; t.Hn2 = 1.0; t.wmax = 1.0; t.Q = 0.0;
+        t.chi2 = 0.0; t.S = 0.0; t.Hn2 = 1.0; t.wmax = 1.0; t.Q = 0.0; t.sc2 = 1.0;
         t.active = 1; t.scratch = 1;
         gh[wave * NP + lane] = p.ghat[(size_t)t.elem * NP + lane];
         vv[wave * NP + lane] = p.v0[(size_t)p.chain_v0[c] * NP + lane];
@@ -157,7 +164,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         if (c >= 0) start_piece(t, c);
         else {
             // empty slot: evaluates v = 0 of a neighbour's element every round (finite, never used)
-            t = Slot{1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0};
+            t = Slot{1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0};
             gh[wave * NP + lane] = 0.0; vv[wave * NP + lane] = 0.0;
             if (lane == 0) { s_elem[wave] = -1; s_kind[wave] = 0; }
         }
@@ -204,26 +211,38 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     // factor through LDS, no back substitution (they were 4-5.6 k cycles of the 10-16 k per slot).
     // The solve only preconditions the (inexact) Newton step; rows >= n_act are identity rows.
     // ------------------------------------------------------------------
-    auto gj_home = [&](auto NTag, double a, int n_act) -> bool {
+    auto gj_home = [&](auto NTag, double a, int n_act, double isc2) -> bool {
         constexpr int N = decltype(NTag)::value;
         const int q = wave, i = lane;
-        const double* Wq = Wm + (size_t)q * NA * LD;
+        const double* Wq = Wt + (size_t)q * NPAIR * 256;
         const double* rq = rhs + q * NP;
         bool ok = true;
         const bool live = i < n_act;
         const double ci_ = live ? cc[i] : 0.0;
+        const double cis = ci_ * isc2;               // the tiles carry the factor sc2 of their operands
         double A[N];
         {
-            // W is kept as upper triangle + diagonal: entry (i, j) sits at [min][max].  All N loads are
-            // issued back to back (clamped lane index, selected afterwards)
+            // W is kept as the upper-triangular 16x16 tiles in the accumulator layout of the MFMA: entry
+            // (a, b), a <= b, sits in tile pair (a >> 4, b >> 4) at register a & 3, lane 16 ((a & 15) >> 2) +
+            // (b & 15).  Lane i needs (min(i, j), max(i, j)) for the static j: offset = (lane part) + (static
+            // part) on either side of the diagonal.  All N loads are issued back to back (clamped lane
+            // index, selected afterwards)
             const int ic = min(i, N - 1);
+            const int imt = ic >> 4, iri = ic & 15;
+            const int up_l = (imt * NT - imt * (imt - 1) / 2 - imt) * 256 + (iri & 3) * 64 + (iri >> 2) * 16;   // row ic, column j >= ic
+            const int lo_l = imt * 256 + iri;                                                                  // row j < ic, column ic
             double wr[N];
 #pragma unroll
-            for (int j = 0; j < N; ++j) wr[j] = Wq[min(j, ic) * LD + max(j, ic)];
+            for (int j = 0; j < N; ++j) {
+                const int jmt = j >> 4, jri = j & 15;
+                const int up_s = jmt * 256 + jri;
+                const int lo_s = (jmt * NT - jmt * (jmt - 1) / 2 - jmt) * 256 + (jri & 3) * 64 + (jri >> 2) * 16;
+                wr[j] = Wq[(j >= ic) ? up_l + up_s : lo_l + lo_s];
+            }
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 const double cj = wave_bcast(ci_, j);        // = c_j for j < n_act, else 0
-                double xv = ci_ * wr[j] * cj;                // 0 in the rows and columns >= n_act
+                double xv = cis * wr[j] * cj;                // 0 in the rows and columns >= n_act
                 if (j == i) xv = live ? xv + a : 1.0;
                 A[j] = xv;
             }
@@ -275,6 +294,17 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             int okflag = 0;
             double dk = 0.0;
             double dtot = 0.0;                       // total step from v of the trial point (dk: operand of the row pass)
+            // binary16 range of the Gram operands: the row pass of this round writes sw = sqrt(w sc2) with
+            // sc2 = 2^(8 - exponent of the largest w of the accepted point), so that sw <= 16 while w stays
+            // below that maximum and a w that grows 2^24-fold still converts to a finite binary16 (the
+            // conversion saturates beyond; such a trial point does not survive the test on Q)
+            const double isc2 = 1.0 / t.sc2;
+            {
+                const double wm = (t.wmax > 1e-290 && t.wmax < 1e290) ? t.wmax : 1.0;
+                const double sc2n = ldexp(1.0, 8 - ilogb(wm));
+                if (lane == 0) { s_scw[q][0] = isc2; s_scw[q][1] = sc2n; }
+                t.sc2 = sc2n;
+            }
             if (t.active && t.scratch) {
                 dk = vv[q * NP + k];                 // evaluation from scratch: the operand is v
             } else if (t.active && t.okprev == 3) {
@@ -297,12 +327,12 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 while (true) {
                     const double a = t.alpha + t.mu;
                     bool ok;
-                    if (na <= 16) ok = gj_home(std::integral_constant<int, 16>{}, a, na);
-                    else if (na <= 20) ok = gj_home(std::integral_constant<int, 20>{}, a, na);
-                    else if (na <= 24) ok = gj_home(std::integral_constant<int, 24>{}, a, na);
-                    else if (na <= 28) ok = gj_home(std::integral_constant<int, 28>{}, a, na);
-                    else if (NA <= 32 || na <= 32) ok = gj_home(std::integral_constant<int, 32>{}, a, na);
-                    else ok = gj_home(std::integral_constant<int, (NA > 32 ? NA : 32)>{}, a, na);
+                    if (na <= 16) ok = gj_home(std::integral_constant<int, 16>{}, a, na, isc2);
+                    else if (na <= 20) ok = gj_home(std::integral_constant<int, 20>{}, a, na, isc2);
+                    else if (na <= 24) ok = gj_home(std::integral_constant<int, 24>{}, a, na, isc2);
+                    else if (na <= 28) ok = gj_home(std::integral_constant<int, 28>{}, a, na, isc2);
+                    else if (NA <= 32 || na <= 32) ok = gj_home(std::integral_constant<int, 32>{}, a, na, isc2);
+                    else ok = gj_home(std::integral_constant<int, (NA > 32 ? NA : 32)>{}, a, na, isc2);
                     if (ok) {
                         double z = 0.0, nrm = 0.0;
                         if (k < na) { z = zz[q * NP + k]; nrm = z * (rhs[q * NP + k] - a * z); }
@@ -364,17 +394,17 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         {
             // the home waves are done with W / L of the previous iteration: zero it for the tile sums of step 3
             {
-                static_assert((MCC * NA * LD) % 2 == 0, "W is zeroed with 16-byte stores");
-                double2* Wz = reinterpret_cast<double2*>(Wm);
+                double2* Wz = reinterpret_cast<double2*>(Wt);
 #pragma unroll
-                for (int idx = 0; idx < (MCC * NA * LD / 2 + T - 1) / T; ++idx)
-                    if (tid + idx * T < MCC * NA * LD / 2) Wz[tid + idx * T] = double2{0.0, 0.0};
+                for (int idx = 0; idx < (MCC * NPAIR * 128 + T - 1) / T; ++idx)
+                    if (tid + idx * T < MCC * NPAIR * 128) Wz[tid + idx * T] = double2{0.0, 0.0};
             }
             const int j = lane & 3;                              // slot of this lane's results
             const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4);      // result row inside the tile
             const int ak = lane >> 4;                            // operand k inside the chunk
             const bool scr_j = s_scr[j] != 0;
             const bool pm_j = s_kind[j] != 0;
+            const double isc_old = s_scw[j][0], sc_new = s_scw[j][1];
             const double* Dj = p.D + (size_t)((s_elem[j] >= 0) ? s_elem[j] : any_elem) * nwp;
             double pS = 0.0, pdH = 0.0, pHn = 0.0, pwm = 0.0, pdu = 0.0;
             const int nblk = nwp >> 5;                           // blocks of 32 omega rows = two 16-row tiles
@@ -398,7 +428,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     acc[tt] = 0.0;
                     Dv[tt] = Dj[row];
                     uo[tt] = ui[row * MCC + j];
-                    wo[tt] = wi[row * MCC + j];
+                    { const float so = swF[row * MCC + j]; wo[tt] = (double)(so * so) * isc_old; }
                 }
                 // V^T operand: row 4 kc + ak of V^T; the blocks of a batch are 32 NWV rows apart (V^T is
                 // padded behind its last row for a partial batch)
@@ -447,8 +477,8 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                             Sq += Hm - Di + Hm * uq;
                         }
                         if (row >= nw) { Hq = 0.0; wq = 0.0; Sq = 0.0; }
-                        ui[row * MCC + j] = uq; wi[row * MCC + j] = wq; Hi[row * MCC + j] = Hq;
-                        wiF[row * MCC + j] = (float)wq;
+                        ui[row * MCC + j] = uq; Hi[row * MCC + j] = Hq;
+                        swF[row * MCC + j] = __builtin_sqrtf(fminf((float)(wq * sc_new), 3.0e38f));
                         pS += Sq;
                         pHn = fma(Hq, Hq, pHn);
                         pwm = fmax(pwm, wq);                      // NaN-ignoring; non-finite states are caught through Q
@@ -469,20 +499,30 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         __syncthreads();                         // Hi, wi, ui and the partial sums complete
         MXE_STAMPW(7);
 
-        // ---- 3. fused pass (V once): h = V^T H and W = V_a^T diag(w) V_a, both on the matrix pipes ----
+        // ---- 3. fused pass (V once): h = V^T H (binary64) and W = V_a^T diag(w) V_a (split binary16) ----
         {
-            // The Gram matrix only preconditions the Newton step (the residual rho that defines the
-            // answer comes from h, binary64): its tiles are accumulated on the binary32 matrix pipe
-            // (v_mfma_f32_16x16x4_f32: 32 cycles per 16x16x4 instead of 64), operands converted from the
-            // same binary64 registers of V that feed h; w comes as the binary32 copy the row pass wrote.
-            // Relative error ~1e-6 of sqrt(W_ii W_jj), next to the decoupling threshold theta = 1e-5
-            // that the Newton matrix carries anyway (MC_GRAM_ERR in the stopping estimate).
             // h_q = V^T H_q of the four slots is v_mfma_f64_4x4x4 (four blocks per instruction: block b =
             // columns 16 t + 4 b .. + 3 of V, the four slots as columns, K = the 4 omega rows of the
-            // group) from the SAME operand registers: A[b][i][k] (lane 16 k + 4 b + i) = V[i0 + k][16 t + 4 b + i]
-            // is exactly f[t]; B[b][k][j] (lane 16 k + 4 b + j) = H[i0 + k][slot j] is one 8-byte LDS read;
+            // group): A[b][i][k] (lane 16 k + 4 b + i) = V[i0 + k][16 t + 4 b + i] is the register f[t] the
+            // lane loaded; B[b][k][j] (lane 16 k + 4 b + j) = H[i0 + k][slot j] is one 8-byte LDS read;
             // D[b][i][j] lands on lane 16 i + 4 b + j: one accumulator per tile and no cross-lane sum.
+            //
+            // The Gram matrix only preconditions the Newton step (the residual rho that defines the answer
+            // comes from h, binary64).  On gfx950 the binary32 and binary64 MFMAs run at the rate of -- and
+            // instead of -- the SIMD's vector instructions; the binary16 / bfloat16 ones have a pipe of their
+            // own, 16 times faster.  So the tiles are W = X^T X with X = diag(sw) V_a, sw = sqrt(w sc2) (the
+            // row pass wrote it), every element of X split into two binary16 numbers, x = hi + lo (hi: x
+            // rounded towards zero, lo: the remainder; 21 bits together), and
+            //     X^T X ~ hi^T hi + hi^T lo + lo^T hi                 (three v_mfma_f32_16x16x32_f16,
+            // binary32 accumulation; the dropped lo^T lo is 2^-20 of it).  Measured against binary64 on the
+            // weights of the BASELINE spectra: 5e-7 of sqrt(W_ii W_jj) (binary32 MFMA: 1e-7; theta = 1e-5).
+            // Operand layout of 16x16x32: lane (g = l >> 4, m = l & 15) holds A[m][8 g + e] / B[8 g + e][m],
+            // e = 0..7.  A and B are the same matrix here, so ANY assignment of omega rows to (g, e) sums
+            // over the right products as long as both operands use it: element e of lane (g, m) is row
+            // 4 (row group e of the trip) + g, column 16 t + m -- exactly the registers the h product uses.
             typedef float g4 __attribute__((ext_vector_type(4)));
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            typedef unsigned u4v __attribute__((ext_vector_type(4)));
             g4 acc[MCC][NPAIR];
             double hp[4];
 #pragma unroll
@@ -492,63 +532,30 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 #pragma unroll
             for (int t = 0; t < 4; ++t) hp[t] = 0.0;
             const int kq = lane >> 4, cn = lane & 15;
-            const int n_groups = nwp >> 2;           // 4 omega rows per MFMA; multiple of 16
-            const double* Vl = V + (size_t)kq * NP + cn;
-            struct HW { double h; float4 w; };       // H of slot (lane & 3), w of the four slots, row i0 + kq
-            struct OP { float ff[NT]; float a[MCC][NT]; };    // binary32 Gram operands of one row group
+            const int n_groups = nwp >> 2;           // 4 omega rows per group; multiple of 32
+            struct HW { double h; float4 w; };       // H of slot (lane & 3), sw of the four slots, row i0 + kq
             auto loadHW = [&](HW& hw, const double* hsrc, const float* wsrc) {
                 hw.h = hsrc[0];
                 hw.w = *reinterpret_cast<const float4*>(wsrc);
             };
-            auto prep = [&](OP& o, const double (&f)[4], const HW& hw) {
-                const float wq[MCC] = {hw.w.x, hw.w.y, hw.w.z, hw.w.w};
-#pragma unroll
-                for (int t = 0; t < NT; ++t) o.ff[t] = (float)f[t];
-#pragma unroll
-                for (int c = 0; c < MCC; ++c)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) o.a[c][t] = o.ff[t] * wq[c];
-            };
-            auto mma = [&](const OP& o, const double (&f)[4], const HW& hw) {
-#ifdef MXE_X_NO_GRAM      // timing experiment only (results are wrong)
-                acc[0][0][0] += o.a[0][0] + o.a[1][1] + o.a[2][0] + o.a[3][1];
-#else
-#pragma unroll
-                for (int c = 0; c < MCC; ++c) {
-                    int pr = 0;
-#pragma unroll
-                    for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-                        for (int nt = mt; nt < NT; ++nt) {
-                            acc[c][pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[c][mt], o.ff[nt], acc[c][pr], 0, 0, 0);
-                            ++pr;
-                        }
-                }
-#endif
-#pragma unroll
-                for (int t = 0; t < 4; ++t) hp[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(f[t], hw.h, hp[t], 0, 0, 0);
-            };
-            // The waves take groups wave, wave + NWV, ...  Software pipeline, no branch inside: the 12 + 4
-            // MFMAs of group j back to back, then the vector instructions that build the binary32
-            // operands of group j + 1 (on gfx950 a wave's vector instructions do not issue in the shadow
-            // of its own MFMAs, tools/mfma_shadow.hip; a row group costs 464 cycles of MFMA plus its
-            // vector and memory instructions, ~720 in all).  V comes through a ring of DEPTH register sets
-            // (DEPTH - 1 row groups in flight), H / w from LDS two groups ahead.  n_groups is a multiple
-            // of DEPTH * NWV (n_omega_pad is a multiple of 128) and every load is unconditional: the
-            // look-ahead past the end reads the zero rows behind V and the padding behind H in LDS, and
-            // what is prepared from them is never multiplied.
+            // The waves take groups wave, wave + 4, ...; a trip = 8 row groups = one K = 32 step of the Gram
+            // tiles.  V comes through a ring of DEPTH register sets (DEPTH - 1 row groups in flight), H / sw
+            // from LDS two groups ahead.  n_groups is a multiple of 8 * 4 (n_omega_pad is a multiple of 128)
+            // and every load is unconditional: the look-ahead past the end reads the zero rows behind V and
+            // the padding behind H / sw in LDS and is not used.
             constexpr int ST = NWV;
-            constexpr int DEPTH = (NWV == 4 && MXE_X_WGPC == 1) ? 8 : 4;
-            static_assert(DEPTH % 4 == 0, "the H / w ring of four is indexed statically across trips");
+            constexpr int TRIP = 8;
+            constexpr int DEPTH = MC_FUSED_DEPTH;
+            static_assert(TRIP % DEPTH == 0 && DEPTH >= 2, "ring indices are static across trips");
             int g = wave;
             {
                 double fr[DEPTH][4];
                 HW hr[4];
-                OP op[2];
+                u4v xh[MCC][NT], xl[MCC][NT];        // packed binary16 hi / lo parts, element e = row group e of the trip
+                float xe[MCC][NT];                   // the even row group of a pair waits for the odd one
                 // V through buffer loads: one resource descriptor for the data set's V (wave-uniform), one
                 // 32-bit lane offset, the position of the row group as a SCALAR offset -- the loop carries
-                // no 64-bit vector address arithmetic (it was four v_add_co / v_addc pairs with their
-                // hazard slots per row group)
+                // no 64-bit vector address arithmetic
                 typedef unsigned u2v __attribute__((ext_vector_type(2)));
                 const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, 0x7fffffff, 0x00020000);
                 const int loff = (kq * NP + cn) * 8;                  // bytes
@@ -559,31 +566,60 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         f[t] = __hiloint2double((int)v2.y, (int)v2.x);
                     }
                 };
-                constexpr size_t VSTEP = (size_t)4 * ST * NP;        // doubles per group step (V)
-                constexpr int HSTEP = 4 * ST * MCC;                  // ... (H, w in LDS)
+                constexpr int VSTEPB = 4 * ST * NP * 8;              // bytes per group step (V)
+                constexpr int HSTEP = 4 * ST * MCC;                  // entries per group step (H, sw in LDS)
                 int vp = 4 * __builtin_amdgcn_readfirstlane(g) * NP * 8;          // byte offset of the wave's first row group (uniform)
                 const double* hb = Hi + (size_t)(4 * g + kq) * MCC + (lane & 3);
-                const float* wb = wiF + (size_t)(4 * g + kq) * MCC;
+                const float* wb = swF + (size_t)(4 * g + kq) * MCC;
 #pragma unroll
-                for (int j = 0; j < DEPTH - 1; ++j) loadV(fr[j], vp + j * (int)(VSTEP * 8));
+                for (int j = 0; j < DEPTH - 1; ++j) loadV(fr[j], vp + j * VSTEPB);
                 loadHW(hr[0], hb, wb);
                 loadHW(hr[1], hb + HSTEP, wb + HSTEP);
-                prep(op[0], fr[0], hr[0]);
-                for (; g < n_groups; g += DEPTH * ST, vp += DEPTH * (int)(VSTEP * 8), hb += DEPTH * HSTEP, wb += DEPTH * HSTEP) {
+                for (; g < n_groups; g += TRIP * ST, vp += TRIP * VSTEPB, hb += TRIP * HSTEP, wb += TRIP * HSTEP) {
 #pragma unroll
-                    for (int j = 0; j < DEPTH; ++j) {
-#ifndef MXE_X_NO_VLOAD     // timing experiment only (results are wrong)
-                        loadV(fr[(j + DEPTH - 1) % DEPTH], vp + (j + DEPTH - 1) * (int)(VSTEP * 8));
-#endif
+                    for (int j = 0; j < TRIP; ++j) {
+                        loadV(fr[(j + DEPTH - 1) % DEPTH], vp + (j + DEPTH - 1) * VSTEPB);
                         loadHW(hr[(j + 2) & 3], hb + (j + 2) * HSTEP, wb + (j + 2) * HSTEP);
-                        // blocks, not a mix (measured, tools/mfma_shadow.hip: a vector instruction placed
-                        // BETWEEN two MFMAs costs 14 cycles, behind the block 7): memory and vector
-                        // instructions of the step first, then the 16 MFMAs back to back
-                        prep(op[(j + 1) & 1], fr[(j + 1) % DEPTH], hr[(j + 1) & 3]);
-                        __builtin_amdgcn_sched_barrier(0);
-                        mma(op[j & 1], fr[j], hr[j & 3]);
-                        __builtin_amdgcn_sched_barrier(0);
+                        const double (&f)[4] = fr[j % DEPTH];
+                        const HW& hw = hr[j & 3];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) hp[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(f[t], hw.h, hp[t], 0, 0, 0);
+                        const float sw[MCC] = {hw.w.x, hw.w.y, hw.w.z, hw.w.w};
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const float ff = (float)f[t];
+#pragma unroll
+                            for (int c = 0; c < MCC; ++c) {
+                                const float xv = ff * sw[c];
+                                if (j & 1) {
+                                    const float x0 = xe[c][t];
+                                    const auto hh = __builtin_amdgcn_cvt_pkrtz(x0, xv);
+                                    const auto ll = __builtin_amdgcn_cvt_pkrtz(x0 - (float)hh[0], xv - (float)hh[1]);
+                                    xh[c][t][j >> 1] = __builtin_bit_cast(unsigned, hh);
+                                    xl[c][t][j >> 1] = __builtin_bit_cast(unsigned, ll);
+                                } else {
+                                    xe[c][t] = xv;
+                                }
+                            }
+                        }
                     }
+                    // the K = 32 step of every tile: hi^T hi, hi^T lo, lo^T hi (independent accumulators between
+                    // the dependent ones)
+#pragma unroll
+                    for (int prod = 0; prod < 3; ++prod)
+#pragma unroll
+                        for (int c = 0; c < MCC; ++c) {
+                            int pr = 0;
+#pragma unroll
+                            for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                                for (int nt = mt; nt < NT; ++nt) {
+                                    const h8 a = __builtin_bit_cast(h8, prod == 2 ? xl[c][mt] : xh[c][mt]);
+                                    const h8 b = __builtin_bit_cast(h8, prod == 1 ? xl[c][nt] : xh[c][nt]);
+                                    acc[c][pr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[c][pr], 0, 0, 0);
+                                    ++pr;
+                                }
+                        }
                 }
             }
             MXE_STAMPW(1);
@@ -594,28 +630,18 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 for (int t = 0; t < 4; ++t) hpart[(wave * MCC + hj) * NP + 16 * t + hcol] = hp[t];
             }
             MXE_STAMPW(6);
-            // Gram tiles: every wave adds its partial tiles into the slots' W with LDS atomics
-            // (ds_add_f64; W was zeroed at the start of the row pass), one barrier instead of four
-            // rotating read-modify-write phases
+            // Gram tiles: every wave adds its partial tiles into the slots' tiles with LDS atomics
+            // (ds_add_f64, one lane-contiguous instruction per accumulator register; the tiles were zeroed
+            // at the start of the row pass)
             {
-                typedef __attribute__((address_space(3))) double lds_double;
 #pragma unroll
-                for (int c = 0; c < MCC; ++c) {
-                    double* Wq = Wm + (size_t)c * NA * LD;
-                    int pr = 0;
+                for (int c = 0; c < MCC; ++c)
 #pragma unroll
-                    for (int mt = 0; mt < NT; ++mt)
+                    for (int pr = 0; pr < NPAIR; ++pr)
 #pragma unroll
-                        for (int nt = mt; nt < NT; ++nt) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                // C/D layout of v_mfma_f32_16x16x4_f32: row 4 (l >> 4) + r, col l & 15
-                                const int row = 16 * mt + 4 * kq + r, col = 16 * nt + cn;
-                                __builtin_amdgcn_ds_atomic_fadd_f64((lds_double*)(Wq + row * LD + col), (double)acc[c][pr][r]);
-                            }
-                            ++pr;
-                        }
-                }
+                        for (int r = 0; r < 4; ++r)
+                            __hip_atomic_fetch_add(Wt + ((c * NPAIR + pr) * 4 + r) * 64 + lane, (double)acc[c][pr][r],
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             __syncthreads();
         }

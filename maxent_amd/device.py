@@ -43,7 +43,8 @@ class MxeOpts(ctypes.Structure):
                 ('alpha_split', ctypes.c_int32),
                 ('stop_estimate', ctypes.c_int32),
                 ('precision', ctypes.c_int32),
-                ('reserved', ctypes.c_int32)]
+                ('reserved', ctypes.c_int32),
+                ('chi2_factor', ctypes.c_double)]
 
 
 _dp = ctypes.POINTER(ctypes.c_double)
