@@ -219,6 +219,46 @@ const char* mxe_last_kernel_name(mxe_ctx* ctx);
 int  mxe_last_launch_info(mxe_ctx* ctx, int* waves_per_chain, int* n_workgroups,
                           int* lds_bytes);
 
+/* ---- the cost function and its derivatives at caller-supplied points --- */
+/* Device side of CostFunction.__call__ / f / d / dd (cost_function.py:73-85),
+ * MaxEntCostFunction.f/dH/d/ddH/dd (maxent_cost_function.py:68-165), BryanCostFunction.f/d/dd
+ * (bryan_cost_function.py:57-128) and of the component functions NormalChi2, NormalEntropy /
+ * PlusMinusEntropy, NormalH_of_v / PlusMinusH_of_v (functions.py:336-796), for a batch of P points.
+ *   elem_of_problem[p]  element (its G, err, D, entropy) the point belongs to
+ *   alpha_scaled[p]     alpha * scale_alpha (>= 0)
+ *   x                   input_is_H = 0: v, [P][n_s], the caller's singular basis
+ *                       input_is_H = 1: the hidden image H itself, [P][n_omega] (the component functions
+ *                       chi2(H), S(H) and H_of_v.inv: u = log(H/D) | log((H + sqrt(H^2 + 4 D^2)) / 2D))
+ *   chi2_factor         eta in Q = eta chi2 / 2 - alpha S
+ * Outputs (host, any may be NULL):
+ *   out_Q, out_chi2, out_S [P];  out_H, out_u (= V v), out_w (= dH/du), out_q (= V g = dQ/dH) [P][n_omega];
+ *   out_h = V^T H, out_g = eta (M h - b) + alpha v  [P][n_s]     (input_is_H: no alpha v term)
+ *   out_W  = V^T diag(w) V,  out_W2 = V^T diag((V g) H) V        [P][n_s][n_s]
+ * from which every derivative of the reference follows with M = S U^T diag(1/err^2) U S:
+ *   default (dA_projection = 2):  d = W g        dd = W M' W + alpha W       (M' = eta M)
+ *   dA_projection = 1:            d = g          dd = M' W + alpha I
+ *   dA_projection = 0:            d = V g        dd = V M' W + alpha V       (n_omega rows)
+ *   d_dv = True:                  d = W g        dd = W M' W + alpha W + W2
+ *   BryanCostFunction:            d = g          dd = M' W
+ *   dQ/dH = V g;  dchi2/dH = 2 V (M h - b);  dS/dH = -u;  d2S/dH2 = -diag(1/w);  dH/dv = diag(w) V */
+int  mxe_eval_batch(mxe_ctx* ctx, int P, const int32_t* elem_of_problem, const double* alpha_scaled,
+                    const double* x, int input_is_H, double chi2_factor,
+                    double* out_Q, double* out_chi2, double* out_S,
+                    double* out_H, double* out_u, double* out_w, double* out_q,
+                    double* out_h, double* out_g, double* out_W, double* out_W2);
+/* NormalEntropy / PlusMinusEntropy as functions of a hidden image given directly (functions.py:508-520,
+ * 544-564): S, dS/dH and the diagonal of d2S/dH2 for P images H [P][n_omega] and one default model D
+ * [n_omega] (including delta-omega).  No context needed; outputs may be NULL. */
+int  mxe_entropy(int device, int kind, int n_omega, int P, const double* H, const double* D,
+                 double* out_S, double* out_dS, double* out_ddS);
+/* Audit of the last launch, every problem, binary64, all n_s directions (no active-subspace cut, no
+ * binary16 tiles): at the returned v the exact Newton correction delta of Bryan's system is computed and
+ *   out_corr[p] = ||w * V delta||_2 / ||H||_2   -- to first order the relative L2 distance of the
+ *                 returned H from the minimiser (the quantity mxe_opts.tol_h bounds by an estimate)
+ *   out_gmax[p] = max_k |g_k| / (|c_k rho_k| + |alpha v_k|)  -- the gradient against its cancelling terms
+ * [n_chain][n_alpha]; either may be NULL. */
+int  mxe_audit(mxe_ctx* ctx, double* out_corr, double* out_gmax);
+
 /* ---- output map A = B H (PreblurA_of_H.f, functions.py:999-1001) ------- */
 /* B: n_omega x n_omega row-major.  Applies to the device-resident H of the
  * last solve; result n_problem x n_omega to host. */

@@ -1,58 +1,53 @@
-"""Alpha meshes: descending arrays of the hyper-parameter.
+"""Alpha meshes: the hyper-parameter values of a scan, largest first.
 
-Public names and semantics of the reference's ``alpha_meshes`` module
-(reference python/alpha_meshes.py:26-103).
+Public names and constructor arguments of the reference's ``alpha_meshes`` module
+(reference python/alpha_meshes.py:26-103), built on :class:`maxent_amd.meshes.Mesh`.
 """
 
 import numpy as np
 
-
-class BaseAlphaMesh(np.ndarray):
-    def __new__(cls, alpha_min=0.0001, alpha_max=20, n_points=20, *args,
-                **kwargs):
-        return super(BaseAlphaMesh, cls).__new__(cls, shape=(n_points,))
-
-    def __init__(self, alpha_min=0.0001, alpha_max=20, n_points=20):
-        if n_points > 1:
-            if alpha_min > alpha_max:
-                raise Exception('alpha_min must be smaller than alpha_max')
-            if (alpha_min <= 0) or (alpha_max <= 0):
-                raise Exception('All alpha values must be positive')
-        self.alpha_min = alpha_min
-        self.alpha_max = alpha_max
-        self.n_points = n_points
-
-    def __array_finalize__(self, obj):
-        for name in ('alpha_min', 'alpha_max', 'n_points'):
-            if obj is not None and hasattr(obj, name):
-                setattr(self, name, getattr(obj, name))
+from .meshes import Mesh
 
 
-class DataAlphaMesh(BaseAlphaMesh):
-    """user-supplied values, sorted descending (alpha_meshes.py:46-65)."""
+class BaseAlphaMesh(Mesh):
+    _defaults = dict(alpha_min=0.0001, alpha_max=20, n_points=20)
+    _spacing = None
 
-    def __new__(cls, data):
-        return super(DataAlphaMesh, cls).__new__(cls, np.min(data),
-                                                 np.max(data), len(data))
+    @classmethod
+    def _check(cls, alpha_min=None, alpha_max=None, n_points=None, **rest):
+        if alpha_min is None or n_points is None or n_points <= 1:
+            return
+        if alpha_min > alpha_max:
+            raise Exception('alpha_min must be smaller than alpha_max')
+        if min(alpha_min, alpha_max) <= 0:
+            raise Exception('All alpha values must be positive')
 
-    def __init__(self, data):
-        super(DataAlphaMesh, self).__init__(np.min(data), np.max(data),
-                                            len(data))
-        self[:] = sorted(data, reverse=True)
+    @classmethod
+    def _points(cls, alpha_min, alpha_max, n_points):
+        ascending = np.zeros(n_points) if cls._spacing is None else cls._spacing(alpha_min, alpha_max, n_points)
+        return ascending[::-1], dict(alpha_min=alpha_min, alpha_max=alpha_max, n_points=n_points)
 
 
 class LogAlphaMesh(BaseAlphaMesh):
-    """logarithmic spacing, largest first (alpha_meshes.py:68-85)."""
-
-    def __init__(self, alpha_min=0.0001, alpha_max=20, n_points=20):
-        super(LogAlphaMesh, self).__init__(alpha_min, alpha_max, n_points)
-        self[:] = np.logspace(np.log10(alpha_min), np.log10(alpha_max),
-                              n_points)[::-1]
+    """equidistant in log(alpha) (alpha_meshes.py:68-85)"""
+    _spacing = staticmethod(lambda lo, hi, n: np.logspace(np.log10(lo), np.log10(hi), n))
 
 
 class LinearAlphaMesh(BaseAlphaMesh):
-    """linear spacing, largest first (alpha_meshes.py:88-103)."""
+    """equidistant in alpha (alpha_meshes.py:88-103)"""
+    _spacing = staticmethod(np.linspace)
 
-    def __init__(self, alpha_min=0.0001, alpha_max=20, n_points=20):
-        super(LinearAlphaMesh, self).__init__(alpha_min, alpha_max, n_points)
-        self[:] = np.linspace(alpha_min, alpha_max, n_points)[::-1]
+
+class DataAlphaMesh(BaseAlphaMesh):
+    """the user's own values, sorted (alpha_meshes.py:46-65)"""
+    _defaults = dict(data=None)
+
+    @classmethod
+    def _check(cls, data=None):
+        if data is None:
+            raise TypeError('DataAlphaMesh needs the alpha values')
+
+    @classmethod
+    def _points(cls, data):
+        data = np.sort(np.asarray(data, dtype=float))
+        return data[::-1], dict(alpha_min=data[0], alpha_max=data[-1], n_points=len(data))

@@ -1011,6 +1011,213 @@ try {
 }
 MXE_CATCH_ALL
 
+// stream + device buffers of a context-free entry point, released on every path
+namespace {
+struct SvdScratch {
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<void*> bufs;
+    template <typename T> hipError_t alloc(T** p, size_t count) {
+        hipError_t e = hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) bufs.push_back((void*)*p);
+        return e;
+    }
+    ~SvdScratch() {
+        for (void* b : bufs) hipFree(b);
+        if (e0) hipEventDestroy(e0);
+        if (e1) hipEventDestroy(e1);
+        if (stream) hipStreamDestroy(stream);
+    }
+};
+#define SVDCHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { \
+    fprintf(stderr, "[mxe] %s: %s\n", #call, hipGetErrorString(e__)); return MXE_ERR_HIP; } } while (0)
+} // namespace
+
+// ---- cost function and derivatives at caller-supplied points; audit of a launch ----------
+namespace {
+size_t eval_lds_bytes(int NP, int nwp) { return ((size_t)NP * (NP + 1) + 2 * (size_t)nwp + 7 * (size_t)NP + 16) * sizeof(double); }
+
+int launch_eval(mxe_ctx* ctx, const mxe::EvalParams& ep, size_t P)
+{
+    const size_t lds = eval_lds_bytes(ctx->NP, ctx->nwp);
+    if (lds > 160 * 1024) return MXE_ERR_LIMIT;
+    hipError_t e;
+#define MXE_LAUNCH_EVAL(NT_) do { \
+        e = hipFuncSetAttribute((const void*)mxe::eval_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) { hipLaunchKernelGGL((mxe::eval_kernel<NT_>), dim3((unsigned)P), dim3(256), lds, ctx->stream, ep); \
+                               e = hipGetLastError(); } } while (0)
+    if (ctx->NP == 64) MXE_LAUNCH_EVAL(4); else MXE_LAUNCH_EVAL(8);
+#undef MXE_LAUNCH_EVAL
+    HIPCHK(ctx, e);
+    return MXE_OK;
+}
+
+void eval_params_base(mxe_ctx* ctx, mxe::EvalParams& ep)
+{
+    std::memset(&ep, 0, sizeof(ep));
+    ep.nw = ctx->n_omega; ep.nwp = ctx->nwp; ep.ns = ctx->n_s; ep.NP = ctx->NP;
+    ep.V = ctx->dV.p; ep.Vt = ctx->dVt.p; ep.c = ctx->dc.p;
+    ep.elem_ds = ctx->delem_ds.p; ep.elem_kind = ctx->delem_kind.p;
+    ep.ghat = ctx->dghat.p; ep.cperp = ctx->dcperp.p; ep.D = ctx->dD.p;
+    ep.eta = 1.0; ep.elem_div = 1;
+}
+} // namespace
+
+extern "C" int mxe_eval_batch(mxe_ctx* ctx, int P, const int32_t* elem_of_problem, const double* alpha_scaled,
+                              const double* x, int input_is_H, double chi2_factor,
+                              double* out_Q, double* out_chi2, double* out_S,
+                              double* out_H, double* out_u, double* out_w, double* out_q,
+                              double* out_h, double* out_g, double* out_W, double* out_W2)
+try {
+    if (!ctx || P < 1 || !elem_of_problem || !alpha_scaled || !x) return MXE_ERR_ARG;
+    if (ctx->n_elem < 1) return MXE_ERR_STATE;
+    if (!(chi2_factor > 0.0) || !std::isfinite(chi2_factor)) return MXE_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->ds_dirty) { int rc = upload_bases(ctx); if (rc != MXE_OK) return rc; }
+    const int ns = ctx->n_s, NP = ctx->NP, nw = ctx->n_omega;
+    const size_t xs = input_is_H ? (size_t)nw : (size_t)NP;
+    std::vector<double> hx((size_t)P * xs, 0.0);
+    for (int p = 0; p < P; ++p) {
+        const int e = elem_of_problem[p];
+        if (e < 0 || e >= ctx->n_elem) return MXE_ERR_ARG;
+        if (!(alpha_scaled[p] >= 0.0) || !std::isfinite(alpha_scaled[p])) return MXE_ERR_ARG;
+        if (input_is_H) { std::copy(x + (size_t)p * nw, x + (size_t)(p + 1) * nw, hx.begin() + (size_t)p * nw); continue; }
+        const DataSet& DS = ctx->ds[ctx->elem_ds[e]];
+        for (int k = 0; k < ns; ++k) {
+            double s;
+            if (DS.identity_q) s = x[(size_t)p * ns + k];
+            else { s = 0.0; for (int j = 0; j < ns; ++j) s += DS.Q[(size_t)j * ns + k] * x[(size_t)p * ns + j]; }   // v' = Q^T v
+            hx[(size_t)p * NP + k] = s;
+        }
+    }
+    const bool wantW = out_W != nullptr, wantW2 = out_W2 != nullptr;
+    HIPCHK(ctx, ctx->ev_x.ensure(hx.size()));
+    HIPCHK(ctx, ctx->ev_alpha.ensure(P));
+    HIPCHK(ctx, ctx->ev_elem.ensure(P));
+    HIPCHK(ctx, ctx->ev_scal.ensure((size_t)5 * P));
+    HIPCHK(ctx, ctx->ev_vecw.ensure((size_t)4 * P * nw));
+    HIPCHK(ctx, ctx->ev_vecs.ensure((size_t)2 * P * NP));
+    HIPCHK(ctx, ctx->ev_mat.ensure((size_t)(wantW ? 1 : 0) * P * NP * NP + (size_t)(wantW2 ? 1 : 0) * P * NP * NP));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ev_x.p, hx.data(), hx.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ev_alpha.p, alpha_scaled, (size_t)P * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ev_elem.p, elem_of_problem, (size_t)P * 4, hipMemcpyHostToDevice, ctx->stream));
+    mxe::EvalParams ep;
+    eval_params_base(ctx, ep);
+    ep.elem = ctx->ev_elem.p; ep.alpha = ctx->ev_alpha.p; ep.x = ctx->ev_x.p; ep.x_stride = (int)xs;
+    ep.input_is_H = input_is_H ? 1 : 0; ep.eta = chi2_factor;
+    ep.want_gram = wantW; ep.want_gram2 = wantW2;
+    ep.Q = ctx->ev_scal.p; ep.chi2 = ep.Q + P; ep.S = ep.chi2 + P;
+    ep.H = ctx->ev_vecw.p; ep.u = ep.H + (size_t)P * nw; ep.w = ep.u + (size_t)P * nw;
+    ep.q = out_q ? ep.w + (size_t)P * nw : nullptr;
+    ep.h = ctx->ev_vecs.p; ep.g = ep.h + (size_t)P * NP;
+    ep.W = wantW ? ctx->ev_mat.p : nullptr;
+    ep.W2 = wantW2 ? ctx->ev_mat.p + (size_t)(wantW ? 1 : 0) * P * NP * NP : nullptr;
+    int rc = launch_eval(ctx, ep, (size_t)P);
+    if (rc != MXE_OK) return rc;
+    if (out_Q) HIPCHK(ctx, hipMemcpyAsync(out_Q, ep.Q, (size_t)P * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_chi2) HIPCHK(ctx, hipMemcpyAsync(out_chi2, ep.chi2, (size_t)P * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_S) HIPCHK(ctx, hipMemcpyAsync(out_S, ep.S, (size_t)P * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_H) HIPCHK(ctx, hipMemcpyAsync(out_H, ep.H, (size_t)P * nw * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_u) HIPCHK(ctx, hipMemcpyAsync(out_u, ep.u, (size_t)P * nw * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_w) HIPCHK(ctx, hipMemcpyAsync(out_w, ep.w, (size_t)P * nw * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_q) HIPCHK(ctx, hipMemcpyAsync(out_q, ep.q, (size_t)P * nw * 8, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<double> hh, hg, hW, hW2;
+    if (out_h) { hh.resize((size_t)P * NP); HIPCHK(ctx, hipMemcpyAsync(hh.data(), ep.h, hh.size() * 8, hipMemcpyDeviceToHost, ctx->stream)); }
+    if (out_g) { hg.resize((size_t)P * NP); HIPCHK(ctx, hipMemcpyAsync(hg.data(), ep.g, hg.size() * 8, hipMemcpyDeviceToHost, ctx->stream)); }
+    if (wantW) { hW.resize((size_t)P * NP * NP); HIPCHK(ctx, hipMemcpyAsync(hW.data(), ep.W, hW.size() * 8, hipMemcpyDeviceToHost, ctx->stream)); }
+    if (wantW2) { hW2.resize((size_t)P * NP * NP); HIPCHK(ctx, hipMemcpyAsync(hW2.data(), ep.W2, hW2.size() * 8, hipMemcpyDeviceToHost, ctx->stream)); }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // whitened basis -> caller basis:  x = Q x',  X = Q X' Q^T
+    std::vector<double> tmp((size_t)ns * ns);
+    for (int p = 0; p < P; ++p) {
+        const DataSet& DS = ctx->ds[ctx->elem_ds[elem_of_problem[p]]];
+        auto vec_out = [&](const std::vector<double>& src, double* dst) {
+            for (int k = 0; k < ns; ++k) {
+                double s;
+                if (DS.identity_q) s = src[(size_t)p * NP + k];
+                else { s = 0.0; for (int j = 0; j < ns; ++j) s += DS.Q[(size_t)k * ns + j] * src[(size_t)p * NP + j]; }
+                dst[(size_t)p * ns + k] = s;
+            }
+        };
+        auto mat_out = [&](const std::vector<double>& src, double* dst) {
+            const double* Xp = src.data() + (size_t)p * NP * NP;
+            double* out = dst + (size_t)p * ns * ns;
+            if (DS.identity_q) {
+                for (int i = 0; i < ns; ++i) for (int j = 0; j < ns; ++j) out[(size_t)i * ns + j] = Xp[(size_t)i * NP + j];
+                return;
+            }
+            for (int i = 0; i < ns; ++i) for (int j = 0; j < ns; ++j) {        // tmp = X' Q^T
+                double s = 0.0;
+                for (int k = 0; k < ns; ++k) s += Xp[(size_t)i * NP + k] * DS.Q[(size_t)j * ns + k];
+                tmp[(size_t)i * ns + j] = s;
+            }
+            for (int i = 0; i < ns; ++i) for (int j = 0; j < ns; ++j) {        // out = Q tmp
+                double s = 0.0;
+                for (int k = 0; k < ns; ++k) s += DS.Q[(size_t)i * ns + k] * tmp[(size_t)k * ns + j];
+                out[(size_t)i * ns + j] = s;
+            }
+        };
+        if (out_h) vec_out(hh, out_h);
+        if (out_g) vec_out(hg, out_g);
+        if (wantW) mat_out(hW, out_W);
+        if (wantW2) mat_out(hW2, out_W2);
+    }
+    return MXE_OK;
+}
+MXE_CATCH_ALL
+
+extern "C" int mxe_entropy(int device, int kind, int n_omega, int P, const double* H, const double* D,
+                           double* out_S, double* out_dS, double* out_ddS)
+try {
+    if (n_omega < 1 || P < 1 || !H || !D || (kind != MXE_ENTROPY_NORMAL && kind != MXE_ENTROPY_PLUSMINUS)) return MXE_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MXE_ERR_NODEVICE;
+    if (device < 0 || device >= ndev) return MXE_ERR_ARG;
+    SvdScratch sc;                    // stream + buffers released on every path
+    SVDCHK(hipSetDevice(device));
+    SVDCHK(hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking));
+    const size_t n = n_omega;
+    double *dH, *dD, *dS, *dd, *ddd;
+    SVDCHK(sc.alloc(&dH, (size_t)P * n)); SVDCHK(sc.alloc(&dD, n)); SVDCHK(sc.alloc(&dS, (size_t)P));
+    SVDCHK(sc.alloc(&dd, (size_t)P * n)); SVDCHK(sc.alloc(&ddd, (size_t)P * n));
+    SVDCHK(hipMemcpyAsync(dH, H, (size_t)P * n * 8, hipMemcpyHostToDevice, sc.stream));
+    SVDCHK(hipMemcpyAsync(dD, D, n * 8, hipMemcpyHostToDevice, sc.stream));
+    hipLaunchKernelGGL(mxe::entropy_kernel, dim3((unsigned)P), dim3(256), 0, sc.stream, kind, n_omega, dH, dD, dS, dd, ddd);
+    SVDCHK(hipGetLastError());
+    if (out_S) SVDCHK(hipMemcpyAsync(out_S, dS, (size_t)P * 8, hipMemcpyDeviceToHost, sc.stream));
+    if (out_dS) SVDCHK(hipMemcpyAsync(out_dS, dd, (size_t)P * n * 8, hipMemcpyDeviceToHost, sc.stream));
+    if (out_ddS) SVDCHK(hipMemcpyAsync(out_ddS, ddd, (size_t)P * n * 8, hipMemcpyDeviceToHost, sc.stream));
+    SVDCHK(hipStreamSynchronize(sc.stream));
+    return MXE_OK;
+}
+MXE_CATCH_ALL
+
+extern "C" int mxe_audit(mxe_ctx* ctx, double* out_corr, double* out_gmax)
+try {
+    if (!ctx || (!out_corr && !out_gmax)) return MXE_ERR_ARG;
+    if (!ctx->launched) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)ctx->n_chain * ctx->n_alpha;
+    HIPCHK(ctx, ctx->ev_scal.ensure(2 * P));
+    HIPCHK(ctx, ctx->dparent_elem.ensure(ctx->chain_elem.size()));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dparent_elem.p, ctx->chain_elem.data(), ctx->chain_elem.size() * sizeof(int),
+                               hipMemcpyHostToDevice, ctx->stream));
+    mxe::EvalParams ep;
+    eval_params_base(ctx, ep);
+    ep.elem = ctx->dparent_elem.p; ep.elem_div = ctx->n_alpha;
+    ep.alpha = ctx->dalpha.p;                 // alpha / eta, as the chain kernel iterated on it
+    ep.x = ctx->dout_v.p; ep.x_stride = ctx->NP;
+    ep.want_audit = 1;
+    ep.corr = ctx->ev_scal.p; ep.gmax = ctx->ev_scal.p + P;
+    int rc = launch_eval(ctx, ep, P);
+    if (rc != MXE_OK) return rc;
+    if (out_corr) HIPCHK(ctx, hipMemcpyAsync(out_corr, ep.corr, P * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_gmax) HIPCHK(ctx, hipMemcpyAsync(out_gmax, ep.gmax, P * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MXE_OK;
+}
+MXE_CATCH_ALL
+
 // ---- output map A = B H ----------------------------------------------------
 namespace mxe {
 // one workgroup per problem; thread j computes A_j = sum_k B[j][k] H[k]
@@ -1060,26 +1267,6 @@ MXE_CATCH_ALL
 // ---- kernel matrix staging on the device: fill, preblur product, truncated SVD -------------
 #include "mxe_svd.hip.h"
 
-namespace {
-struct SvdScratch {
-    hipStream_t stream = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    std::vector<void*> bufs;
-    template <typename T> hipError_t alloc(T** p, size_t count) {
-        hipError_t e = hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T));
-        if (e == hipSuccess) bufs.push_back((void*)*p);
-        return e;
-    }
-    ~SvdScratch() {
-        for (void* b : bufs) hipFree(b);
-        if (e0) hipEventDestroy(e0);
-        if (e1) hipEventDestroy(e1);
-        if (stream) hipStreamDestroy(stream);
-    }
-};
-#define SVDCHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { \
-    fprintf(stderr, "[mxe] %s: %s\n", #call, hipGetErrorString(e__)); return MXE_ERR_HIP; } } while (0)
-} // namespace
 
 extern "C" int mxe_kernel_svd(int device, int n_tau, int n_omega, const double* tau, const double* omega,
                               const double* delta, double beta, int n_b, const double* preblur_b,

@@ -41,7 +41,7 @@ struct EvalParams {
     int want_gram, want_gram2, want_audit;
     // outputs (device; any may be null)
     double* Q; double* chi2; double* S;         // [P]
-    double* H; double* u; double* w;            // [P][nw]
+    double* H; double* u; double* w; double* q; // [P][nw]   q = V g = dQ/dH
     double* h; double* g;                       // [P][NP]  whitened basis
     double* W; double* W2;                      // [P][NP][NP] whitened basis, full symmetric
     double* corr; double* gmax;                 // [P] audit: ||w * V delta|| / ||H||, max |g_k| / (|eta c rho|_k + |alpha v|_k)
@@ -226,6 +226,13 @@ void eval_kernel(const EvalParams ep)
         if (ep.Q) ep.Q[prob] = 0.5 * eta * chi2 - a * Sval;
         if (ep.gmax) ep.gmax[prob] = gm;
     }
+    if (ep.q) {
+        for (int i = tid; i < nw; i += 256) {
+            double q = 0.0;
+            for (int k = 0; k < ns; ++k) q = fma(Vt[(size_t)k * nwp + i], gsh[k], q);
+            ep.q[prob * nw + i] = q;
+        }
+    }
     if (!(ep.want_gram || ep.want_gram2 || ep.want_audit)) return;
     // ---- W ----
     if (ep.want_gram || ep.want_audit) {
@@ -306,6 +313,39 @@ void eval_kernel(const EvalParams ep)
             ep.W2[prob * NP * NP + idx] = (i < ns && j < ns) ? Bm[i * LD + j] : 0.0;
         }
     }
+}
+
+// ---- entropy of a hidden image given directly (NormalEntropy / PlusMinusEntropy .f/.d/.dd, functions.py:508-520,
+//      544-564, with their safelog): one workgroup per image
+__global__ __launch_bounds__(256)
+void entropy_kernel(int kind, int n, const double* __restrict__ H, const double* __restrict__ D,
+                    double* __restrict__ outS, double* __restrict__ outd, double* __restrict__ outdd)
+{
+    __shared__ double red[4];
+    const size_t p = blockIdx.x;
+    auto slog = [](double x) { return log(fabs(x) > 1e-100 ? x : 1e-100); };
+    double acc[1] = {0.0};
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double h = H[p * n + i], d = D[i];
+        double Sv, dS, wsum;
+        if (kind == 0) {
+            Sv = h - d - h * slog(h / d);
+            dS = -(slog(h) - slog(d));
+            wsum = h;
+        } else {
+            const double r = sqrt(h * h + 4.0 * d * d);
+            const double hp = 0.5 * (r + h), hm = 0.5 * (r - h);
+            Sv = (hp - d - hp * slog(hp / d)) + (hm - d - hm * slog(hm / d));
+            dS = -(slog(hp) - slog(d));
+            wsum = hp + hm;
+        }
+        if (!(fabs(wsum) > 1e-100)) wsum = 1e-100;
+        acc[0] += Sv;
+        if (outd) outd[p * n + i] = dS;
+        if (outdd) outdd[p * n + i] = -1.0 / wsum;
+    }
+    eval_block_sum<1>(acc, red);
+    if (threadIdx.x == 0 && outS) outS[p] = acc[0];
 }
 
 } // namespace mxe

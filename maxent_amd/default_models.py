@@ -1,7 +1,8 @@
-"""Default models D(omega); ``.D`` already contains delta-omega.
-
-Public names and semantics of the reference's ``default_models`` module
-(reference python/default_models.py:26-115).
+"""Default models.  ``model.D`` is the density times delta-omega, the quantity
+the entropy is written in (reference python/default_models.py:26-115; public
+names and constructor arguments as there).  A model is its density function;
+the product with the mesh weights is formed on demand and dropped whenever the
+mesh changes (``parameter_change``).
 """
 
 import numpy as np
@@ -10,64 +11,53 @@ import numpy as np
 class BaseDefaultModel(object):
     def __init__(self, omega):
         self.omega = omega
-        self._D = None
+
+    def density(self, omega):
+        raise NotImplementedError('Use a subclass of BaseDefaultModel')
+
+    def parameter_change(self):
+        self.__dict__.pop('_D', None)
+
+    _fill_values = parameter_change
 
     @property
     def D(self):
+        if '_D' not in self.__dict__ or self.__dict__.get('_D_for') is not self.omega:
+            self._D = np.asarray(self.density(self.omega), dtype=float) * self.omega.delta
+            self._D_for = self.omega
         return self._D
 
-    def parameter_change(self):
-        self._fill_values()
-
-    def _fill_values(self):
-        raise NotImplementedError('Use a subclass of BaseDefaultModel')
-
     def __len__(self):
-        return len(self._D)
+        return len(self.omega)
 
 
 class FlatDefaultModel(BaseDefaultModel):
-    """D_i = delta_i / sum(delta) (default_models.py:48-63)."""
+    """constant density, normalised on the mesh (default_models.py:48-63)"""
 
-    def __init__(self, omega):
-        super(FlatDefaultModel, self).__init__(omega)
-        self._fill_values()
-
-    def _fill_values(self):
-        delta = self.omega.delta
-        self._D = np.ones(len(delta)) / np.sum(delta) * delta
+    def density(self, omega):
+        return np.full(len(omega), 1.0 / np.sum(omega.delta))
 
 
 class DataDefaultModel(BaseDefaultModel):
-    """tabulated default model, interpolated onto ``omega`` if needed
-    (default_models.py:66-93)."""
+    """tabulated density ``default`` on ``omega_in``; linear interpolation onto another mesh
+    (default_models.py:66-93)"""
 
     def __init__(self, default, omega_in, omega=None):
-        if omega is None:
-            omega = omega_in
-        super(DataDefaultModel, self).__init__(omega)
-        self.omega_in = omega_in
-        self.default = default
-        self._fill_values()
+        self.default, self.omega_in = default, omega_in
+        super(DataDefaultModel, self).__init__(omega_in if omega is None else omega)
 
-    def _fill_values(self):
-        same = len(self.omega_in) == len(self.omega) and \
-            np.all(np.asarray(self.omega_in) == np.asarray(self.omega))
-        if same:
-            D = np.asarray(self.default, dtype=float)
-        else:
-            D = np.interp(np.asarray(self.omega), np.asarray(self.omega_in),
-                          np.asarray(self.default, dtype=float))
-        self._D = D * self.omega.delta
+    def density(self, omega):
+        src, dst = np.asarray(self.omega_in, dtype=float), np.asarray(omega, dtype=float)
+        table = np.asarray(self.default, dtype=float)
+        if src.shape == dst.shape and np.array_equal(src, dst):
+            return table
+        return np.interp(dst, src, table)
 
 
 class FileDefaultModel(DataDefaultModel):
-    """two-column text file: omega, D (default_models.py:96-115; the
-    reference's constructor is broken, this one works)."""
+    """text file with the columns omega, density (default_models.py:96-115)"""
 
     def __init__(self, filename, omega=None):
         from .omega_meshes import DataOmegaMesh
-        data = np.loadtxt(filename)
-        super(FileDefaultModel, self).__init__(
-            default=data[:, 1], omega_in=DataOmegaMesh(data[:, 0]),
-            omega=omega)
+        table = np.loadtxt(filename)
+        super(FileDefaultModel, self).__init__(table[:, 1], DataOmegaMesh(table[:, 0]), omega)

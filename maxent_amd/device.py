@@ -91,6 +91,9 @@ SYMBOLS = [
     ('mxe_last_launch_info', ctypes.c_int, [_vp] +
      [ctypes.POINTER(ctypes.c_int)] * 3),
     ('mxe_apply_output_map', ctypes.c_int, [_vp, _dp, _dp]),
+    ('mxe_eval_batch', ctypes.c_int, [_vp, ctypes.c_int, _ip, _dp, _dp, ctypes.c_int, ctypes.c_double] + [_dp] * 11),
+    ('mxe_entropy', ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp]),
+    ('mxe_audit', ctypes.c_int, [_vp, _dp, _dp]),
     ('mxe_kernel_svd', ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp,
                                       ctypes.c_double, ctypes.c_int, _dp, ctypes.c_double,
                                       ctypes.c_int, _dp, _dp, _dp, _dp, _ip, _ip,
@@ -187,6 +190,23 @@ def kernel_svd(tau, omega, delta, beta, preblur_b=(0.0,), threshold=1.e-14,
                         K=(K[ib] if want_K else None), qr_rank=int(info[ib, 0]),
                         sweeps=int(info[ib, 1]), ms=float(ms.value)))
     return out
+
+
+def entropy(kind, H, D, device=0):
+    """``mxe_entropy``: S, dS/dH and diag(d2S/dH2) of hidden images given directly; ``H``: (P, n) or (n,)."""
+    lib = load_library()
+    if device_count() < 1:
+        raise MaxEntDeviceError('no HIP device visible; the entropy functions have no CPU fallback')
+    H2 = _c(np.atleast_2d(H))
+    D = _c(D)
+    P, n = H2.shape
+    S, dS, ddS = np.empty(P), np.empty((P, n)), np.empty((P, n))
+    rc = lib.mxe_entropy(int(device), int(kind), n, P, _p(H2), _p(D), _p(S), _p(dS), _p(ddS))
+    if rc != 0:
+        raise MaxEntDeviceError('mxe_entropy failed: ' + lib.mxe_strerror(rc).decode())
+    if np.ndim(H) == 1:
+        return S[0], dS[0], ddS[0]
+    return S, dS, ddS
 
 
 class DeviceContext(object):
@@ -345,6 +365,36 @@ class DeviceContext(object):
         self.upload_chains(elem_of_chain, alpha_scaled, v0, opts)
         self.launch()
         return self.fetch(want_v, want_H)
+
+    def eval_batch(self, elem_of_problem, alpha_scaled, x, input_is_H=False, chi2_factor=1.0,
+                   want=('Q', 'chi2', 'S', 'H', 'g', 'W')):
+        """``mxe_eval_batch``: cost function and derivative ingredients at caller-supplied points.
+        ``x``: (P, n_s) vectors v, or (P, n_omega) hidden images with ``input_is_H``.  ``want``: any of
+        Q, chi2, S, H, u, w, q, h, g, W, W2.  Returns a dict of arrays."""
+        el = _c(np.atleast_1d(elem_of_problem), np.int32)
+        P = len(el)
+        al = _c(np.broadcast_to(np.asarray(alpha_scaled, dtype=float), (P,)))
+        x = _c(x).reshape(P, self.n_omega if input_is_H else self.n_s)
+        shapes = dict(Q=(P,), chi2=(P,), S=(P,), H=(P, self.n_omega), u=(P, self.n_omega),
+                      w=(P, self.n_omega), q=(P, self.n_omega), h=(P, self.n_s), g=(P, self.n_s),
+                      W=(P, self.n_s, self.n_s), W2=(P, self.n_s, self.n_s))
+        out = {}
+        for k in want:
+            if k not in shapes:
+                raise TypeError('unknown output {!r}'.format(k))
+            out[k] = np.empty(shapes[k])
+        args = [_p(out.get(k)) for k in ('Q', 'chi2', 'S', 'H', 'u', 'w', 'q', 'h', 'g', 'W', 'W2')]
+        self._check(self._lib.mxe_eval_batch(self._h, P, _p(el), _p(al), _p(x), int(bool(input_is_H)),
+                                             float(chi2_factor), *args), 'mxe_eval_batch')
+        return out
+
+    def audit(self):
+        """``mxe_audit``: exact Newton correction size and relative gradient of every problem of the
+        last launch, each [n_chain][n_alpha]."""
+        corr = np.empty((self._n_chain, self._n_alpha))
+        gmax = np.empty((self._n_chain, self._n_alpha))
+        self._check(self._lib.mxe_audit(self._h, _p(corr), _p(gmax)), 'mxe_audit')
+        return dict(corr=corr, gmax=gmax)
 
     def apply_output_map(self, B):
         B = _c(B).reshape(self.n_omega, self.n_omega)

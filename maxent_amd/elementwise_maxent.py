@@ -151,7 +151,8 @@ class ElementwiseMaxEnt(object):
             res.start_timing(element, cidx, time=t0)
         sols, info = solve_elements(loop.K, specs, loop.minimizer,
                                     device_id=loop.device_id,
-                                    want_logdet=loop.probability is not None)
+                                    want_logdet=loop.probability is not None,
+                                    chi2_factor=loop.cost_function.chi2_factor)
         self.last_launches.append(info)
         t1 = datetime.now()
         per_alpha = (t1 - t0) / max(1, len(specs) * len(specs[0]['alpha']))

@@ -47,7 +47,7 @@ class _LazyProduct(object):
 
 
 def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0,
-                   want_logdet=False):
+                   want_logdet=False, chi2_factor=1.0):
     """Solve the alpha scans of several elements in ONE kernel launch.
 
     ``K``: kernel whose singular space has been reduced (U, S, V staged once).
@@ -91,7 +91,7 @@ def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0,
         ctx.set_elements(ds_ids, [s['G'] for s in specs],
                          np.stack([np.asarray(s['D'], dtype=float) for s in specs]),
                          [s['kind'] for s in specs])
-        opts = minimizer.to_opts(waves_per_chain=waves_per_chain)
+        opts = minimizer.to_opts(waves_per_chain=waves_per_chain, chi2_factor=float(chi2_factor))
         out = ctx.solve_chains(np.arange(len(specs), dtype=np.int32),
                                np.stack([np.asarray(s['alpha'], dtype=float) for s in specs]),
                                np.stack([np.asarray(s['v0'], dtype=float) for s in specs]),
@@ -131,7 +131,7 @@ def solve_single(cost_function, v0, minimizer, device_id=0):
     spec = dict(G=cf.G, err=cf.err, U_rot=(K.U if K._T is not None else None),
                 D=cf.D.D, kind=cf.entropy_kind, v0=np.asarray(v0, dtype=float),
                 alpha=np.array([cf._alpha], dtype=float))
-    res, _ = solve_elements(K, [spec], minimizer, device_id=device_id)
+    res, _ = solve_elements(K, [spec], minimizer, device_id=device_id, chi2_factor=cf.chi2_factor)
     r = res[0]
     return r['v'][0], dict(n_iter=r['n_iter'][0], converged=r['converged'][0])
 
@@ -283,6 +283,33 @@ class MaxEntLoop(object):
         self.minimizer.n_iter += int(np.sum(sol['n_iter']))
         self.minimizer.converged = bool(sol['converged'][-1])
 
+    def scan_with_user_minimizer(self, spec):
+        """The reference's loop body (maxent_loop.py:241-266) for a minimiser that is not the device
+        solver: any object with ``minimize(function, v0) -> v`` (minimizers/minimizer.py:23-28).  It works
+        on the device-evaluated cost function (``f`` / ``d`` / ``dd`` are ``mxe_eval_batch`` calls), one
+        alpha after the other, warm started; ``n_iter_last`` and ``converged`` are read off the minimiser
+        where it has them."""
+        cf = self.cost_function
+        v = np.array(spec['v0'], dtype=float)
+        keys = ('v', 'H', 'chi2', 'S', 'Q', 'n_iter', 'converged')
+        rows = dict((k, []) for k in keys)
+        for a in spec['alpha']:
+            cf.set_alpha(float(a))
+            v = np.array(self.minimizer.minimize(cf, v), dtype=float)
+            at = cf(v)
+            rows['v'].append(v.copy())
+            rows['H'].append(np.array(at.H_of_v.f()))
+            rows['chi2'].append(at.chi2.f())
+            rows['S'].append(at.S.f())
+            rows['Q'].append(at.f())
+            rows['n_iter'].append(int(getattr(self.minimizer, 'n_iter_last', 0)))
+            rows['converged'].append(bool(getattr(self.minimizer, 'converged', True)))
+        sol = dict((k, np.array(rows[k])) for k in keys)
+        sol['alpha'] = np.asarray(spec['alpha'], dtype=float)
+        sol['n_evals'] = sol['n_iter']
+        sol['A'] = None
+        return sol
+
     # ---- main entry ------------------------------------------------------
     def run(self, result=None, matrix_element=None, complex_index=None):
         """Run the alpha scan; returns the :class:`MaxEntResult` (or None if
@@ -311,11 +338,15 @@ class MaxEntLoop(object):
         self.check_consistency()
         result.start_timing(matrix_element, complex_index)
         t0 = datetime.now()
-        sols, info = solve_elements(self.K, [spec], self.minimizer,
-                                    want_logdet=self.probability is not None,
-                                    device_id=self.device_id)
+        if hasattr(self.minimizer, 'to_opts'):
+            sols, info = solve_elements(self.K, [spec], self.minimizer,
+                                        want_logdet=self.probability is not None,
+                                        device_id=self.device_id,
+                                        chi2_factor=self.cost_function.chi2_factor)
+            sol = sols[0]
+        else:
+            sol, info = self.scan_with_user_minimizer(spec), dict(kernel_ms=0.0)
         self.last_launch = info
-        sol = sols[0]
         self.log_alpha_lines(sol)
         rec = self.make_record(spec, sol)
         dt = (datetime.now() - t0) / max(len(sol['alpha']), 1)
@@ -352,64 +383,21 @@ class MaxEntLoop(object):
         if remove is not None:
             self.logtaker.verbose &= ~remove
 
-    # attribute forwarding to the cost function (maxent_loop.py:384-502)
-    def _fwd(name):                                            # noqa: N805
-        def getter(self):
-            return getattr(self.cost_function, 'get_' + name)()
 
-        def setter(self, value):
-            getattr(self.cost_function, 'set_' + name)(value)
-        return getter, setter
+# the parameters of the problem live in the cost function; the loop offers them under the same names
+# (get_X / set_X / property X; reference maxent_loop.py:384-502)
+def _forwarded(name):
+    def getter(self):
+        return getattr(self.cost_function, 'get_' + name)()
 
-    get_K, _set_K = _fwd('K')
-    get_G, _set_G = _fwd('G')
-    get_err, _set_err = _fwd('err')
-    get_omega, _set_omega = _fwd('omega')
-    get_data_variable, _set_dv = _fwd('data_variable')
-    get_D, _set_D = _fwd('D')
-    get_chi2, _set_chi2 = _fwd('chi2')
-    get_S, _set_S = _fwd('S')
-    get_H_of_v, _set_H_of_v = _fwd('H_of_v')
-    get_A_of_H, _set_A_of_H = _fwd('A_of_H')
-    del _fwd
+    def setter(self, value, **update_flags):
+        getattr(self.cost_function, 'set_' + name)(value, **update_flags)
+    return getter, setter
 
-    def set_K(self, K, **kw):
-        self.cost_function.set_K(K, **kw)
 
-    def set_G(self, G, **kw):
-        self.cost_function.set_G(G, **kw)
-
-    def set_err(self, err, **kw):
-        self.cost_function.set_err(err, **kw)
-
-    def set_omega(self, omega, **kw):
-        self.cost_function.set_omega(omega, **kw)
-
-    def set_data_variable(self, data_variable, **kw):
-        self.cost_function.set_data_variable(data_variable, **kw)
-
-    def set_D(self, D, **kw):
-        self.cost_function.set_D(D, **kw)
-
-    def set_chi2(self, chi2, **kw):
-        self.cost_function.set_chi2(chi2, **kw)
-
-    def set_S(self, S, **kw):
-        self.cost_function.set_S(S, **kw)
-
-    def set_H_of_v(self, H_of_v, **kw):
-        self.cost_function.set_H_of_v(H_of_v, **kw)
-
-    def set_A_of_H(self, A_of_H, **kw):
-        self.cost_function.set_A_of_H(A_of_H, **kw)
-
-    K = property(get_K, set_K)
-    G = property(get_G, set_G)
-    err = property(get_err, set_err)
-    omega = property(get_omega, set_omega)
-    data_variable = property(get_data_variable, set_data_variable)
-    D = property(get_D, set_D)
-    chi2 = property(get_chi2, set_chi2)
-    S = property(get_S, set_S)
-    H_of_v = property(get_H_of_v, set_H_of_v)
-    A_of_H = property(get_A_of_H, set_A_of_H)
+for _name in ('K', 'G', 'err', 'omega', 'data_variable', 'D', 'chi2', 'S', 'H_of_v', 'A_of_H'):
+    _get, _set = _forwarded(_name)
+    setattr(MaxEntLoop, 'get_' + _name, _get)
+    setattr(MaxEntLoop, 'set_' + _name, _set)
+    setattr(MaxEntLoop, _name, property(_get, _set))
+del _name, _get, _set

@@ -1,119 +1,95 @@
-"""Frequency meshes (host-side inputs of the alpha scan).
+"""Frequency meshes.
 
-Same public names and semantics as the reference's ``omega_meshes`` module
-(reference python/omega_meshes.py:25-222): ndarray subclasses carrying
-``omega_min``, ``omega_max``, ``n_points`` and a lazily computed trapezoid
-weight vector ``delta``.
+Public names, constructor arguments and point sets of the reference's
+``omega_meshes`` module (reference python/omega_meshes.py:25-222); the attribute
+``delta`` holds the trapezoid weights (:54-62).  Built on :class:`maxent_amd.meshes.Mesh`:
+each class is its point formula.
 """
 
 import numpy as np
 
+from .meshes import Mesh
 
-class BaseOmegaMesh(np.ndarray):
-    """ndarray of frequencies with trapezoid weights ``delta``
-    (reference omega_meshes.py:25-62)."""
 
-    def __new__(cls, omega_min=-10, omega_max=10, n_points=100, *args,
-                **kwargs):
-        return super(BaseOmegaMesh, cls).__new__(cls, shape=(n_points,))
+class BaseOmegaMesh(Mesh):
+    _defaults = dict(omega_min=-10, omega_max=10, n_points=100)
 
-    def __init__(self, omega_min=-10, omega_max=10, n_points=100, *args,
-                 **kwargs):
-        if omega_min > omega_max:
+    @classmethod
+    def _check(cls, omega_min=None, omega_max=None, **rest):
+        if omega_min is not None and omega_max is not None and omega_min > omega_max:
             raise Exception('omega_min must be smaller than omega_max')
-        self.omega_min = omega_min
-        self.omega_max = omega_max
-        self.n_points = n_points
-        self._delta = None
 
-    def __array_finalize__(self, obj):
-        for name in ('omega_min', 'omega_max', 'n_points'):
-            if obj is not None and hasattr(obj, name):
-                setattr(self, name, getattr(obj, name))
-        self._delta = None
+    @classmethod
+    def _points(cls, omega_min, omega_max, n_points, **shape):
+        return cls._grid(omega_min, omega_max, n_points, **shape), \
+            dict(omega_min=omega_min, omega_max=omega_max, n_points=n_points, **shape)
+
+    @staticmethod
+    def _grid(lo, hi, n):
+        return np.zeros(n)
 
     @property
     def delta(self):
-        if self._delta is None:
+        """half the distance between the two neighbours (end points: half the first / last interval)"""
+        cached = self.__dict__.get('_delta')
+        if cached is None or len(cached) != len(self):
             w = np.asarray(self)
-            d = np.empty(len(w))
-            d[1:-1] = (w[2:] - w[:-2]) / 2.0
-            d[0] = (w[1] - w[0]) / 2.0
-            d[-1] = (w[-1] - w[-2]) / 2.0
-            self._delta = d
-        return self._delta
+            span = np.concatenate(([w[1] - w[0]], w[2:] - w[:-2], [w[-1] - w[-2]]))
+            cached = self.__dict__['_delta'] = 0.5 * span
+        return cached
 
 
 class LinearOmegaMesh(BaseOmegaMesh):
-    """equidistant mesh (reference omega_meshes.py:65-88)."""
-
-    def __init__(self, omega_min=-10, omega_max=10, n_points=100):
-        super(LinearOmegaMesh, self).__init__(omega_min, omega_max, n_points)
-        self[:] = np.linspace(omega_min, omega_max, n_points)
+    """equidistant (omega_meshes.py:65-88)"""
+    _grid = staticmethod(lambda lo, hi, n: np.linspace(lo, hi, n))
 
 
 class DataOmegaMesh(BaseOmegaMesh):
-    """mesh from a user array (reference omega_meshes.py:91-110)."""
+    """the user's own points (omega_meshes.py:91-110)"""
+    _defaults = dict(data=None)
 
-    def __new__(cls, data):
-        return super(DataOmegaMesh, cls).__new__(cls, np.min(data),
-                                                 np.max(data), len(data))
+    @classmethod
+    def _check(cls, data=None):
+        if data is None:
+            raise TypeError('DataOmegaMesh needs the mesh points')
 
-    def __init__(self, data):
-        super(DataOmegaMesh, self).__init__(np.min(data), np.max(data),
-                                            len(data))
-        self[:] = data
+    @classmethod
+    def _points(cls, data):
+        data = np.asarray(data, dtype=float)
+        return data, dict(omega_min=np.min(data), omega_max=np.max(data), n_points=len(data))
 
 
-def _lorentzian_points(omega_min, omega_max, n_points, cut):
-    u = np.linspace(0, 1, n_points + 1)
-    t = np.tan(np.pi * (u * (1. - 2 * cut) + cut - 0.5))
-    t = (t - t[0]) / (t[-1] - t[0])
-    w = omega_min + (omega_max - omega_min) * t
-    return (w[:-1] + w[1:]) / 2.0
+def _tan_midpoints(lo, hi, n, cut):
+    # midpoints of n intervals whose edges are tan-spaced between the cut-off angles
+    edges = np.tan(np.pi * (np.linspace(0, 1, n + 1) * (1. - 2 * cut) + cut - 0.5))
+    edges = lo + (hi - lo) * ((edges - edges[0]) / (edges[-1] - edges[0]))
+    return 0.5 * (edges[1:] + edges[:-1])
+
+
+def _onto(w, lo, hi):
+    # first point on lo, last on hi (the order of operations fixes the last bit of the points, and the
+    # kernel matrix is compared bit for bit with the reference's)
+    return (w - w[0]) / (w[-1] - w[0]) * (hi - lo) + lo
 
 
 class LorentzianOmegaMesh(BaseOmegaMesh):
-    """tan-spaced mesh, end points on omega_min/max
-    (reference omega_meshes.py:113-152)."""
-
-    def __init__(self, omega_min=-10, omega_max=10, n_points=100, cut=0.01):
-        super(LorentzianOmegaMesh, self).__init__(omega_min, omega_max,
-                                                  n_points)
-        self.cut = cut
-        w = _lorentzian_points(omega_min, omega_max, n_points, cut)
-        self[:] = (w - w[0]) / (w[-1] - w[0]) * (omega_max - omega_min) \
-            + omega_min
-
-    def __array_finalize__(self, obj):
-        super(LorentzianOmegaMesh, self).__array_finalize__(obj)
-        if obj is not None and hasattr(obj, 'cut'):
-            self.cut = obj.cut
+    """tan spacing, first and last point on omega_min / omega_max (omega_meshes.py:113-152)"""
+    _defaults = dict(omega_min=-10, omega_max=10, n_points=100, cut=0.01)
+    _grid = staticmethod(lambda lo, hi, n, cut: _onto(_tan_midpoints(lo, hi, n, cut), lo, hi))
 
 
 class LorentzianSmallerOmegaMesh(BaseOmegaMesh):
-    """tan-spaced mesh without the end-point rescaling
-    (reference omega_meshes.py:155-196)."""
+    """tan spacing, the interval midpoints as they are (omega_meshes.py:155-196)"""
+    _defaults = dict(omega_min=-10, omega_max=10, n_points=100, cut=0.01)
+    _grid = staticmethod(_tan_midpoints)
 
-    def __init__(self, omega_min=-10, omega_max=10, n_points=100, cut=0.01):
-        super(LorentzianSmallerOmegaMesh, self).__init__(omega_min, omega_max,
-                                                         n_points)
-        self.cut = cut
-        self[:] = _lorentzian_points(omega_min, omega_max, n_points, cut)
 
-    def __array_finalize__(self, obj):
-        super(LorentzianSmallerOmegaMesh, self).__array_finalize__(obj)
-        if obj is not None and hasattr(obj, 'cut'):
-            self.cut = obj.cut
+def _hyperbola(lo, hi, n):
+    u = np.linspace(-1, 1, n)
+    w = np.sign(u) * (np.sqrt(1 + u ** 2) - 1)
+    return lo + (hi - lo) * (w - w[0]) / (w[-1] - w[0])
 
 
 class HyperbolicOmegaMesh(BaseOmegaMesh):
-    """sign(u)(sqrt(1+u^2)-1) spacing (reference omega_meshes.py:199-222)."""
-
-    def __init__(self, omega_min=-10, omega_max=10, n_points=100):
-        super(HyperbolicOmegaMesh, self).__init__(omega_min, omega_max,
-                                                  n_points)
-        u = np.linspace(-1, 1, n_points)
-        w = np.sign(u) * (np.sqrt(1 + u ** 2) - 1)
-        self[:] = omega_min + (omega_max - omega_min) * (w - w[0]) / \
-            (w[-1] - w[0])
+    """sign(u) (sqrt(1 + u^2) - 1), u equidistant in [-1, 1] (omega_meshes.py:199-222)"""
+    _grid = staticmethod(_hyperbola)

@@ -47,82 +47,100 @@ class TauMaxEnt(object):
 
     set_G_iw = set_G_tau
 
-    # ---- data ------------------------------------------------------------
+    # ---- data, errors and the rotation of the data space -------------------
+    # State: ``G`` (the data as the solver sees them, possibly rotated), ``cost_function._G_orig``
+    # (as supplied) and the absolute rotation ``K._T`` of the kernel (None: unrotated).  Two moves:
+    # ``_adopt_data`` -- new data arrive in the original basis and are brought into the current
+    # rotation; ``_rotate_to`` -- data and kernel go from the current rotation to another one.
+    # (reference tau_maxent.py:181-325)
+
+    @staticmethod
+    def _hop(T_to, T_from):
+        """matrix that takes data from rotation ``T_from`` to rotation ``T_to`` (None = unrotated)"""
+        back = None if T_from is None else T_from.conjugate().transpose()
+        if T_to is None:
+            return back
+        return T_to if back is None else np.dot(T_to, back)
+
+    def _move_data(self, hop):
+        if hop is not None:
+            self.G = np.dot(hop, self.G)
+
+    def _announce_kernel(self, T):
+        self.K.transform(T)          # sets K._T
+        self.K = self.K              # chi2 and H_of_v hear about the changed kernel
+
+    def _adopt_data(self, keep_rotation=True):
+        T = self._T if keep_rotation else None
+        self.cost_function._G_orig = copy.deepcopy(self.G)
+        self._move_data(self._hop(T, None))
+        self._announce_kernel(T)
+
+    def _rotate_to(self, T):
+        self._move_data(self._hop(T, self._T))
+        self._announce_kernel(T)
+
+    def _transform(self, T_, G_original_basis=False):
+        """the reference's name for the two moves (tau_maxent.py:303-325)"""
+        if G_original_basis:
+            self.cost_function._G_orig = copy.deepcopy(self.G)
+            self._move_data(self._hop(T_, None))
+            self._announce_kernel(T_)
+        else:
+            self._rotate_to(T_)
+
     def set_G_tau_data(self, tau, G_tau):
-        """G(tau) from arrays (reference tau_maxent.py:181-196)."""
-        assert len(tau) == len(G_tau), \
-            "tau and G_tau don't have the same dimension"
-        self.tau = tau
-        self.G = G_tau
-        self._transform(self._T, G_original_basis=True)
+        """G(tau) from arrays (reference tau_maxent.py:181-196)"""
+        if len(tau) != len(G_tau):
+            raise AssertionError("tau and G_tau don't have the same dimension")
+        self.tau, self.G = tau, G_tau
+        self._adopt_data()
 
     def set_G_tau_file(self, filename, tau_col=0, G_col=1, err_col=None):
-        """G(tau) (and optionally its error) from a text file
-        (reference tau_maxent.py:198-225)."""
-        dat = np.loadtxt(filename)
-        self.tau = dat[:, tau_col]
-        self.G = dat[:, G_col]
+        """G(tau), optionally with its error bar, from the columns of a text file
+        (reference tau_maxent.py:198-225); a file that brings errors ends any rotation"""
+        table = np.loadtxt(filename)
+        self.tau, self.G = table[:, tau_col], table[:, G_col]
         if err_col is not None:
-            self.err = dat[:, err_col]
-            self._transform(None, G_original_basis=True)
-        else:
-            self._transform(self._T, G_original_basis=True)
+            self.err = table[:, err_col]
+        self._adopt_data(keep_rotation=err_col is None)
 
     def set_error(self, error):
-        """scalar or per-tau standard deviation; undoes a covariance rotation
-        (reference tau_maxent.py:227-251)."""
+        """one standard deviation for all tau or one per tau; ends a covariance rotation
+        (reference tau_maxent.py:227-251)"""
         if not np.all(np.isreal(error)):
             raise Exception('complex error supplied, only real accepted')
-        error = np.real(error)
-        if np.ndim(error) == 0:
-            self.err = float(error) * np.ones(np.shape(self.G))
-        elif len(error) == len(self.G):
-            self.err = np.asarray(error, dtype=float)
-        else:
+        sigma = np.real(error) * np.ones(np.shape(self.G)) if np.ndim(error) == 0 \
+            else np.asarray(np.real(error), dtype=float)
+        if sigma.shape != np.shape(self.G):
             raise Exception('Supply scalar error or with length of G_tau.')
-        self._transform(None)
+        self.err = sigma
+        self._rotate_to(None)
 
     def set_cov(self, cov):
-        """full covariance matrix: diagonalise, drop eigenvalues below
-        ``cov_threshold``, rotate G and K into the eigenbasis, use
-        sqrt(eigenvalues) as errors (reference tau_maxent.py:253-288)."""
+        """Full covariance matrix of the data (reference tau_maxent.py:253-288): the problem is rotated
+        into the eigenbasis of ``cov`` (eigenvalues below ``cov_threshold`` dropped), where the errors are
+        the square roots of the eigenvalues.  As in the reference, the data are first reset to the supplied
+        ones and then moved by the hop from the PREVIOUS rotation to the new one -- after an earlier
+        ``set_cov`` that is not the new rotation alone; the element-wise drivers rely on reproducing it."""
+        cov = np.asarray(cov)
+        if np.max(np.abs(cov - cov.transpose())) >= 1.e-10:
+            raise AssertionError('Supplied covariance matrix is not symmetric.')
         self.cov = cov
-        assert np.max(np.abs(cov - cov.transpose())) < 1.e-10, \
-            'Supplied covariance matrix is not symmetric.'
-        e, vec = np.linalg.eigh(cov)
-        if np.any(e < 0):
+        var, vec = np.linalg.eigh(cov)
+        if var.min() < 0:
             self.logtaker.error_message(
-                'Eigenvalues of the covariance matrix are not all positive; '
-                'they will be ignored. Smallest negative value: {}', np.min(e))
-        keep = e >= self.cov_threshold
-        e, vec = e[keep], vec[:, keep]
-        self.err = None
+                'Eigenvalues of the covariance matrix are not all positive; they will be ignored. '
+                'Smallest negative value: {}', var.min())
+        keep = var >= self.cov_threshold
+        self.err = None              # no chi2 with stale errors while the kernel changes
         if hasattr(self.cost_function, '_G_orig'):
             self.G = self.cost_function._G_orig
-        self._transform(vec.conjugate().transpose())
-        self.err = np.sqrt(e)
+        self._rotate_to(vec[:, keep].conjugate().transpose())
+        self.err = np.sqrt(var[keep])
 
     def set_cov_file(self, filename):
         self.set_cov(np.loadtxt(filename))
-
-    # ---- rotation bookkeeping -------------------------------------------
-    def _transform_G(self, T_to, T_from=None):
-        if T_to is None:
-            T = 1 if T_from is None else T_from.conjugate().transpose()
-        elif T_from is None:
-            T = T_to
-        else:
-            T = np.dot(T_to, T_from.conjugate().transpose())
-        self.G = np.dot(T, self.G)
-
-    def _transform(self, T_, G_original_basis=False):
-        """rotate G and K from the left by the absolute rotation ``T_``
-        (reference tau_maxent.py:303-325)."""
-        if G_original_basis:
-            self.cost_function._G_orig = copy.deepcopy(self.G)
-        self._transform_G(T_, None if G_original_basis else self._T)
-        self.K.transform(T_)
-        self.K = self.K        # re-announce K to chi2 / H_of_v
 
     # ---- tau ----------------------------------------------------------------
     def get_tau(self):

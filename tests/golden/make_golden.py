@@ -13,7 +13,7 @@ on the GPU box).  It
      to obtain a golden H that is good to ~1e-12,
   5. writes small .npz fixtures (inputs, U/S/V, reference outputs, truth).
 
-Usage:  python tests/golden/make_golden.py
+Usage:  python tests/golden/make_golden.py [case_function ...]     (no argument: every fixture)
 """
 
 import os
@@ -328,7 +328,171 @@ def cov_case():
                         v_ref=np.array(vs), H_truth=Htruth, G_rec_ref=np.array(res.G_rec))
 
 
+def derivs_case():
+    """reference test/python/maxent_cost_function_d.py:27-58 (same inputs and seed): f, d, dd of the
+    cost function in every mode of MaxEntCostFunction, of BryanCostFunction, of the plus-minus pair,
+    and the component functions, at a random v."""
+    np.random.seed(658436166)
+    beta = 40
+    tau = np.linspace(0, beta, 100)
+    omega = HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=100)
+    K = TauKernel(tau=tau, omega=omega, beta=beta)
+    A = np.exp(-omega ** 2)
+    A /= np.trapezoid(A, omega)
+    G = np.dot(K.K, A)
+    G += 1.e-4 * np.random.randn(len(G))
+    err = 1.e-4 * np.ones(len(G))
+    D = FlatDefaultModel(omega=omega)
+    out = dict(tau=tau, omega=np.array(omega), delta=omega.delta, beta=float(beta), G=G, err=err,
+               D=np.array(D.D), U=K.U, S=K.S, V=K.V, alpha=0.1)
+    v = np.random.rand(len(K.S))
+    v = np.random.rand(len(v))          # the reference test draws twice (lines 49, 53)
+    out['v'] = v
+
+    def components(prefix, Q, v):
+        b = Q(v)
+        H = b.H_of_v.f()
+        out[prefix + 'H'] = np.array(H)
+        out[prefix + 'dH_dv'] = np.array(b.H_of_v.d())
+        out[prefix + 'chi2'] = float(b.chi2.f())
+        out[prefix + 'dchi2_dH'] = np.array(b.chi2.d())
+        out[prefix + 'S'] = float(b.S.f())
+        out[prefix + 'dS_dH'] = np.array(b.S.d())
+        out[prefix + 'ddS_diag'] = np.array(np.diag(b.S.dd()))
+        out[prefix + 'v_of_H'] = np.array(Q.H_of_v.inv(np.array(H)))
+
+    chi2 = NormalChi2(K=K, G=G, err=err)
+    Q = MaxEntCostFunction(chi2=chi2, S=NormalEntropy(D=D), H_of_v=NormalH_of_v(D=D, K=K))
+    Q.set_alpha(0.1)
+    # the reference's own finite-difference check (maxent_cost_function_d.py:55-58)
+    for Q.d_dv in [True]:
+        for Q.dA_projection in range(3):
+            assert Q.check_derivatives(v, Q.f(v), prec=1.e-8)
+    for d_dv in (False, True):
+        for proj in range(3):
+            Q.d_dv, Q.dA_projection = d_dv, proj
+            tag = 'n_ddv%d_p%d_' % (int(d_dv), proj)
+            out[tag + 'f'] = float(Q.f(v))
+            out[tag + 'd'] = np.array(Q.d(v))
+            out[tag + 'dd'] = np.array(Q.dd(v))
+    Q.d_dv, Q.dA_projection = False, 2
+    components('n_', Q, v)
+    Qe = MaxEntCostFunction(chi2=NormalChi2(K=K, G=G, err=err), S=NormalEntropy(D=D),
+                            H_of_v=NormalH_of_v(D=D, K=K), chi2_factor=2.5)
+    Qe.set_alpha(0.1)
+    out['n_eta_f'], out['n_eta_d'], out['n_eta_dd'] = float(Qe.f(v)), np.array(Qe.d(v)), np.array(Qe.dd(v))
+    out['chi2_factor'] = 2.5
+    Qb = BryanCostFunction()
+    Qb.chi2 = NormalChi2(K=K, G=G, err=err)
+    Qb.set_D(D)
+    Qb.H_of_v.set_K(K)
+    Qb.set_alpha(0.1)
+    out['b_f'], out['b_d'], out['b_dd'] = float(Qb.f(v)), np.array(Qb.d(v)), np.array(Qb.dd(v))
+    vp = 0.3 * (v - 0.5)
+    out['v_pm'] = vp
+    Qp = MaxEntCostFunction(chi2=NormalChi2(K=K, G=G, err=err), S=PlusMinusEntropy(D=D),
+                            H_of_v=PlusMinusH_of_v(D=D, K=K))
+    Qp.set_alpha(0.1)
+    for d_dv in (False, True):
+        Qp.d_dv = d_dv
+        tag = 'pm_ddv%d_p2_' % int(d_dv)
+        out[tag + 'f'], out[tag + 'd'], out[tag + 'dd'] = float(Qp.f(vp)), np.array(Qp.d(vp)), np.array(Qp.dd(vp))
+    Qp.d_dv = False
+    components('pm_', Qp, vp)
+    # the oracle restates the default and the Bryan form: pin it here too
+    p = R.Problem(np.array(K.K), K.U, K.S, K.V, G, err, np.array(D.D))
+    assert np.allclose(R.Q_d(p, 0.1, v), out['n_ddv0_p2_d'], rtol=1e-12, atol=0)
+    assert np.allclose(R.Q_dd(p, 0.1, v), out['n_ddv0_p2_dd'], rtol=1e-12, atol=0)
+    print('%-28s n_s=%d' % ('derivs', len(K.S)))
+    np.savez_compressed(os.path.join(HERE, 'derivs.npz'), **out)
+
+
+def plusminus_entropy_case():
+    """reference test/python/plus_minus_entropy.py:46-59: PlusMinusEntropy f, d, dd on a linear mesh
+    with D = 0.9 at a random A (its closed-form twin lives in the test that reads this fixture)."""
+    from triqs_maxent.functions import PlusMinusEntropy as PME, NormalEntropy as NE
+    w = LinearOmegaMesh(-10, 10, 101)
+    D = DataDefaultModel(0 * w + 0.9, w)
+    np.random.seed(6666)
+    A = np.random.rand(len(w))
+    S2 = PME(D=D)(A)
+    Sn = NE(D=D)(A)
+    print('%-28s' % 'plusminus_entropy')
+    np.savez_compressed(os.path.join(HERE, 'plusminus_entropy.npz'), omega=np.array(w), D=np.array(D.D),
+                        A=A, f=float(S2.f()), d=np.array(S2.d()), dd_diag=np.array(np.diag(S2.dd())),
+                        normal_f=float(Sn.f()), normal_d=np.array(Sn.d()), normal_dd_diag=np.array(np.diag(Sn.dd())))
+
+
+def complex_elementwise_case():
+    """ElementwiseMaxEnt(use_complex=True) (elementwise_maxent.py:203-219, 236-241, 266): a complex
+    hermitian 2x2 G(tau); real and imaginary parts of the off-diagonals are separate real problems."""
+    with np.load(os.path.join(TESTDATA, 'elementwise_g_tau.npz')) as data:
+        tau = data['tau']
+        G_re = data['G_tau_noise']
+    rng = np.random.RandomState(99)
+    G = np.array(G_re, dtype=complex)
+    im = 0.4 * G_re[0, 1] + 2e-3 * rng.randn(len(tau))
+    G[0, 1] = G_re[0, 1] + 1j * im
+    G[1, 0] = G_re[0, 1] - 1j * im
+    out = dict(tau=tau, G_tau=G, noise=1e-3)
+    for herm in (True, False):
+        ew = ElementwiseMaxEnt(use_hermiticity=herm, use_complex=True)
+        ew.set_verbosity(VerbosityFlags.Quiet)
+        ew.set_G_tau_data(tau, G)
+        ew.omega = HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=60)
+        ew.alpha_mesh = LogAlphaMesh(alpha_min=0.05, alpha_max=500, n_points=6)
+        ew.set_error(1e-3)
+        res = ew.run()
+        tag = 'herm%d_' % int(herm)
+        for k in ('H', 'A', 'chi2', 'S', 'Q', 'alpha', 'A_out'):
+            out[tag + k] = np.array(getattr(res, k))
+        out[tag + 'zero_elements'] = np.array(res.zero_elements, dtype=int)
+        out['omega'] = np.array(ew.omega)
+    print('%-28s shapes H %s A_out %s' % ('complex_elementwise', out['herm1_H'].shape, out['herm1_A_out'].shape))
+    np.savez_compressed(os.path.join(HERE, 'complex_elementwise.npz'), **out)
+
+
+def elementwise_cov_case():
+    """ElementwiseMaxEnt.set_cov with one covariance per element, (M, N, T, T)
+    (elementwise_maxent.py:502-515, tau_maxent.py:253-288), with and without preblur."""
+    with np.load(os.path.join(TESTDATA, 'elementwise_g_tau.npz')) as data:
+        tau = data['tau'][::3]
+        G = data['G_tau_noise'][:, :, ::3]
+    T = len(tau)
+    rng = np.random.RandomState(2718)
+    cov = np.empty((2, 2, T, T))
+    for i in range(2):
+        for j in range(2):
+            L = 1e-3 * (np.eye(T) * (1.0 + 0.2 * (i + 2 * j)) + 0.25 * np.diag(np.ones(T - 1), 1) +
+                        0.1 * rng.randn(T, T) / np.sqrt(T))
+            cov[i, j] = L @ L.T
+    out = dict(tau=tau, G_tau=G, cov=cov)
+    for blur in (False, True):
+        ew = ElementwiseMaxEnt(use_hermiticity=False)
+        ew.set_verbosity(VerbosityFlags.Quiet)
+        ew.set_G_tau_data(tau, G)
+        ew.omega = HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=60)
+        if blur:
+            ew.maxent_offdiagonal.A_of_H = PreblurA_of_H(b=0.3, omega=ew.omega)
+            ew.maxent_offdiagonal.K = PreblurKernel(K=ew.maxent_offdiagonal.K, b=0.3)
+        ew.alpha_mesh = LogAlphaMesh(alpha_min=0.05, alpha_max=500, n_points=6)
+        ew.set_cov(cov)
+        res = ew.run()
+        tag = 'blur%d_' % int(blur)
+        for k in ('H', 'A', 'chi2', 'S', 'Q', 'alpha', 'A_out'):
+            out[tag + k] = np.array(getattr(res, k))
+        out['omega'] = np.array(ew.omega)
+    print('%-28s' % 'elementwise_cov')
+    np.savez_compressed(os.path.join(HERE, 'elementwise_cov.npz'), **out)
+
+
 if __name__ == '__main__':
+    only = sys.argv[1:]
+    if only:
+        for name in only:
+            globals()[name]()
+        shutil.rmtree(TMP, ignore_errors=True)
+        sys.exit(0)
     single_case('cfg1_normal', 100, 200, 20, 'normal', list(range(20)))
     single_case('cfg1_bryan', 100, 200, 20, 'bryan', list(range(20)))
     single_case('cfg1_plusminus', 100, 200, 20, 'plusminus', list(range(20)), off=True)
@@ -341,5 +505,9 @@ if __name__ == '__main__':
     kat_srvo3()
     elementwise_case()
     cov_case()
+    derivs_case()
+    plusminus_entropy_case()
+    complex_elementwise_case()
+    elementwise_cov_case()
     shutil.rmtree(TMP, ignore_errors=True)
     print('fixtures written to', HERE)
