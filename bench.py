@@ -185,6 +185,7 @@ def main():
     ap.add_argument('--waves-per-chain', type=int, default=0)
     ap.add_argument('--chains-per-wg', type=int, default=0)
     ap.add_argument('--alpha-split', type=int, default=0)
+    ap.add_argument('--wg-per-cu', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise torch.distributed and run the RCCL gather even with one rank (plumbing test)')
@@ -226,7 +227,7 @@ def main():
     P = n_chain * args.n_alpha
     opts = device.default_opts(waves_per_chain=args.waves_per_chain,
                                chains_per_wg=args.chains_per_wg,
-                               alpha_split=args.alpha_split)
+                               alpha_split=args.alpha_split, wg_per_cu=args.wg_per_cu)
     ctx.upload_chains(np.arange(n_chain, dtype=np.int32), batch['alphas'],
                       batch['v0'], opts)
 

@@ -105,7 +105,10 @@ typedef struct mxe_opts {
                                 reached the rounding floor (it no longer shrinks).  n_s <= 64,
                                 one chain per workgroup.  For the fp32-vs-fp64 tolerance sweep of
                                 BASELINE config 5 (tools/cfg5_tolerance_sweep.py)              */
-    int32_t reserved;        /* keep 0 */
+    int32_t wg_per_cu;       /* lock-step layout: workgroups per CU.  0 = auto (2 where the kernel has a
+                                build for it: n_s <= 64 active block 32, n_omega <= 512 -- u then lives in
+                                registers and two workgroups of 73 KB share a CU, so that the serial
+                                sections of one overlap the streaming passes of the other), 1, 2   */
     double  chi2_factor;     /* eta in Q = eta chi2 / 2 - alpha S (CostFunction(chi2_factor=...),
                                 cost_function.py:60, bryan_cost_function.py:71); default 1       */
 } mxe_opts;

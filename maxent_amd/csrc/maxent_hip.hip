@@ -63,7 +63,7 @@ struct mxe_ctx {
     int n_chain = 0, n_alpha = 0;
     std::vector<int> chain_elem;      // per parent chain
     std::vector<int> sub_elem, sub_prob0, sub_len, sub_v0, wg_chains;   // per launched (sub-)chain
-    int n_sub = 0, n_wg = 0, mc_na = 0, mc_nwv = 4, n_queue = 0;
+    int n_sub = 0, n_wg = 0, mc_na = 0, mc_wgpc = 1, n_queue = 0;
     std::vector<int> queue;
     mxe_opts opts;
     bool chains_ready = false, launched = false;
@@ -232,12 +232,12 @@ int upload_bases(mxe_ctx* ctx)
     return MXE_OK;
 }
 
-// dynamic LDS of chain_kernel_mc<NA, 4> in bytes (the carve at the top of the kernel)
-size_t mc_lds_bytes(int NA, int nwp)
+// dynamic LDS of chain_kernel_mc<NA, WGPC> in bytes (the carve at the top of the kernel)
+size_t mc_lds_bytes(int NA, int nwp, int wgpc)
 {
     const int NT = NA / 16, NPAIR = NT * (NT + 1) / 2;
-    const size_t doubles = 8 * 4 * 64 + 2 * 64 + 64 * 4 + 4 * 4 * 64 + 4 * 32 +        // vectors, c, 1/c, step, h parts, sums
-                           (size_t)2 * nwp * 4 + (size_t)4 * NPAIR * 256;               // u, H, Gram tiles
+    const size_t doubles = 8 * 4 * 64 + 2 * 64 + 64 * 4 + (wgpc == 2 ? 1 : 4) * 4 * 64 + 4 * 32 +   // vectors, c, 1/c, step, h, sums
+                           (size_t)(wgpc == 2 ? 1 : 2) * nwp * 4 + (size_t)4 * NPAIR * 256;          // (u,) H, Gram tiles
     const size_t floats = (size_t)nwp * 4;                                              // sw
     return doubles * 8 + floats * 4;
 }
@@ -308,7 +308,7 @@ void mxe_opts_default(mxe_opts* o)
     o->step_max = 0.2; o->mu_first = 1e-3; o->mu_grow = 4.0; o->mu_max = 1e20;
     o->decouple_tol = 1e-5;
     o->waves_per_chain = 0; o->chains_per_wg = 0; o->alpha_split = 0; o->stop_estimate = 1;
-    o->precision = MXE_PRECISION_F64; o->reserved = 0;
+    o->precision = MXE_PRECISION_F64; o->wg_per_cu = 0;
     o->chi2_factor = 1.0;
 }
 
@@ -458,6 +458,7 @@ try {
         o.waves_per_chain != 4 && o.waves_per_chain != 8) return MXE_ERR_ARG;
     if (o.chains_per_wg != 0 && o.chains_per_wg != 1 && o.chains_per_wg != 4) return MXE_ERR_ARG;
     if (o.alpha_split < 0) return MXE_ERR_ARG;
+    if (o.wg_per_cu < 0 || o.wg_per_cu > 2) return MXE_ERR_ARG;
     if (o.precision != MXE_PRECISION_F64 && o.precision != MXE_PRECISION_F32) return MXE_ERR_ARG;
     if (o.precision == MXE_PRECISION_F32 && NP != 64) return MXE_ERR_LIMIT;
     if (!(o.chi2_factor > 0.0) || !std::isfinite(o.chi2_factor)) return MXE_ERR_ARG;
@@ -496,7 +497,9 @@ try {
         // about as much as 3 warm alphas)
         hipDeviceProp_t prop;
         HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
-        const int n_slots = 4 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+        // (two workgroups per CU where the lock-step kernel has a build for it: n_omega_pad <= 512)
+        const int wgpc_guess = (o.wg_per_cu != 1 && ctx->nwp <= 512 && NP == 64 && o.chains_per_wg != 1) ? 2 : 1;
+        const int n_slots = 4 * wgpc_guess * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
         const int want = (5 * n_slots / 2 + n_chain - 1) / n_chain;
         split = std::max(1, std::min(std::min(want, 16), n_alpha / 6));
         // a small batch that cannot fill the lock-step layout (>= 768 pieces) with pieces of six alphas,
@@ -542,8 +545,9 @@ try {
         }
         if (worst32 <= 1e-2) ctx->mc_na = 32; else if (worst48 <= 1e-2) ctx->mc_na = 48; else layout = 1;
         if (layout == 4) {
-            ctx->mc_nwv = 4;
-            if (mc_lds_bytes(ctx->mc_na, ctx->nwp) > 160 * 1024 - 2048) { layout = 1; ctx->mc_na = 0; }
+            ctx->mc_wgpc = (o.wg_per_cu != 1 && ctx->mc_na == 32 && ctx->nwp <= 512 &&
+                            mc_lds_bytes(32, ctx->nwp, 2) <= 80 * 1024 - 2048) ? 2 : 1;
+            if (mc_lds_bytes(ctx->mc_na, ctx->nwp, ctx->mc_wgpc) > 160 * 1024 - 6144) { layout = 1; ctx->mc_na = 0; }
         }
     }
     ctx->wg_chains.clear(); ctx->queue.clear(); ctx->n_queue = 0;
@@ -569,7 +573,7 @@ try {
             hipDeviceProp_t prop;
             HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
             const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            ctx->n_wg = std::min((ctx->n_sub + 3) / 4, n_cu * MXE_X_WGPC);
+            ctx->n_wg = std::min((ctx->n_sub + 3) / 4, n_cu * ctx->mc_wgpc);
         } else {
             // static layout: group by data set, four per workgroup, -1 pads
             std::vector<std::vector<int>> by_ds(ctx->ds.size());
@@ -651,23 +655,26 @@ try {
     hipError_t e;
     if (ctx->mc_na > 0) {
         // four chains per workgroup, lock-step (mxe_kernel_mc.hip.h)
-        const int NA = ctx->mc_na, NWV = ctx->mc_nwv;
-        const size_t lds = mc_lds_bytes(NA, ctx->nwp);
-        if (lds > 160 * 1024 - 2048) return MXE_ERR_LIMIT;
+        const int NA = ctx->mc_na, WGPC = ctx->mc_wgpc, NWV = 4;
+        const size_t lds = mc_lds_bytes(NA, ctx->nwp, WGPC);
+        if (lds > 160 * 1024 - 6144) return MXE_ERR_LIMIT;
         mxe::MCExtra ex; ex.wg_chains = ctx->dwg_chains.p; ex.n_wg = ctx->n_wg;
         ex.queue = ctx->dqueue.p; ex.n_queue = ctx->n_queue; ex.counter = ctx->dcounter.p;
+        ex.stagger = 5;
+        if (const char* sg = getenv("MXE_X_STAGGER")) ex.stagger = atoi(sg);
         HIPCHK(ctx, hipMemsetAsync(ctx->dcounter.p, 0, sizeof(int), ctx->stream));
         ctx->last_nw = NWV; ctx->last_lds = (int)lds;
-        ctx->last_kernel = "mxe::chain_kernel_mc<" + std::to_string(NA) + ", " + std::to_string(NWV) + ">";
+        ctx->last_kernel = "mxe::chain_kernel_mc<" + std::to_string(NA) + ", " + std::to_string(WGPC) + ">";
         HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-#define MXE_LAUNCH_MC(NA_, NWV_) do { \
-        e = hipFuncSetAttribute((const void*)mxe::chain_kernel_mc<NA_, NWV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+#define MXE_LAUNCH_MC(NA_, WG_) do { constexpr int NWV_ = 4; \
+        e = hipFuncSetAttribute((const void*)mxe::chain_kernel_mc<NA_, WG_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e == hipSuccess && getenv("MXE_DEBUG_OCC")) { int nb__ = 0; \
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb__, (const void*)mxe::chain_kernel_mc<NA_, NWV_>, 64 * NWV_, lds); \
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb__, (const void*)mxe::chain_kernel_mc<NA_, WG_>, 64 * NWV_, lds); \
             fprintf(stderr, "[mxe] lock-step kernel NA=%d NWV=%d lds=%zu: %d workgroup(s) per CU resident\n", NA_, NWV_, (size_t)lds, nb__); } \
-        if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<NA_, NWV_>), dim3(ctx->n_wg), dim3(64 * NWV_), lds, ctx->stream, kp, ex); e = hipGetLastError(); } } while (0)
-        if (NA == 32) MXE_LAUNCH_MC(32, 4);
-        else MXE_LAUNCH_MC(48, 4);
+        if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<NA_, WG_>), dim3(ctx->n_wg), dim3(64 * NWV_), lds, ctx->stream, kp, ex); e = hipGetLastError(); } } while (0)
+        if (NA == 32 && WGPC == 2) MXE_LAUNCH_MC(32, 2);
+        else if (NA == 32) MXE_LAUNCH_MC(32, 1);
+        else MXE_LAUNCH_MC(48, 1);
 #undef MXE_LAUNCH_MC
         HIPCHK(ctx, e);
     } else {

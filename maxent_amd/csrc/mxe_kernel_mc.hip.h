@@ -37,26 +37,31 @@ struct MCExtra {
     const int* queue;             // dynamic layout: chain ids in the order they are handed out
     int n_queue;                  //   (0 = static layout)
     int* counter;                 //   next queue position (zeroed before every launch)
+    int stagger;                  // WGPC = 2: the second half of the grid starts this many units of 4096 cycles late
 };
 
-// NA  capacity of the active block: 32 or 48
-// NWV wavefronts per workgroup: 4 (the home waves)
+// NA    capacity of the active block: 32 or 48
+// WGPC  workgroups per CU the kernel is built for:
+//       1  u, H, sw of the four slots in LDS (any n_omega the 160 KB hold), 512 registers per lane;
+//       2  (n_omega_pad <= 512) u lives in registers -- every lane keeps the eight (row, slot) elements it
+//          updates in the row pass --, the partial h of the waves are summed with LDS atomics, the fused pass
+//          keeps four instead of eight row groups of V in flight: 73 KB of LDS and 256 registers, so that
+//          two workgroups share a CU and the serial sections of one (the solve of the home waves, the accept
+//          step; vector instructions only) run beside the streaming passes of the other, which wait for L2.
 // rows of V behind the last omega row (and LDS entries behind H / sw) that the look-ahead of the
 // fused pass may read without using them: (DEPTH + 2) groups * 4 waves * 4 rows, rounded up
 constexpr double MC_GRAM_ERR = 0.0;              // allowance for the inexact Gram tiles in the stopping estimate
 constexpr int MC_LOOKAHEAD_ROWS = 512;
-#ifndef MXE_X_WGPC
-#define MXE_X_WGPC 1        // workgroups per CU the register budget is sized for
-#endif
-constexpr int MC_FUSED_DEPTH = (MXE_X_WGPC == 1) ? 8 : 4;
-constexpr int MC_LOOKAHEAD_LDS = (MC_FUSED_DEPTH + 2) * 4 * 4 * 4 + 64;       // entries
-template <int NA, int NWV>
-__global__ __launch_bounds__(64 * NWV, MXE_X_WGPC)
+constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
+template <int NA, int WGPC>
+__global__ __launch_bounds__(256, WGPC)
 void chain_kernel_mc(const KParams p, const MCExtra x)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int NWV = 4;                        // one wavefront per chain slot
     constexpr int T = 64 * NWV;
-    static_assert(NWV == 4, "one wavefront per chain slot");
+    static_assert(WGPC == 1 || WGPC == 2, "one or two workgroups per CU");
+    constexpr bool UREG = (WGPC == 2);            // u in registers, h summed with atomics
     constexpr int NP = 64;
     constexpr int NT = NA / 16;                   // 16-column tiles of the Gram block
     constexpr int NPAIR = NT * (NT + 1) / 2;
@@ -85,12 +90,13 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     double* cc   = eacc + MCC * NP;              // [NP]
     double* ci   = cc + NP;                      // [NP]
     double* vecI = ci + NP;                      // [NP][MCC]   step / v, chain minor (row-pass operand)
-    double* hpart = vecI + NP * MCC;             // [NWV waves][MCC chains][NP]
-    double* red  = hpart + NWV * MCC * NP;       // [NWV waves][32]
-    double* ui   = red + NWV * 32;               // [nwp][MCC]
+    constexpr int HPW = UREG ? 1 : NWV;          // copies of the partial h: one per wave, or one summed with atomics
+    double* hpart = vecI + NP * MCC;             // [HPW][MCC chains][NP]
+    double* red  = hpart + HPW * MCC * NP;       // [NWV waves][32]
+    double* ui   = red + NWV * 32;               // [nwp][MCC]   (WGPC = 1 only)
     // (the look-ahead of the fused pass reads up to MC_LOOKAHEAD_LDS entries past the end of Hi and of swF:
     //  they land in swF and Wt, are never used, and need no padding)
-    double* Hi   = ui + (size_t)nwp * MCC;       // [nwp][MCC]
+    double* Hi   = ui + (UREG ? (size_t)0 : (size_t)nwp * MCC);       // [nwp][MCC]
     float*  swF  = reinterpret_cast<float*>(Hi + (size_t)nwp * MCC);    // [nwp][MCC]
     double* Wt   = reinterpret_cast<double*>(swF + (size_t)nwp * MCC);  // [MCC][NPAIR][4][64]
     static_assert(MCC * NPAIR * 256 * 2 >= MC_LOOKAHEAD_LDS, "the look-ahead stays inside the allocation");
@@ -105,7 +111,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         int elem, prob0, clen, ia, niter, nevals, nact, active, scratch, okprev, bt, capp;
     };
     // the alphas of a slot's piece (a dependent global load in the accept step costs its full latency)
-    constexpr int ACAP = 128;
+    constexpr int ACAP = UREG ? 32 : 128;
     __shared__ double s_alpha[MCC][ACAP];
     __shared__ double s_sd[MCC][12];
     __shared__ double s_scw[MCC][2];             // row pass: 1 / sc2 of the sw it reads, sc2 of the sw it writes
@@ -213,7 +219,11 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     // ------------------------------------------------------------------
     auto gj_home = [&](auto NTag, double a, int n_act, double isc2) -> bool {
         constexpr int N = decltype(NTag)::value;
-        const int q = wave, i = lane;
+        const int q = wave;
+        int i = lane;
+        // (opaque to the optimiser: the N load addresses below depend on the lane only, and hoisted out of the
+        //  round loop -- five instantiations of N -- they cost 150 registers for the whole kernel)
+        if (UREG) asm volatile("" : "+v"(i));
         const double* Wq = Wt + (size_t)q * NPAIR * 256;
         const double* rq = rhs + q * NP;
         bool ok = true;
@@ -231,20 +241,29 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             const int imt = ic >> 4, iri = ic & 15;
             const int up_l = (imt * NT - imt * (imt - 1) / 2 - imt) * 256 + (iri & 3) * 64 + (iri >> 2) * 16;   // row ic, column j >= ic
             const int lo_l = imt * 256 + iri;                                                                  // row j < ic, column ic
-            double wr[N];
+            // (in two halves when the kernel is built for 256 registers)
+            constexpr int NH = UREG ? 2 : 1, HL = N / NH;
+            static_assert(N % NH == 0, "");
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                const int jmt = j >> 4, jri = j & 15;
-                const int up_s = jmt * 256 + jri;
-                const int lo_s = (jmt * NT - jmt * (jmt - 1) / 2 - jmt) * 256 + (jri & 3) * 64 + (jri >> 2) * 16;
-                wr[j] = Wq[(j >= ic) ? up_l + up_s : lo_l + lo_s];
-            }
+            for (int hf = 0; hf < NH; ++hf) {
+                double wr[HL];
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                const double cj = wave_bcast(ci_, j);        // = c_j for j < n_act, else 0
-                double xv = cis * wr[j] * cj;                // 0 in the rows and columns >= n_act
-                if (j == i) xv = live ? xv + a : 1.0;
-                A[j] = xv;
+                for (int jj = 0; jj < HL; ++jj) {
+                    const int j = hf * HL + jj;
+                    const int jmt = j >> 4, jri = j & 15;
+                    const int up_s = jmt * 256 + jri;
+                    const int lo_s = (jmt * NT - jmt * (jmt - 1) / 2 - jmt) * 256 + (jri & 3) * 64 + (jri >> 2) * 16;
+                    wr[jj] = Wq[(j >= ic) ? up_l + up_s : lo_l + lo_s];
+                }
+#pragma unroll
+                for (int jj = 0; jj < HL; ++jj) {
+                    const int j = hf * HL + jj;
+                    const double cj = wave_bcast(ci_, j);    // = c_j for j < n_act, else 0
+                    double xv = cis * wr[jj] * cj;           // 0 in the rows and columns >= n_act
+                    if (j == i) xv = live ? xv + a : 1.0;
+                    A[j] = xv;
+                }
+                if (NH > 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
         double b = live ? rq[i] : 0.0;
@@ -279,6 +298,15 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         return ok;
     };
 
+    // WGPC = 2: u of the eight (row, slot) elements this lane updates in the row pass (n_omega_pad <= 512:
+    // one batch of eight tiles per wave covers every row)
+    double ureg[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    // Two workgroups that share a CU run the same program from the same start: left alone they sit in the
+    // same phase at the same time (solve beside solve, stream beside stream) and overlap nothing.  The
+    // second half of the grid -- dispatched onto the CUs the first half already occupies -- starts half a
+    // round late.
+    if (WGPC == 2 && (int)blockIdx.x >= (int)(gridDim.x + 1) / 2)
+        for (int sl = 0; sl < x.stagger; ++sl) __builtin_amdgcn_s_sleep(64);
     long long guard = 0;
     const long long guard_max = (long long)(dynamic ? x.n_queue : 1) * p.n_alpha * (p.maxiter + 64) + 64;
 
@@ -398,6 +426,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 #pragma unroll
                 for (int idx = 0; idx < (MCC * NPAIR * 128 + T - 1) / T; ++idx)
                     if (tid + idx * T < MCC * NPAIR * 128) Wz[tid + idx * T] = double2{0.0, 0.0};
+                if (UREG) hpart[tid] = 0.0;              // [MCC][NP] = 256 sums of h, added to in step 3
             }
             const int j = lane & 3;                              // slot of this lane's results
             const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4);      // result row inside the tile
@@ -427,7 +456,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     rowt[tt] = row;
                     acc[tt] = 0.0;
                     Dv[tt] = Dj[row];
-                    uo[tt] = ui[row * MCC + j];
+                    uo[tt] = UREG ? ureg[tt] : ui[row * MCC + j];
                     { const float so = swF[row * MCC + j]; wo[tt] = (double)(so * so) * isc_old; }
                 }
                 // V^T operand: row 4 kc + ak of V^T; the blocks of a batch are 32 NWV rows apart (V^T is
@@ -477,7 +506,8 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                             Sq += Hm - Di + Hm * uq;
                         }
                         if (row >= nw) { Hq = 0.0; wq = 0.0; Sq = 0.0; }
-                        ui[row * MCC + j] = uq; Hi[row * MCC + j] = Hq;
+                        if (UREG) ureg[tt] = uq; else ui[row * MCC + j] = uq;
+                        Hi[row * MCC + j] = Hq;
                         swF[row * MCC + j] = __builtin_sqrtf(fminf((float)(wq * sc_new), 3.0e38f));
                         pS += Sq;
                         pHn = fma(Hq, Hq, pHn);
@@ -545,7 +575,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             // the padding behind H / sw in LDS and is not used.
             constexpr int ST = NWV;
             constexpr int TRIP = 8;
-            constexpr int DEPTH = MC_FUSED_DEPTH;
+            constexpr int DEPTH = (WGPC == 1) ? 8 : 4;
             static_assert(TRIP % DEPTH == 0 && DEPTH >= 2, "ring indices are static across trips");
             int g = wave;
             {
@@ -627,7 +657,10 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             {
                 const int hj = lane & 3, hcol = 4 * ((lane >> 2) & 3) + (lane >> 4);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) hpart[(wave * MCC + hj) * NP + 16 * t + hcol] = hp[t];
+                for (int t = 0; t < 4; ++t) {
+                    if (UREG) __hip_atomic_fetch_add(hpart + hj * NP + 16 * t + hcol, hp[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else hpart[(wave * MCC + hj) * NP + 16 * t + hcol] = hp[t];
+                }
             }
             MXE_STAMPW(6);
             // Gram tiles: every wave adds its partial tiles into the slots' tiles with LDS atomics
@@ -652,7 +685,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             const int q = wave, k = lane;
             double h = 0.0;
 #pragma unroll
-            for (int wv = 0; wv < NWV; ++wv) h += hpart[(wv * MCC + q) * NP + k];
+            for (int wv = 0; wv < HPW; ++wv) h += hpart[(wv * MCC + q) * NP + k];
             const double r = (k < ns) ? cc[k] * h - gh[q * NP + k] : 0.0;
             const double r2 = wave_sum(r * r);
             double sS = 0.0, sdH = 0.0, sHn = 0.0, swm = 0.0, sdu = 0.0;

@@ -43,7 +43,7 @@ class MxeOpts(ctypes.Structure):
                 ('alpha_split', ctypes.c_int32),
                 ('stop_estimate', ctypes.c_int32),
                 ('precision', ctypes.c_int32),
-                ('reserved', ctypes.c_int32),
+                ('wg_per_cu', ctypes.c_int32),
                 ('chi2_factor', ctypes.c_double)]
 
 

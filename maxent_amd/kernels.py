@@ -73,9 +73,10 @@ class KernelSVD(object):
                 self._invalidate_svd()
         self._last_threshold = threshold
         keep = np.where(self.S >= threshold)[0]
-        self._U = self._U[:, keep]
-        self._S = self._S[keep]
-        self._V = self._V[:, keep]
+        if len(keep) < len(self._S):             # nothing to drop: U, S, V stay the objects they are
+            self._U = self._U[:, keep]
+            self._S = self._S[keep]
+            self._V = self._V[:, keep]
         return self
 
 
@@ -106,17 +107,24 @@ class Kernel(KernelSVD):
     def transform(self, T_):
         """Left-multiply K (and U) by ``T_``, given as the absolute rotation
         with respect to the unrotated kernel; ``None`` undoes it."""
-        if T_ is None:
-            if self._T is None:
-                return
-            T = self._T.conjugate().transpose()
-        elif self._T is not None:
-            T = np.dot(T_, self._T.conjugate().transpose())
-        else:
-            T = T_
+        T = self._relative_rotation(T_, self._T)
+        if T is None:
+            return
         self._T = T_
         self._U = np.dot(T, self.U)
         self._K = np.dot(T, self._K)
+
+    @staticmethod
+    def _relative_rotation(T_to, T_from):
+        """the matrix that takes the kernel from rotation ``T_from`` to ``T_to``; None if there is
+        nothing to do (the same rotation object, or unrotated to unrotated)"""
+        if T_to is T_from:
+            return None
+        if T_to is None:
+            return T_from.conjugate().transpose()
+        if T_from is None:
+            return T_to
+        return np.dot(T_to, T_from.conjugate().transpose())
 
 
 class DataKernel(Kernel):
@@ -238,8 +246,17 @@ class PreblurKernel(Kernel):
         self._K_delta = self.kernel.K_delta
 
     def transform(self, T):
+        """rotate the blurred kernel like the plain one: ``U <- T U``, ``K <- T K``, S and V stay.  (The
+        reference refills and decomposes T K' again for every rotation, kernels.py:395-397; the
+        decomposition of the unrotated K' spans every rotated kernel's row space, so one V serves all
+        matrix elements of a job and the SVD is done once.)"""
+        rel = self._relative_rotation(T, self.kernel._T)
+        if rel is None:
+            return
+        U = self.U
         self.kernel.transform(T)
-        self._fill_values()
+        self._U = np.dot(rel, U)
+        self._K = np.dot(rel, self._K)
 
     @property
     def _T(self):

@@ -54,17 +54,15 @@ class TauMaxEnt(object):
     # rotation; ``_rotate_to`` -- data and kernel go from the current rotation to another one.
     # (reference tau_maxent.py:181-325)
 
-    @staticmethod
-    def _hop(T_to, T_from):
-        """matrix that takes data from rotation ``T_from`` to rotation ``T_to`` (None = unrotated)"""
-        back = None if T_from is None else T_from.conjugate().transpose()
-        if T_to is None:
-            return back
-        return T_to if back is None else np.dot(T_to, back)
-
-    def _move_data(self, hop):
-        if hop is not None:
-            self.G = np.dot(hop, self.G)
+    def _move_data(self, T_to, T_from):
+        """data from rotation ``T_from`` to rotation ``T_to`` (None = unrotated): back, then forth"""
+        G = self.G
+        if T_from is not None:
+            G = np.dot(T_from.conjugate().transpose(), G)
+        if T_to is not None:
+            G = np.dot(T_to, G)
+        if G is not self.G:
+            self.G = G
 
     def _announce_kernel(self, T):
         self.K.transform(T)          # sets K._T
@@ -73,18 +71,18 @@ class TauMaxEnt(object):
     def _adopt_data(self, keep_rotation=True):
         T = self._T if keep_rotation else None
         self.cost_function._G_orig = copy.deepcopy(self.G)
-        self._move_data(self._hop(T, None))
+        self._move_data(T, None)
         self._announce_kernel(T)
 
     def _rotate_to(self, T):
-        self._move_data(self._hop(T, self._T))
+        self._move_data(T, self._T)
         self._announce_kernel(T)
 
     def _transform(self, T_, G_original_basis=False):
         """the reference's name for the two moves (tau_maxent.py:303-325)"""
         if G_original_basis:
             self.cost_function._G_orig = copy.deepcopy(self.G)
-            self._move_data(self._hop(T_, None))
+            self._move_data(T_, None)
             self._announce_kernel(T_)
         else:
             self._rotate_to(T_)

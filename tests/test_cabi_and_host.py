@@ -43,7 +43,7 @@ def test_opts_defaults_and_struct_layout():
     assert o.step_max == 0.2 and o.mu_grow == 4.0 and o.decouple_tol == 1e-5
     assert (o.waves_per_chain, o.chains_per_wg, o.alpha_split) == (0, 0, 0)      # all automatic
     assert o.stop_estimate == 1
-    assert o.precision == device.PRECISION_F64 and o.reserved == 0
+    assert o.precision == device.PRECISION_F64 and o.wg_per_cu == 0
     assert o.chi2_factor == 1.0
     # the struct of include/maxent_hip.h: 2 int32, 8 double, 6 int32, 1 double, no padding holes
     import ctypes

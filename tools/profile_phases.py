@@ -26,6 +26,7 @@ ap.add_argument('--theta', type=float, default=1e-6)
 ap.add_argument('--layout', type=int, default=1)
 ap.add_argument('--split', type=int, default=1)
 ap.add_argument('--n-omega', type=int, default=500)
+ap.add_argument('--wgpc', type=int, default=0)
 ap.add_argument('--home', action='store_true', help='library built with -DMXE_PROFILE_HOME: split the home phase')
 args = ap.parse_args()
 batch = bench.build_batch(args.n_orb, 200, args.n_omega, 100, 0)
@@ -33,13 +34,13 @@ ctx = bench.stage(batch, 0)
 n_chain = len(batch['elems'])
 ctx.upload_chains(np.arange(n_chain, dtype=np.int32), batch['alphas'], batch['v0'],
                   device.default_opts(waves_per_chain=args.waves, decouple_tol=args.theta,
-                                      chains_per_wg=args.layout, alpha_split=args.split))
+                                      chains_per_wg=args.layout, alpha_split=args.split, wg_per_cu=args.wgpc))
 for _ in range(2):
     ctx.launch(); ctx.sync()
 lib = device.load_library()
 lib.mxe_prof_fetch.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
 info = ctx.last_launch_info()
-n_sub = n_chain * max(args.split, 1)
+n_sub = n_chain * 100            # upper bound on the pieces (alpha_split = 0: the library chooses)
 prof = np.zeros((n_sub + 8192, 8), dtype=np.int64)
 rc = lib.mxe_prof_fetch(ctx._h, prof.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)))
 assert rc == 0
@@ -70,6 +71,7 @@ if args.layout == 4:
         print('  %-16s' % names[q] + ''.join((' %7.2f' if names[q].startswith('#') else ' %7.0f') % x for x in per))
     print('  %-16s' % 'total' + ''.join(' %7.0f' % x for x in tot))
 else:
+    n_sub = n_chain * max(args.split, 1)
     prof = prof[:n_sub]
     names = ['prep', 'gram', 'chol+solve', 'step/norm', 'eval', 'accept', 'output', '-']
     iters = np.full(n_sub, out['n_iter'].sum() / n_sub)
