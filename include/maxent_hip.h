@@ -262,6 +262,46 @@ int  mxe_entropy(int device, int kind, int n_omega, int P, const double* H, cons
  * [n_chain][n_alpha]; either may be NULL. */
 int  mxe_audit(mxe_ctx* ctx, double* out_corr, double* out_gmax);
 
+/* ---- the default analyzer's alpha on the device; selected rows ---------- */
+/* LineFitAnalyzer (analyzers/linefit_analyzer.py:28-87,151-183: the kink of log chi2 over log alpha,
+ * linefit_deg = p2_deg) for every scan of the last launch, enqueued on the ctx stream behind it; the H
+ * of the chosen alpha is copied next to chi2 / S / Q, which makes the COMPACT result pack
+ *     chi2 [P] | S [P] | Q [P] | H_selected [n_chain][n_omega] | index [n_chain] (as doubles)
+ * contiguous on the device (P = n_chain * n_alpha).  index = -1: no fit (fewer than five alphas, chi2 NaN). */
+int  mxe_select_launch(mxe_ctx* ctx, int p2_deg);
+int  mxe_select_fetch(mxe_ctx* ctx, int32_t* out_index, double* out_H_selected);
+/* n_rows hidden images of the last launch by problem index (chain * n_alpha + i), [n_rows][n_omega]:
+ * what an analyzer needs (one row per scan) without moving all of H */
+int  mxe_fetch_rows(mxe_ctx* ctx, int n_rows, const int32_t* problem_index, double* out_H);
+
+/* ---- several GPUs: shard by matrix element, one gather ------ */
+/* The (element, alpha) problems are independent given U, S, V: element e goes to rank e mod n_ranks
+ * (mxe_shard_plan), every rank stages the basis itself and solves its shard with the same entry points;
+ * afterwards ONE gather brings the result packs to the root's device (and, if asked, to its host):
+ * RCCL send / recv over xGMI, called directly from this library (librccl.so.1 is loaded on first use).
+ *   ranks in separate processes:  rank 0 calls mxe_comm_unique_id and hands the 128 bytes to the others
+ *                                 (file, socket, environment: the caller's business); every rank calls
+ *                                 mxe_comm_init(ctx, n_ranks, rank, id) and, per step, mxe_gather.
+ *   ranks in one process:         mxe_comm_init_local(ctxs, n) (rank = position; contexts on the same
+ *                                 device -- used for tests on one GPU -- gather with device copies
+ *                                 instead of RCCL) and, per step, mxe_gather_local.
+ * what: MXE_GATHER_COMPACT (the pack above; needs mxe_select_launch first) or MXE_GATHER_FULL (all H
+ * in front of it).  counts[r]: doubles rank r contributes (checked against the rank's own launch).
+ * The gather is enqueued on the ctx streams; with recv_host != NULL the root copies the gathered packs,
+ * rank after rank, to the host and waits for it.  recv_host may be NULL on the other ranks. */
+#define MXE_GATHER_COMPACT 0
+#define MXE_GATHER_FULL    1
+int  mxe_shard_plan(int n_elem, int n_ranks, int32_t* rank_of_elem, int32_t* local_index, int32_t* n_local);
+int  mxe_comm_unique_id(char* out_id128);
+int  mxe_comm_init(mxe_ctx* ctx, int n_ranks, int rank, const char* id128);
+int  mxe_comm_init_local(mxe_ctx** ctxs, int n);
+int  mxe_comm_destroy(mxe_ctx* ctx);
+int  mxe_gather(mxe_ctx* ctx, int root, int what, const int64_t* counts, double* recv_host);
+/* sum (op = 0) or maximum (op = 1) of n <= 64 doubles over the ranks, result on every rank; with it the
+ * ranks of separate processes agree on a timing or wait for each other (a barrier is a sum of zeros) */
+int  mxe_comm_allreduce(mxe_ctx* ctx, double* inout_host, int n, int op);
+int  mxe_gather_local(mxe_ctx** ctxs, int n, int root, int what, const int64_t* counts, double* recv_host);
+
 /* ---- output map A = B H (PreblurA_of_H.f, functions.py:999-1001) ------- */
 /* B: n_omega x n_omega row-major.  Applies to the device-resident H of the
  * last solve; result n_problem x n_omega to host. */

@@ -123,6 +123,104 @@ def fit_piecewise(logx, logy, p2_deg=0):
     return int(np.nanargmin(dist)), (p1[i], p2[i])
 
 
+def fit_piecewise_many(logx, logY, p2_deg=0, max_candidates=6):
+    """:func:`fit_piecewise` for the rows of ``logY`` (m x n) at once: the break points of all rows from
+    prefix sums, then the exact two-pass misfit of every row's candidate break points, row-parallel.  A row
+    whose candidates cannot be settled that way (more than ``max_candidates`` near-ties, nothing finite) is
+    handed to the scalar routine.  Returns (index array, -1 where the fit fails; list of (p1, p2) or None)."""
+    logx = np.asarray(logx, dtype=float)
+    Y = np.asarray(logY, dtype=float)
+    m, n = Y.shape
+    out_idx = np.full(m, -1, dtype=int)
+    out_par = [None] * m
+    todo_scalar = np.zeros(m, dtype=bool)
+    if n <= 8:
+        todo_scalar[:] = True
+    else:
+        ok = np.logical_not(np.isnan(Y))
+        w = ok.astype(float)
+        Y0 = np.where(ok, Y, 0.0)
+        x0 = logx - np.mean(logx)
+        yc = Y0 - (np.sum(Y0, axis=1) / np.maximum(np.sum(w, axis=1), 1.0))[:, None] * w
+        zero = np.zeros((m, 1))
+        cs = [np.concatenate((zero, np.cumsum(v, axis=1)), axis=1) for v in
+              (w, w * x0, yc, w * x0 * x0, x0 * yc, yc * yc)]
+        brk = np.arange(2, n - 2)
+
+        def sse(lo, hi, line):
+            mm, sx, sy, sxx, sxy, syy = [c[:, hi] - c[:, lo] for c in cs]
+            with np.errstate(all='ignore'):
+                vyy = syy - sy * sy / mm
+                if not line:
+                    return np.where(mm >= 1, vyy, np.nan)
+                vxx = sxx - sx * sx / mm
+                vxy = sxy - sx * sy / mm
+                fit = np.where(vxx > 0, vyy - vxy * vxy / vxx, vyy)
+                return np.where(mm >= 1, np.where(mm >= 2, fit, vyy), np.nan)
+        approx = sse(np.zeros_like(brk), brk, True) + sse(brk, np.full_like(brk, n), p2_deg == 1)
+        finite = np.isfinite(approx)
+        todo_scalar |= ~finite.any(axis=1)
+        with np.errstate(all='ignore'):
+            best = np.nanmin(np.where(finite, approx, np.inf), axis=1)
+        scale = np.abs(cs[5][:, -1]) + 1e-300
+        cand = finite & (approx <= (best + 1e-9 * scale + 1e-6 * np.abs(best))[:, None])
+        ncand = cand.sum(axis=1)
+        todo_scalar |= ncand > max_candidates
+        rows = np.where(~todo_scalar)[0]
+        if len(rows):
+            ar = np.arange(n)[None, :]
+            Yr, okr = Y0[rows], ok[rows]
+            xb = np.broadcast_to(logx, Yr.shape)
+
+            def part(mask, line):
+                cnt = mask.sum(axis=1)
+                safe = np.maximum(cnt, 1)
+                xm = (xb * mask).sum(axis=1) / safe
+                ym = (Yr * mask).sum(axis=1) / safe
+                dx = (xb - xm[:, None]) * mask
+                sxx = (dx * dx).sum(axis=1)
+                sxy = (dx * (Yr - ym[:, None])).sum(axis=1)
+                with np.errstate(all='ignore'):
+                    slope = np.where(line & (cnt >= 2) & (sxx != 0.0), sxy / np.where(sxx != 0.0, sxx, 1.0), 0.0)
+                icpt = ym - slope * xm
+                r = (Yr - (slope[:, None] * xb + icpt[:, None])) * mask
+                return slope, icpt, (r * r).sum(axis=1), cnt
+            kmax = int(ncand[rows].max())
+            order = np.argsort(~cand[rows], axis=1, kind='stable')[:, :kmax]      # candidate positions, ascending
+            mis = np.full((len(rows), kmax), np.nan)
+            keep = []
+            for k in range(kmax):
+                bi = brk[order[:, k]]
+                valid = k < ncand[rows]
+                m1 = (ar < bi[:, None]) & okr
+                m2 = (ar >= bi[:, None]) & okr
+                s1, c1, e1, n1 = part(m1, np.ones(len(rows), dtype=bool))
+                s2, c2, e2, n2 = part(m2, np.full(len(rows), p2_deg == 1))
+                good = valid & (n1 >= 1) & (n2 >= 1)
+                mis[:, k] = np.where(good, e1 + e2, np.nan)
+                keep.append((bi, s1, c1, s2, c2))
+            for q, r in enumerate(rows):
+                if np.all(np.isnan(mis[q])):
+                    continue
+                k = int(np.nanargmin(mis[q]))
+                bi, s1, c1, s2, c2 = [a[q] for a in keep[k]]
+                p1 = np.array([s1, c1])
+                p2 = np.array([s2, c2]) if p2_deg == 1 else np.array([c2])
+                with np.errstate(all='ignore'):
+                    x_cross = (c2 - c1) / (s1 - (s2 if p2_deg == 1 else 0.0))
+                    dist = np.abs(logx - x_cross)
+                if np.all(np.isnan(dist)):
+                    continue
+                out_idx[r] = int(np.nanargmin(dist))
+                out_par[r] = (p1, p2)
+    for r in np.where(todo_scalar)[0]:
+        try:
+            out_idx[r], out_par[r] = fit_piecewise(logx, Y[r], p2_deg)
+        except ValueError:
+            pass
+    return out_idx, out_par
+
+
 def curv(x, y):
     """curvature y'' / (1 + y'^2)^(3/2) from second-order central
     differences; NaN at both ends (chi2_curvature_analyzer.py:25-49)."""
@@ -159,14 +257,27 @@ class LineFitAnalyzer(Analyzer):
         with np.errstate(all='ignore'):
             idx, params = fit_piecewise(np.log(alpha), np.log(chi2),
                                         self.linefit_deg)
+        return self._result(maxent_result, matrix_element, alpha, idx, params)
+
+    def _result(self, maxent_result, matrix_element, alpha, idx, params):
+        res = AnalyzerResult()
         res['alpha_index'] = idx
         res['linefit_params'] = params
-        res['A_out'] = _element(maxent_result, 'A', matrix_element)[idx]
+        res['A_out'] = maxent_result.element_row('A', matrix_element, idx)
         res['linefit_deg'] = self.linefit_deg
         res['name'] = self.name
         res['info'] = 'Ideal alpha (linefit): {} (= index {} zero-based)' \
             .format(alpha[idx], idx)
         return res
+
+    def analyze_many(self, maxent_result, keys):
+        """one result (or the error message) per key; all break points in one vectorised pass"""
+        alpha = np.asarray(maxent_result.alpha)
+        chi2 = np.array([np.asarray(_element(maxent_result, 'chi2', k), dtype=float) for k in keys])
+        with np.errstate(all='ignore'):
+            idx, params = fit_piecewise_many(np.log(alpha), np.log(chi2), self.linefit_deg)
+        return [self._result(maxent_result, k, alpha, int(i), p) if i >= 0 else 'chi2 is all NaN'
+                for k, i, p in zip(keys, idx, params)]
 
 
 class Chi2CurvatureAnalyzer(Analyzer):
@@ -183,11 +294,34 @@ class Chi2CurvatureAnalyzer(Analyzer):
         with np.errstate(all='ignore'):
             res['curvature'], _, _ = curv(self.gamma * np.log10(alpha),
                                           np.log10(chi2))
+        return self._finish(res, maxent_result, matrix_element, alpha)
+
+    def analyze_many(self, maxent_result, keys):
+        alpha = np.asarray(maxent_result.alpha)
+        x = self.gamma * np.log10(alpha)
+        out = []
+        with np.errstate(all='ignore'):
+            Y = np.log10(np.array([np.asarray(_element(maxent_result, 'chi2', k), dtype=float) for k in keys]))
+            hp, hm = x[2:] - x[1:-1], x[1:-1] - x[:-2]
+            der2 = (Y[:, 2:] - 2 * Y[:, 1:-1] + Y[:, :-2]) / (hp * hm)
+            der1 = ((Y[:, 2:] - Y[:, 1:-1]) / hp + (Y[:, 1:-1] - Y[:, :-2]) / hm) / 2
+            c = np.full(Y.shape, np.nan)
+            c[:, 1:-1] = der2 / (1 + der1 * der1) ** 1.5
+        for k, row in zip(keys, c):
+            res = AnalyzerResult()
+            res['curvature'] = row
+            try:
+                out.append(self._finish(res, maxent_result, k, alpha))
+            except ValueError as e:
+                out.append(str(e))
+        return out
+
+    def _finish(self, res, maxent_result, matrix_element, alpha):
         if np.all(np.isnan(res['curvature'])):
             raise ValueError('curvature is all NaN')
         idx = int(np.nanargmax(res['curvature']))
         res['alpha_index'] = idx
-        res['A_out'] = _element(maxent_result, 'A', matrix_element)[idx]
+        res['A_out'] = maxent_result.element_row('A', matrix_element, idx)
         res['gamma'] = self.gamma
         res['name'] = self.name
         res['info'] = 'Ideal alpha (curvature): {} (= index {} zero-based)' \
@@ -205,11 +339,30 @@ class EntropyAnalyzer(Analyzer):
         d = np.full(len(alpha), np.nan)
         d[1:-1] = (S[2:] - S[:-2]) / (np.log(alpha[2:]) - np.log(alpha[:-2]))
         res['dS_dalpha'] = d
+        return self._finish(res, maxent_result, matrix_element, alpha)
+
+    def analyze_many(self, maxent_result, keys):
+        alpha = np.asarray(maxent_result.alpha)
+        S = np.array([np.asarray(_element(maxent_result, 'S', k), dtype=float) for k in keys])
+        D = np.full(S.shape, np.nan)
+        D[:, 1:-1] = (S[:, 2:] - S[:, :-2]) / (np.log(alpha[2:]) - np.log(alpha[:-2]))
+        out = []
+        for k, row in zip(keys, D):
+            res = AnalyzerResult()
+            res['dS_dalpha'] = row
+            try:
+                out.append(self._finish(res, maxent_result, k, alpha))
+            except ValueError as e:
+                out.append(str(e))
+        return out
+
+    def _finish(self, res, maxent_result, matrix_element, alpha):
+        d = res['dS_dalpha']
         if np.all(np.isnan(d)):
             raise ValueError('dS_dalpha is all NaN')
         idx = int(np.nanargmin(d ** 2))
         res['alpha_index'] = idx
-        res['A_out'] = _element(maxent_result, 'A', matrix_element)[idx]
+        res['A_out'] = maxent_result.element_row('A', matrix_element, idx)
         res['name'] = self.name
         res['info'] = 'Ideal alpha (entropy): {} (= index {} zero-based)' \
             .format(alpha[idx], idx)
@@ -264,7 +417,7 @@ class ClassicAnalyzer(Analyzer):
             return res
         idx = int(np.nanargmax(logp))
         res['alpha_index'] = idx
-        res['A_out'] = _element(maxent_result, 'A', matrix_element)[idx]
+        res['A_out'] = maxent_result.element_row('A', matrix_element, idx)
         res['info'] = 'Ideal alpha (classic): {} (= index {} zero-based)' \
             .format(np.asarray(maxent_result.alpha)[idx], idx)
         return res

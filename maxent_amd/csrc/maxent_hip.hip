@@ -86,6 +86,7 @@ struct mxe_ctx {
     DevBuf<double> ev_x, ev_alpha, ev_scal, ev_vecw, ev_vecs, ev_mat;
     DevBuf<int> ev_elem;
     double chi2_factor = 1.0;     // of the staged chains (mxe_opts.chi2_factor)
+    struct mxe_comm_state* comm = nullptr;      // gather between GPUs (mxe_comm_*)
     std::string hip_err;
 };
 
@@ -341,10 +342,13 @@ try {
 }
 MXE_CATCH_ALL
 
+static void comm_release(mxe_ctx* ctx);
+
 void mxe_ctx_destroy(mxe_ctx* ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    comm_release(ctx);
     ctx->dlogdet.release(); ctx->dparent_elem.release(); ctx->dV.release(); ctx->dVt.release(); ctx->dVf.release(); ctx->dVtf.release(); ctx->dc.release(); ctx->dcinv.release();
     ctx->dghat.release(); ctx->dcperp.release(); ctx->dD.release(); ctx->dsumD.release();
     ctx->dalpha.release(); ctx->dv0.release(); ctx->delem_ds.release(); ctx->delem_kind.release();
@@ -598,7 +602,9 @@ try {
     HIPCHK(ctx, ctx->dalpha.ensure(P));
     HIPCHK(ctx, ctx->dv0.ensure(hv0.size()));
     HIPCHK(ctx, ctx->dout_v.ensure(P * NP));
-    HIPCHK(ctx, ctx->dout_pack.ensure(P * nw + 3 * P));
+    // one allocation: H [P][nw] | chi2 S Q [3P] | H of the analyzer's alpha [n_chain][nw] | its index [n_chain]
+    // (everything behind H is the COMPACT result pack that a gather between GPUs moves)
+    HIPCHK(ctx, ctx->dout_pack.ensure(P * nw + 3 * P + (size_t)n_chain * (nw + 1)));
     ctx->result_buffer = 0;
     ctx->dout_H.p = ctx->dout_pack.p;
     ctx->dout_chi2.p = ctx->dout_pack.p + P * nw;
@@ -824,7 +830,7 @@ int mxe_set_result_buffer(mxe_ctx* ctx, int which)
     if (!ctx->chains_ready) return MXE_ERR_STATE;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t P = (size_t)ctx->n_chain * ctx->n_alpha, nw = ctx->n_omega;
-    if (which == 1) HIPCHK(ctx, ctx->dout_pack2.ensure(P * nw + 3 * P));
+    if (which == 1) HIPCHK(ctx, ctx->dout_pack2.ensure(P * nw + 3 * P + (size_t)ctx->n_chain * (nw + 1)));
     double* base = which ? ctx->dout_pack2.p : ctx->dout_pack.p;
     ctx->result_buffer = which;
     ctx->dout_H.p = base; ctx->dout_chi2.p = base + P * nw; ctx->dout_S.p = ctx->dout_chi2.p + P; ctx->dout_Q.p = ctx->dout_S.p + P;
@@ -1224,6 +1230,299 @@ try {
     return MXE_OK;
 }
 MXE_CATCH_ALL
+
+// ---- the default analyzer's alpha on the device, and the compact result pack ----------------
+extern "C" int mxe_select_launch(mxe_ctx* ctx, int p2_deg)
+try {
+    if (!ctx || (p2_deg != 0 && p2_deg != 1)) return MXE_ERR_ARG;
+    if (!ctx->launched) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)ctx->n_chain * ctx->n_alpha;
+    double* sel = ctx->dout_Q.p + P;
+    double* idx = sel + (size_t)ctx->n_chain * ctx->n_omega;
+    hipLaunchKernelGGL(mxe::linefit_kernel, dim3(ctx->n_chain), dim3(64), (size_t)2 * ctx->n_alpha * sizeof(double), ctx->stream,
+                       ctx->dalpha.p, ctx->dout_chi2.p, ctx->dout_H.p, ctx->n_alpha, ctx->n_omega, p2_deg, sel, idx);
+    HIPCHK(ctx, hipGetLastError());
+    return MXE_OK;
+}
+MXE_CATCH_ALL
+
+extern "C" int mxe_select_fetch(mxe_ctx* ctx, int32_t* out_index, double* out_H_selected)
+try {
+    if (!ctx) return MXE_ERR_ARG;
+    if (!ctx->launched) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)ctx->n_chain * ctx->n_alpha, nc = ctx->n_chain, nw = ctx->n_omega;
+    const double* sel = ctx->dout_Q.p + P;
+    HIPCHK(ctx, stream_wait(ctx->stream));
+    if (out_H_selected) HIPCHK(ctx, hipMemcpy(out_H_selected, sel, nc * nw * 8, hipMemcpyDeviceToHost));
+    if (out_index) {
+        std::vector<double> hi(nc);
+        HIPCHK(ctx, hipMemcpy(hi.data(), sel + nc * nw, nc * 8, hipMemcpyDeviceToHost));
+        for (size_t c = 0; c < nc; ++c) out_index[c] = (int32_t)hi[c];
+    }
+    return MXE_OK;
+}
+MXE_CATCH_ALL
+
+extern "C" int mxe_fetch_rows(mxe_ctx* ctx, int n_rows, const int32_t* problem_index, double* out_H)
+try {
+    if (!ctx || n_rows < 1 || !problem_index || !out_H) return MXE_ERR_ARG;
+    if (!ctx->launched) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)ctx->n_chain * ctx->n_alpha, nw = ctx->n_omega;
+    HIPCHK(ctx, stream_wait(ctx->stream));
+    for (int r = 0; r < n_rows; ++r) {
+        if (problem_index[r] < 0 || (size_t)problem_index[r] >= P) return MXE_ERR_ARG;
+        HIPCHK(ctx, hipMemcpyAsync(out_H + (size_t)r * nw, ctx->dout_H.p + (size_t)problem_index[r] * nw, nw * 8,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MXE_OK;
+}
+MXE_CATCH_ALL
+
+// ---- gather between GPUs: RCCL over xGMI, called directly (no framework in between) --------
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool load() {
+        if (lib) return true;
+        const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+        for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+        if (!lib) return false;
+#define MXE_SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(lib, name)); if (!field) { dlclose(lib); lib = nullptr; return false; }
+        MXE_SYM(GetUniqueId, "ncclGetUniqueId"); MXE_SYM(CommInitRank, "ncclCommInitRank"); MXE_SYM(CommInitAll, "ncclCommInitAll");
+        MXE_SYM(CommDestroy, "ncclCommDestroy"); MXE_SYM(Send, "ncclSend"); MXE_SYM(Recv, "ncclRecv");
+        MXE_SYM(AllReduce, "ncclAllReduce"); MXE_SYM(GroupStart, "ncclGroupStart"); MXE_SYM(GroupEnd, "ncclGroupEnd"); MXE_SYM(GetErrorString, "ncclGetErrorString");
+#undef MXE_SYM
+        return true;
+    }
+};
+Rccl g_rccl;
+#define NCCLCHK(ctx, call) do { ncclResult_t r__ = (call); if (r__ != ncclSuccess) { \
+    (ctx)->hip_err = std::string(#call) + ": " + g_rccl.GetErrorString(r__); return MXE_ERR_HIP; } } while (0)
+} // namespace
+
+struct mxe_comm_state {
+    ncclComm_t comm = nullptr;
+    int n_ranks = 1, rank = 0;
+    bool copy_transport = false;                 // ranks of ONE process on one device: plain device copies
+    std::vector<mxe_ctx*> local;                 // ... the contexts of that process, by rank
+    DevBuf<double> recv;                         // root: [sum of counts]
+    DevBuf<double> small;                        // mxe_comm_allreduce
+};
+
+extern "C" int mxe_comm_unique_id(char* out_id128)
+{
+    if (!out_id128) return MXE_ERR_ARG;
+    if (!g_rccl.load()) return MXE_ERR_NODEVICE;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return MXE_ERR_HIP;
+    std::memcpy(out_id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return MXE_OK;
+}
+
+extern "C" int mxe_comm_init(mxe_ctx* ctx, int n_ranks, int rank, const char* id128)
+try {
+    if (!ctx || n_ranks < 1 || rank < 0 || rank >= n_ranks || !id128) return MXE_ERR_ARG;
+    if (!g_rccl.load()) { ctx->hip_err = "librccl.so.1 could not be loaded"; return MXE_ERR_NODEVICE; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    comm_release(ctx);
+    ctx->comm = new mxe_comm_state();
+    ctx->comm->n_ranks = n_ranks; ctx->comm->rank = rank;
+    ncclUniqueId id;
+    std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    NCCLCHK(ctx, g_rccl.CommInitRank(&ctx->comm->comm, n_ranks, id, rank));
+    return MXE_OK;
+}
+MXE_CATCH_ALL
+
+extern "C" int mxe_comm_init_local(mxe_ctx** ctxs, int n)
+try {
+    if (!ctxs || n < 1) return MXE_ERR_ARG;
+    for (int r = 0; r < n; ++r) if (!ctxs[r]) return MXE_ERR_ARG;
+    bool distinct = true;
+    for (int a = 0; a < n; ++a) for (int b = a + 1; b < n; ++b) if (ctxs[a]->device == ctxs[b]->device) distinct = false;
+    std::vector<ncclComm_t> comms(n, nullptr);
+    if (distinct && n > 1) {
+        if (!g_rccl.load()) { ctxs[0]->hip_err = "librccl.so.1 could not be loaded"; return MXE_ERR_NODEVICE; }
+        std::vector<int> devs(n);
+        for (int r = 0; r < n; ++r) devs[r] = ctxs[r]->device;
+        NCCLCHK(ctxs[0], g_rccl.CommInitAll(comms.data(), n, devs.data()));
+    }
+    for (int r = 0; r < n; ++r) {
+        comm_release(ctxs[r]);
+        ctxs[r]->comm = new mxe_comm_state();
+        ctxs[r]->comm->n_ranks = n; ctxs[r]->comm->rank = r;
+        ctxs[r]->comm->comm = comms[r];
+        ctxs[r]->comm->copy_transport = !(distinct && n > 1);
+        ctxs[r]->comm->local.assign(ctxs, ctxs + n);
+    }
+    return MXE_OK;
+}
+MXE_CATCH_ALL
+
+static void comm_release(mxe_ctx* ctx)
+{
+    if (!ctx || !ctx->comm) return;
+    if (ctx->comm->comm && g_rccl.lib) g_rccl.CommDestroy(ctx->comm->comm);
+    ctx->comm->recv.release();
+    ctx->comm->small.release();
+    delete ctx->comm;
+    ctx->comm = nullptr;
+}
+
+extern "C" int mxe_comm_destroy(mxe_ctx* ctx)
+{
+    if (!ctx) return MXE_ERR_ARG;
+    hipSetDevice(ctx->device);
+    comm_release(ctx);
+    return MXE_OK;
+}
+
+// what a rank contributes: the compact pack (chi2, S, Q of every alpha + the H row and index of the
+// analyzer's alpha per scan) or the full one (all H in front of it)
+static void gather_span(mxe_ctx* ctx, int what, double** p, size_t* count)
+{
+    const size_t P = (size_t)ctx->n_chain * ctx->n_alpha, nw = ctx->n_omega, nc = ctx->n_chain;
+    const size_t compact = 3 * P + nc * (nw + 1);
+    if (what == MXE_GATHER_FULL) { *p = ctx->dout_H.p; *count = P * nw + compact; }
+    else { *p = ctx->dout_chi2.p; *count = compact; }
+}
+
+// enqueue this rank's part of the gather on its stream (inside a group when called for several local ranks)
+static int gather_enqueue(mxe_ctx* ctx, int root, int what, const int64_t* counts)
+{
+    mxe_comm_state* cm = ctx->comm;
+    double* mine; size_t n_mine;
+    gather_span(ctx, what, &mine, &n_mine);
+    if ((int64_t)n_mine != counts[cm->rank]) return MXE_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (cm->rank == root) {
+        size_t total = 0;
+        for (int r = 0; r < cm->n_ranks; ++r) total += (size_t)counts[r];
+        HIPCHK(ctx, cm->recv.ensure(total));
+        size_t off = 0;
+        for (int r = 0; r < cm->n_ranks; ++r) {
+            if (r == root) HIPCHK(ctx, hipMemcpyAsync(cm->recv.p + off, mine, n_mine * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            else if (!cm->copy_transport) NCCLCHK(ctx, g_rccl.Recv(cm->recv.p + off, (size_t)counts[r], ncclDouble, r, cm->comm, ctx->stream));
+            off += (size_t)counts[r];
+        }
+    } else if (!cm->copy_transport) {
+        NCCLCHK(ctx, g_rccl.Send(mine, n_mine, ncclDouble, root, cm->comm, ctx->stream));
+    }
+    return MXE_OK;
+}
+
+extern "C" int mxe_gather(mxe_ctx* ctx, int root, int what, const int64_t* counts, double* recv_host)
+try {
+    if (!ctx || !counts || (what != MXE_GATHER_COMPACT && what != MXE_GATHER_FULL)) return MXE_ERR_ARG;
+    if (!ctx->comm || !ctx->launched) return MXE_ERR_STATE;
+    mxe_comm_state* cm = ctx->comm;
+    if (root < 0 || root >= cm->n_ranks) return MXE_ERR_ARG;
+    if (!cm->local.empty()) return MXE_ERR_STATE;            // ranks of one process gather together: mxe_gather_local
+    if (cm->n_ranks > 1) NCCLCHK(ctx, g_rccl.GroupStart());
+    const int rc = gather_enqueue(ctx, root, what, counts);
+    if (cm->n_ranks > 1) NCCLCHK(ctx, g_rccl.GroupEnd());
+    if (rc != MXE_OK) return rc;
+    if (recv_host && cm->rank == root) {
+        size_t total = 0;
+        for (int r = 0; r < cm->n_ranks; ++r) total += (size_t)counts[r];
+        HIPCHK(ctx, hipMemcpyAsync(recv_host, cm->recv.p, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, stream_wait(ctx->stream));
+    }
+    return MXE_OK;
+}
+MXE_CATCH_ALL
+
+extern "C" int mxe_gather_local(mxe_ctx** ctxs, int n, int root, int what, const int64_t* counts, double* recv_host)
+try {
+    if (!ctxs || n < 1 || root < 0 || root >= n || !counts || (what != MXE_GATHER_COMPACT && what != MXE_GATHER_FULL)) return MXE_ERR_ARG;
+    for (int r = 0; r < n; ++r)
+        if (!ctxs[r] || !ctxs[r]->comm || ctxs[r]->comm->n_ranks != n || ctxs[r]->comm->rank != r || !ctxs[r]->launched) return MXE_ERR_STATE;
+    mxe_ctx* rt = ctxs[root];
+    const bool copy = rt->comm->copy_transport;
+    if (copy) {
+        // ranks that share a device (or a single rank): the root waits for the others' launches with events
+        // and copies their packs itself
+        for (int r = 0; r < n; ++r) {
+            if (r == root) continue;
+            HIPCHK(ctxs[r], hipSetDevice(ctxs[r]->device));
+            HIPCHK(ctxs[r], hipEventRecord(ctxs[r]->ev_mark, ctxs[r]->stream));
+            HIPCHK(rt, hipSetDevice(rt->device));
+            HIPCHK(rt, hipStreamWaitEvent(rt->stream, ctxs[r]->ev_mark, 0));
+        }
+    } else {
+        NCCLCHK(rt, g_rccl.GroupStart());
+    }
+    int rc = MXE_OK;
+    for (int r = 0; r < n && rc == MXE_OK; ++r) rc = gather_enqueue(ctxs[r], root, what, counts);
+    if (!copy) NCCLCHK(rt, g_rccl.GroupEnd());
+    if (rc != MXE_OK) return rc;
+    if (copy) {
+        HIPCHK(rt, hipSetDevice(rt->device));
+        size_t off = 0;
+        for (int r = 0; r < n; ++r) {
+            if (r != root) {
+                double* src; size_t cnt;
+                gather_span(ctxs[r], what, &src, &cnt);
+                HIPCHK(rt, hipMemcpyAsync(rt->comm->recv.p + off, src, cnt * 8, hipMemcpyDeviceToDevice, rt->stream));
+            }
+            off += (size_t)counts[r];
+        }
+    }
+    if (recv_host) {
+        size_t total = 0;
+        for (int r = 0; r < n; ++r) total += (size_t)counts[r];
+        HIPCHK(rt, hipSetDevice(rt->device));
+        HIPCHK(rt, hipMemcpyAsync(recv_host, rt->comm->recv.p, total * 8, hipMemcpyDeviceToHost, rt->stream));
+        HIPCHK(rt, stream_wait(rt->stream));
+    }
+    return MXE_OK;
+}
+MXE_CATCH_ALL
+
+extern "C" int mxe_comm_allreduce(mxe_ctx* ctx, double* inout_host, int n, int op)
+try {
+    if (!ctx || !inout_host || n < 1 || n > 64 || (op != 0 && op != 1)) return MXE_ERR_ARG;
+    if (!ctx->comm) return MXE_ERR_STATE;
+    mxe_comm_state* cm = ctx->comm;
+    if (cm->n_ranks == 1 || !cm->local.empty()) return MXE_OK;        // one process: nothing to agree on
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, cm->small.ensure(64));
+    HIPCHK(ctx, hipMemcpyAsync(cm->small.p, inout_host, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    NCCLCHK(ctx, g_rccl.AllReduce(cm->small.p, cm->small.p, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, cm->comm, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(inout_host, cm->small.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));
+    return MXE_OK;
+}
+MXE_CATCH_ALL
+
+// element e -> rank e mod n_ranks (an element's alpha scan stays on one device); pure host arithmetic
+extern "C" int mxe_shard_plan(int n_elem, int n_ranks, int32_t* rank_of_elem, int32_t* local_index, int32_t* n_local)
+{
+    if (n_elem < 0 || n_ranks < 1 || !rank_of_elem || !local_index || !n_local) return MXE_ERR_ARG;
+    for (int r = 0; r < n_ranks; ++r) n_local[r] = 0;
+    for (int e = 0; e < n_elem; ++e) {
+        const int r = e % n_ranks;
+        rank_of_elem[e] = r;
+        local_index[e] = n_local[r]++;
+    }
+    return MXE_OK;
+}
 
 // ---- output map A = B H ----------------------------------------------------
 namespace mxe {

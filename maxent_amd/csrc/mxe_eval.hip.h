@@ -349,3 +349,77 @@ void entropy_kernel(int kind, int n, const double* __restrict__ H, const double*
 }
 
 } // namespace mxe
+
+// ---- the default analyzer on the device: LineFitAnalyzer's alpha (linefit_analyzer.py:28-87, 151-183) --
+// Two-piece fit of log chi2 (log alpha): a line through the first i points, a constant (p2_deg = 0) or a
+// line (p2_deg = 1) through the rest, i = 2 .. n-3 chosen for the smallest summed squared misfit; the answer
+// is the index of the alpha closest to the intersection.  NaN chi2 are left out.  One wavefront per scan:
+// lane t evaluates the break points t, t + 64, ... with the two-pass formulas of the host analyzer
+// (maxent_amd/analyzers.py: _linfit_sse), then the H of the chosen alpha is copied out, so that a caller
+// (or a gather between GPUs) moves one row per scan instead of all of them.
+namespace mxe {
+
+struct LineSSE { double slope, icpt, sse; int n; };
+
+__device__ inline LineSSE line_sse(const double* x, const double* y, int lo, int hi, bool line)
+{
+    LineSSE r; r.slope = 0.0; r.icpt = 0.0; r.sse = 0.0; r.n = 0;
+    double sx = 0.0, sy = 0.0;
+    for (int k = lo; k < hi; ++k) if (y[k] == y[k]) { sx += x[k]; sy += y[k]; ++r.n; }
+    if (r.n < 1) return r;
+    const double xm = sx / r.n, ym = sy / r.n;
+    double sxx = 0.0, sxy = 0.0;
+    for (int k = lo; k < hi; ++k) if (y[k] == y[k]) { const double dx = x[k] - xm; sxx += dx * dx; sxy += dx * (y[k] - ym); }
+    if (line && r.n >= 2 && sxx != 0.0) { r.slope = sxy / sxx; r.icpt = ym - r.slope * xm; }
+    else r.icpt = ym;
+    for (int k = lo; k < hi; ++k) if (y[k] == y[k]) { const double d = y[k] - (r.slope * x[k] + r.icpt); r.sse += d * d; }
+    return r;
+}
+
+__global__ __launch_bounds__(64)
+void linefit_kernel(const double* __restrict__ alpha, const double* __restrict__ chi2, const double* __restrict__ H,
+                    int n_alpha, int nw, int p2_deg, double* __restrict__ out_sel /*[n_chain][nw] or null*/,
+                    double* __restrict__ out_idx /*[n_chain], as doubles (they travel in the result pack)*/)
+{
+    extern __shared__ double sm[];
+    double* x = sm;                  // log alpha
+    double* y = x + n_alpha;         // log chi2
+    const int lane = threadIdx.x, n = n_alpha;
+    const size_t c = blockIdx.x;
+    for (int k = lane; k < n; k += 64) { x[k] = log(alpha[c * n + k]); y[k] = log(chi2[c * n + k]); }
+    wave_sync();
+    double best = __builtin_inf(); int best_i = -1;
+    for (int i = 2 + lane; i < n - 2; i += 64) {
+        const LineSSE a = line_sse(x, y, 0, i, true), b = line_sse(x, y, i, n, p2_deg == 1);
+        if (a.n < 1 || b.n < 1) continue;
+        const double m = a.sse + b.sse;
+        if (m == m && (m < best || (m == best && i < best_i))) { best = m; best_i = i; }
+    }
+    // smallest misfit, lowest index among equals (np.nanargmin)
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ob = __shfl_xor(best, off); const int oi = __shfl_xor(best_i, off);
+        if (oi >= 0 && (best_i < 0 || ob < best || (ob == best && oi < best_i))) { best = ob; best_i = oi; }
+    }
+    int idx = -1;
+    if (best_i >= 0) {
+        const LineSSE a = line_sse(x, y, 0, best_i, true), b = line_sse(x, y, best_i, n, p2_deg == 1);
+        const double xc = (b.icpt - a.icpt) / (a.slope - b.slope);
+        double dbest = __builtin_inf(); int di = -1;
+        for (int k = lane; k < n; k += 64) {
+            const double d = fabs(x[k] - xc);
+            if (d == d && (d < dbest || (d == dbest && k < di))) { dbest = d; di = k; }
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double od = __shfl_xor(dbest, off); const int oi = __shfl_xor(di, off);
+            if (oi >= 0 && (di < 0 || od < dbest || (od == dbest && oi < di))) { dbest = od; di = oi; }
+        }
+        idx = di;
+    }
+    if (lane == 0) out_idx[c] = (double)idx;
+    if (out_sel) {
+        const double* row = H + (c * n + (idx >= 0 ? idx : 0)) * nw;
+        for (int k = lane; k < nw; k += 64) out_sel[c * nw + k] = (idx >= 0) ? row[k] : __builtin_nan("");
+    }
+}
+
+} // namespace mxe

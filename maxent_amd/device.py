@@ -94,6 +94,17 @@ SYMBOLS = [
     ('mxe_eval_batch', ctypes.c_int, [_vp, ctypes.c_int, _ip, _dp, _dp, ctypes.c_int, ctypes.c_double] + [_dp] * 11),
     ('mxe_entropy', ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp]),
     ('mxe_audit', ctypes.c_int, [_vp, _dp, _dp]),
+    ('mxe_select_launch', ctypes.c_int, [_vp, ctypes.c_int]),
+    ('mxe_select_fetch', ctypes.c_int, [_vp, _ip, _dp]),
+    ('mxe_fetch_rows', ctypes.c_int, [_vp, ctypes.c_int, _ip, _dp]),
+    ('mxe_shard_plan', ctypes.c_int, [ctypes.c_int, ctypes.c_int, _ip, _ip, _ip]),
+    ('mxe_comm_unique_id', ctypes.c_int, [ctypes.c_char_p]),
+    ('mxe_comm_init', ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
+    ('mxe_comm_init_local', ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int]),
+    ('mxe_comm_destroy', ctypes.c_int, [_vp]),
+    ('mxe_gather', ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _lp, _dp]),
+    ('mxe_gather_local', ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int, _lp, _dp]),
+    ('mxe_comm_allreduce', ctypes.c_int, [_vp, _dp, ctypes.c_int, ctypes.c_int]),
     ('mxe_kernel_svd', ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp,
                                       ctypes.c_double, ctypes.c_int, _dp, ctypes.c_double,
                                       ctypes.c_int, _dp, _dp, _dp, _dp, _ip, _ip,
@@ -123,6 +134,51 @@ def load_library():
         fn.argtypes = argtypes
     _LIB = lib
     return lib
+
+
+def comm_unique_id():
+    """128 bytes that rank 0 hands to the other ranks before ``DeviceContext.comm_init`` (ncclGetUniqueId)"""
+    lib = load_library()
+    buf = ctypes.create_string_buffer(128)
+    rc = lib.mxe_comm_unique_id(buf)
+    if rc != 0:
+        raise MaxEntDeviceError('mxe_comm_unique_id failed: ' + lib.mxe_strerror(rc).decode())
+    return buf.raw
+
+
+def shard_plan(n_elem, n_ranks):
+    """``mxe_shard_plan``: (rank of every element, its index inside the rank's shard, shard sizes);
+    host arithmetic only, works without a GPU"""
+    lib = load_library()
+    rk = np.zeros(max(n_elem, 1), dtype=np.int32)
+    li = np.zeros(max(n_elem, 1), dtype=np.int32)
+    nl = np.zeros(n_ranks, dtype=np.int32)
+    rc = lib.mxe_shard_plan(int(n_elem), int(n_ranks), _p(rk), _p(li), _p(nl))
+    if rc != 0:
+        raise MaxEntDeviceError('mxe_shard_plan failed: ' + lib.mxe_strerror(rc).decode())
+    return rk[:n_elem], li[:n_elem], nl
+
+
+def comm_init_local(contexts):
+    """ranks of one process: rank = position in ``contexts`` (``mxe_comm_init_local``)"""
+    lib = load_library()
+    arr = (_vp * len(contexts))(*[c._h for c in contexts])
+    rc = lib.mxe_comm_init_local(arr, len(contexts))
+    if rc != 0:
+        raise MaxEntDeviceError('mxe_comm_init_local failed: ' + lib.mxe_strerror(rc).decode())
+
+
+def gather_local(contexts, root, counts, full=False, recv=None):
+    lib = load_library()
+    arr = (_vp * len(contexts))(*[c._h for c in contexts])
+    counts = _c(counts, np.int64)
+    rc = lib.mxe_gather_local(arr, len(contexts), int(root), 1 if full else 0, _p(counts), _p(recv))
+    if rc != 0:
+        msg = lib.mxe_strerror(rc).decode()
+        if rc == -2:
+            msg += ': ' + lib.mxe_last_hip_error(contexts[root]._h).decode()
+        raise MaxEntDeviceError('mxe_gather_local failed: ' + msg)
+    return recv
 
 
 def device_count():
@@ -395,6 +451,47 @@ class DeviceContext(object):
         gmax = np.empty((self._n_chain, self._n_alpha))
         self._check(self._lib.mxe_audit(self._h, _p(corr), _p(gmax)), 'mxe_audit')
         return dict(corr=corr, gmax=gmax)
+
+    # -- the analyzer's alpha on the device, selected rows --------------------
+    def select_launch(self, linefit_deg=0):
+        self._check(self._lib.mxe_select_launch(self._h, int(linefit_deg)), 'mxe_select_launch')
+
+    def select_fetch(self, want_H=True):
+        idx = np.empty(self._n_chain, dtype=np.int32)
+        Hs = np.empty((self._n_chain, self.n_omega)) if want_H else None
+        self._check(self._lib.mxe_select_fetch(self._h, _p(idx), _p(Hs)), 'mxe_select_fetch')
+        return idx, Hs
+
+    def fetch_rows(self, problem_index):
+        pi = _c(np.atleast_1d(problem_index), np.int32)
+        out = np.empty((len(pi), self.n_omega))
+        self._check(self._lib.mxe_fetch_rows(self._h, len(pi), _p(pi), _p(out)), 'mxe_fetch_rows')
+        return out
+
+    def compact_count(self):
+        """doubles of the compact result pack of the staged chains (mxe_gather)"""
+        P = self._n_chain * self._n_alpha
+        return 3 * P + self._n_chain * (self.n_omega + 1)
+
+    def full_count(self):
+        return self._n_chain * self._n_alpha * self.n_omega + self.compact_count()
+
+    # -- ranks in separate processes -----------------------------------------
+    def comm_init(self, n_ranks, rank, unique_id):
+        self._check(self._lib.mxe_comm_init(self._h, int(n_ranks), int(rank), bytes(unique_id)), 'mxe_comm_init')
+
+    def comm_destroy(self):
+        self._check(self._lib.mxe_comm_destroy(self._h), 'mxe_comm_destroy')
+
+    def gather(self, root, counts, full=False, recv=None):
+        counts = _c(counts, np.int64)
+        self._check(self._lib.mxe_gather(self._h, int(root), 1 if full else 0, _p(counts), _p(recv)), 'mxe_gather')
+        return recv
+
+    def allreduce(self, values, op='sum'):
+        x = _c(np.atleast_1d(values))
+        self._check(self._lib.mxe_comm_allreduce(self._h, _p(x), len(x), 0 if op == 'sum' else 1), 'mxe_comm_allreduce')
+        return x
 
     def apply_output_map(self, B):
         B = _c(B).reshape(self.n_omega, self.n_omega)

@@ -49,7 +49,12 @@ class ElementwiseMaxEnt(object):
     maxent_diagonal = None
     maxent_offdiagonal = None
 
-    def __init__(self, use_hermiticity=True, use_complex=False, **kwargs):
+    def __init__(self, use_hermiticity=True, use_complex=False, n_gpus=None, device_ids=None, **kwargs):
+        """``n_gpus`` / ``device_ids``: shard the matrix elements over several GPUs of this process
+        (element e of a phase on device e mod N, one gather).  Default: device 0."""
+        if device_ids is None and n_gpus is not None:
+            device_ids = tuple(range(int(n_gpus)))
+        object.__setattr__(self, 'device_ids', None if device_ids is None else tuple(device_ids))
         self.maxent_diagonal = TauMaxEnt(**kwargs)
         self.maxent_offdiagonal = TauMaxEnt(cost_function='plusminus',
                                             **kwargs)
@@ -127,11 +132,29 @@ class ElementwiseMaxEnt(object):
         res = self.maxent_result
         loop = worker.maxent_loop
         specs, live = [], []
+        self._share_decomposition()
+        direct = self._direct_input(worker) and per_job_D is None
         for n, (element, re) in enumerate(jobs):
+            cidx = 0 if re else 1
+            if direct and n > 0:
+                # array input, plain errors, unrotated kernel: the spec of every further element straight
+                # from the arrays (the worker keeps the first element's state until the last is loaded below)
+                g = self.G_mat[1][tuple(element)]
+                g = np.real(g) if (re or element[0] == element[1]) else np.imag(g)
+                if np.max(np.abs(g)) < loop.G_threshold:
+                    res._zero_elements.append(tuple(element) + ((cidx,) if self.use_complex else ()))
+                    worker.logtaker.error_message('G below threshold, not performing the calculation.')
+                    continue
+                spec = loop.make_spec(G=g, err=self.get_error(tuple(element)))
+                spec['A_map'] = loop.A_of_H
+                specs.append(spec)
+                live.append((element, cidx))
+                if n == len(jobs) - 1:
+                    self._load_element(worker, element, re)      # the state the reference leaves behind
+                continue
             if per_job_D is not None:
                 worker.set_D(per_job_D[n])
             self._load_element(worker, element, re)
-            cidx = 0 if re else 1
             if loop.below_threshold():
                 key = tuple(element) + ((cidx,) if self.use_complex else ())
                 res._zero_elements.append(key)
@@ -150,31 +173,62 @@ class ElementwiseMaxEnt(object):
         for (element, cidx) in live:
             res.start_timing(element, cidx, time=t0)
         sols, info = solve_elements(loop.K, specs, loop.minimizer,
-                                    device_id=loop.device_id,
+                                    device_id=loop.device_id, device_ids=self.device_ids,
                                     want_logdet=loop.probability is not None,
                                     chi2_factor=loop.cost_function.chi2_factor)
         self.last_launches.append(info)
         t1 = datetime.now()
         per_alpha = (t1 - t0) / max(1, len(specs) * len(specs[0]['alpha']))
+        talk = bool(worker.logtaker.verbose & (VerbosityFlags.ElementInfo | VerbosityFlags.AlphaLoop))
         for spec, sol, (element, cidx) in zip(specs, sols, live):
-            worker.logtaker.message(
-                VerbosityFlags.ElementInfo,
-                'Element {} {}{}'.format(element[0], element[1],
-                                         '' if cidx == 0 else ' (imaginary part)'))
-            loop.log_alpha_lines(sol)
+            if talk:
+                worker.logtaker.message(
+                    VerbosityFlags.ElementInfo,
+                    'Element {} {}{}'.format(element[0], element[1],
+                                             '' if cidx == 0 else ' (imaginary part)'))
+                loop.log_alpha_lines(sol)
             rec = loop.make_record(spec, sol)
             rec['run_times'] = [per_alpha] * len(sol['alpha'])
             res.add_element_results(rec, element, cidx)
             res.end_timing(element, cidx, time=t1)
-        # analyzers after every record of the batch is in (adding a record drops the
-        # assembled-array cache of the result)
-        for (element, cidx) in live:
-            res.analyze(loop.analyzers, element, cidx)
+        if not talk and sols:
+            loop.note_minimizer_state(sols[-1], sum(int(np.sum(x['n_iter'])) for x in sols))
+        # analyzers after every record of the batch is in (adding a record drops the assembled-array cache
+        # of the result); the rows of A they select come off the device in one go
+        res.analyze_batch(loop.analyzers, [res._key(element, cidx) for (element, cidx) in live])
         worker.logtaker.message(
             VerbosityFlags.Timing,
             '{} alpha scans x {} alpha in one launch: kernel {:.3f} ms',
             len(specs), len(specs[0]['alpha']), info['kernel_ms'])
         return res
+
+    def _direct_input(self, worker):
+        """G(tau) came as one array and the errors are plain (no covariance): specs can be cut from the
+        arrays without sending every element through the worker's setters"""
+        return (getattr(self, '_array_input', False) and self.error_dimension == 1 and
+                worker.K._T is None and not isinstance(self.error, str))
+
+    def _share_decomposition(self):
+        """the two workers have kernels of their own; where these are the same matrix (same class, tau,
+        omega, beta, no preblur on one side only) the second takes the SVD of the first instead of
+        repeating it"""
+        a, b = self.maxent_diagonal.K, self.maxent_offdiagonal.K
+        if a is b or type(a) is not type(b) or not hasattr(a, 'tau') or a._T is not None or b._T is not None:
+            return
+        try:
+            same = (np.array_equal(np.asarray(a.tau), np.asarray(b.tau)) and
+                    np.array_equal(np.asarray(a.omega), np.asarray(b.omega)) and a.beta == b.beta and
+                    a.svd_backend == b.svd_backend)
+        except Exception:
+            return
+        if not same:
+            return
+        src, dst = (a, b) if b._U is None else ((b, a) if a._U is None else (None, None))
+        if src is None:
+            return
+        src.S
+        dst._U, dst._S, dst._V = src._U, src._S, src._V
+        dst._last_threshold = src._last_threshold
 
     def _diag_jobs(self):
         return [((i, i), True) for i in range(self.shape[0])]
@@ -219,6 +273,7 @@ class ElementwiseMaxEnt(object):
         self.set_G_element = set_G_element
         self.determine_shape = determine_shape
         self.maxent_result = None
+        object.__setattr__(self, '_array_input', False)
 
     def set_G_tau(self, *args, **kwargs):
         raise NotImplementedError('set_G_tau needs TRIQS Green functions; '
@@ -233,6 +288,7 @@ class ElementwiseMaxEnt(object):
             maxent.set_G_tau_data(G_mat[0], np.real(g) if re else np.imag(g),
                                   *args, **kwargs)
         self.set_G((tau, G_tau), feed, lambda G_mat: G_mat[1].shape[:2])
+        object.__setattr__(self, '_array_input', not args and not kwargs)
 
     def set_G_tau_filename_pattern(self, filename, dimension, tau_col=0,
                                    G_col_re=1, G_col_im=2, *args, **kwargs):

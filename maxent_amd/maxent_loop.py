@@ -41,84 +41,35 @@ class _LazyProduct(object):
 
     def __array__(self, dtype=None, copy=None):
         if self._val is None:
-            self._val = np.dot(self._A, self._K.T)
+            self._val = np.dot(np.asarray(self._A), self._K.T)
             self._A = self._K = None
         return self._val if dtype is None else self._val.astype(dtype, copy=False)
 
 
 def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0,
-                   want_logdet=False, chi2_factor=1.0):
-    """Solve the alpha scans of several elements in ONE kernel launch.
+                   want_logdet=False, chi2_factor=1.0, device_ids=None, want_H='lazy'):
+    """Solve the alpha scans of several elements in ONE kernel launch per device.
 
-    ``K``: kernel whose singular space has been reduced (U, S, V staged once).
+    ``K``: kernel whose singular space has been reduced (U, S, V are staged once per device and kept,
+    :class:`maxent_amd.batch_solver.BatchSolver`).
     ``specs``: list of dicts with keys
         G (data vector in the element's data space), err (same length),
         U_rot (left factor if that space is rotated, else None),
         D (default model incl. delta), kind (device.ENTROPY_*),
         v0 (start vector), alpha (scaled alphas, in visiting order).
     All specs must have the same number of alphas.
-    ``want_logdet``: also return log det(I + M W/alpha) per alpha (device
-    kernel; the expensive term of NormalLogProbability).
-    Returns (list of per-spec dicts(alpha, v, H, chi2, S, Q, n_iter,
-    converged, n_evals[, logdet]), info dict).
+    ``device_ids``: the GPUs of this process to shard the elements over (element e of the batch on
+    device e mod N, one gather at the end); default: the single ``device_id``.
+    ``want_logdet``: also return log det(I + M W/alpha) per alpha (device kernel; the expensive term of
+    NormalLogProbability).  ``want_H``: 'lazy' (H stays on the device until it is looked at), True, False.
+    Returns (list of per-spec dicts(alpha, v, H, chi2, S, Q, n_iter, converged, n_evals[, logdet]), info).
     """
     if not specs:
         return [], dict(kernel_ms=0.0)
-    n_alpha = len(specs[0]['alpha'])
-    for s in specs:
-        if len(s['alpha']) != n_alpha:
-            raise ValueError('all elements of a batch need the same number '
-                             'of alpha values')
-    ctx = device.DeviceContext(K.U if K._T is None else None, K.S, K.V,
-                               device=device_id)
-    try:
-        ds_ids = []
-        cache = []
-        for s in specs:
-            err = np.asarray(s['err'], dtype=float) * np.ones(len(s['G']))
-            U_rot = s.get('U_rot')
-            found = None
-            for (e0, u0, i0) in cache:
-                if u0 is U_rot and e0.shape == err.shape and np.array_equal(e0, err):
-                    found = i0
-                    break
-            if found is None:
-                if U_rot is None and K._T is not None:
-                    U_rot = K.U
-                found = ctx.add_dataset(err, U_rot)
-                cache.append((err, s.get('U_rot'), found))
-            ds_ids.append(found)
-        ctx.set_elements(ds_ids, [s['G'] for s in specs],
-                         np.stack([np.asarray(s['D'], dtype=float) for s in specs]),
-                         [s['kind'] for s in specs])
-        opts = minimizer.to_opts(waves_per_chain=waves_per_chain, chi2_factor=float(chi2_factor))
-        out = ctx.solve_chains(np.arange(len(specs), dtype=np.int32),
-                               np.stack([np.asarray(s['alpha'], dtype=float) for s in specs]),
-                               np.stack([np.asarray(s['v0'], dtype=float) for s in specs]),
-                               opts)
-        info = dict(kernel_ms=ctx.last_kernel_ms())
-        info.update(ctx.last_launch_info())
-        # output map A = B H on the device when every element shares it
-        # (PreblurA_of_H.f, reference functions.py:999-1001)
-        A_dev = None
-        B0 = specs[0].get('A_matrix')
-        if B0 is not None and all(s.get('A_matrix') is B0 for s in specs):
-            A_dev = ctx.apply_output_map(B0)
-        logdet = ctx.logdet() if want_logdet else None
-    finally:
-        ctx.close()
-    res = []
-    for c, s in enumerate(specs):
-        res.append(dict(alpha=np.asarray(s['alpha'], dtype=float),
-                        A=(None if A_dev is None else A_dev[c]),
-                        v=out['v'][c], H=out['H'][c], chi2=out['chi2'][c],
-                        S=out['S'][c], Q=out['Q'][c],
-                        n_iter=out['n_iter'][c],
-                        converged=out['converged'][c].astype(bool),
-                        n_evals=out['n_evals'][c]))
-        if logdet is not None:
-            res[-1]['logdet'] = logdet[c]
-    return res, info
+    from .batch_solver import BatchSolver
+    solver = BatchSolver.for_kernel(K, (device_id,) if device_ids is None else device_ids)
+    opts = minimizer.to_opts(waves_per_chain=waves_per_chain, chi2_factor=float(chi2_factor))
+    return solver.solve(K, specs, opts, want_logdet=want_logdet, want_H=want_H)
 
 
 def solve_single(cost_function, v0, minimizer, device_id=0):
@@ -131,7 +82,8 @@ def solve_single(cost_function, v0, minimizer, device_id=0):
     spec = dict(G=cf.G, err=cf.err, U_rot=(K.U if K._T is not None else None),
                 D=cf.D.D, kind=cf.entropy_kind, v0=np.asarray(v0, dtype=float),
                 alpha=np.array([cf._alpha], dtype=float))
-    res, _ = solve_elements(K, [spec], minimizer, device_id=device_id, chi2_factor=cf.chi2_factor)
+    res, _ = solve_elements(K, [spec], minimizer, device_id=device_id, chi2_factor=cf.chi2_factor,
+                            want_H=False)
     r = res[0]
     return r['v'][0], dict(n_iter=r['n_iter'][0], converged=r['converged'][0])
 
@@ -147,7 +99,7 @@ class MaxEntLoop(object):
                  probability=None, analyzers=None, logtaker=None,
                  G_threshold=1.e-10, reduce_singular_space=1.e-14,
                  A_init=None, interactive=True, scale_alpha='Ndata',
-                 device_id=0):
+                 device_id=0, device_ids=None):
         if cost_function is None:
             cost_function = MaxEntCostFunction()
         elif isinstance(cost_function, str):
@@ -186,6 +138,7 @@ class MaxEntLoop(object):
         self.reduce_singular_space = reduce_singular_space
         self.scale_alpha = scale_alpha
         self.device_id = device_id
+        self.device_ids = device_ids
         self.last_launch = None
 
     # ---- pieces of run(), also used by the element-wise driver --------
@@ -200,38 +153,46 @@ class MaxEntLoop(object):
                 self.scale_alpha))
         return float(self.scale_alpha)
 
-    _v0_cache = {}
-
     def below_threshold(self):
         return np.max(np.abs(self.G)) < self.G_threshold
 
-    def make_spec(self):
-        """everything the device needs for this loop's current G/err/D/K."""
-        assert self.err is not None, 'No error specified'
+    def make_spec(self, G=None, err=None):
+        """everything the device needs for this loop's current G / err / D / K.  ``G`` and ``err`` given:
+        the spec of ANOTHER data vector of the same (unrotated) problem, the loop itself untouched -- the
+        element-wise drivers build the specs of all matrix elements this way"""
+        other = G is not None
+        if other:
+            assert self.K._T is None, 'specs of other data vectors need an unrotated kernel'
+            G_use = np.array(G, dtype=float)
+            err_use = np.asarray(err, dtype=float) * np.ones(len(G_use))
+        else:
+            assert self.err is not None, 'No error specified'
+            G_use = np.array(self.G, dtype=float)
+            err_use = np.array(self.err, dtype=float) * np.ones(len(G_use))
         self.K.reduce_singular_space(self.reduce_singular_space)
         start = (self.D.D if self.A_init is None else
                  np.asarray(self.A_init)) * self.omega.delta
         start = np.array(start, dtype=float)
         # the start vector depends on (V, D, start image, entropy kind) only: the element-wise drivers ask
-        # for it once per matrix element with the same arguments
-        key = (id(self.K.V), self.H_of_v.kind, start.tobytes(), np.asarray(self.D.D, dtype=float).tobytes())
-        cache = MaxEntLoop._v0_cache
-        if cache.get('key') != key:
-            cache['key'] = key
-            cache['K_V'] = self.K.V          # keeps id() valid
-            cache['v0'] = self.H_of_v.inv(start)
-        v0 = cache['v0'].copy()
+        # for it once per matrix element with the same objects (the cache holds them, so the identities
+        # it compares stay valid)
+        V, Dv, Ai = self.K.V, self.D.D, self.A_init
+        held = self.__dict__.get('_v0_held')
+        if held is None or held[0] is not V or held[1] is not Dv or held[2] is not Ai or held[3] != self.H_of_v.kind \
+                or not np.array_equal(held[4], self.omega.delta):
+            held = self._v0_held = (V, Dv, Ai, self.H_of_v.kind, np.array(self.omega.delta), self.H_of_v.inv(start))
+        v0 = held[5].copy()
         scale = self._alpha_scale()
         K = self.K
-        return dict(G=np.array(self.G, dtype=float),
-                    err=np.array(self.err, dtype=float) * np.ones(len(self.G)),
+        return dict(G=G_use,
+                    err=err_use,
                     U_rot=(K.U if K._T is not None else None),
                     D=np.array(self.D.D, dtype=float),
                     kind=self.cost_function.entropy_kind,
                     v0=v0,
                     alpha=np.asarray(self.alpha_mesh, dtype=float) * scale,
                     scale_alpha=scale,
-                    G_orig=np.array(self.cost_function.G_orig, dtype=float),
+                    G_orig=(G_use if other else np.array(self.cost_function.G_orig, dtype=float)),
                     data_variable=np.array(self.data_variable, dtype=float),
                     A_matrix=self.A_of_H.matrix(),
                     T=K._T)
@@ -240,7 +201,8 @@ class MaxEntLoop(object):
         """MaxEntResult arrays of one finished scan (maxent_result.py:835-967)."""
         A = sol.get('A')
         if A is None:
-            A = self.A_of_H.f(sol['H'])
+            from .batch_solver import LazyA, LazyH
+            A = LazyA(sol['H'], self.A_of_H) if isinstance(sol['H'], LazyH) else self.A_of_H.f(sol['H'])
         rec = dict(sol)
         rec['A'] = A
         rec['G'] = spec['G']
@@ -279,9 +241,15 @@ class MaxEntLoop(object):
             self.logtaker.message(
                 VerbosityFlags.AlphaLoop,
                 '\n! ... The minimizer did not converge. Results might be wrong.\n')
-        self.minimizer.n_iter_last = int(sol['n_iter'][-1])
-        self.minimizer.n_iter += int(np.sum(sol['n_iter']))
-        self.minimizer.converged = bool(sol['converged'][-1])
+        self.note_minimizer_state(sol, int(np.sum(sol['n_iter'])))
+
+    def note_minimizer_state(self, last_sol, n_iter_total):
+        """``n_iter_last`` / ``n_iter`` / ``converged`` of the minimiser as after the reference's loop
+        (levenberg_minimizer.py:143,245-246): those of the last alpha of the last scan"""
+        if hasattr(self.minimizer, 'to_opts'):
+            self.minimizer.n_iter_last = int(last_sol['n_iter'][-1])
+            self.minimizer.n_iter += int(n_iter_total)
+            self.minimizer.converged = bool(last_sol['converged'][-1])
 
     def scan_with_user_minimizer(self, spec):
         """The reference's loop body (maxent_loop.py:241-266) for a minimiser that is not the device
@@ -341,7 +309,7 @@ class MaxEntLoop(object):
         if hasattr(self.minimizer, 'to_opts'):
             sols, info = solve_elements(self.K, [spec], self.minimizer,
                                         want_logdet=self.probability is not None,
-                                        device_id=self.device_id,
+                                        device_id=self.device_id, device_ids=self.device_ids,
                                         chi2_factor=self.cost_function.chi2_factor)
             sol = sols[0]
         else:

@@ -296,6 +296,70 @@ class MaxEntResult(MaxEntResultData):
         self._analysis[key] = out
         self._cache.pop('analyzer_results', None)
 
+    # ---- single rows of H / A without moving the rest off the device -----------
+    class _RowPlaceholder(object):
+        """stands for ``record[name][idx]`` until :meth:`analyze_batch` has fetched all rows at once"""
+
+        def __init__(self, lazy, idx):
+            self.lazy, self.idx, self.value = lazy, int(idx), None
+
+    def element_row(self, name, matrix_element, idx):
+        """``element_array(name, matrix_element)[idx]``; when the element's H still lives on the device
+        only that row is fetched (inside :meth:`analyze_batch`: later, together with everybody else's)"""
+        key = None if (self.matrix_structure is None or not self.element_wise) else tuple(matrix_element)
+        rec = self._records.get(key)
+        val = None if rec is None else rec.get(name)
+        if val is None or getattr(val, 'on_host', True) or not hasattr(val, 'row_request'):
+            return np.asarray(self.element_array(name, matrix_element))[idx]
+        deferred = self.__dict__.get('_deferred_rows')
+        if deferred is None:
+            return val[int(idx)]
+        ph = MaxEntResult._RowPlaceholder(val, idx)
+        deferred.append(ph)
+        return ph
+
+    def analyze_batch(self, analyzers, keys):
+        """:meth:`analyze` for many elements (``keys``: tuples as :meth:`_key` makes them); the rows of A
+        the analyzers pick are fetched from the device in ONE go at the end"""
+        self._deferred_rows = []
+        try:
+            many = {}
+            for analyzer in analyzers:
+                if hasattr(analyzer, 'analyze_many') and len(keys) > 1:
+                    many[analyzer.name] = analyzer.analyze_many(self, keys)
+            for n, key in enumerate(keys):
+                out = OrderedDict()
+                for analyzer in analyzers:
+                    try:
+                        res = many[analyzer.name][n] if analyzer.name in many else analyzer.analyze(self, key)
+                        if isinstance(res, str):
+                            out[analyzer.name] = res
+                        else:
+                            res.maxent_result = self
+                            out[res['name']] = res
+                    except ValueError as e:
+                        out[analyzer.name] = str(e)
+                self._analysis[key] = out
+            self._cache.pop('analyzer_results', None)
+            pending = self._deferred_rows
+        finally:
+            self._deferred_rows = None
+        if pending:
+            owner = None
+            for ph in pending:
+                H = getattr(ph.lazy, '_H', ph.lazy)
+                owner = H._owner
+                break
+            rows = owner.rows([ph.lazy.row_request(ph.idx) for ph in pending])
+            for ph, row in zip(pending, rows):
+                ph.value = ph.lazy.from_H_row(row) if hasattr(ph.lazy, 'from_H_row') else row
+            for key in keys:
+                for res in self._analysis.get(key, {}).values():
+                    if isinstance(res, dict):
+                        for k, v in list(res.items()):
+                            if isinstance(v, MaxEntResult._RowPlaceholder):
+                                res[k] = v.value
+
     def element_array(self, name, matrix_element=None):
         """field ``name`` of one element straight from its record (no assembly of the
         array over all elements); mirrored / missing elements go the general way."""
