@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py -- alpha-solves/s of the MI355X alpha-scan solver.
+"""bench.py -- alpha-solves/s of the MI355X alpha-scan solver (BASELINE.json's metric).
 
-A "step" is one pass of the hot path (one launch of the chain kernel) over one
-batch of synthetic input that is already resident in HBM.  At N=1 the workload
-is BASELINE.json's cfg4 batch on ONE GPU: 16x16 matrix elements x 100 alpha
-(25 600 alpha-solves; n_tau=200, n_omega=500, fp64) -- the batch the
-north-star target is quoted on.  For N>1 every rank solves its own 16x16x100
-batch (different noise seed per rank: weak scaling, no data-path collective
-inside the solve); after each pass the per-alpha results chi2/S/Q/H are
-gathered on rank 0 with one RCCL gather, inside the timed region.
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident in
+HBM: one launch of the chain kernel, the device line fit that picks the analyzer's alpha per scan
+(one tiny kernel) and, with more than one GPU, the ONE gather of the compact result packs to rank 0.
 
-Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 under
-``python -m torch.distributed.run``); rank 0 prints ONE JSON line.
+  N = 1   BASELINE cfg4 on ONE GPU: 16 x 16 matrix elements x 100 alpha = 25 600 alpha-solves per
+          step (n_tau = 200, n_omega = 500, fp64) -- the batch the north-star target is quoted on.
+  N > 1   --scaling strong (default): the SAME 256-element batch sharded over the ranks, element e on
+          rank e mod N (mxe_shard_plan), timed until every rank's results are on rank 0 -- BASELINE cfg4
+          as written.  --scaling weak: one full batch per rank (different noise per rank).
+          The gather is RCCL send / recv issued by libmaxent_hip.so itself (mxe_gather); no framework is
+          imported: ranks find each other through RANK / WORLD_SIZE / LOCAL_RANK and a file in /tmp that
+          carries the ncclUniqueId.  --gather compact (default): chi2, S, Q of every alpha + the H row and
+          index of the line-fit alpha per scan (1.6 MB for the whole batch); --gather full: all H as well.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N > 1 under ``python -m
+torch.distributed.run``, which only serves as the process launcher); rank 0 prints ONE JSON line.
 """
 
 import argparse
@@ -19,13 +24,6 @@ import json
 import os
 import sys
 import time
-
-# torchrun exports OMP_NUM_THREADS=1 when the variable is unset; with a single
-# OpenMP thread the RCCL gather path of this script ran 2x slower per step on the
-# MI355X box (measured: 14.1 vs 6.5 ms), so give the few host threads back.
-if os.environ.get('TORCHELASTIC_RUN_ID') and os.environ.get('OMP_NUM_THREADS') == '1':
-    os.environ['OMP_NUM_THREADS'] = str(max(1, min(8, (os.cpu_count() or 8) //
-                                                   max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1'))))))
 
 import numpy as np
 
@@ -36,17 +34,30 @@ if ROOT not in sys.path:
 from maxent_amd import device, synthetic, hostprep   # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-N_EVAL_NOMINAL = {'normal': 160, 'plusminus': 84}
-# HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE /
-# WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md);
-# filled in from profiles/ when measured, else None
-TRAFFIC_PMC_BYTES_PER_LAUNCH = None      # see main(): set for the default workload
+L2_PEAK_GBS = 34500.0          # ... aggregate L2
+N_EVAL_NOMINAL = {'normal': 160, 'plusminus': 84}   # the reference's passes per alpha-solve
+
+# Counter values per launch of the default workload (rocprofv3 --pmc on this very command, summaries under
+# profiles/r02_c_pmc_*.csv; they count events, not time, and do not depend on the clock):
+PMC_DEFAULT = dict(
+    source='profiles/r02_c_pmc_summary.csv',
+    # mean per dispatch of mxe::chain_kernel_mc<32, 2> over ~160 dispatches
+    valu_active_quadcycles=3.783e8,      # SQ_ACTIVE_INST_VALU (counts quad-cycles: MI355X_MICROARCH.md, cycle constants)
+    mfma_busy_cycles=4.7316e8,           # SQ_VALU_MFMA_BUSY_CYCLES (cycles)
+    coexec_cycles=3.544e7,               # SQ_VALU_MFMA_COEXEC_CYCLES: both at once, counted once below
+    any_active_quadcycles=5.082e8,       # SQ_ACTIVE_INST_ANY
+    wave_quadcycles=1.3375e9,            # SQ_WAVE_CYCLES
+    wait_inst_quadcycles=3.607e8, wait_any_quadcycles=4.686e8,
+    gui_active_cycles_all_xcd=2.454e7,   # GRBM_GUI_ACTIVE (sum over the 8 XCDs)
+    fetch_kb=28172.4, write_kb=135939.0, # FETCH_SIZE (x 2 on gfx950, MI355X_MICROARCH.md section HBM), WRITE_SIZE
+    l2_hit=8.8884e7, l2_miss=1.48387e6)
+N_SIMD = 256 * 4
+CLOCK_PEAK_GHZ = 2.4                      # MI355X_MICROARCH.md: max clock
 
 
 def build_batch(n_orb, n_tau, n_omega, n_alpha, rank):
-    """Synthetic cfg3/cfg4 batch -> staged DeviceContext."""
-    tau, omega, K, Gmat, _ = synthetic.matrix_G(n_orb, n_tau, n_omega,
-                                                noise_seed=2025 + rank)
+    """Synthetic cfg3/cfg4 batch."""
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(n_orb, n_tau, n_omega, noise_seed=2025 + rank)
     t0 = time.perf_counter()
     K.reduce_singular_space(1e-14)
     t_svd = time.perf_counter() - t0
@@ -54,82 +65,59 @@ def build_batch(n_orb, n_tau, n_omega, n_alpha, rank):
     err = synthetic.SIGMA * np.ones(n_tau)
     alphas = np.array(synthetic.alpha_mesh(n_alpha)) * n_tau
     elems = [(i, j) for i in range(n_orb) for j in range(n_orb)]
-    kinds = [device.ENTROPY_NORMAL if i == j else device.ENTROPY_PLUSMINUS
-             for (i, j) in elems]
+    kinds = [device.ENTROPY_NORMAL if i == j else device.ENTROPY_PLUSMINUS for (i, j) in elems]
     v0n = hostprep.initial_v(K.V, D, omega.delta, device.ENTROPY_NORMAL)
     v0p = hostprep.initial_v(K.V, D, omega.delta, device.ENTROPY_PLUSMINUS)
     v0 = np.stack([v0n if k == device.ENTROPY_NORMAL else v0p for k in kinds])
-    return dict(tau=tau, omega=omega, K=K, Gmat=Gmat, D=D, err=err,
-                alphas=alphas, elems=elems, kinds=kinds, v0=v0, t_svd=t_svd)
+    return dict(tau=tau, omega=omega, K=K, Gmat=Gmat, D=D, err=err, alphas=alphas, elems=elems, kinds=kinds,
+                v0=v0, t_svd=t_svd)
 
 
-def stage(batch, dev):
+def stage(batch, dev, which=None):
+    """DeviceContext with the elements ``which`` (default: all) of the batch staged"""
     K = batch['K']
+    which = list(range(len(batch['elems']))) if which is None else list(which)
     ctx = device.DeviceContext(K.U, K.S, K.V, device=dev)
     ds = ctx.add_dataset(batch['err'])
-    n_elem = len(batch['elems'])
-    ctx.set_elements([ds] * n_elem,
-                     [batch['Gmat'][i, j] for (i, j) in batch['elems']],
-                     np.tile(batch['D'], (n_elem, 1)), batch['kinds'])
+    ctx.set_elements([ds] * len(which), [batch['Gmat'][batch['elems'][e]] for e in which],
+                     np.tile(batch['D'], (len(which), 1)), [batch['kinds'][e] for e in which])
     return ctx
 
 
-class _DevArray(object):
-    """zero-copy view of a library-owned device buffer for torch."""
-
-    def __init__(self, ptr, shape, typestr):
-        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr,
-                                             data=(int(ptr), False), version=2)
-
-
+# ---------------------------------------------------------------------------------------------------
+#  CPU side-by-side (SURVEY 8d): the oracle port of the reference's algorithm on the host cores
+# ---------------------------------------------------------------------------------------------------
 def cpu_baseline(batch, out_gpu, n_chains=2):
-    """The oracle port of the reference's algorithm, timed on the host on a
-    bounded sample (first diagonal + first off-diagonal element, all alphas).
-    Also reports how far the GPU result is from it and from the
-    extended-precision truth on that sample."""
-    from oracle import ref_numpy as R, hp_truth
-    try:                                  # really one core: no BLAS worker threads for the 56 x 500 products
+    """oracle/ref_numpy.py (step-faithful numpy port of LevenbergMinimizer + MaxEntCostFunction) timed on
+    one core on a bounded sample: the first diagonal and the first off-diagonal element, all alphas"""
+    from oracle import ref_numpy as R
+    try:
         from threadpoolctl import threadpool_limits
         threadpool_limits(1)
     except Exception:
         pass
     K = batch['K']
-    n_alpha = len(batch['alphas'])
-    n_tau = len(batch['tau'])
+    n_alpha, n_tau = len(batch['alphas']), len(batch['tau'])
     mesh = batch['alphas'] / n_tau
-    picks = [0, 1][:n_chains]
-    t_total, solves, err_ref, err_truth = 0.0, 0, 0.0, 0.0
-    for c in picks:
+    t_total, solves, err_ref = 0.0, 0, 0.0
+    for c in [0, 1][:n_chains]:
         i, j = batch['elems'][c]
         ent = 'normal' if batch['kinds'][c] == device.ENTROPY_NORMAL else 'plusminus'
-        p = R.Problem(np.array(K.K), K.U, K.S, K.V, batch['Gmat'][i, j],
-                      batch['err'], batch['D'], entropy=ent)
+        p = R.Problem(np.array(K.K), K.U, K.S, K.V, batch['Gmat'][i, j], batch['err'], batch['D'], entropy=ent)
         timing = []
         ref = R.alpha_loop(p, batch['omega'].delta, mesh, timing=timing)
         t_total += timing[0]
         solves += n_alpha
         H = out_gpu['H'][c]
-        err_ref = max(err_ref, float(np.max(
-            np.linalg.norm(H - ref['H'], axis=1) / np.linalg.norm(ref['H'], axis=1))))
-        for ia in (0, n_alpha // 2, n_alpha - 1):
-            _, Ht = hp_truth.polish(p.K, p.G, p.err, p.D, p.V, p.S,
-                                    batch['alphas'][ia], out_gpu['v'][c, ia],
-                                    ent, iters=4)
-            err_truth = max(err_truth, float(np.linalg.norm(H[ia] - Ht) /
-                                             np.linalg.norm(Ht)))
-    return dict(value=solves / t_total, unit='alpha-solves/s', cores=1,
-                kind='port',
-                sample='oracle/ref_numpy.py (step-faithful numpy port of '
-                       'LevenbergMinimizer + MaxEntCostFunction) on elements '
-                       '(0,0) normal and (0,1) plusminus x %d alpha, %.1f s'
-                       % (n_alpha, t_total),
-                gpu_vs_port_max_rel_l2=err_ref,
-                gpu_vs_extended_precision_truth_max_rel_l2=err_truth)
+        err_ref = max(err_ref, float(np.max(np.linalg.norm(H - ref['H'], axis=1) / np.linalg.norm(ref['H'], axis=1))))
+    return dict(value=solves / t_total, unit='alpha-solves/s', cores=1, kind='port',
+                sample='oracle/ref_numpy.py (step-faithful numpy port of LevenbergMinimizer + MaxEntCostFunction) '
+                       'on elements (0,0) normal and (0,1) plusminus x %d alpha, %.1f s' % (n_alpha, t_total),
+                gpu_vs_port_max_rel_l2=err_ref)
 
 
 def _pool_worker(c):
-    """one alpha scan of element c with the oracle port (forked worker: inherits _POOL_BATCH)"""
-    try:                                  # one BLAS thread per worker (the pool is the parallelism)
+    try:
         from threadpoolctl import threadpool_limits
         threadpool_limits(1)
     except Exception:
@@ -149,8 +137,8 @@ _POOL_BATCH = None
 
 
 def cpu_pool_baseline(batch):
-    """the same oracle port on all host cores, one process per core, one matrix element
-    (100 alpha) per process.  Runs BEFORE this process touches the GPU (workers are forked)."""
+    """the same port on all host cores, one process per core, one matrix element (100 alpha) per process.
+    Runs BEFORE this process touches the GPU (the workers are forked)."""
     global _POOL_BATCH
     import multiprocessing as mp
     n = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 16,
@@ -170,14 +158,126 @@ def cpu_pool_baseline(batch):
                 sample='%d matrix elements x %d alpha, one process each, %.1f s wall' % (n, len(batch['alphas']), wall))
 
 
+# ---------------------------------------------------------------------------------------------------
+#  parity and audit blocks
+# ---------------------------------------------------------------------------------------------------
+def parity_per_alpha():
+    """BASELINE cfg2 from the committed reference fixture (tests/golden/cfg2_normal.npz: the reference's own
+    run and its optimum polished in extended precision): relative L2 of H per stored alpha -- the GPU
+    against the reference, the reference against the truth, the GPU against the truth.  The first two
+    belong together: what separates the GPU from the reference is the reference's own stopping slack."""
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'cfg2_normal.npz'))
+    ctx = device.DeviceContext(z['U'], z['S'], z['V'])
+    ds = ctx.add_dataset(z['err'])
+    ctx.set_elements([ds], [z['G']], z['D'][np.newaxis, :], [device.ENTROPY_NORMAL])
+    v0 = hostprep.initial_v(z['V'], z['D'], z['delta'], device.ENTROPY_NORMAL)
+    out = ctx.solve_chains([0], z['alpha'], v0[np.newaxis, :])
+    ctx.close()
+    rows = z['rows']
+    H = out['H'][0][rows]
+
+    def rel(a, b):
+        return [float(x) for x in np.linalg.norm(a - b, axis=1) / np.linalg.norm(b, axis=1)]
+    return dict(config='cfg2: n_tau=200 n_omega=500, 100 alpha, normal entropy; fixture rows (alpha index)',
+                alpha_index=[int(r) for r in rows], alpha_scaled=[float(a) for a in z['alpha'][rows]],
+                gpu_vs_ref=rel(H, z['H_ref']), ref_vs_truth=rel(z['H_ref'], z['H_truth']),
+                gpu_vs_truth=rel(H, z['H_truth']), gate_gpu_vs_truth=1e-6)
+
+
+def audit_block(ctx):
+    """mxe_audit over every problem of the last launch: the exact Newton correction at the returned v
+    (binary64, all n_s directions), as ||w * V delta|| / ||H|| -- to first order the distance of the returned
+    H from the minimiser"""
+    c = ctx.audit()['corr'].ravel()
+    return dict(problems=int(c.size), corr_max=float(np.nanmax(c)), corr_p99=float(np.nanpercentile(c, 99)),
+                corr_median=float(np.nanmedian(c)), above_1e_6=int(np.sum(~(c <= 1e-6))),
+                definition='exact Newton correction ||w * V delta||_2 / ||H||_2 at the returned v, every problem')
+
+
+def end_to_end_block(batch, n_orb, n_alpha):
+    """what a caller of the reference's API sees: ElementwiseMaxEnt on the same input -- H2D, two launches,
+    D2H of what the result object needs, records, analyzers -- next to the device-resident figure"""
+    import maxent_amd as mx
+
+    def make():
+        ew = mx.ElementwiseMaxEnt(use_hermiticity=False)
+        ew.set_verbosity(mx.VerbosityFlags.Quiet)
+        ew.set_G_tau_data(batch['tau'], batch['Gmat'])
+        ew.omega = batch['omega']
+        ew.alpha_mesh = mx.LogAlphaMesh(alpha_min=1e-2, alpha_max=1e4, n_points=n_alpha)
+        ew.set_error(synthetic.SIGMA)
+        return ew
+    cold = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        ew = make()
+        ew.run()
+        cold.append(time.perf_counter() - t0)
+    warm, res = [], None
+    for _ in range(3):
+        ew.maxent_result = res = None     # (a result that is still held claims its H: it would be fetched first)
+        t0 = time.perf_counter()
+        res = ew.run()
+        warm.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    nbytes = np.asarray(res.H).nbytes
+    t_H = time.perf_counter() - t0
+    P = n_orb * n_orb * n_alpha
+    return dict(api='ElementwiseMaxEnt(use_hermiticity=False).run()', problems=P,
+                fresh_object_ms=1e3 * min(cold), same_object_ms=1e3 * min(warm),
+                alpha_solves_per_s_same_object=P / min(warm), alpha_solves_per_s_fresh_object=P / min(cold),
+                includes='kernel fill + SVD + staging (fresh object only), H2D of G / D / alpha, two launches, D2H of '
+                         'chi2 / S / Q / v, records, LineFit / Chi2Curvature / Entropy analyzers, D2H of the A_out rows',
+                first_access_of_all_H_ms=1e3 * t_H, all_H_MB=nbytes / 1e6)
+
+
+# ---------------------------------------------------------------------------------------------------
+#  ranks in separate processes
+# ---------------------------------------------------------------------------------------------------
+def comm_setup(ctx, rank, world):
+    """ncclUniqueId from rank 0 to the others through a file (single node: one /tmp)"""
+    tag = '%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'))
+    path = os.path.join('/tmp', 'mxe_bench_id_%s_%d' % (tag, os.getppid()))
+    if rank == 0:
+        uid = device.comm_unique_id()
+        with open(path + '.tmp', 'wb') as f:
+            f.write(uid)
+        os.replace(path + '.tmp', path)
+    else:
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > 300:
+                raise SystemExit('bench.py: rank 0 never published the communicator id')
+            time.sleep(0.01)
+        with open(path, 'rb') as f:
+            uid = f.read()
+    # RCCL prints a version banner on stdout when it initialises: keep stdout for the one JSON line
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        ctx.comm_init(world, rank, uid)
+        ctx.allreduce([0.0])                   # everybody is in
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+    if rank == 0:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    # a step is 1.7 ms: 200 of them keep the timed region long enough (0.33 s) for the tens of
-    # milliseconds by which a fresh submission is sometimes picked up late on the MI355X boxes (seen in a
-    # quarter of the processes: device time of the region unchanged, host-side wait 33-47 ms longer)
+    # a step is ~1.3 ms: 200 of them keep the timed region long enough (0.27 s) for the tens of milliseconds
+    # by which a fresh submission is sometimes picked up late on the MI355X boxes
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--scaling', choices=('strong', 'weak'), default='strong')
+    ap.add_argument('--gather', choices=('compact', 'full'), default='compact')
     ap.add_argument('--n-orb', type=int, default=16)
     ap.add_argument('--n-tau', type=int, default=200)
     ap.add_argument('--n-omega', type=int, default=500)
@@ -187,8 +287,9 @@ def main():
     ap.add_argument('--alpha-split', type=int, default=0)
     ap.add_argument('--wg-per-cu', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--force-dist', action='store_true',
-                    help='initialise torch.distributed and run the RCCL gather even with one rank (plumbing test)')
+    ap.add_argument('--no-extras', action='store_true', help='skip the audit / parity / end-to-end blocks')
+    ap.add_argument('--force-comm', action='store_true',
+                    help='initialise the communicator and run the gather even with one rank (plumbing test)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -196,227 +297,231 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         if rank == 0:
-            print('bench.py: --gpus %d but WORLD_SIZE=%d; launch with '
-                  'python -m torch.distributed.run --nproc-per-node %d'
-                  % (args.gpus, world, args.gpus), file=sys.stderr)
+            print('bench.py: --gpus %d but WORLD_SIZE=%d; launch with python -m torch.distributed.run '
+                  '--nproc-per-node %d' % (args.gpus, world, args.gpus), file=sys.stderr)
         if args.gpus > 1:
             sys.exit(2)
+    use_comm = world > 1 or args.force_comm
+    default_workload = (args.n_orb, args.n_tau, args.n_omega, args.n_alpha) == (16, 200, 500, 100)
 
     pool_baseline = None
-    if world == 1 and not args.force_dist and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline:
         # host cores first, before anything initialises the GPU in this process (forked workers)
-        pool_baseline = cpu_pool_baseline(build_batch(args.n_orb, args.n_tau, args.n_omega, args.n_alpha, rank))
-
-    dist = None
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        pool_baseline = cpu_pool_baseline(build_batch(args.n_orb, args.n_tau, args.n_omega, args.n_alpha, 0))
 
     if device.device_count() < 1:
         raise SystemExit('bench.py needs a GPU: the solver has no CPU fallback')
 
-    batch = build_batch(args.n_orb, args.n_tau, args.n_omega, args.n_alpha, rank)
-    ctx = stage(batch, local_rank)
-    n_chain = len(batch['elems'])
-    P = n_chain * args.n_alpha
-    opts = device.default_opts(waves_per_chain=args.waves_per_chain,
-                               chains_per_wg=args.chains_per_wg,
+    strong = args.scaling == 'strong'
+    batch = build_batch(args.n_orb, args.n_tau, args.n_omega, args.n_alpha, 0 if strong else rank)
+    n_elem = len(batch['elems'])
+    rank_of, local_of, n_local = device.shard_plan(n_elem, world)
+    mine = [e for e in range(n_elem) if rank_of[e] == rank] if strong else list(range(n_elem))
+    ctx = stage(batch, local_rank, mine)
+    opts = device.default_opts(waves_per_chain=args.waves_per_chain, chains_per_wg=args.chains_per_wg,
                                alpha_split=args.alpha_split, wg_per_cu=args.wg_per_cu)
-    ctx.upload_chains(np.arange(n_chain, dtype=np.int32), batch['alphas'],
-                      batch['v0'], opts)
+    ctx.upload_chains(np.arange(len(mine), dtype=np.int32), batch['alphas'], batch['v0'][mine], opts)
+    P_rank = len(mine) * args.n_alpha
+    P_job = n_elem * args.n_alpha * (1 if strong else world)
+    full = args.gather == 'full'
+    counts = None
+    if use_comm:
+        comm_setup(ctx, rank, world)
 
-    gather_bufs = None
-    if use_dist:
-        import torch
-        nw = args.n_omega
-        packs, gathered = [], []
-        for b in (0, 1):
-            # H, chi2, S, Q are contiguous in one device allocation of the library
-            ctx.set_result_buffer(b)
-            ptrs = ctx.result_device_ptrs()
-            assert ptrs['chi2'] == ptrs['H'] + P * nw * 8 and ptrs['Q'] == ptrs['H'] + (P * nw + 2 * P) * 8
-            t = torch.as_tensor(_DevArray(ptrs['H'], (P * nw + 3 * P,), '<f8'), device='cuda')
-            assert t.data_ptr() == ptrs['H'], 'zero-copy view of the result buffer failed'
-            packs.append(t)
-            gathered.append([torch.empty_like(t) for _ in range(world)] if rank == 0 else None)
-        gather_bufs = dict(packs=packs, gathered=gathered, pending=[None, None], k=0,
-                           ext=torch.cuda.ExternalStream(ctx.stream_handle(), device=torch.device('cuda', local_rank)))
+        def per(n):
+            return n * args.n_alpha * (args.n_omega if full else 0) + 3 * n * args.n_alpha + n * (args.n_omega + 1)
+        counts = [per(int(n_local[r]) if strong else n_elem) for r in range(world)]
 
     def one_step():
-        """one pass of the solver; with several ranks the ONE RCCL gather of the
-        packed per-alpha results of pass k runs while pass k+1 computes into the
-        other result buffer (the gather of pass k-1 is waited for first)."""
-        if not use_dist:
-            ctx.launch()        # enqueued back to back: no host synchronisation inside the timed region
-            return
-        g = gather_bufs
-        b = g['k'] % 2
-        g['k'] += 1
-        cur = torch.cuda.current_stream()
-        if g['pending'][b] is not None:
-            # buffer b is free again once its gather has run: the wait is a dependency of the current
-            # stream, passed on to the library's stream with an event -- no host synchronisation
-            g['pending'][b].wait()
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            g['ext'].wait_event(ev)
-        ctx.set_result_buffer(b)
-        ctx.launch()
-        done = torch.cuda.Event()
-        done.record(g['ext'])
-        cur.wait_event(done)                  # the gather is enqueued behind the pass that fills its source
-        g['pending'][b] = dist.gather(g['packs'][b], g['gathered'][b], dst=0, async_op=True)
-
-    def drain():
-        if not use_dist:
-            ctx.sync()
-        if use_dist:
-            for w in gather_bufs['pending']:
-                if w is not None:
-                    w.wait()
-            torch.cuda.synchronize()
+        ctx.launch()                 # enqueued back to back: no host synchronisation inside the timed region
+        ctx.select_launch(0)
+        if use_comm:
+            ctx.gather(0, counts, full=full)          # to rank 0's device, on the ctx stream
 
     def barrier():
-        if use_dist:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
+        ctx.sync()
+        if use_comm:
+            ctx.allreduce([0.0])
 
-    if use_dist:
-        import torch
     for _ in range(args.warmup):
         one_step()
-    drain()
-    # the first collectives of a process group finish initialising in the background
-    # (measured with one rank: a single 75 ms stall of one launch, 20-40 ms after the
-    # first barrier); take the barrier here and let that settle outside the timed region
-    # ... and without a process group: with only a few warm-up passes, the first submission after the
-    # synchronisation that opens the timed region was picked up 30-50 ms late in a quarter of the
-    # processes on the MI355X boxes (12 of 12 clean with ten warm-up passes).  Both settle in untimed
-    # passes: half a second of them with a process group, a quarter of a second without.
     barrier()
+    # settle: with only a few warm-up passes the first submission after a synchronisation was picked up
+    # 30-50 ms late in a quarter of the processes on the MI355X boxes; a quarter of a second of untimed
+    # passes (half a second with a communicator, whose first collectives finish initialising in the background)
     t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < (0.5 if use_dist else 0.25):
+    while time.perf_counter() - t_settle < (0.5 if use_comm else 0.25):
         one_step()
-        if not use_dist:
-            ctx.sync()
-    drain()
-    kernel_ms = []
-    barrier()
-    if not use_dist:
         ctx.sync()
-        ctx.timing_mark()
+    barrier()
+    ctx.timing_mark()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     t_enq = time.perf_counter()
-    drain()                     # every gather has landed on rank 0 inside the timed region
-    if use_dist:
-        kernel_ms = [ctx.last_kernel_ms()]      # the last pass of the region (HIP events on the library's stream)
-    if not use_dist:
-        # device time from the first launch of the region to the end of the last one / steps (HIP events
-        # on the library's stream; includes the few microseconds between consecutive launches)
-        kernel_ms = [ctx.ms_since_mark() / args.steps]
+    ctx.sync()                       # on rank 0: every gather of the region has landed
     t_drained = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    if use_comm:
+        elapsed = float(ctx.allreduce([elapsed], 'max')[0])
     host_split = dict(enqueue_ms=1e3 * (t_enq - t0), wait_ms=1e3 * (t_drained - t_enq))
-    if use_dist:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    # the dominant kernel's own duration: HIP events around launches on the library's stream, back to back
+    ctx.sync()
+    ctx.timing_mark()
+    for _ in range(50):
+        ctx.launch()
+    k_ms = ctx.ms_since_mark() / 50
+
+    gather_checked = None
+    if use_comm and rank == 0:
+        # what arrived: rank 0's own block must be its own results, and (strong scaling) everybody's chi2 must
+        # be what rank 0 gets when it solves the whole batch itself
+        one_step()
+        recv = np.empty(int(np.sum(counts)))
+        ctx.gather(0, counts, full=full, recv=recv)
+        own = ctx.fetch(want_v=False, want_H=False)
+        lead = P_rank * args.n_omega if full else 0
+        ok = np.array_equal(recv[lead:lead + P_rank], own['chi2'].ravel())
+        if strong and world > 1:
+            whole = stage(batch, local_rank)
+            whole.upload_chains(np.arange(n_elem, dtype=np.int32), batch['alphas'], batch['v0'], opts)
+            whole.launch()
+            ref = whole.fetch(want_v=False, want_H=False)['chi2']
+            whole.close()
+            off = 0
+            for r in range(world):
+                nr = int(n_local[r])
+                lead_r = nr * args.n_alpha * args.n_omega if full else 0
+                got = recv[off + lead_r: off + lead_r + nr * args.n_alpha].reshape(nr, args.n_alpha)
+                elems_r = [e for e in range(n_elem) if rank_of[e] == r]
+                ok = ok and bool(np.allclose(got, ref[elems_r], rtol=1e-6, atol=0))
+                off += counts[r]
+        gather_checked = bool(ok)
+    elif use_comm:
+        one_step()
+        ctx.gather(0, counts, full=full)
+        ctx.sync()
+    if use_comm:
+        ctx.allreduce([0.0])
 
     if rank != 0:
-        if use_dist:
-            dist.destroy_process_group()
+        ctx.comm_destroy()
+        ctx.close()
         return
 
+    ctx.launch()
     out = ctx.fetch()
     info = ctx.last_launch_info()
     n_conv = int(out['converged'].sum())
-    total_solves = P * world
-    value = total_solves * args.steps / elapsed
-    k_ms = float(np.mean(kernel_ms))
+    value = P_job * args.steps / elapsed
 
-    # algorithmic bytes per launch (SURVEY.md 8d): one cost evaluation pass
-    # streams V once: B_eval = n_omega*n_s*8 + 2*n_omega*8
+    # ---- roofline of the dominant kernel (mxe::chain_kernel_mc) ----
     n_s = ctx.n_s
-    b_eval = args.n_omega * n_s * 8 + 2 * args.n_omega * 8
-    n_diag = sum(1 for k in batch['kinds'] if k == device.ENTROPY_NORMAL)
-    n_off = n_chain - n_diag
+    b_eval = args.n_omega * n_s * 8 + 2 * args.n_omega * 8       # one evaluation pass streams V once
+    kinds_mine = [batch['kinds'][e] for e in mine]
+    n_diag = sum(1 for k in kinds_mine if k == device.ENTROPY_NORMAL)
     bytes_nominal = args.n_alpha * b_eval * (n_diag * N_EVAL_NOMINAL['normal'] +
-                                             n_off * N_EVAL_NOMINAL['plusminus'])
-    bytes_actual = float(out['n_evals'].sum()) * b_eval
-    # every Newton iteration also streams V once more for the Gram matrix
-    bytes_streamed = float(out['n_evals'].sum() + out['n_iter'].sum()) * b_eval
-    # achieved: evaluation passes the launch actually executed (counted by the
-    # kernel) x B_eval / kernel time.  Extra fields: the same with the Gram
-    # passes (each Newton iteration streams the active columns of V once
-    # more), and SURVEY 8d's nominal figure that prices the kernel's time
-    # against the reference's 160/84 passes per alpha-solve.
-    achieved = bytes_actual / (k_ms * 1e-3) / 1e9
-    # profiles/r01_f_pmc_hbm_traffic.csv: FETCH_SIZE 8 063 KB (x2, gfx950
-    # correction) + WRITE_SIZE 116 548 KB per launch of the default workload
-    traffic = (2 * 8063.0e3 + 116548.0e3) if (args.n_orb, args.n_tau, args.n_omega, args.n_alpha) == (16, 200, 500, 100) else None
-    roofline = dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS,
-                    unit='GB/s', frac=achieved / HBM_PEAK_GBS,
-                    traffic=traffic,
-                    kernel=info['kernel'], kernel_ms=k_ms,
-                    definition='evaluation passes executed (kernel counter) x '
-                               'B_eval = %d B / kernel time (HIP events).  V (224 KB) is '
-                               'L2 resident: the algorithmic rate may exceed the HBM peak '
-                               '(frac > 1), the HBM traffic measured with PMC counters is '
-                               'the `traffic` bytes per launch (`hbm_measured`); the kernel '
-                               'is bound by the matrix / vector pipes, see DESIGN.md '
-                               'section 4' % b_eval,
-                    hbm_measured=(None if traffic is None else traffic / (k_ms * 1e-3) / 1e9),
-                    algorithmic_bytes_per_launch=bytes_actual,
-                    achieved_incl_gram_passes=bytes_streamed / (k_ms * 1e-3) / 1e9,
-                    achieved_survey_nominal_reference_work=bytes_nominal / (k_ms * 1e-3) / 1e9,
-                    evals_per_solve=float(out['n_evals'].mean()),
-                    newton_iters_per_solve=float(out['n_iter'].mean()),
-                    fp64_tflops_gram_dense_equiv=float(out['n_iter'].sum()) * 2.0 *
-                    args.n_omega * n_s * n_s / (k_ms * 1e-3) / 1e12)
+                                             (len(mine) - n_diag) * N_EVAL_NOMINAL['plusminus'])
+    rounds = float(out['n_evals'].sum())          # one evaluation pass = one Newton round of one chain
+    # binary64 work the kernel executes per chain-round (counted from the code):
+    #   row pass  du = V delta        2 n_omega_pad NP            (v_mfma_f64_4x4x4, padded columns included)
+    #   fused     h = V^T H           2 n_omega_pad NP
+    #   exp / entropy / sums          ~40 n_omega
+    #   Gauss-Jordan                  2 N^3 (N = active block, 32 here)
+    nwp = ((args.n_omega + 127) // 128) * 128
+    f64_per_round = 2 * nwp * 64 + 2 * nwp * 64 + 40 * args.n_omega + 2 * 32 ** 3
+    f16_per_round = 3 * 2 * nwp * 3 * 256          # three binary16 products for the three 16 x 16 tiles of W
+    pmc = PMC_DEFAULT if (default_workload and world == 1 and info['kernel'].endswith('<32, 2>')) else {}
+    achieved = peak = frac = traffic = counters = None
+    if pmc:
+        # SIMD-cycles per launch in which a vector or an FP-MFMA instruction was executing (events, clock free)
+        busy = 4 * pmc['valu_active_quadcycles'] + pmc['mfma_busy_cycles'] - pmc['coexec_cycles']
+        achieved = busy / (k_ms * 1e-3) / 1e9                   # G busy SIMD-cycles per second, live kernel time
+        peak = N_SIMD * CLOCK_PEAK_GHZ                          # every SIMD busy every cycle at the maximum clock
+        frac = achieved / peak
+        traffic = 2 * pmc['fetch_kb'] * 1e3 + pmc['write_kb'] * 1e3
+        kcyc = pmc['gui_active_cycles_all_xcd'] / 8
+        counters = dict(source=pmc['source'],
+                        busy_frac_by_counters_alone=busy / (N_SIMD * kcyc),
+                        any_instruction_active_frac=4 * pmc['any_active_quadcycles'] / (N_SIMD * kcyc),
+                        wave_time_split=dict(issuing=pmc['any_active_quadcycles'] / pmc['wave_quadcycles'],
+                                             waiting_for_issue=pmc['wait_inst_quadcycles'] / pmc['wave_quadcycles'],
+                                             waiting_waitcnt_or_barrier=pmc['wait_any_quadcycles'] / pmc['wave_quadcycles']),
+                        clock_GHz_in_kernel=kcyc / (k_ms * 1e-3) / 1e9,
+                        l2_hit_rate=pmc['l2_hit'] / (pmc['l2_hit'] + pmc['l2_miss']))
+    achieved_tflops = rounds * f64_per_round / (k_ms * 1e-3) / 1e12
+    roofline = dict(
+        bound='simd-issue',
+        kernel=info['kernel'], kernel_ms=k_ms,
+        achieved=achieved, peak=peak, unit='G busy SIMD-cycles/s', frac=frac,
+        traffic=traffic, counters=counters,
+        definition='The kernel is bound by the instruction issue of the four SIMDs of a CU: on gfx950 the binary64 and '
+                   'binary32 MFMAs run at the rate of -- and instead of -- the vector instructions (profiles/'
+                   'r01_f_microbench_mfma_shadow.txt), so the solve of the home waves (v_readlane + v_fma_f64), the '
+                   'exp / entropy arithmetic, the binary64 matrix products and the operand splitting of the Gram '
+                   'tiles all queue for the same pipe; only the binary16 Gram MFMAs have a pipe of their own.  achieved = '
+                   '(4 SQ_ACTIVE_INST_VALU + SQ_VALU_MFMA_BUSY_CYCLES - SQ_VALU_MFMA_COEXEC_CYCLES) per launch '
+                   '(rocprofv3 --pmc on this command, %s) / the kernel time measured here with HIP events; peak = 1024 '
+                   'SIMDs x 2.4 GHz.  Two workgroups per CU run the serial and the streaming phases of different '
+                   'workgroups side by side (8 %% over one per CU); what is left idle is waiting on L2 latency and '
+                   'barriers inside phases that are too short to fill from elsewhere.  HBM and L2 are far from binding '
+                   '(hbm_frac, l2_frac); traffic = 2 FETCH_SIZE + WRITE_SIZE per launch, of which 117 MB are the '
+                   'compulsory per-alpha results.' % pmc.get('source', 'counters not collected for this workload / kernel'),
+        hbm_frac=(None if traffic is None else traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS),
+        l2_frac=(rounds / 4.0 * (2 * nwp * 64 * 8) / (k_ms * 1e-3) / 1e9 / L2_PEAK_GBS),
+        l2_definition='V^T + V (2 x %d KB) streamed once per round of a workgroup of four chains / kernel time, against '
+                      'the 34.5 TB/s aggregate L2' % (nwp * 64 * 8 // 1024),
+        fp64_tflops=achieved_tflops, fp64_peak_tflops=78.6, fp64_frac=achieved_tflops / 78.6,
+        fp16_gram_tflops=rounds * f16_per_round / (k_ms * 1e-3) / 1e12,
+        evals_per_solve=float(out['n_evals'].mean()), newton_iters_per_solve=float(out['n_iter'].mean()),
+        survey_8d=dict(
+            note='SURVEY 8(d) prices the path as HBM-bound with B_eval = %d B per evaluation pass; V (224 KB) is L2 '
+                 'resident, so these algorithmic rates are not bounded by the HBM peak and are reported as labelled '
+                 'extras, not as the roofline' % b_eval,
+            algorithmic_GBs_executed_passes=rounds * b_eval / (k_ms * 1e-3) / 1e9,
+            algorithmic_GBs_reference_nominal_passes=bytes_nominal / (k_ms * 1e-3) / 1e9,
+            hbm_peak_GBs=HBM_PEAK_GBS))
 
+    what = 'chi2, S, Q of every alpha + H row and index of the line-fit alpha per scan' if not full else \
+        'all H, chi2, S, Q + H row and index of the line-fit alpha per scan'
     line = dict(metric='alpha-solves/s', value=value, unit='alpha-solves/s',
                 n_gpus=world, steps=args.steps, warmup=args.warmup,
                 ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
-                scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
-                config=dict(workload='cfg4: ElementwiseMaxEnt %dx%d G(tau), %d '
-                                     'chains x %d alpha = %d alpha-solves per GPU, '
-                                     'n_tau=%d n_omega=%d n_s=%d'
-                                     % (args.n_orb, args.n_orb, n_chain,
-                                        args.n_alpha, P, args.n_tau,
-                                        args.n_omega, n_s),
-                            waves_per_chain=info['waves_per_chain'],
-                            workgroups=info['n_workgroups'],
-                            lds_bytes=info['lds_bytes'],
-                            converged=n_conv, problems=P,
-                            gather='one torch.distributed nccl (RCCL) gather per step of the packed H, chi2, S, Q '
-                                   '(%.1f MB per rank) to rank 0, double buffered against the next pass, inside the timed region' % ((P * args.n_omega + 3 * P) * 8 / 1e6)
-                            if use_dist else 'none (1 GPU)',
-                            svd_seconds_host=batch['t_svd'], host_split=host_split),
+                scaling=('strong' if strong else 'weak'), vs_baseline=None, dtype='f64', data='synthetic',
+                config=dict(
+                    workload=('cfg4: ElementwiseMaxEnt %dx%d G(tau) = %d alpha scans x %d alpha = %d alpha-solves, '
+                              'n_tau=%d n_omega=%d n_s=%d; ' % (args.n_orb, args.n_orb, n_elem, args.n_alpha,
+                                                               n_elem * args.n_alpha, args.n_tau, args.n_omega, n_s)) +
+                             ('the one batch sharded over %d GPU(s), element e on rank e mod N' % world if strong
+                              else 'one such batch per GPU (%d GPUs, weak scaling)' % world),
+                    step='chain kernel + device line fit' + (' + one RCCL gather (%s) to rank 0: %.2f MB per step'
+                                                            % (what, float(np.sum(counts)) * 8 / 1e6) if use_comm else ''),
+                    problems_per_step=P_job, problems_on_rank0=P_rank,
+                    waves_per_chain=info['waves_per_chain'], workgroups=info['n_workgroups'],
+                    lds_bytes=info['lds_bytes'], converged_on_rank0=n_conv,
+                    svd_seconds_host=batch['t_svd'], host_split=host_split,
+                    gather_checked=gather_checked,
+                    multi_gpu_note='N > 1 has not been run by the builders (one-GPU boxes); the gather path is '
+                                   'exercised with one rank (--force-comm) and with several contexts on one device '
+                                   '(tests/test_gpu_multi.py)'),
                 roofline=roofline)
     if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(batch, out)
         line['cpu_baseline']['all_cores'] = pool_baseline
     else:
         line['cpu_baseline'] = None
-    if use_dist:
-        # rank 0 holds every rank's results: check its own block against the source
-        for b in (0, 1):
-            assert torch.equal(gather_bufs['gathered'][b][0], gather_bufs['packs'][b]), 'gathered block differs'
-        line['config']['gather_checked'] = True
+    if world == 1 and not args.no_extras:
+        line['audit'] = audit_block(ctx)
+        if default_workload:
+            line['parity_per_alpha'] = parity_per_alpha()
+    if use_comm:
+        ctx.comm_destroy()
+    ctx.close()
+    if world == 1 and not args.no_extras:
+        line['end_to_end'] = end_to_end_block(batch, args.n_orb, args.n_alpha)
     print(json.dumps(line))
-    if use_dist:
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

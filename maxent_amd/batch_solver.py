@@ -17,6 +17,8 @@ is fetched when it is first asked for (:class:`LazyH`), single rows -- what an a
 ``rows()`` without touching the rest.
 """
 
+import weakref
+
 import numpy as np
 
 from . import device
@@ -102,7 +104,7 @@ class BatchSolver(object):
         self.n_s, self.n_omega = self.ctxs[0].n_s, self.ctxs[0].n_omega
         if len(self.ctxs) > 1:
             device.comm_init_local(self.ctxs)
-        self._pending = []                          # LazyH objects whose data still live in a result buffer
+        self._pending = []                          # weak references to the LazyH whose data still live in a result buffer
         self._layout = None
         self.last_info = None
 
@@ -179,7 +181,7 @@ class BatchSolver(object):
             r, c = int(rank_of[i]), int(local_of[i])
             o = outs[r]
             H = LazyH(self, r, c, n_alpha, self.n_omega)
-            self._pending.append(H)
+            self._pending.append(weakref.ref(H))
             d = dict(alpha=np.asarray(s['alpha'], dtype=float), H=H,
                      A=(maps[r][c] if r in maps else None),
                      v=o['v'][c], chi2=o['chi2'][c], S=o['S'][c], Q=o['Q'][c],
@@ -229,17 +231,27 @@ class BatchSolver(object):
         return out
 
     # ---- H on demand ----------------------------------------------------------
+    def _alive(self):
+        """the LazyH somebody still holds and that have not been fetched (a result that was dropped takes
+        its claim on the device buffer with it)"""
+        out = []
+        for ref in self._pending:
+            h = ref()
+            if h is not None and h._val is None:
+                out.append(h)
+        return out
+
     def _materialize_rank(self, rank):
-        mine = [h for h in self._pending if h._rank == rank and h._val is None]
-        if not mine:
-            return
-        H = self.ctxs[rank].fetch(want_v=False, want_H=True)['H']
-        for h in mine:
-            h._val = H[h._chain]
-        self._pending = [h for h in self._pending if h._val is None]
+        alive = self._alive()
+        mine = [h for h in alive if h._rank == rank]
+        if mine:
+            H = self.ctxs[rank].fetch(want_v=False, want_H=True)['H']
+            for h in mine:
+                h._val = H[h._chain]
+        self._pending = [weakref.ref(h) for h in alive if h._val is None]
 
     def materialize_pending(self):
-        for r in sorted(set(h._rank for h in self._pending)):
+        for r in sorted(set(h._rank for h in self._alive())):
             self._materialize_rank(r)
         self._pending = []
 

@@ -238,7 +238,8 @@ size_t mc_lds_bytes(int NA, int nwp, int wgpc)
 {
     const int NT = NA / 16, NPAIR = NT * (NT + 1) / 2;
     const size_t doubles = 8 * 4 * 64 + 2 * 64 + 64 * 4 + (wgpc == 2 ? 1 : 4) * 4 * 64 + 4 * 32 +   // vectors, c, 1/c, step, h, sums
-                           (size_t)(wgpc == 2 ? 1 : 2) * nwp * 4 + (size_t)4 * NPAIR * 256;          // (u,) H, Gram tiles
+                           (wgpc == 2 ? (size_t)MXE_X_UL * 256 + (size_t)nwp * 4 : (size_t)2 * nwp * 4) +
+                           (size_t)4 * NPAIR * 256;                                                  // u, H, Gram tiles
     const size_t floats = (size_t)nwp * 4;                                              // sw
     return doubles * 8 + floats * 4;
 }
@@ -1240,7 +1241,7 @@ try {
     const size_t P = (size_t)ctx->n_chain * ctx->n_alpha;
     double* sel = ctx->dout_Q.p + P;
     double* idx = sel + (size_t)ctx->n_chain * ctx->n_omega;
-    hipLaunchKernelGGL(mxe::linefit_kernel, dim3(ctx->n_chain), dim3(64), (size_t)2 * ctx->n_alpha * sizeof(double), ctx->stream,
+    hipLaunchKernelGGL(mxe::linefit_kernel, dim3(ctx->n_chain), dim3(64), ((size_t)9 * ctx->n_alpha + 6) * sizeof(double), ctx->stream,
                        ctx->dalpha.p, ctx->dout_chi2.p, ctx->dout_H.p, ctx->n_alpha, ctx->n_omega, p2_deg, sel, idx);
     HIPCHK(ctx, hipGetLastError());
     return MXE_OK;

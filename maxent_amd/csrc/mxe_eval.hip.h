@@ -361,18 +361,26 @@ namespace mxe {
 
 struct LineSSE { double slope, icpt, sse; int n; };
 
+// least-squares line (or constant) through the points lo .. hi-1 that are not NaN, by the whole wavefront:
+// lane t takes the points lo + t, lo + t + 64, ...; two-pass formulas (mean first, then centred sums)
 __device__ inline LineSSE line_sse(const double* x, const double* y, int lo, int hi, bool line)
 {
+    const int lane = threadIdx.x & 63;
     LineSSE r; r.slope = 0.0; r.icpt = 0.0; r.sse = 0.0; r.n = 0;
-    double sx = 0.0, sy = 0.0;
-    for (int k = lo; k < hi; ++k) if (y[k] == y[k]) { sx += x[k]; sy += y[k]; ++r.n; }
+    double sx = 0.0, sy = 0.0, cnt = 0.0;
+    for (int k = lo + lane; k < hi; k += 64) if (y[k] == y[k]) { sx += x[k]; sy += y[k]; cnt += 1.0; }
+    sx = wave_sum(sx); sy = wave_sum(sy); cnt = wave_sum(cnt);
+    r.n = (int)cnt;
     if (r.n < 1) return r;
-    const double xm = sx / r.n, ym = sy / r.n;
+    const double xm = sx / cnt, ym = sy / cnt;
     double sxx = 0.0, sxy = 0.0;
-    for (int k = lo; k < hi; ++k) if (y[k] == y[k]) { const double dx = x[k] - xm; sxx += dx * dx; sxy += dx * (y[k] - ym); }
+    for (int k = lo + lane; k < hi; k += 64) if (y[k] == y[k]) { const double dx = x[k] - xm; sxx += dx * dx; sxy += dx * (y[k] - ym); }
+    sxx = wave_sum(sxx); sxy = wave_sum(sxy);
     if (line && r.n >= 2 && sxx != 0.0) { r.slope = sxy / sxx; r.icpt = ym - r.slope * xm; }
     else r.icpt = ym;
-    for (int k = lo; k < hi; ++k) if (y[k] == y[k]) { const double d = y[k] - (r.slope * x[k] + r.icpt); r.sse += d * d; }
+    double e = 0.0;
+    for (int k = lo + lane; k < hi; k += 64) if (y[k] == y[k]) { const double d = y[k] - (r.slope * x[k] + r.icpt); e += d * d; }
+    r.sse = wave_sum(e);
     return r;
 }
 
@@ -381,39 +389,95 @@ void linefit_kernel(const double* __restrict__ alpha, const double* __restrict__
                     int n_alpha, int nw, int p2_deg, double* __restrict__ out_sel /*[n_chain][nw] or null*/,
                     double* __restrict__ out_idx /*[n_chain], as doubles (they travel in the result pack)*/)
 {
+    // Break points are first ranked with running sums (O(n) for all of them; centred, like the host
+    // analyzer's fit_piecewise), then only those within a whisker of the best are evaluated exactly with the
+    // two-pass formulas -- the same two stages, with the same tolerance, as the host code.
     extern __shared__ double sm[];
-    double* x = sm;                  // log alpha
-    double* y = x + n_alpha;         // log chi2
     const int lane = threadIdx.x, n = n_alpha;
+    double* x = sm;                  // log alpha
+    double* y = x + n;               // log chi2
+    double* cs = y + n;              // [6][n + 1] running sums of w, w x0, yc, w x0^2, x0 yc, yc^2
+    double* ap = cs + 6 * (n + 1);   // [n] approximate misfit of break point i
     const size_t c = blockIdx.x;
     for (int k = lane; k < n; k += 64) { x[k] = log(alpha[c * n + k]); y[k] = log(chi2[c * n + k]); }
     wave_sync();
-    double best = __builtin_inf(); int best_i = -1;
-    for (int i = 2 + lane; i < n - 2; i += 64) {
-        const LineSSE a = line_sse(x, y, 0, i, true), b = line_sse(x, y, i, n, p2_deg == 1);
-        if (a.n < 1 || b.n < 1) continue;
-        const double m = a.sse + b.sse;
-        if (m == m && (m < best || (m == best && i < best_i))) { best = m; best_i = i; }
-    }
-    // smallest misfit, lowest index among equals (np.nanargmin)
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double ob = __shfl_xor(best, off); const int oi = __shfl_xor(best_i, off);
-        if (oi >= 0 && (best_i < 0 || ob < best || (ob == best && oi < best_i))) { best = ob; best_i = oi; }
-    }
     int idx = -1;
-    if (best_i >= 0) {
-        const LineSSE a = line_sse(x, y, 0, best_i, true), b = line_sse(x, y, best_i, n, p2_deg == 1);
-        const double xc = (b.icpt - a.icpt) / (a.slope - b.slope);
-        double dbest = __builtin_inf(); int di = -1;
-        for (int k = lane; k < n; k += 64) {
-            const double d = fabs(x[k] - xc);
-            if (d == d && (d < dbest || (d == dbest && k < di))) { dbest = d; di = k; }
+    if (n > 4) {
+        // means for the centring
+        double sx = 0.0, sy = 0.0, sw = 0.0;
+        for (int k = lane; k < n; k += 64) { sx += x[k]; if (y[k] == y[k]) { sy += y[k]; sw += 1.0; } }
+        sx = wave_sum(sx); sy = wave_sum(sy); sw = wave_sum(sw);
+        const double xm = sx / n, ym = sy / fmax(sw, 1.0);
+        {
+            // running sums of the six quantities: lane t holds element c0 + t of a chunk of 64, inclusive scan
+            // over the lanes (six shuffle steps), carry from chunk to chunk
+            double carry[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (lane < 6) cs[lane * (n + 1)] = 0.0;
+            for (int c0 = 0; c0 < n; c0 += 64) {
+                const int k = c0 + lane;
+                const bool in = k < n, ok = in && y[in ? k : 0] == y[in ? k : 0];
+                const double w = ok ? 1.0 : 0.0, x0 = in ? x[k] - xm : 0.0, yc = ok ? y[k] - ym : 0.0;
+                double v[6] = {w, w * x0, yc, w * x0 * x0, x0 * yc, yc * yc};
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const double up = __shfl_up(v[q], off);
+                        if (lane >= off) v[q] += up;
+                    }
+                    v[q] += carry[q];
+                    if (in) cs[q * (n + 1) + k + 1] = v[q];
+                    carry[q] = __shfl(v[q], 63);
+                }
+            }
         }
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double od = __shfl_xor(dbest, off); const int oi = __shfl_xor(di, off);
-            if (oi >= 0 && (di < 0 || od < dbest || (od == dbest && oi < di))) { dbest = od; di = oi; }
+        wave_sync();
+        auto sse = [&](int lo, int hi, bool line) -> double {
+            const double m = cs[hi] - cs[lo], s1 = cs[(n + 1) + hi] - cs[(n + 1) + lo], s2 = cs[2 * (n + 1) + hi] - cs[2 * (n + 1) + lo];
+            const double sxx = cs[3 * (n + 1) + hi] - cs[3 * (n + 1) + lo], sxy = cs[4 * (n + 1) + hi] - cs[4 * (n + 1) + lo];
+            const double syy = cs[5 * (n + 1) + hi] - cs[5 * (n + 1) + lo];
+            if (!(m >= 1.0)) return __builtin_nan("");
+            const double vyy = syy - s2 * s2 / m;
+            if (!line || m < 2.0) return vyy;
+            const double vxx = sxx - s1 * s1 / m, vxy = sxy - s1 * s2 / m;
+            return vxx > 0.0 ? vyy - vxy * vxy / vxx : vyy;
+        };
+        double best = __builtin_inf();
+        for (int i = 2 + lane; i < n - 2; i += 64) {
+            const double a = sse(0, i, true) + sse(i, n, p2_deg == 1);
+            ap[i] = a;
+            if (a == a && fabs(a) < 1.7e308 && a < best) best = a;
         }
-        idx = di;
+        best = -wave_max(-best);
+        wave_sync();
+        const double tol = best + 1e-9 * (fabs(cs[5 * (n + 1) + n]) + 1e-300) + 1e-6 * fabs(best);
+        const bool rank_ok = best < 1.7e308 && n > 8;
+        // exact misfit of the candidates, one after the other, each by the whole wave; the smallest wins,
+        // the lowest index among equals (np.nanargmin)
+        double ebest = __builtin_inf(); int ebest_i = -1;
+        LineSSE abest, bbest;
+        for (int i = 2; i < n - 2; ++i) {
+            const bool cand = rank_ok ? (ap[i] == ap[i] && ap[i] <= tol) : true;      // wave-uniform
+            if (!cand) continue;
+            const LineSSE a = line_sse(x, y, 0, i, true), b = line_sse(x, y, i, n, p2_deg == 1);
+            if (a.n < 1 || b.n < 1) continue;
+            const double m = a.sse + b.sse;
+            if (m == m && m < ebest) { ebest = m; ebest_i = i; abest = a; bbest = b; }
+        }
+        if (ebest_i >= 0) {
+            const LineSSE a = abest, b = bbest;
+            const double xc = (b.icpt - a.icpt) / (a.slope - b.slope);
+            double dbest = __builtin_inf(); int di = -1;
+            for (int k = lane; k < n; k += 64) {
+                const double d = fabs(x[k] - xc);
+                if (d == d && (d < dbest || (d == dbest && k < di))) { dbest = d; di = k; }
+            }
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double od = __shfl_xor(dbest, off); const int oi = __shfl_xor(di, off);
+                if (oi >= 0 && (di < 0 || od < dbest || (od == dbest && oi < di))) { dbest = od; di = oi; }
+            }
+            idx = di;
+        }
     }
     if (lane == 0) out_idx[c] = (double)idx;
     if (out_sel) {

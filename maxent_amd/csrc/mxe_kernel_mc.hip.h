@@ -53,6 +53,12 @@ struct MCExtra {
 constexpr double MC_GRAM_ERR = 0.0;              // allowance for the inexact Gram tiles in the stopping estimate
 constexpr int MC_LOOKAHEAD_ROWS = 512;
 constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
+#ifndef MXE_X_DEPTH2
+#define MXE_X_DEPTH2 2        // V ring of the fused pass at two workgroups per CU (4: 1.33 ms and 300 MB of spill stores per launch; 2: 1.29 ms, none)
+#endif
+#ifndef MXE_X_UL
+#define MXE_X_UL 0            // u elements per lane kept in LDS instead of registers (0: all eight in registers)
+#endif
 template <int NA, int WGPC>
 __global__ __launch_bounds__(256, WGPC)
 void chain_kernel_mc(const KParams p, const MCExtra x)
@@ -96,7 +102,10 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     double* ui   = red + NWV * 32;               // [nwp][MCC]   (WGPC = 1 only)
     // (the look-ahead of the fused pass reads up to MC_LOOKAHEAD_LDS entries past the end of Hi and of swF:
     //  they land in swF and Wt, are never used, and need no padding)
-    double* Hi   = ui + (UREG ? (size_t)0 : (size_t)nwp * MCC);       // [nwp][MCC]
+    // WGPC = 2: u of a lane's eight (row, slot) elements: the first 8 - UL in registers, the last UL in LDS
+    // ([UL][256], one 8-byte slot per thread: what the 80 KB of a half CU leave room for)
+    constexpr int UL = UREG ? MXE_X_UL : 0;
+    double* Hi   = ui + (UREG ? (size_t)UL * T : (size_t)nwp * MCC);  // [nwp][MCC]
     float*  swF  = reinterpret_cast<float*>(Hi + (size_t)nwp * MCC);    // [nwp][MCC]
     double* Wt   = reinterpret_cast<double*>(swF + (size_t)nwp * MCC);  // [MCC][NPAIR][4][64]
     static_assert(MCC * NPAIR * 256 * 2 >= MC_LOOKAHEAD_LDS, "the look-ahead stays inside the allocation");
@@ -300,7 +309,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 
     // WGPC = 2: u of the eight (row, slot) elements this lane updates in the row pass (n_omega_pad <= 512:
     // one batch of eight tiles per wave covers every row)
-    double ureg[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double ureg[8 - UL];
+#pragma unroll
+    for (int tt = 0; tt < 8 - UL; ++tt) ureg[tt] = 0.0;
     // Two workgroups that share a CU run the same program from the same start: left alone they sit in the
     // same phase at the same time (solve beside solve, stream beside stream) and overlap nothing.  The
     // second half of the grid -- dispatched onto the CUs the first half already occupies -- starts half a
@@ -456,7 +467,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     rowt[tt] = row;
                     acc[tt] = 0.0;
                     Dv[tt] = Dj[row];
-                    uo[tt] = UREG ? ureg[tt] : ui[row * MCC + j];
+                    uo[tt] = !UREG ? ui[row * MCC + j] : (tt < 8 - UL) ? ureg[tt < 8 - UL ? tt : 0] : ui[(tt - (8 - UL)) * T + tid];
                     { const float so = swF[row * MCC + j]; wo[tt] = (double)(so * so) * isc_old; }
                 }
                 // V^T operand: row 4 kc + ak of V^T; the blocks of a batch are 32 NWV rows apart (V^T is
@@ -506,7 +517,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                             Sq += Hm - Di + Hm * uq;
                         }
                         if (row >= nw) { Hq = 0.0; wq = 0.0; Sq = 0.0; }
-                        if (UREG) ureg[tt] = uq; else ui[row * MCC + j] = uq;
+                        if (!UREG) ui[row * MCC + j] = uq;
+                        else if (tt < 8 - UL) ureg[tt < 8 - UL ? tt : 0] = uq;
+                        else ui[(tt - (8 - UL)) * T + tid] = uq;
                         Hi[row * MCC + j] = Hq;
                         swF[row * MCC + j] = __builtin_sqrtf(fminf((float)(wq * sc_new), 3.0e38f));
                         pS += Sq;
@@ -575,7 +588,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             // the padding behind H / sw in LDS and is not used.
             constexpr int ST = NWV;
             constexpr int TRIP = 8;
-            constexpr int DEPTH = (WGPC == 1) ? 8 : 4;
+            constexpr int DEPTH = (WGPC == 1) ? 8 : MXE_X_DEPTH2;
             static_assert(TRIP % DEPTH == 0 && DEPTH >= 2, "ring indices are static across trips");
             int g = wave;
             {

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""condense the counter_collection CSVs of rocprofv3 --pmc runs (one directory per pass under <dir>) into one small
+table: mean per dispatch of mxe::chain_kernel_mc, for every counter"""
+import csv, glob, os, sys
+root = sys.argv[1]
+rows = {}
+for path in glob.glob(os.path.join(root, 'pmc_*', '**', '*counter_collection.csv'), recursive=True):
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if 'chain_kernel_mc' not in r.get('Kernel_Name', ''):
+                continue
+            name, val = r['Counter_Name'], float(r['Counter_Value'])
+            rows.setdefault(name, []).append(val)
+print('counter,dispatches,mean_per_dispatch,min,max')
+for name in sorted(rows):
+    v = rows[name]
+    # the first dispatches of a process run cold (L2, clocks): report all, the table says how many
+    print('%s,%d,%.6g,%.6g,%.6g' % (name, len(v), sum(v) / len(v), min(v), max(v)))
