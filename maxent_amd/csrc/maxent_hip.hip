@@ -63,7 +63,7 @@ struct mxe_ctx {
     int n_chain = 0, n_alpha = 0;
     std::vector<int> chain_elem;      // per parent chain
     std::vector<int> sub_elem, sub_prob0, sub_len, sub_v0, wg_chains;   // per launched (sub-)chain
-    int n_sub = 0, n_wg = 0, mc_na = 0, mc_wgpc = 1, n_queue = 0;
+    int n_sub = 0, n_wg = 0, mc_na = 0, mc_wgpc = 1, wgpc_auto = 2, n_queue = 0;
     std::vector<int> queue;
     mxe_opts opts;
     bool chains_ready = false, launched = false;
@@ -495,18 +495,29 @@ try {
     //      from the same v0 (the minimiser of each alpha does not depend on the path)
     int split = o.alpha_split;
     if (split <= 0) {
-        // about 2.5 pieces per chain slot of the GPU (CUs x 4 slots) so that the persistent grid
-        // balances (pieces have unequal costs and are handed out most expensive first; measured on
-        // cfg4 with the alpha-path predictor: 7 pieces per scan 2.07 ms, 8: 2.21, 9: 2.08, 10: 1.98,
-        // 11: 2.06, 12: 2.13, 14: 2.04, 16: 2.14), none shorter than 6 alphas (a cold start costs
-        // about as much as 3 warm alphas)
+        // about two pieces per chain slot of the GPU (CUs x workgroups per CU x 4 slots): the persistent grid
+        // then balances (pieces have unequal costs and are handed out most expensive first), and a batch that
+        // is small for the GPU -- one rank's shard of a job that is spread over several -- is cut into many
+        // short cold-started pieces rather than left on a fraction of the CUs.  None shorter than two alphas
+        // (a cold start costs 4-10 iterations, a warm alpha 2-3).  Measured, kernel time of 256 / 128 / 64 / 32
+        // scans of 100 alphas (profiles/r02_d_shard_sweep.txt): 16 pieces per scan 1.28 / 1.09 / 0.93 / 1.54 ms,
+        // 34: 2.95 / 0.84 / 0.73 / 0.62, 50: 3.27 / 0.87 / 0.67 / 0.57.
         hipDeviceProp_t prop;
         HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
         // (two workgroups per CU where the lock-step kernel has a build for it: n_omega_pad <= 512)
-        const int wgpc_guess = (o.wg_per_cu != 1 && ctx->nwp <= 512 && NP == 64 && o.chains_per_wg != 1) ? 2 : 1;
-        const int n_slots = 4 * wgpc_guess * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
-        const int want = (5 * n_slots / 2 + n_chain - 1) / n_chain;
-        split = std::max(1, std::min(std::min(want, 16), n_alpha / 6));
+        const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        int wgpc_guess = (o.wg_per_cu != 1 && ctx->nwp <= 512 && NP == 64 && o.chains_per_wg != 1) ? 2 : 1;
+        for (;;) {
+            const int n_slots = 4 * wgpc_guess * n_cu;
+            const int want = (2 * n_slots + n_chain - 1) / n_chain;
+            split = std::max(1, std::min(want, n_alpha / 2));
+            // two workgroups per CU pay when there is work for two rounds of them; a batch that cannot be cut
+            // into that many pieces runs at one per CU, where a round of a workgroup takes 45 k instead of 73 k
+            // cycles (the 3 200-problem shard of cfg4 / 8: 0.48 against 0.59 ms)
+            if (wgpc_guess == 2 && o.wg_per_cu == 0 && (long long)n_chain * split < 2LL * n_slots) { wgpc_guess = 1; continue; }
+            break;
+        }
+        ctx->wgpc_auto = wgpc_guess;
         // a small batch that cannot fill the lock-step layout (>= 768 pieces) with pieces of six alphas,
         // but can with shorter ones, takes those: the lock-step kernel serves four pieces with the loads
         // and the time the one-chain kernel spends on one (cfg3, 16 scans: 1.9 ms with 256 pieces in the
@@ -550,7 +561,7 @@ try {
         }
         if (worst32 <= 1e-2) ctx->mc_na = 32; else if (worst48 <= 1e-2) ctx->mc_na = 48; else layout = 1;
         if (layout == 4) {
-            ctx->mc_wgpc = (o.wg_per_cu != 1 && ctx->mc_na == 32 && ctx->nwp <= 512 &&
+            ctx->mc_wgpc = (o.wg_per_cu != 1 && (o.wg_per_cu == 2 || ctx->wgpc_auto == 2) && ctx->mc_na == 32 && ctx->nwp <= 512 &&
                             mc_lds_bytes(32, ctx->nwp, 2) <= 80 * 1024 - 2048) ? 2 : 1;
             if (mc_lds_bytes(ctx->mc_na, ctx->nwp, ctx->mc_wgpc) > 160 * 1024 - 6144) { layout = 1; ctx->mc_na = 0; }
         }
