@@ -99,7 +99,7 @@ class BatchSolver(object):
         if not self.device_ids:
             raise ValueError('at least one device is needed')
         self._token = self._kernel_token(K)
-        U = None if K._T is not None else K.U
+        U = None if K.rotation is not None else K.U
         self.ctxs = [device.DeviceContext(U, K.S, K.V, device=d) for d in self.device_ids]
         self.n_s, self.n_omega = self.ctxs[0].n_s, self.ctxs[0].n_omega
         if len(self.ctxs) > 1:
@@ -111,7 +111,7 @@ class BatchSolver(object):
     # ---- reuse -------------------------------------------------------------
     @staticmethod
     def _kernel_token(K):
-        return (id(K._S), id(K._V), len(K._S), K._T is None)
+        return (id(K._S), id(K._V), len(K._S), K.rotation is None)
 
     @classmethod
     def for_kernel(cls, K, device_ids=(0,)):
@@ -212,7 +212,7 @@ class BatchSolver(object):
                     found = i0
                     break
             if found is None:
-                found = ctx.add_dataset(err, K.U if (U_rot is None and K._T is not None) else U_rot)
+                found = ctx.add_dataset(err, K.U if (U_rot is None and K.rotation is not None) else U_rot)
                 seen.append((err, U_rot, found))
             ds_ids.append(found)
         ctx.set_elements(ds_ids, [s['G'] for s in specs],

@@ -511,6 +511,9 @@ try {
             const int n_slots = 4 * wgpc_guess * n_cu;
             const int want = (2 * n_slots + n_chain - 1) / n_chain;
             split = std::max(1, std::min(want, n_alpha / 2));
+            // (the binary32 streaming variant stops an alpha at its rounding floor, which a cold start reaches
+            //  from further away: it keeps pieces of at least six alphas, at most 16 per scan)
+            if (o.precision == MXE_PRECISION_F32) split = std::max(1, std::min(std::min(want, 16), n_alpha / 6));
             // two workgroups per CU pay when there is work for two rounds of them; a batch that cannot be cut
             // into that many pieces runs at one per CU, where a round of a workgroup takes 45 k instead of 73 k
             // cycles (the 3 200-problem shard of cfg4 / 8: 0.48 against 0.59 ms)

@@ -206,14 +206,14 @@ class ElementwiseMaxEnt(object):
         """G(tau) came as one array and the errors are plain (no covariance): specs can be cut from the
         arrays without sending every element through the worker's setters"""
         return (getattr(self, '_array_input', False) and self.error_dimension == 1 and
-                worker.K._T is None and not isinstance(self.error, str))
+                worker.K.rotation is None and not isinstance(self.error, str))
 
     def _share_decomposition(self):
         """the two workers have kernels of their own; where these are the same matrix (same class, tau,
         omega, beta, no preblur on one side only) the second takes the SVD of the first instead of
         repeating it"""
         a, b = self.maxent_diagonal.K, self.maxent_offdiagonal.K
-        if a is b or type(a) is not type(b) or not hasattr(a, 'tau') or a._T is not None or b._T is not None:
+        if a is b or type(a) is not type(b) or not hasattr(a, 'tau') or a.rotation is not None or b.rotation is not None:
             return
         try:
             same = (np.array_equal(np.asarray(a.tau), np.asarray(b.tau)) and

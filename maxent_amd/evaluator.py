@@ -33,8 +33,8 @@ class Evaluator(object):
                 'K.reduce_singular_space() first ({} kept now)'.format(len(S)))
         G = np.asarray(G, dtype=float)
         err = np.asarray(err, dtype=float) * np.ones(len(G))
-        self.ctx = device.DeviceContext(None if K._T is not None else U, S, V, device=device_id)
-        ds = self.ctx.add_dataset(err, U if K._T is not None else None)
+        self.ctx = device.DeviceContext(None if K.rotation is not None else U, S, V, device=device_id)
+        ds = self.ctx.add_dataset(err, U if K.rotation is not None else None)
         self.ctx.set_elements([ds], [G], np.asarray(D, dtype=float)[np.newaxis, :], [kind])
         self.U, self.S, self.V, self.err = U, S, V, err
         self._M = None

@@ -79,7 +79,7 @@ def solve_single(cost_function, v0, minimizer, device_id=0):
         raise Exception('call set_alpha on the cost function first')
     K = cf.K
     K.S        # trigger the SVD if needed
-    spec = dict(G=cf.G, err=cf.err, U_rot=(K.U if K._T is not None else None),
+    spec = dict(G=cf.G, err=cf.err, U_rot=(K.U if K.rotation is not None else None),
                 D=cf.D.D, kind=cf.entropy_kind, v0=np.asarray(v0, dtype=float),
                 alpha=np.array([cf._alpha], dtype=float))
     res, _ = solve_elements(K, [spec], minimizer, device_id=device_id, chi2_factor=cf.chi2_factor,
@@ -162,7 +162,7 @@ class MaxEntLoop(object):
         element-wise drivers build the specs of all matrix elements this way"""
         other = G is not None
         if other:
-            assert self.K._T is None, 'specs of other data vectors need an unrotated kernel'
+            assert self.K.rotation is None, 'specs of other data vectors need an unrotated kernel'
             G_use = np.array(G, dtype=float)
             err_use = np.asarray(err, dtype=float) * np.ones(len(G_use))
         else:
@@ -186,7 +186,7 @@ class MaxEntLoop(object):
         K = self.K
         return dict(G=G_use,
                     err=err_use,
-                    U_rot=(K.U if K._T is not None else None),
+                    U_rot=(K.U if K.rotation is not None else None),
                     D=np.array(self.D.D, dtype=float),
                     kind=self.cost_function.entropy_kind,
                     v0=v0,
@@ -195,7 +195,7 @@ class MaxEntLoop(object):
                     G_orig=(G_use if other else np.array(self.cost_function.G_orig, dtype=float)),
                     data_variable=np.array(self.data_variable, dtype=float),
                     A_matrix=self.A_of_H.matrix(),
-                    T=K._T)
+                    T=K.rotation)
 
     def make_record(self, spec, sol):
         """MaxEntResult arrays of one finished scan (maxent_result.py:835-967)."""

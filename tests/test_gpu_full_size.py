@@ -3,12 +3,17 @@
 problem, stationarity of the returned points, symmetry, invariance under the
 way the library cuts and schedules the alpha scans, and agreement with the
 extended-precision truth on a sample."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
-import bench
-from maxent_amd import device
-from oracle import sform as SF, hp_truth
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import anchor                                                # noqa: E402
+import bench                                                 # noqa: E402
+from maxent_amd import device                                # noqa: E402
+from oracle import ref_numpy as R, sform as SF               # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -37,6 +42,18 @@ def test_cfg4_all_converged_and_finite(cfg4):
     np.testing.assert_allclose(out['Q'], 0.5 * out['chi2'] - batch['alphas'][None, :] * out['S'], rtol=1e-12)
 
 
+def test_cfg4_every_problem_passes_the_device_audit(cfg4):
+    """mxe_audit: the exact Newton correction (binary64, all n_s directions) at the returned v of ALL 25 600
+    problems -- to first order the distance of the returned H from the minimiser.  The sampled truth
+    comparison below calibrates it: where both exist they agree in magnitude."""
+    batch, ctx, out, info = cfg4
+    a = ctx.audit()
+    c = a['corr']
+    assert c.shape == (256, 100) and np.all(np.isfinite(c))
+    assert c.max() < 1e-6, c.max()               # the parity gate, every problem
+    assert np.percentile(c, 99) < 1e-8 and np.median(c) < 1e-10
+
+
 def test_cfg4_symmetric_input_gives_symmetric_output(cfg4):
     """G_ij = G_ji (symmetrised noise): chains (i,j) and (j,i) are solved by
     different slots / pieces and must agree to the convergence level."""
@@ -57,11 +74,15 @@ def test_cfg4_stationarity_and_truth_on_a_sample(cfg4):
     basis = SF.Basis(K.U, K.S, K.V, batch['err'])
     rng = np.random.RandomState(7)
     worst = 0.0
-    for c in [0, 1, 16, 17, 100, 255] + list(rng.randint(0, 256, 4)):
+    rows = (0, 37, 87, 99)
+    for c in [0, 1, 17, 100, 255] + list(rng.randint(0, 256, 2)):
         i, j = batch['elems'][c]
         ent = 'normal' if batch['kinds'][c] == device.ENTROPY_NORMAL else 'plusminus'
         el = SF.Element(basis, batch['Gmat'][i, j], batch['D'], ent)
-        for ia in (0, 37, 87, 99):
+        # the truth is reached from the iterates of the reference's algorithm (oracle port), not from the GPU's
+        p = R.Problem(np.array(K.K), K.U, K.S, K.V, batch['Gmat'][i, j], batch['err'], batch['D'], entropy=ent)
+        truth, _ = anchor.truth_rows(p, batch['omega'].delta, batch['alphas'], len(batch['tau']), rows, ent)
+        for ia in rows:
             a, v = batch['alphas'][ia], out['v'][c, ia]
             ev = SF.evaluate(basis, el, a, basis.from_v(v))
             assert np.linalg.norm(ev['H'] - out['H'][c, ia]) / np.linalg.norm(ev['H']) < 1e-11
@@ -72,9 +93,7 @@ def test_cfg4_stationarity_and_truth_on_a_sample(cfg4):
             # gradient small against the size of its (cancelling) terms; the accuracy of H
             # itself is checked against the extended-precision truth below
             assert np.max(np.abs(d)) < 5e-3 * np.max(scale)
-            _, Ht = hp_truth.polish(np.array(K.K), batch['Gmat'][i, j], batch['err'], batch['D'], K.V, K.S,
-                                    a, v, ent, iters=4)
-            worst = max(worst, np.linalg.norm(out['H'][c, ia] - Ht) / np.linalg.norm(Ht))
+            worst = max(worst, np.linalg.norm(out['H'][c, ia] - truth[ia]) / np.linalg.norm(truth[ia]))
     assert worst < 1e-6, worst
 
 
