@@ -42,15 +42,15 @@ N_EVAL_NOMINAL = {'normal': 160, 'plusminus': 84}   # the refere
 PMC_DEFAULT = dict(
     source='profiles/r02_c_pmc_summary.csv',
     # mean per dispatch of mxe::chain_kernel_mc<32, 2> over ~160 dispatches
-    valu_active_quadcycles=3.783e8,      # SQ_ACTIVE_INST_VALU (counts quad-cycles: MI355X_MICROARCH.md, cycle constants)
-    mfma_busy_cycles=4.7316e8,           # SQ_VALU_MFMA_BUSY_CYCLES (cycles)
-    coexec_cycles=3.544e7,               # SQ_VALU_MFMA_COEXEC_CYCLES: both at once, counted once below
-    any_active_quadcycles=5.082e8,       # SQ_ACTIVE_INST_ANY
-    wave_quadcycles=1.3375e9,            # SQ_WAVE_CYCLES
-    wait_inst_quadcycles=3.607e8, wait_any_quadcycles=4.686e8,
-    gui_active_cycles_all_xcd=2.454e7,   # GRBM_GUI_ACTIVE (sum over the 8 XCDs)
-    fetch_kb=28172.4, write_kb=135939.0, # FETCH_SIZE (x 2 on gfx950, MI355X_MICROARCH.md section HBM), WRITE_SIZE
-    l2_hit=8.8884e7, l2_miss=1.48387e6)
+    valu_active_quadcycles=3.789e8,      # SQ_ACTIVE_INST_VALU (counts quad-cycles: MI355X_MICROARCH.md, cycle constants)
+    mfma_busy_cycles=4.7355e8,           # SQ_VALU_MFMA_BUSY_CYCLES (cycles)
+    coexec_cycles=3.555e7,               # SQ_VALU_MFMA_COEXEC_CYCLES: both at once, counted once below
+    any_active_quadcycles=5.103e8,       # SQ_ACTIVE_INST_ANY
+    wave_quadcycles=1.3384e9,            # SQ_WAVE_CYCLES
+    wait_inst_quadcycles=3.617e8, wait_any_quadcycles=4.664e8,
+    gui_active_cycles_all_xcd=2.4514e7,   # GRBM_GUI_ACTIVE (sum over the 8 XCDs)
+    fetch_kb=28225.2, write_kb=135923.0, # FETCH_SIZE (x 2 on gfx950, MI355X_MICROARCH.md section HBM), WRITE_SIZE
+    l2_hit=8.88596e7, l2_miss=1.48731e6)
 N_SIMD = 256 * 4
 CLOCK_PEAK_GHZ = 2.4                      # MI355X_MICROARCH.md: max clock
 

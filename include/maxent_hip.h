@@ -74,8 +74,12 @@ typedef struct mxe_opts {
     double  tol_h;        /* converged when the Newton correction satisfies
                              ||dH||_2 / ||H||_2 < tol_h   (0 = off); with stop_estimate
                              the ESTIMATED next correction is tested as well             */
-    double  tol_d;        /* MaxDerivativeConvergenceMethod: max|W g| < tol_d (0 = off;
-                             reference default 1e-4)                                      */
+    double  tol_d;        /* MaxDerivativeConvergenceMethod: max|W g| < tol_d (0 = off; reference default
+                             1e-4).  The maximum runs over the coupled block (rows and columns of the
+                             directions with c_k^2 max(w) > decouple_tol * alpha): the gradient
+                             components of the decoupled directions are zeroed by their own diagonal
+                             Newton step to relative decouple_tol and add nothing at that level; with
+                             decouple_tol = 0 it is the reference's max over all n_s              */
     double  tol_relq;     /* RelativeFunctionChangeConvergenceMethod: |Q0-Q1|/|Q1| <
                              tol_relq (0 = off; reference default 1e-16)                  */
     double  step_max;     /* step bound  delta^T W delta <= step_max * sum(D)  (0.2)      */
@@ -160,6 +164,8 @@ int  mxe_elements_set(mxe_ctx* ctx, int n_elem, const int32_t* dataset_of_elem,
  *   out_v[p*n_s+k]  optimum in the caller's singular basis
  *   out_H[p*n_omega+j] hidden image H(v)   out_chi2/out_S/out_Q[p]
  *   out_niter[p] iterations (minimizer.n_iter_last)   out_converged[p] 0/1
+ *   (an alpha whose minimisation FAILED -- damping exhausted, nothing finite to evaluate: converged 0
+ *    before maxiter -- reports v, chi2, S, Q of its last accepted iterate and H = NaN)
  *   out_nevals[p] cost evaluation passes spent on p
  * Blocking: returns after the results are in the host buffers. */
 int  mxe_solve_chains(mxe_ctx* ctx, int n_chain, int n_alpha,

@@ -562,7 +562,10 @@ try {
             if (ns > 32) worst32 = std::max(worst32, DS.c[32] * DS.c[32] * wbound / amin);
             if (ns > 48) worst48 = std::max(worst48, DS.c[48] * DS.c[48] * wbound / amin);
         }
-        if (worst32 <= 1e-2) ctx->mc_na = 32; else if (worst48 <= 1e-2) ctx->mc_na = 48; else layout = 1;
+        // (an active block of 48 in the lock-step kernel spilled registers in every tiling that was tried: problems
+        //  that couple more than 32 directions run in the one-chain layout, whose solve lives in LDS)
+        (void)worst48;
+        if (worst32 <= 1e-2) ctx->mc_na = 32; else layout = 1;
         if (layout == 4) {
             ctx->mc_wgpc = (o.wg_per_cu != 1 && (o.wg_per_cu == 2 || ctx->wgpc_auto == 2) && ctx->mc_na == 32 && ctx->nwp <= 512 &&
                             mc_lds_bytes(32, ctx->nwp, 2) <= 80 * 1024 - 2048) ? 2 : 1;
@@ -694,16 +697,15 @@ try {
             fprintf(stderr, "[mxe] lock-step kernel NA=%d NWV=%d lds=%zu: %d workgroup(s) per CU resident\n", NA_, NWV_, (size_t)lds, nb__); } \
         if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<NA_, WG_>), dim3(ctx->n_wg), dim3(64 * NWV_), lds, ctx->stream, kp, ex); e = hipGetLastError(); } } while (0)
         if (NA == 32 && WGPC == 2) MXE_LAUNCH_MC(32, 2);
-        else if (NA == 32) MXE_LAUNCH_MC(32, 1);
-        else MXE_LAUNCH_MC(48, 1);
+        else MXE_LAUNCH_MC(32, 1);
 #undef MXE_LAUNCH_MC
         HIPCHK(ctx, e);
     } else {
-        int NW = o.waves_per_chain;
+        int NW = std::min(o.waves_per_chain, 4);     // (eight waves per chain: two per SIMD at 256 registers each spilled; not built)
         if (NW == 0) {
             // fill the 256 CUs x 4 SIMDs: few chains -> more waves per chain
             const int nc = ctx->n_sub;
-            NW = (nc >= 2048) ? 1 : (nc >= 1024) ? 2 : (nc >= 256) ? 4 : 8;
+            NW = (nc >= 2048) ? 1 : (nc >= 1024) ? 2 : 4;
         }
         const bool f32 = (o.precision == MXE_PRECISION_F32);
         size_t lds = lds_bytes(ctx->NP, ctx->nwp, NW, f32);
@@ -717,14 +719,14 @@ try {
                 case 1: e = launch_t<1, 2, float>(kp, lds, ctx->stream); break;
                 case 2: e = launch_t<2, 2, float>(kp, lds, ctx->stream); break;
                 case 4: e = launch_t<4, 2, float>(kp, lds, ctx->stream); break;
-                default: e = launch_t<8, 2, float>(kp, lds, ctx->stream); break;
+                default: e = launch_t<4, 2, float>(kp, lds, ctx->stream); break;
             }
         } else
         switch (NW) {
             case 1: e = launch_nab<1>(ctx->NP, kp, lds, ctx->stream); break;
             case 2: e = launch_nab<2>(ctx->NP, kp, lds, ctx->stream); break;
             case 4: e = launch_nab<4>(ctx->NP, kp, lds, ctx->stream); break;
-            default: e = launch_nab<8>(ctx->NP, kp, lds, ctx->stream); break;
+            default: e = launch_nab<4>(ctx->NP, kp, lds, ctx->stream); break;
         }
         HIPCHK(ctx, e);
     }

@@ -232,7 +232,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         int i = lane;
         // (opaque to the optimiser: the N load addresses below depend on the lane only, and hoisted out of the
         //  round loop -- five instantiations of N -- they cost 150 registers for the whole kernel)
-        if (UREG) asm volatile("" : "+v"(i));
+        if (UREG || NA > 32) asm volatile("" : "+v"(i));
         const double* Wq = Wt + (size_t)q * NPAIR * 256;
         const double* rq = rhs + q * NP;
         bool ok = true;
@@ -251,7 +251,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             const int up_l = (imt * NT - imt * (imt - 1) / 2 - imt) * 256 + (iri & 3) * 64 + (iri >> 2) * 16;   // row ic, column j >= ic
             const int lo_l = imt * 256 + iri;                                                                  // row j < ic, column ic
             // (in two halves when the kernel is built for 256 registers)
-            constexpr int NH = UREG ? 2 : 1, HL = N / NH;
+            constexpr int NH = (UREG || N > 32) ? 2 : 1, HL = N / NH;
             static_assert(N % NH == 0, "");
 #pragma unroll
             for (int hf = 0; hf < NH; ++hf) {
@@ -715,14 +715,14 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 const double chi2t = r2 + t.cperp, St = sS;
                 const double Qt = 0.5 * chi2t - t.alpha * St;
                 const bool finite = fabs(Qt) <= 1.7e308;
-                bool finish_alpha = false; int conv = 0;
+                bool finish_alpha = false, failed = false; int conv = 0;
                 if (t.scratch) {
                     // state restored from v (or first evaluation of the piece); damping kept
                     ++t.nevals;
                     if (finite) { t.scratch = 0; t.chi2 = chi2t; t.S = St; t.Hn2 = sHn; t.wmax = swm; t.Q = Qt; }
-                    else finish_alpha = true;                   // cannot even evaluate: give up on this alpha
+                    else { finish_alpha = true; failed = true; }   // cannot even evaluate: give up on this alpha
                 } else if (!t.okprev) {
-                    finish_alpha = true;                        // the damping loop ran out of range
+                    finish_alpha = true; failed = true;         // the damping loop ran out of range
                 } else if (!finite || ((t.mu > 0.0 || (t.okprev >= 2 && t.okprev <= 4)) && Qt > t.Q + 1e-12 * fabs(t.Q)) ||   // (margin: rounding of Q)
                            // a predicted step may overshoot like any undamped Newton step (measured: a strict test
                            // rejects 20 % of them and costs more than the predictor gains); only a gross increase
@@ -744,7 +744,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         // need it at every iteration)
                         t.mu = (t.mu == 0.0) ? fmax(p.mu_first * t.alpha, t.muh / p.mu_grow) : t.mu * p.mu_grow;
                         t.scratch = 1; t.bt = 0;
-                        if (!(t.mu <= p.mu_max * t.alpha)) finish_alpha = true;
+                        if (!(t.mu <= p.mu_max * t.alpha)) { finish_alpha = true; failed = true; }
                     }
                 } else {
                     // accepted
@@ -779,9 +779,11 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 if (finish_alpha) {
                     const size_t prob = (size_t)t.prob0 + t.ia;
                     if (p.out_H) {
-                        // H of the point just evaluated (the accepted one unless the alpha failed)
+                        // H of the point just evaluated = the accepted one.  An alpha that FAILED (damping out of
+                        // range, nothing finite to evaluate) ends on a rejected trial point: its H does not belong
+                        // to the v, chi2, S, Q of the record (the last accepted state) and is written as NaN
                         double* Ho = p.out_H + prob * nw;
-                        for (int i = lane; i < nw; i += 64) Ho[i] = Hi[i * MCC + q];
+                        for (int i = lane; i < nw; i += 64) Ho[i] = failed ? __builtin_nan("") : Hi[i * MCC + q];
                     }
                     if (p.out_v) p.out_v[prob * NP + lane] = vv[q * NP + lane];
                     if (lane == 0) {

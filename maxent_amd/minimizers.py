@@ -54,8 +54,10 @@ class OrConvergenceMethod(_Pair):
 
 
 class MaxDerivativeConvergenceMethod(ConvergenceMethod):
-    """max |dQ/dv| < criterion with dQ/dv = W g (the reference's
-    MaxEntCostFunction.d, maxent_cost_function.py:85-118)."""
+    """max |dQ/dv| < criterion with dQ/dv = W g (the reference's MaxEntCostFunction.d,
+    maxent_cost_function.py:85-118).  On the device the maximum runs over the coupled block of
+    singular directions (``mxe_opts.tol_d``); the decoupled ones are solved by their diagonal
+    Newton step and contribute at the level of ``decouple_tol`` only."""
 
     def __init__(self, convergence_criterion):
         self.convergence_criterion = convergence_criterion

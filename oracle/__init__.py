@@ -14,7 +14,7 @@ ref_numpy    step-faithful numpy restatement of the reference's Python path
              file:line it follows.  Pinned against the imported reference by
              ``tests/golden/make_golden.py`` (identical per-alpha iteration
              counts, fields to <=1e-12) and against the reference's own
-             known-answer tests (``tests/test_oracle_kat.py``).
+             known-answer tests (``tests/test_oracle_golden.py``).
 sform        the same mathematics in the whitened singular-space form the HIP
              kernel computes in (chi2 as a sum of squares in the rotated data
              space, diagonal M), plus a numpy model of the kernel's damped

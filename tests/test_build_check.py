@@ -1,0 +1,21 @@
+"""Build-time guarantees of the shipped kernels: no instantiation spills registers beyond the one documented
+allowance (``make -C maxent_amd/csrc check``: hipcc's own resource report)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which('hipcc') is None and not os.path.exists('/opt/rocm/bin/hipcc'), reason='no hipcc')
+def test_no_shipped_kernel_spills():
+    r = subprocess.run(['make', '-C', os.path.join(ROOT, 'maxent_amd', 'csrc'), 'check'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if 'scratch' in l]
+    assert len(lines) >= 20
+    for l in lines:
+        scratch = int(l.split('scratch')[1].split('B')[0])
+        assert scratch == 0 or ('chain_kernel_mcILi32ELi2' in l and scratch <= 160), l
+    assert not any('chain_kernel_mcILi48' in l or 'chain_kernelILi8' in l for l in lines)
