@@ -323,7 +323,6 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 
     while (guard++ < guard_max) {
         // (a slot that finishes its piece takes the next one from the queue right away, in step 4)
-        if (!(s_act[0] | s_act[1] | s_act[2] | s_act[3])) break;      // uniform: LDS flags behind a barrier
 
         // ---- 1. home wave: right-hand side, active block, factorise, solve, step ----
         if (wave < MCC) {
@@ -421,6 +420,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         }
         __syncthreads();
         MXE_STAMPW(2);
+        if (!(s_act[0] | s_act[1] | s_act[2] | s_act[3])) break;      // uniform: LDS flags behind a barrier
 
         // ---- 2. row pass (V^T once): u, w, H of the four trial points, in place ----
         // du = V delta of the four slots as v_mfma_f64_4x4x4 (four independent 4x4x4 blocks per
@@ -827,7 +827,10 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 store_slot(t);
             }
         }
-        __syncthreads();                         // slot flags, v, rho visible to the next round
+        // No barrier here: steps 4 and 1 are ONE serial section of the home wave.  Everything step 1 reads
+        // (its own slot, v, rho, the slot's Gram tiles) was written by this wave or lies behind the barrier
+        // of step 3, and nothing it writes is read by another wave's step 4.  A wave with a short accept
+        // starts its solve while a neighbour still writes results.
         MXE_STAMPW(5);
 #ifdef MXE_PROFILE
         ++prof_rounds;

@@ -237,6 +237,12 @@ class MaxEntLoop(object):
                 'alpha[{:' + str(width) + 'd}] = {:16.8e}, chi2 = {:16.8e}, n_iter={:8d}{}',
                 i, sol['alpha'][i], sol['chi2'][i], int(sol['n_iter'][i]),
                 ' ' if sol['converged'][i] else '!')
+        callback = getattr(self.minimizer, 'verbose_callback', None)
+        if callback is not None and hasattr(self.minimizer, 'to_opts'):
+            # SolverDetails (levenberg_minimizer.py:165-170): the last iterate of every alpha
+            for i in range(n):
+                callback('{:6d} Q: {:12.6e}, evaluations: {:d}, conv: {:d}'.format(
+                    int(sol['n_iter'][i]), sol['Q'][i], int(sol['n_evals'][i]), int(sol['converged'][i])))
         if not np.all(sol['converged']):
             self.logtaker.message(
                 VerbosityFlags.AlphaLoop,
@@ -350,6 +356,9 @@ class MaxEntLoop(object):
             self.logtaker.verbose |= add
         if remove is not None:
             self.logtaker.verbose &= ~remove
+        if change_callback:          # maxent_loop.py:375-382
+            wanted = self.logtaker.verbose & VerbosityFlags.SolverDetails
+            self.minimizer.verbose_callback = self.logtaker.solver_verbose_callback if wanted else None
 
 
 # the parameters of the problem live in the cost function; the loop offers them under the same names

@@ -116,6 +116,17 @@ class LevenbergMinimizer(Minimizer):
     V, u, H, exp, both mat-vecs and the Gram matrix in binary32, the Newton
     system and all scalars in binary64.
 
+    ``J_squared`` and ``marquardt`` (levenberg_minimizer.py:177-185) choose the
+    damping matrix of the reference's search (J^T J instead of J; diag J instead
+    of 1).  They change the iterates, not the point where dQ/dv = 0; the device
+    iteration damps in the entropy metric and raises mu only when Bryan's bound
+    or the descent test asks for it, so both flags are accepted and recorded
+    and the result is the same minimum.
+
+    ``verbose_callback`` (levenberg_minimizer.py:165-170) is called once per
+    alpha, after the launch, with the record of the last iterate -- the
+    iterations themselves happen inside one kernel and have no host in them.
+
     ``n_iter_last`` / ``n_iter`` / ``converged`` are filled after a run like
     in the reference (levenberg_minimizer.py:143,245-246); for a batched run
     they refer to the last alpha of the last chain, per-problem values are in
@@ -129,9 +140,6 @@ class LevenbergMinimizer(Minimizer):
         if precision not in ('f64', 'f32'):
             raise ValueError("precision must be 'f64' or 'f32'")
         self.precision = precision
-        if J_squared or marquardt:
-            raise NotImplementedError('J_squared / marquardt variants are not '
-                                      'part of the device solver')
         self.convergence = convergence if convergence is not None \
             else NewtonStepConvergenceMethod(1.e-9)
         self.maxiter = maxiter

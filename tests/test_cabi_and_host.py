@@ -170,8 +170,18 @@ def test_attribute_shadowing_and_errors():
     assert np.all(ew.get_error((2, 1)) == 2.0)
     with pytest.raises(TypeError):
         mx.DiagonalMaxEnt().run_offdiagonal()
-    with pytest.raises(NotImplementedError):
-        mx.LevenbergMinimizer(marquardt=True)
+    m = mx.LevenbergMinimizer(marquardt=True, J_squared=True)      # accepted: same minimum, other iterates
+    assert m.marquardt and m.J_squared
+
+
+def test_solver_details_callback_follows_the_verbosity():
+    # reference maxent_loop.py:375-382
+    loop = mx.MaxEntLoop()
+    assert loop.minimizer.verbose_callback is None
+    loop.set_verbosity(add=mx.VerbosityFlags.SolverDetails)
+    assert loop.minimizer.verbose_callback == loop.logtaker.solver_verbose_callback
+    loop.set_verbosity(remove=mx.VerbosityFlags.SolverDetails)
+    assert loop.minimizer.verbose_callback is None
 
 
 def test_minimizer_options_map_to_kernel_options():

@@ -253,6 +253,21 @@ def test_single_minimize_call_and_reference_stopping_rule():
     assert np.linalg.norm(H - g['H_truth'][3]) / np.linalg.norm(g['H_truth'][3]) < 1e-4
 
 
+def test_solver_details_lines_and_damping_flags():
+    """SolverDetails (levenberg_minimizer.py:165-170): one line per alpha from the device run; the
+    J_squared / marquardt damping variants reach the same minimum (levenberg_minimizer.py:177-185)"""
+    g = load('cfg1_normal')
+    lines = []
+    tm = make_tm(g, 'normal')
+    tm.minimizer = mx.LevenbergMinimizer(J_squared=True, marquardt=True, verbose_callback=lines.append)
+    tm.alpha_mesh = mx.DataAlphaMesh(g['alpha'] / len(g['tau']))
+    res = tm.run()
+    assert len(lines) == len(g['alpha']) and all(' Q: ' in ln and 'conv: 1' in ln for ln in lines)
+    assert int(lines[0].split()[0]) == int(res.n_iter[0])
+    assert rel_l2(res.H[g['rows']], g['H_truth']).max() < GATE
+
+
+@pytest.mark.gpu
 def test_cfg5_matrix_with_preblurred_offdiagonals():
     """BASELINE cfg5 (fp64 part): 8x8 matrix G, off-diagonal worker with
     PreblurKernel + PreblurA_of_H (plus-minus entropy), diagonal worker plain.
