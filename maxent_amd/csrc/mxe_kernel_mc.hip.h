@@ -53,6 +53,12 @@ struct MCExtra {
 constexpr double MC_GRAM_ERR = 0.0;              // allowance for the inexact Gram tiles in the stopping estimate
 constexpr int MC_LOOKAHEAD_ROWS = 512;
 constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
+// f(integral_constant<int, J>) for every J of the sequence, in order
+template <int... J, class F>
+__device__ __forceinline__ void static_for_seq(std::integer_sequence<int, J...>, F&& f) {
+    (f(std::integral_constant<int, J>{}), ...);
+}
+
 #ifndef MXE_X_DEPTH2
 #define MXE_X_DEPTH2 2        // V ring of the fused pass at two workgroups per CU (4: 1.33 ms and 300 MB of spill stores per launch; 2: 1.29 ms, none)
 #endif
@@ -216,90 +222,106 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 
     // ------------------------------------------------------------------
     // home wave: the slot's Newton system  (c W c + a I) z = rhs  on the active block, in registers.
-    // Lane i holds the FULL row i of the symmetric matrix (N doubles, static indices: the j and k
-    // loops are fully unrolled) and its right-hand side.  Gauss-Jordan elimination without pivoting
-    // (the matrix is positive definite): for pivot j every other lane subtracts f = A_ij / A_jj times
-    // row j -- broadcast from lane j with v_readlane, eight entries at a time -- from the columns
-    // k > j of its row and from its right-hand side.  A wave issues the same instructions for the
-    // lanes above the pivot as a Cholesky factorisation does for the lanes below it alone, so the
-    // elimination costs what the factorisation cost, and when it ends z_i = b_i / A_ii: no transposed
-    // factor through LDS, no back substitution (they were 4-5.6 k cycles of the 10-16 k per slot).
+    // All 64 lanes work on the one N x N system (N <= 32): lane (h = lane >> 5, i = lane & 31) holds of
+    // row i the columns of parity h -- A[kk] = column 2 kk + h, N / 2 doubles -- and the right-hand side b_i
+    // (both halves carry it).  Gauss-Jordan elimination without pivoting (positive definite matrix): for
+    // pivot j every row subtracts f_i = A_ij / A_jj times row j from its columns k > j and from b_i.
+    //   * row j, as far as a lane needs it, sits in the lane of ITS OWN half that holds row j: a broadcast
+    //     inside the groups of 32 lanes, ds_swizzle_b32 (the LDS crossbar; no memory, static pattern);
+    //   * column j sits in one half (parity of j); v_permlane32_swap hands it to the other.
+    // Per pivot a wave issues (N - j) / 2 fused multiply-adds and N - j swizzles where the one-half layout
+    // (lane = row, v_readlane broadcasts) issued N - j and 2 (N - j) readlanes: a third of the vector
+    // instructions.  When the elimination ends z_i = b_i / A_ii: no back substitution.
     // The solve only preconditions the (inexact) Newton step; rows >= n_act are identity rows.
     // ------------------------------------------------------------------
+    auto half_bcast = [&](double x, auto JTag) -> double {       // lane j of the lane's own group of 32
+        constexpr int pat = decltype(JTag)::value << 5;            // bit-mask mode: and 0, or j, xor 0
+        const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(x), pat);
+        const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), pat);
+        return __hiloint2double(hi, lo);
+    };
     auto gj_home = [&](auto NTag, double a, int n_act, double isc2) -> bool {
         constexpr int N = decltype(NTag)::value;
+        static_assert(N <= 32 && N % 2 == 0, "two half-waves of 32 rows");
+        constexpr int NHALF = N / 2;
         const int q = wave;
-        int i = lane;
-        // (opaque to the optimiser: the N load addresses below depend on the lane only, and hoisted out of the
+        int ln = lane;
+        // (opaque to the optimiser: the load addresses below depend on the lane only, and hoisted out of the
         //  round loop -- five instantiations of N -- they cost 150 registers for the whole kernel)
-        if (UREG || NA > 32) asm volatile("" : "+v"(i));
+        asm volatile("" : "+v"(ln));
+        const int i = ln & 31, h = ln >> 5;
         const double* Wq = Wt + (size_t)q * NPAIR * 256;
         const double* rq = rhs + q * NP;
         bool ok = true;
         const bool live = i < n_act;
         const double ci_ = live ? cc[i] : 0.0;
         const double cis = ci_ * isc2;               // the tiles carry the factor sc2 of their operands
-        double A[N];
+        double A[NHALF];
         {
             // W is kept as the upper-triangular 16x16 tiles in the accumulator layout of the MFMA: entry
-            // (a, b), a <= b, sits in tile pair (a >> 4, b >> 4) at register a & 3, lane 16 ((a & 15) >> 2) +
-            // (b & 15).  Lane i needs (min(i, j), max(i, j)) for the static j: offset = (lane part) + (static
-            // part) on either side of the diagonal.  All N loads are issued back to back (clamped lane
-            // index, selected afterwards)
+            // (r, c), r <= c, sits in tile pair (r >> 4, c >> 4) at register r & 3, lane 16 ((r & 15) >> 2) +
+            // (c & 15).  The lane needs (min(i, k), max(i, k)) for k = 2 kk + h: offset = (lane part) + (static
+            // part in kk) on either side of the diagonal; 2 kk is even, so the h of k adds without carry.
+            // All loads are issued back to back (clamped row index, selected afterwards)
             const int ic = min(i, N - 1);
             const int imt = ic >> 4, iri = ic & 15;
-            const int up_l = (imt * NT - imt * (imt - 1) / 2 - imt) * 256 + (iri & 3) * 64 + (iri >> 2) * 16;   // row ic, column j >= ic
-            const int lo_l = imt * 256 + iri;                                                                  // row j < ic, column ic
-            // (in two halves when the kernel is built for 256 registers)
-            constexpr int NH = (UREG || N > 32) ? 2 : 1, HL = N / NH;
-            static_assert(N % NH == 0, "");
+            const int up_l = (imt * NT - imt * (imt - 1) / 2 - imt) * 256 + (iri & 3) * 64 + (iri >> 2) * 16 + h;   // row ic, column k >= ic
+            const int lo_l = imt * 256 + iri + h * 64;                                                             // row k < ic, column ic
+            double wr[NHALF], ck[NHALF];
 #pragma unroll
-            for (int hf = 0; hf < NH; ++hf) {
-                double wr[HL];
+            for (int kk = 0; kk < NHALF; ++kk) {
+                const int k0 = 2 * kk;
+                const int kmt = k0 >> 4, kri = k0 & 15;
+                const int up_s = kmt * 256 + kri;
+                const int lo_s = (kmt * NT - kmt * (kmt - 1) / 2 - kmt) * 256 + (kri & 3) * 64 + (kri >> 2) * 16;
+                wr[kk] = Wq[(k0 + h >= ic) ? up_l + up_s : lo_l + lo_s];
+                ck[kk] = cc[k0 + h];
+            }
 #pragma unroll
-                for (int jj = 0; jj < HL; ++jj) {
-                    const int j = hf * HL + jj;
-                    const int jmt = j >> 4, jri = j & 15;
-                    const int up_s = jmt * 256 + jri;
-                    const int lo_s = (jmt * NT - jmt * (jmt - 1) / 2 - jmt) * 256 + (jri & 3) * 64 + (jri >> 2) * 16;
-                    wr[jj] = Wq[(j >= ic) ? up_l + up_s : lo_l + lo_s];
-                }
-#pragma unroll
-                for (int jj = 0; jj < HL; ++jj) {
-                    const int j = hf * HL + jj;
-                    const double cj = wave_bcast(ci_, j);    // = c_j for j < n_act, else 0
-                    double xv = cis * wr[jj] * cj;           // 0 in the rows and columns >= n_act
-                    if (j == i) xv = live ? xv + a : 1.0;
-                    A[j] = xv;
-                }
-                if (NH > 1) __builtin_amdgcn_sched_barrier(0);
+            for (int kk = 0; kk < NHALF; ++kk) {
+                const int k = 2 * kk + h;
+                double xv = (k < n_act) ? cis * wr[kk] * ck[kk] : 0.0;      // 0 in the rows and columns >= n_act
+                if (k == i) xv = live ? xv + a : 1.0;
+                A[kk] = xv;
             }
         }
         double b = live ? rq[i] : 0.0;
         double dinv_i = 1.0;
         MXE_STAMPH(1);
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            const double piv = wave_bcast(A[j], j);
+        auto pivot = [&](auto JTag) {
+            constexpr int j = decltype(JTag)::value;
+            constexpr int kj = j >> 1, hj = j & 1;
+            // column j for both halves
+            double cj;
+            {
+                const unsigned xlo = (unsigned)__double2loint(A[kj]), xhi = (unsigned)__double2hiint(A[kj]);
+                const auto slo = __builtin_amdgcn_permlane32_swap(xlo, xlo, false, false);
+                const auto shi = __builtin_amdgcn_permlane32_swap(xhi, xhi, false, false);
+                // [0]: the lower half's values in both halves, [1]: the upper half's
+                cj = __hiloint2double((int)shi[hj], (int)slo[hj]);
+            }
+            const double piv = wave_bcast(cj, j);
             if (!(piv > 0.0)) ok = false;
             double inv = __builtin_amdgcn_rcp(piv);
             inv = fma(fma(-piv, inv, 1.0), inv, inv);
             if (i == j) dinv_i = inv;
-            const double f = (i != j) ? A[j] * inv : 0.0;    // multiplier of row j for this lane's row
+            const double f = (i != j) ? cj * inv : 0.0;      // multiplier of row j for this lane's row
             b = fma(-f, wave_bcast(b, j), b);
+            // columns k = 2 kk + h > j: kk >= (j + 1) >> 1 (for even j the lower half also "updates" column j
+            // itself, which nobody reads again)
+            constexpr int K0 = (j + 1) >> 1;
 #pragma unroll
-            for (int k0 = j + 1; k0 < N; k0 += 8) {
+            for (int k0 = K0; k0 < NHALF; k0 += 8) {
                 double rk[8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) if (k0 + r < N) rk[r] = wave_bcast(A[k0 + r], j);     // row j, column k
-                __builtin_amdgcn_sched_barrier(0);
+                for (int r = 0; r < 8; ++r) if (k0 + r < NHALF) rk[r] = half_bcast(A[k0 + r], JTag);     // row j, column k
 #pragma unroll
-                for (int r = 0; r < 8; ++r) if (k0 + r < N) A[k0 + r] = fma(-f, rk[r], A[k0 + r]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int r = 0; r < 8; ++r) if (k0 + r < NHALF) A[k0 + r] = fma(-f, rk[r], A[k0 + r]);
             }
-        }
+        };
+        static_for_seq(std::make_integer_sequence<int, N>{}, pivot);
         MXE_STAMPH(3);
-        if (ok && live) zz[q * NP + i] = b * dinv_i;
+        if (ok && live && h == 0) zz[q * NP + i] = b * dinv_i;
         MXE_STAMPH(4);
 #ifdef MXE_PROFILE_HOME
         prof_acc[6] += 1;                        // solves (slot 6 is a count in this build)
