@@ -291,6 +291,7 @@ def main():
     ap.add_argument('--shard-of', type=int, default=0,
                     help='one process, one GPU: solve only the rank-0 shard of an N-way split of the batch (what one '
                          'rank of --gpus N does per step, without the gather); not a bench line')
+    ap.add_argument('--shard-rank', type=int, default=0, help='with --shard-of N: time the shard of this rank')
     ap.add_argument('--force-comm', action='store_true',
                     help='initialise the communicator and run the gather even with one rank (plumbing test)')
     args = ap.parse_args()
@@ -321,7 +322,7 @@ def main():
     rank_of, local_of, n_local = device.shard_plan(n_elem, world)
     mine = [e for e in range(n_elem) if rank_of[e] == rank] if strong else list(range(n_elem))
     if args.shard_of > 1 and world == 1:
-        mine = [e for e in range(n_elem) if e % args.shard_of == 0]
+        mine = [e for e in range(n_elem) if e % args.shard_of == args.shard_rank % args.shard_of]
     ctx = stage(batch, local_rank, mine)
     opts = device.default_opts(waves_per_chain=args.waves_per_chain, chains_per_wg=args.chains_per_wg,
                                alpha_split=args.alpha_split, wg_per_cu=args.wg_per_cu)

@@ -65,6 +65,8 @@ struct mxe_ctx {
     std::vector<int> sub_elem, sub_prob0, sub_len, sub_v0, wg_chains;   // per launched (sub-)chain
     int n_sub = 0, n_wg = 0, mc_na = 0, mc_wgpc = 1, wgpc_auto = 2, n_queue = 0;
     std::vector<int> queue;
+    std::vector<int> sub_pre;                                           // leading alpha of a piece: entries before its first alpha (0: none)
+    bool has_pre = false;
     mxe_opts opts;
     bool chains_ready = false, launched = false;
     int last_nw = 0, last_lds = 0;
@@ -82,6 +84,7 @@ struct mxe_ctx {
     DevBuf<int> dout_niter, dout_conv, dout_nevals, dout_nact;
     DevBuf<long long> dprof;
     DevBuf<int> dqueue, dcounter;
+    DevBuf<int> dsub_pre;
     // mxe_eval_batch / mxe_audit scratch
     DevBuf<double> ev_x, ev_alpha, ev_scal, ev_vecw, ev_vecs, ev_mat;
     DevBuf<int> ev_elem;
@@ -353,7 +356,7 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
     ctx->dlogdet.release(); ctx->dparent_elem.release(); ctx->dV.release(); ctx->dVt.release(); ctx->dVf.release(); ctx->dVtf.release(); ctx->dc.release(); ctx->dcinv.release();
     ctx->dghat.release(); ctx->dcperp.release(); ctx->dD.release(); ctx->dsumD.release();
     ctx->dalpha.release(); ctx->dv0.release(); ctx->delem_ds.release(); ctx->delem_kind.release();
-    ctx->dchain_elem.release(); ctx->dsub_prob0.release(); ctx->dsub_len.release(); ctx->dsub_v0.release(); ctx->dwg_chains.release(); ctx->dqueue.release(); ctx->dcounter.release(); ctx->dout_v.release(); ctx->dout_pack.release(); ctx->dout_pack2.release();
+    ctx->dchain_elem.release(); ctx->dsub_prob0.release(); ctx->dsub_len.release(); ctx->dsub_v0.release(); ctx->dwg_chains.release(); ctx->dqueue.release(); ctx->dcounter.release(); ctx->dsub_pre.release(); ctx->dout_v.release(); ctx->dout_pack.release(); ctx->dout_pack2.release();
     ctx->dout_niter.release(); ctx->dout_conv.release(); ctx->dout_nevals.release(); ctx->dout_nact.release();
     ctx->dB.release(); ctx->dA.release(); ctx->dprof.release();
     ctx->ev_x.release(); ctx->ev_alpha.release(); ctx->ev_scal.release(); ctx->ev_vecw.release(); ctx->ev_vecs.release();
@@ -531,14 +534,39 @@ try {
     }
     if (split > n_alpha) split = n_alpha;
     ctx->sub_elem.clear(); ctx->sub_prob0.clear(); ctx->sub_len.clear(); ctx->sub_v0.clear();
+    // Normal entropy: from the default model the smallest alphas of a scan are far away.  Measured on the BASELINE
+    // batch (profiles/r02_f_cold_start_profile.txt), a cold start in the last 6 % of the logarithmic alpha range takes
+    // 20-30 evaluations on average and 50-390 for single scans (above that range: 10-18, at most 21) -- and a launch
+    // ends with its slowest piece.  A piece that starts there is led by the last alpha ABOVE the range: cold start
+    // where it is cheap and safe, then one warm step down to the piece's first alpha (lock-step kernel: chain_pre);
+    // in the other layouts, and where that step would be long, the piece is joined to the one before it.
+    ctx->sub_pre.clear(); ctx->has_pre = false;
     for (int c = 0; c < n_chain; ++c) {
+        const double* ac = alpha_dev.data() + (size_t)c * n_alpha;
+        double pre_alpha = 0.0, lguard = 0.0;
+        int pre_index = -1;
+        if (ctx->elem_kind[elem_of_chain[c]] == MXE_ENTROPY_NORMAL && split > 1) {
+            double lmax = -1e300, lmin = 1e300;
+            for (int i = 0; i < n_alpha; ++i) { const double l = std::log(ac[i]); lmax = std::max(lmax, l); lmin = std::min(lmin, l); }
+            lguard = lmax - 0.94 * (lmax - lmin);
+            double best = 1e300;                     // the smallest alpha of the scan that is still above the guarded range
+            for (int i = 0; i < n_alpha; ++i) if (std::log(ac[i]) >= lguard && ac[i] < best) { best = ac[i]; pre_index = i; }
+            if (lmax > lmin && best < 1e300) pre_alpha = best;
+        }
         for (int sidx = 0; sidx < split; ++sidx) {
             const int a0 = (int)((long long)n_alpha * sidx / split), a1 = (int)((long long)n_alpha * (sidx + 1) / split);
             if (a1 <= a0) continue;
+            const bool guarded = pre_alpha > 0.0 && sidx > 0 && std::log(ac[a0]) < lguard && pre_index < a0;
+            // (the warm step from the leading alpha is safe over a factor of 1.5 in alpha -- measured: at most 11
+            //  evaluations; over a factor of 2 single scans took 100-300 --: deeper into the range, the piece
+            //  before runs on instead)
+            if (guarded && std::log(pre_alpha / ac[a0]) > 0.45) { ctx->sub_len.back() += a1 - a0; continue; }
             ctx->sub_elem.push_back(elem_of_chain[c]);
             ctx->sub_prob0.push_back(c * n_alpha + a0);
             ctx->sub_len.push_back(a1 - a0);
             ctx->sub_v0.push_back(c);
+            ctx->sub_pre.push_back(guarded ? a0 - pre_index : 0);
+            if (guarded) ctx->has_pre = true;
         }
     }
     ctx->n_sub = (int)ctx->sub_elem.size();
@@ -571,6 +599,17 @@ try {
                             mc_lds_bytes(32, ctx->nwp, 2) <= 80 * 1024 - 2048) ? 2 : 1;
             if (mc_lds_bytes(ctx->mc_na, ctx->nwp, ctx->mc_wgpc) > 160 * 1024 - 6144) { layout = 1; ctx->mc_na = 0; }
         }
+    }
+    if (layout != 4 && ctx->has_pre) {
+        size_t w = 0;
+        for (size_t sc = 0; sc < ctx->sub_elem.size(); ++sc) {
+            if (ctx->sub_pre[sc] > 0 && w > 0 && ctx->sub_v0[w - 1] == ctx->sub_v0[sc]) { ctx->sub_len[w - 1] += ctx->sub_len[sc]; continue; }
+            ctx->sub_elem[w] = ctx->sub_elem[sc]; ctx->sub_prob0[w] = ctx->sub_prob0[sc]; ctx->sub_len[w] = ctx->sub_len[sc];
+            ctx->sub_v0[w] = ctx->sub_v0[sc]; ++w;
+        }
+        ctx->sub_elem.resize(w); ctx->sub_prob0.resize(w); ctx->sub_len.resize(w); ctx->sub_v0.resize(w);
+        ctx->sub_pre.assign(w, 0); ctx->has_pre = false;
+        ctx->n_sub = (int)w;
     }
     ctx->wg_chains.clear(); ctx->queue.clear(); ctx->n_queue = 0;
     if (layout == 4) {
@@ -616,6 +655,7 @@ try {
     HIPCHK(ctx, ctx->dsub_prob0.ensure(ctx->n_sub));
     HIPCHK(ctx, ctx->dsub_len.ensure(ctx->n_sub));
     HIPCHK(ctx, ctx->dsub_v0.ensure(ctx->n_sub));
+    HIPCHK(ctx, ctx->dsub_pre.ensure(std::max(ctx->n_sub, 1)));
     HIPCHK(ctx, ctx->dwg_chains.ensure(std::max<size_t>(ctx->wg_chains.size(), 1)));
     HIPCHK(ctx, ctx->dalpha.ensure(P));
     HIPCHK(ctx, ctx->dv0.ensure(hv0.size()));
@@ -636,6 +676,8 @@ try {
     HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_prob0.p, ctx->sub_prob0.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_len.p, ctx->sub_len.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_v0.p, ctx->sub_v0.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->has_pre)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_pre.p, ctx->sub_pre.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
     if (!ctx->wg_chains.empty())
         HIPCHK(ctx, hipMemcpyAsync(ctx->dwg_chains.p, ctx->wg_chains.data(), ctx->wg_chains.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dalpha.p, alpha_dev.data(), P * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -662,6 +704,7 @@ try {
     kp.ghat = ctx->dghat.p; kp.cperp = ctx->dcperp.p; kp.D = ctx->dD.p; kp.sumD = ctx->dsumD.p;
     kp.chain_elem = ctx->dchain_elem.p; kp.alpha = ctx->dalpha.p; kp.v0 = ctx->dv0.p;
     kp.chain_prob0 = ctx->dsub_prob0.p; kp.chain_len = ctx->dsub_len.p; kp.chain_v0 = ctx->dsub_v0.p;
+    kp.chain_lead = (ctx->has_pre && ctx->mc_na > 0) ? ctx->dsub_pre.p : nullptr;
     kp.n_chain = ctx->n_sub;
     kp.out_v = ctx->dout_v.p; kp.out_H = ctx->dout_H.p; kp.out_chi2 = ctx->dout_chi2.p;
     kp.out_S = ctx->dout_S.p; kp.out_Q = ctx->dout_Q.p; kp.out_niter = ctx->dout_niter.p;
@@ -688,16 +731,17 @@ try {
         if (const char* sg = getenv("MXE_X_STAGGER")) ex.stagger = atoi(sg);
         HIPCHK(ctx, hipMemsetAsync(ctx->dcounter.p, 0, sizeof(int), ctx->stream));
         ctx->last_nw = NWV; ctx->last_lds = (int)lds;
-        ctx->last_kernel = "mxe::chain_kernel_mc<" + std::to_string(NA) + ", " + std::to_string(WGPC) + ">";
+        const bool lead = kp.chain_lead != nullptr;
+        ctx->last_kernel = "mxe::chain_kernel_mc<" + std::to_string(NA) + ", " + std::to_string(WGPC) + (lead ? ", lead>" : ">");
         HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-#define MXE_LAUNCH_MC(NA_, WG_) do { constexpr int NWV_ = 4; \
-        e = hipFuncSetAttribute((const void*)mxe::chain_kernel_mc<NA_, WG_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+#define MXE_LAUNCH_MC(NA_, WG_, LD_) do { constexpr int NWV_ = 4; \
+        e = hipFuncSetAttribute((const void*)mxe::chain_kernel_mc<NA_, WG_, LD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e == hipSuccess && getenv("MXE_DEBUG_OCC")) { int nb__ = 0; \
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb__, (const void*)mxe::chain_kernel_mc<NA_, WG_>, 64 * NWV_, lds); \
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb__, (const void*)mxe::chain_kernel_mc<NA_, WG_, LD_>, 64 * NWV_, lds); \
             fprintf(stderr, "[mxe] lock-step kernel NA=%d NWV=%d lds=%zu: %d workgroup(s) per CU resident\n", NA_, NWV_, (size_t)lds, nb__); } \
-        if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<NA_, WG_>), dim3(ctx->n_wg), dim3(64 * NWV_), lds, ctx->stream, kp, ex); e = hipGetLastError(); } } while (0)
-        if (NA == 32 && WGPC == 2) MXE_LAUNCH_MC(32, 2);
-        else MXE_LAUNCH_MC(32, 1);
+        if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<NA_, WG_, LD_>), dim3(ctx->n_wg), dim3(64 * NWV_), lds, ctx->stream, kp, ex); e = hipGetLastError(); } } while (0)
+        if (NA == 32 && WGPC == 2) { if (lead) MXE_LAUNCH_MC(32, 2, true); else MXE_LAUNCH_MC(32, 2, false); }
+        else { if (lead) MXE_LAUNCH_MC(32, 1, true); else MXE_LAUNCH_MC(32, 1, false); }
 #undef MXE_LAUNCH_MC
         HIPCHK(ctx, e);
     } else {

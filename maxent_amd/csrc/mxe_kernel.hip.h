@@ -59,6 +59,7 @@ struct KParams {
     const int* chain_prob0; // [n_chain] first problem (index into alpha[] and the outputs)
     const int* chain_len;   // [n_chain] number of alphas of the (sub-)chain
     const int* chain_v0;    // [n_chain] row of v0[] to start from
+    const int* chain_lead;  // [n_chain] or nullptr: solve alpha[chain_prob0 - chain_lead] BEFORE the piece's first one (no record; 0 = none); lock-step kernel only
     const double* alpha;    // [P]
     const double* v0;       // [n_parent][NP]   whitened basis
     // outputs, problem p = chain_prob0[chain] + i

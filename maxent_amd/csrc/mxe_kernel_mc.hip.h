@@ -65,7 +65,9 @@ __device__ __forceinline__ void static_for_seq(std::integer_sequence<int, J...>,
 #ifndef MXE_X_UL
 #define MXE_X_UL 0            // u elements per lane kept in LDS instead of registers (0: all eight in registers)
 #endif
-template <int NA, int WGPC>
+// LEAD  pieces may be led by an earlier alpha of their scan (KParams::chain_lead); a build of its own, because the
+//       two extra instructions of start_piece cost the schedule without such pieces 1.6 % (register allocation)
+template <int NA, int WGPC, bool LEAD = false>
 __global__ __launch_bounds__(256, WGPC)
 void chain_kernel_mc(const KParams p, const MCExtra x)
 {
@@ -154,9 +156,13 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         t.cperp = p.cperp[t.elem];
         t.steplim = p.step_max * p.sumD[t.elem];
         t.prob0 = p.chain_prob0[c]; t.clen = p.chain_len[c];
-        t.ia = 0; t.niter = 0; t.nevals = 0; t.nact = 0; t.okprev = 0; t.bt = 0; t.capp = 0;
+        // a piece may be led by an earlier (larger) alpha of its scan, where the cold start from the default model is
+        // cheap and safe: chain_lead = how many entries before the piece's first alpha it sits (0: none).  It is
+        // solved as alpha number -1 and leaves no record of its own
+        const int lead = LEAD ? p.chain_lead[c] : 0;
+        t.ia = lead ? -1 : 0; t.niter = 0; t.nevals = 0; t.nact = 0; t.okprev = 0; t.bt = 0; t.capp = 0;
         for (int i = lane; i < min(t.clen, ACAP); i += 64) s_alpha[wave][i] = p.alpha[(size_t)t.prob0 + i];
-        t.alpha = p.alpha[(size_t)t.prob0];
+        t.alpha = p.alpha[(size_t)(t.prob0 - lead)];
         t.mu = 0.0; t.muh = 0.0; t.Qprev = __builtin_nan("");
         t.chi2 = 0.0; t.S = 0.0; t.Hn2 = 1.0; t.wmax = 1.0; t.Q = 0.0; t.sc2 = 1.0;
         t.active = 1; t.scratch = 1;
@@ -799,7 +805,10 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     else if (t.niter >= p.maxiter) finish_alpha = true;
                 }
                 if (finish_alpha) {
-                    const size_t prob = (size_t)t.prob0 + t.ia;
+                    // (the leading alpha of a piece, number -1, writes its record where the piece's first alpha will
+                    //  write its own over it -- no branch; where it fails, the first alpha starts from the state it
+                    //  ended in and reports what becomes of it)
+                    const size_t prob = (size_t)t.prob0 + max(t.ia, 0);
                     if (p.out_H) {
                         // H of the point just evaluated = the accepted one.  An alpha that FAILED (damping out of
                         // range, nothing finite to evaluate) ends on a rejected trial point: its H does not belong

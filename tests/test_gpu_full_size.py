@@ -114,6 +114,22 @@ def test_cfg4_invariant_under_scheduling(cfg4, opts):
     np.testing.assert_allclose(other['S'], out['S'], rtol=1e-7, atol=1e-12)
 
 
+def test_pieces_in_the_tail_of_a_normal_entropy_scan_are_led_or_joined(cfg4):
+    """50 pieces of two alphas per scan: pieces of the normal-entropy scans that start in the last 6 % of the
+    logarithmic alpha range are led by the last alpha above it (the `lead` build of the kernel) or joined to the piece
+    before them; the answers are those of the default schedule, and no cold start runs away (the rank of a sharded job
+    that holds element 221 took 2.7 ms instead of 0.5 before, profiles/r02_f_cold_start_profile.txt)"""
+    batch, ctx, out, info = cfg4
+    diag = np.array([e for e in range(256) if batch['kinds'][e] == 0], dtype=np.int32)
+    assert len(diag) == 16
+    other = ctx.solve_chains(diag, batch['alphas'], batch['v0'][diag], device.default_opts(alpha_split=50, chains_per_wg=4), want_v=False)
+    assert ctx.last_launch_info()['kernel'].endswith('lead>')
+    assert other['converged'].all()
+    e = np.linalg.norm(other['H'] - out['H'][diag], axis=-1) / np.linalg.norm(out['H'][diag], axis=-1)
+    assert e.max() < 3e-8, e.max()
+    assert other['n_evals'].max() <= 30, other['n_evals'].max()          # was 157 (element 221, alpha index 98)
+
+
 def test_cfg3_elementwise_api_matches_direct_batch():
     """cfg3 (4x4 elements x 100 alpha) through ElementwiseMaxEnt equals the same
     problems handed to the C-ABI directly."""

@@ -56,7 +56,19 @@ if args.layout == 4:
     if args.home:
         names = ['home:refill+rhs', 'home:load A', 'home:barrier', 'home:factor', 'home:solve', 'all passes', '#factorisations', 'row:barrier']
         order = (0, 1, 3, 4, 6, 2, 5)
-    print('workgroups %d, rounds per workgroup: mean %.1f' % (n_wg, rounds.mean()))
+    print('workgroups %d, rounds per workgroup: mean %.1f (min %d, median %d, max %d)' %
+          (n_wg, rounds.mean(), rounds.min(), np.median(rounds), rounds.max()))
+    out_all = ctx.fetch(want_v=False, want_H=False)
+    print('slot use: %d evaluations / (4 slots x %d rounds) = %.3f' %
+          (out_all['n_evals'].sum(), rounds.sum(), out_all['n_evals'].sum() / (4.0 * rounds.sum())))
+    wg_cycles = pw[:, 0, :7].sum(axis=1)
+    print('cycles per workgroup: mean %.3e, min %.3e, max %.3e' % (wg_cycles.mean(), wg_cycles.min(), wg_cycles.max()))
+    top = np.argsort(-wg_cycles)[:8]
+    print('slowest workgroups (index: rounds, cycles, cycles per round): ' +
+          '; '.join('%d: %d, %.2e, %.0f' % (w, rounds[w], wg_cycles[w], wg_cycles[w] / rounds[w]) for w in top))
+    by_r = np.argsort(-rounds)[:8]
+    print('most rounds (index: rounds, cycles per round): ' + '; '.join('%d: %d, %.0f' % (w, rounds[w], wg_cycles[w] / rounds[w]) for w in by_r))
+    print('cycles per round over workgroups: mean %.0f, min %.0f, max %.0f' % ((wg_cycles / rounds).mean(), (wg_cycles / rounds).min(), (wg_cycles / rounds).max()))
     print('cycles per round, by wave (mean over workgroups):')
     print('  %-16s' % 'phase' + ''.join('   wave%d' % w for w in range(nwv)))
     tot = np.zeros(nwv)
