@@ -11,12 +11,29 @@ arrays the device returned; the piecewise line fit is done with running sums
 once per matrix element and once between the two phases of PoormanMaxEnt.
 """
 
+import weakref
+
 import numpy as np
 
 
 class AnalyzerResult(dict):
     """dict with the keys ``A_out``, ``name``, ``info`` and, where it applies,
     ``alpha_index`` (reference analyzers/analyzer.py:25-46)."""
+
+    # ``maxent_result`` (reference analyzers/analyzer.py:52-64: the result the analysis belongs to) is held
+    # weakly: the result owns its analyses, and a strong reference back would keep a dropped result -- with
+    # its claim on 100 MB of H on the device -- alive until the cycle collector gets to it
+    @property
+    def maxent_result(self):
+        ref = self.__dict__.get('_result_ref')
+        return None if ref is None else ref()
+
+    @maxent_result.setter
+    def maxent_result(self, value):
+        self.__dict__['_result_ref'] = None if value is None else weakref.ref(value)
+
+    def __getstate__(self):
+        return dict((k, v) for k, v in self.__dict__.items() if k != '_result_ref')
 
     def __reduce_to_dict__(self):
         return self
