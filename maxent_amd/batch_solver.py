@@ -173,7 +173,8 @@ class BatchSolver(object):
         logdets = {r: self.ctxs[r].logdet() for r in active} if want_logdet else {}
         maps = {r: self.ctxs[r].apply_output_map(output_map) for r in active} if output_map is not None else {}
         ms = [self.ctxs[r].last_kernel_ms() for r in active]
-        info = dict(kernel_ms=max(ms), kernel_ms_per_device=ms, devices=[self.device_ids[r] for r in active])
+        info = dict(kernel_ms=max(ms), kernel_ms_per_device=ms, devices=[self.device_ids[r] for r in active],
+                    n_datasets=[self._n_datasets.get(id(self.ctxs[r]), 0) for r in active])
         info.update(self.ctxs[active[0]].last_launch_info())
         self.last_info = info
         res = []
@@ -203,6 +204,7 @@ class BatchSolver(object):
     def _stage(self, ctx, K, specs, opts):
         ctx.clear_datasets()
         ds_ids, seen = [], []
+        self.__dict__.setdefault('_n_datasets', {})
         for s in specs:
             err = np.asarray(s['err'], dtype=float) * np.ones(len(s['G']))
             U_rot = s.get('U_rot')
@@ -215,6 +217,7 @@ class BatchSolver(object):
                 found = ctx.add_dataset(err, K.U if (U_rot is None and K.rotation is not None) else U_rot)
                 seen.append((err, U_rot, found))
             ds_ids.append(found)
+        self._n_datasets[id(ctx)] = len(seen)
         ctx.set_elements(ds_ids, [s['G'] for s in specs],
                          np.stack([np.asarray(s['D'], dtype=float) for s in specs]),
                          [s['kind'] for s in specs])

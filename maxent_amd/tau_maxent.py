@@ -121,21 +121,31 @@ class TauMaxEnt(object):
         the square roots of the eigenvalues.  As in the reference, the data are first reset to the supplied
         ones and then moved by the hop from the PREVIOUS rotation to the new one -- after an earlier
         ``set_cov`` that is not the new rotation alone; the element-wise drivers rely on reproducing it."""
-        cov = np.asarray(cov)
-        if np.max(np.abs(cov - cov.transpose())) >= 1.e-10:
-            raise AssertionError('Supplied covariance matrix is not symmetric.')
+        given = cov
+        known = self.__dict__.get('_cov_eig')
+        if known is not None and known[0] is given and known[1] == self.cov_threshold:
+            # the same matrix again (one covariance for all matrix elements of an element-wise job): its
+            # eigenbasis, and the SAME rotation object -- the kernel then has nothing to do, and the batch
+            # solver sees one data set instead of one per element
+            cov, sigma, T = known[2:]
+        else:
+            cov = np.asarray(cov)
+            if np.max(np.abs(cov - cov.transpose())) >= 1.e-10:
+                raise AssertionError('Supplied covariance matrix is not symmetric.')
+            var, vec = np.linalg.eigh(cov)
+            if var.min() < 0:
+                self.logtaker.error_message(
+                    'Eigenvalues of the covariance matrix are not all positive; they will be ignored. '
+                    'Smallest negative value: {}', var.min())
+            keep = var >= self.cov_threshold
+            sigma, T = np.sqrt(var[keep]), vec[:, keep].conjugate().transpose()
+            object.__setattr__(self, '_cov_eig', (given, self.cov_threshold, cov, sigma, T))
         self.cov = cov
-        var, vec = np.linalg.eigh(cov)
-        if var.min() < 0:
-            self.logtaker.error_message(
-                'Eigenvalues of the covariance matrix are not all positive; they will be ignored. '
-                'Smallest negative value: {}', var.min())
-        keep = var >= self.cov_threshold
         self.err = None              # no chi2 with stale errors while the kernel changes
         if hasattr(self.cost_function, '_G_orig'):
             self.G = self.cost_function._G_orig
-        self._rotate_to(vec[:, keep].conjugate().transpose())
-        self.err = np.sqrt(var[keep])
+        self._rotate_to(T)
+        self.err = sigma
 
     def set_cov_file(self, filename):
         self.set_cov(np.loadtxt(filename))

@@ -486,6 +486,30 @@ def elementwise_cov_case():
     np.savez_compressed(os.path.join(HERE, 'elementwise_cov.npz'), **out)
 
 
+def elementwise_shared_cov_case():
+    """ElementwiseMaxEnt.set_cov with ONE (T, T) covariance for all elements (elementwise_maxent.py:502-515):
+    every element goes through TauMaxEnt.set_cov with the same matrix (tau_maxent.py:253-288)."""
+    with np.load(os.path.join(TESTDATA, 'elementwise_g_tau.npz')) as data:
+        tau = data['tau'][::3]
+        G = data['G_tau_noise'][:, :, ::3]
+    T = len(tau)
+    rng = np.random.RandomState(1414)
+    L = 1e-3 * (np.eye(T) + 0.3 * np.diag(np.ones(T - 1), 1) + 0.1 * rng.randn(T, T) / np.sqrt(T))
+    cov = L @ L.T
+    ew = ElementwiseMaxEnt(use_hermiticity=False)
+    ew.set_verbosity(VerbosityFlags.Quiet)
+    ew.set_G_tau_data(tau, G)
+    ew.omega = HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=60)
+    ew.alpha_mesh = LogAlphaMesh(alpha_min=0.05, alpha_max=500, n_points=6)
+    ew.set_cov(cov)
+    res = ew.run()
+    out = dict(tau=tau, G_tau=G, cov=cov, omega=np.array(ew.omega))
+    for k in ('H', 'A', 'chi2', 'S', 'Q', 'alpha', 'A_out'):
+        out[k] = np.array(getattr(res, k))
+    print('%-28s' % 'elementwise_shared_cov')
+    np.savez_compressed(os.path.join(HERE, 'elementwise_shared_cov.npz'), **out)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     if only:
@@ -509,5 +533,6 @@ if __name__ == '__main__':
     plusminus_entropy_case()
     complex_elementwise_case()
     elementwise_cov_case()
+    elementwise_shared_cov_case()
     shutil.rmtree(TMP, ignore_errors=True)
     print('fixtures written to', HERE)

@@ -329,3 +329,33 @@ def test_fast_linefit_picks_the_index_of_the_plain_loop():
             idx, (q1, q2) = an.fit_piecewise(logx, logy, deg)
             np.testing.assert_array_equal(q1, bp[0])
             np.testing.assert_array_equal(q2, bp[1])
+
+
+def test_one_covariance_for_many_elements_is_decomposed_once():
+    """set_cov with the SAME matrix object again (ElementwiseMaxEnt with one (T, T) covariance does that per
+    element, reference elementwise_maxent.py:502-515): same rotation object -- one data set on the device --
+    and the data the reference's bookkeeping gives (tau_maxent.py:253-325), as without the shortcut"""
+    rng = np.random.default_rng(1)
+    tau = np.linspace(0, 10, 20)
+    G = -np.exp(-tau) - 0.5 * np.exp(-(10 - tau))
+    A = rng.standard_normal((20, 20))
+    cov = np.dot(A, A.T) * 1e-6 + 1e-6 * np.eye(20)
+
+    def states(seq):
+        tm = mx.TauMaxEnt()
+        tm.set_verbosity(mx.VerbosityFlags.Quiet)
+        tm.omega = mx.HyperbolicOmegaMesh(-5, 5, 30)
+        out = []
+        for g, c in seq:
+            tm.set_G_tau_data(tau, g)
+            tm.set_cov(c)
+            out.append((np.array(tm.G), np.array(tm.err), tm.K.rotation, np.array(tm.K.K), tm.K.U))
+        return out
+    same = states([(G, cov), (1.1 * G, cov)])
+    copy = states([(G, cov), (1.1 * G, cov.copy())])
+    assert same[1][2] is same[0][2] and same[1][4] is same[0][4]          # rotation and U untouched
+    assert copy[1][2] is not copy[0][2]
+    for x, y in zip(same, copy):
+        np.testing.assert_array_equal(x[0], y[0])
+        np.testing.assert_array_equal(x[1], y[1])
+        np.testing.assert_allclose(x[3], y[3], rtol=0, atol=1e-13)

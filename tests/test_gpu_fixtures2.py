@@ -73,6 +73,27 @@ def test_one_covariance_per_element_matches_the_reference(blur):
     assert K.rotation is not None and K.V.shape[0] == 60
 
 
+def test_one_covariance_for_all_elements_matches_the_reference_and_is_one_data_set():
+    """ElementwiseMaxEnt.set_cov((T, T)) (elementwise_maxent.py:502-515): the reference's results, from ONE
+    eigendecomposition and ONE rotated data set on the device (the same matrix object is recognised by
+    TauMaxEnt.set_cov; a data set per element would also switch off the lock-step layout)"""
+    g = np.load(os.path.join(GOLD, 'elementwise_shared_cov.npz'))
+    ew = mx.ElementwiseMaxEnt(use_hermiticity=False)
+    ew.set_verbosity(mx.VerbosityFlags.Quiet)
+    ew.set_G_tau_data(g['tau'], g['G_tau'])
+    ew.omega = mx.HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=60)
+    ew.alpha_mesh = mx.LogAlphaMesh(alpha_min=0.05, alpha_max=500, n_points=6)
+    ew.set_cov(g['cov'])
+    res = ew.run()
+    assert res.A.shape == g['A'].shape == (2, 2, 6, 60)
+    for i in range(2):
+        for j in range(2):
+            assert rel_l2(res.A[i, j], g['A'][i, j]).max() < 2e-4, (i, j)
+            np.testing.assert_allclose(res.chi2[i, j], g['chi2'][i, j], rtol=1e-4)
+    assert rel_l2(res.A_out, g['A_out']).max() < 2e-4
+    assert [info['n_datasets'] for info in ew.last_launches] == [[1], [1]]
+
+
 def test_cfg5_full_size_fp32_against_fp64_and_the_reference_port():
     """BASELINE cfg5 as written: 8 x 8 G(tau), n_tau = 200, n_omega = 500, 100 alpha, off-diagonals with
     PlusMinusEntropy + preblur (b = 0.1); binary32 streaming variant against binary64 (tolerance classes), and
