@@ -1,9 +1,15 @@
 """Verbosity flags and message sink (reference python/logtaker.py:25-230).
 
-Only what the alpha-scan path prints is kept: the header, the per-alpha line
-``alpha[i] = ..., chi2 = ..., n_iter=...`` (reference maxent_loop.py:248-255),
-timing and error messages, each behind the same bit flags.
+Same contract as the reference's ``Logtaker``: a message carries a set of flags and is shown when ALL of
+them are switched on in ``verbose`` (so flag 0, ``Quiet``, always shows); errors are kept in a list and
+shown with an ``ERROR: `` prefix under the ``Errors`` flag; a log file, opened with ``open_logfile``, gets
+every message its own level (``logfile_verbose``, by default the terminal's) lets through, one per line;
+messages of the kinds in ``one_line`` (the per-iteration solver details) overwrite each other on the
+terminal instead of scrolling.  What the alpha-scan path prints through it: the header, the per-alpha line
+``alpha[i] = ..., chi2 = ..., n_iter=...`` (reference maxent_loop.py:248-255), timing and errors.
 """
+
+from __future__ import print_function
 
 import sys
 from datetime import datetime
@@ -20,32 +26,84 @@ class VerbosityFlags(object):
     Default = Header | ElementInfo | Timing | AlphaLoop | Errors
 
 
-class Logtaker(object):
-    """print and/or append to a log file, filtered by ``verbose``."""
+class _Terminal(object):
+    """stdout with the memory of whether the last thing written left the cursor inside a line"""
 
+    def __init__(self):
+        self.inside_line = False
+
+    def show(self, text, overwrite):
+        out = sys.stdout
+        if overwrite:
+            out.write('\r' + text)
+            self.inside_line = True
+        else:
+            if self.inside_line:
+                out.write('\n')
+                self.inside_line = False
+            out.write(text + '\n')
+
+
+class Logtaker(object):
     def __init__(self, verbose=VerbosityFlags.Default, logfile=None):
         self.verbose = verbose
-        self.logfile = logfile
+        self.one_line = VerbosityFlags.SolverDetails
+        self.logfile = None
+        self.logfile_verbose = None          # None: the terminal's level
+        self._errors = []
+        self._terminal = _Terminal()
         self._welcomed = False
+        if logfile is not None:
+            self.open_logfile(logfile)
 
-    def _emit(self, text, stream=None):
-        print(text, file=stream or sys.stdout)
+    # ---- where messages go ---------------------------------------------------
+    def open_logfile(self, name, append=True):
+        self.close_logfile()
+        self.logfile = open(name, 'a' if append else 'w')
+
+    def close_logfile(self):
         if self.logfile is not None:
-            with open(self.logfile, 'a') as f:
-                f.write(text + '\n')
+            self.logfile.close()
+        self.logfile = None
 
-    def message(self, flag, fmt, *args):
-        if self.verbose & flag:
-            self._emit(fmt.format(*args) if args else fmt)
+    @staticmethod
+    def _passes(level, flags):
+        return (level & flags) == flags
 
-    def error_message(self, fmt, *args):
-        if self.verbose & VerbosityFlags.Errors:
-            self._emit(fmt.format(*args) if args else fmt, sys.stderr)
+    def message(self, message_verbosity, msg, *args, **kwargs):
+        text = msg.format(*args, **kwargs) if (args or kwargs) else msg
+        if self._passes(self.verbose, message_verbosity):
+            self._terminal.show(text, overwrite=bool(message_verbosity & self.one_line))
+        if self.logfile is not None:
+            level = self.verbose if self.logfile_verbose is None else self.logfile_verbose
+            if self._passes(level, message_verbosity):
+                self.logfile.write(text + '\n')
 
-    def welcome_message(self):
-        if self.verbose & VerbosityFlags.Header:
-            self._emit('{}\nMaxEnt alpha scan on MI355X (maxent_amd)'.format(
-                datetime.now().strftime('%Y-%m-%d %H:%M:%S')))
+    def logged_message(self, msg, *args, **kwargs):
+        """(deprecated in the reference: a message that always shows)"""
+        self.message(VerbosityFlags.Quiet, msg, *args, **kwargs)
 
-    def solver_verbose_callback(self, msg):
-        self.message(VerbosityFlags.SolverDetails, '{}', msg)
+    # ---- errors -----------------------------------------------------------------
+    def error_message(self, msg, *args, **kwargs):
+        self._errors.append(msg.format(*args, **kwargs) if (args or kwargs) else msg)
+        self.message(VerbosityFlags.Errors, 'ERROR: ' + msg, *args, **kwargs)
+
+    def get_error_messages(self):
+        return self._errors
+
+    def clear_error_messages(self):
+        del self._errors[:]
+
+    # ---- fixed texts ------------------------------------------------------------
+    def log_time(self, message_verbosity=VerbosityFlags.Header):
+        self.message(message_verbosity, str(datetime.now()))
+
+    def welcome_message(self, always=False, message_verbosity=VerbosityFlags.Header):
+        if self._welcomed and not always:
+            return
+        self.log_time(message_verbosity)
+        self.message(message_verbosity, 'MaxEnt alpha scan on MI355X (maxent_amd)')
+        self._welcomed = True
+
+    def solver_verbose_callback(self, *args, **kwargs):
+        self.message(VerbosityFlags.SolverDetails, *args, **kwargs)

@@ -486,6 +486,14 @@ def elementwise_cov_case():
     np.savez_compressed(os.path.join(HERE, 'elementwise_cov.npz'), **out)
 
 
+def logtaker_case():
+    """expected terminal and log-file output of the reference's own logtaker test (test/python/logtaker.py with
+    logtaker.ref / logtaker.dat.ref): data files of the reference's test suite, kept byte for byte"""
+    for name in ('logtaker.ref', 'logtaker.dat.ref'):
+        shutil.copyfile(os.path.join(TESTDATA, name), os.path.join(HERE, name))
+    print('%-28s' % 'logtaker')
+
+
 def elementwise_shared_cov_case():
     """ElementwiseMaxEnt.set_cov with ONE (T, T) covariance for all elements (elementwise_maxent.py:502-515):
     every element goes through TauMaxEnt.set_cov with the same matrix (tau_maxent.py:253-288)."""
@@ -534,5 +542,6 @@ if __name__ == '__main__':
     complex_elementwise_case()
     elementwise_cov_case()
     elementwise_shared_cov_case()
+    logtaker_case()
     shutil.rmtree(TMP, ignore_errors=True)
     print('fixtures written to', HERE)

@@ -359,3 +359,30 @@ def test_one_covariance_for_many_elements_is_decomposed_once():
         np.testing.assert_array_equal(x[0], y[0])
         np.testing.assert_array_equal(x[1], y[1])
         np.testing.assert_allclose(x[3], y[3], rtol=0, atol=1e-13)
+
+
+def test_logtaker_reproduces_the_reference_test_output(tmp_path, capsys):
+    """reference test/python/logtaker.py:25-58 against its own logtaker.ref (terminal) and logtaker.dat.ref (log file)"""
+    from maxent_amd.logtaker import Logtaker, VerbosityFlags as F
+    levels = [F.Quiet, F.Header, F.ElementInfo, F.Timing, F.AlphaLoop, F.SolverDetails, F.Errors, F.Header | F.Timing, F.Default]
+    log = Logtaker()
+    logfile = str(tmp_path / 'logtaker.dat')
+    log.open_logfile(logfile, False)
+    for i, level in enumerate(levels):
+        log.verbose = level
+        log.message(F.Quiet, "=== Test #{} ===", i)
+        log.message(F.Header, "This is a header message.")
+        log.message(F.ElementInfo, "This is an element info message.")
+        log.message(F.Timing, "This is a timing message.")
+        log.message(F.AlphaLoop, "This is an alpha loop message.")
+        log.message(F.SolverDetails, "This is a solver details message.")
+        log.error_message("This is an error message")
+        log.message(F.Timing | F.Header, "This is a header + timing message.")
+    log.close_logfile()
+    shown = capsys.readouterr().out
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    with open(os.path.join(gold, 'logtaker.ref'), newline='') as f:
+        assert shown == f.read()
+    with open(os.path.join(gold, 'logtaker.dat.ref'), newline='') as f, open(logfile, newline='') as mine:
+        assert mine.read() == f.read()
+    assert log.get_error_messages() == ['This is an error message'] * len(levels)

@@ -443,3 +443,40 @@ def test_preblur_b_scan_from_one_batched_device_launch():
     assert np.all(outs[1].converged)
     assert rel_l2(outs[1].A, outs[0].A).max() < GATE
     assert rel_l2(outs[1].H, g['H_truth']).max() < GATE
+
+
+@pytest.mark.gpu
+def test_loop_assembled_by_hand_equals_the_facade():
+    """reference test/python/maxent_loop.py:46-70: chi2, S, H_of_v, cost function, minimiser, alpha mesh and
+    logtaker built one by one and handed to MaxEntLoop; the same problem through TauMaxEnt gives the same scan"""
+    rng = np.random.RandomState(658436166)
+    beta = 40
+    tau = np.linspace(0, beta, 100)
+    omega = mx.HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=100)
+    K = mx.TauKernel(tau=tau, omega=omega, beta=beta)
+    A = np.exp(-np.asarray(omega) ** 2)
+    A /= np.trapezoid(A, np.asarray(omega))
+    G = np.dot(K.K, A) + 1.e-4 * rng.randn(len(tau))
+    err = 1.e-4 * np.ones(len(G))
+    D = mx.FlatDefaultModel(omega=omega)
+    Q = mx.MaxEntCostFunction(chi2=mx.NormalChi2(K=K, G=G, err=err), S=mx.NormalEntropy(D=D),
+                              H_of_v=mx.NormalH_of_v(D=D, K=K))
+    log = mx.Logtaker()
+    log.verbose = mx.VerbosityFlags.Quiet
+    ml = mx.MaxEntLoop(cost_function=Q, minimizer=mx.LevenbergMinimizer(maxiter=10000),
+                       alpha_mesh=mx.LogAlphaMesh(alpha_max=6000, alpha_min=8, n_points=5), logtaker=log)
+    res = ml.run()
+    assert res.A.shape == (5, 100) and np.all(res.converged)
+    tm = mx.TauMaxEnt()
+    tm.set_verbosity(mx.VerbosityFlags.Quiet)
+    tm.omega = omega
+    tm.set_G_tau_data(tau, G)
+    tm.set_error(1.e-4)
+    tm.alpha_mesh = mx.LogAlphaMesh(alpha_max=6000, alpha_min=8, n_points=5)
+    res2 = tm.run()
+    assert rel_l2(res.H, res2.H).max() < 1e-8
+    np.testing.assert_allclose(res.chi2, res2.chi2, rtol=1e-8)
+    assert res.analyzer_results['LineFitAnalyzer']['alpha_index'] == res2.analyzer_results['LineFitAnalyzer']['alpha_index']
+    # (the data are K.K applied to A, not to A delta-omega, as in the reference's test: the weight is sum(A))
+    w = np.asarray(omega)
+    assert abs(np.trapezoid(res.A[-1], w) / np.sum(A) - 1.0) < 2e-2

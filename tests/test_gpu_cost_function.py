@@ -209,3 +209,33 @@ def test_chi2_factor_reaches_the_solver(case):
     e = np.linalg.norm(out[2.5].H - out[1.0].H, axis=1) / np.linalg.norm(out[1.0].H, axis=1)
     assert e.max() < 1e-8
     np.testing.assert_allclose(out[2.5].Q, 2.5 * out[1.0].Q, rtol=1e-9)
+
+
+def test_chi2_and_entropy_do_not_depend_on_the_omega_grid():
+    """reference test/python/functions_different_grid.py:27-60: the same A(omega) on a hyperbolic and on a linear
+    mesh of 1000 points gives the same chi2 and S (device evaluation at a caller-supplied H, n_omega = 1000)"""
+    beta = 40
+    tau = np.linspace(0, beta, 100)
+    omega = mx.LinearOmegaMesh(omega_min=-10, omega_max=10, n_points=100)
+    K = mx.TauKernel(tau=tau, omega=omega, beta=beta)
+    A = np.exp(-np.asarray(omega) ** 2)
+    A /= np.trapezoid(A, np.asarray(omega))
+    G = np.dot(K.K_delta, A)
+    err = np.ones(len(G))
+    grids = [mx.HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=1000),
+             mx.LinearOmegaMesh(omega_min=-10, omega_max=10, n_points=1000)]
+    for test_A in (lambda w: w / w, lambda w: np.exp(-w ** 2)):
+        c2, s = [], []
+        for om in grids:
+            Kg = mx.TauKernel(tau=tau, omega=om, beta=beta)
+            Ag = test_A(np.asarray(om))
+            Ag /= np.trapezoid(Ag, np.asarray(om))
+            D = mx.FlatDefaultModel(omega=om)
+            chi2 = mx.NormalChi2(K=Kg, G=G, err=err)
+            S = mx.NormalEntropy(D=D)
+            c2.append(chi2.f(Ag * om.delta))
+            s.append(S.f(Ag * om.delta))
+            # and against plain numpy on the full kernel
+            assert abs(c2[-1] - np.sum((np.dot(Kg.K, Ag * om.delta) - G) ** 2)) < 1e-9 * max(1.0, c2[-1])
+        assert abs(c2[1] - c2[0]) < 1.e-4, 'chi2 not equal'
+        assert abs(s[1] - s[0]) < 1.e-4, 'S not equal'
