@@ -272,6 +272,49 @@ class MaxEntResult(MaxEntResultData):
         self._records[key] = record
         self._cache = dict()
 
+    def add_result(self, cost_function, log_probability=None, matrix_element=None, complex_index=None):
+        """Append the result of ONE alpha (reference maxent_result.py:751-791): ``cost_function`` is a cost
+        function evaluated at its optimum, ``Q(v)`` -- chi2, S, Q, H, A are read off it (device evaluation,
+        cost_functions.py) and become one more row of the element's arrays.  A result that a launch filled
+        scan by scan (``add_element_results``) can be extended the same way; its H then comes to the host."""
+        if self.matrix_structure is None or not self.element_wise:
+            assert matrix_element is None, 'this result has no matrix structure: matrix_element must not be given'
+        key = self._key(matrix_element, complex_index)
+        q = cost_function
+        H = np.array(q.H_of_v.f(), dtype=float)
+        A = np.asarray(q.A_of_H.f(H))
+        K = q.K
+        now = datetime.now()
+        last = self.__dict__.get('_last_add', now)
+        self._last_add = now
+        row = dict(alpha=float(q._alpha), v=np.array(q._x, dtype=float), H=H, A=A,
+                   chi2=float(q.chi2.f()), S=float(q.S.f()), Q=float(q.f()),
+                   G_rec=np.dot(K.K_delta, A),
+                   probability=np.nan if log_probability is None else log_probability,
+                   n_iter=0, converged=True, n_evals=0, run_times=now - last)
+        rec = self._records.get(key)
+        if rec is None:
+            rec = dict((k, np.array([val])) for k, val in row.items())
+            rec.update(G=np.array(q.G), G_orig=np.array(q.G_orig), data_variable=np.array(K.data_variable), omega=q.omega)
+        else:
+            rec = dict(rec)
+            for k, val in row.items():
+                if k in rec and rec[k] is not None:
+                    rec[k] = np.concatenate([np.asarray(rec[k]), np.array([val])])
+        self._records[key] = rec
+        self._cache = dict()
+
+    def _get_empty(self, fill_with=list):
+        """a nested list in the shape of the matrix structure, every entry a fresh ``fill_with()``
+        (reference maxent_result.py:268-290)"""
+        shape = self.effective_matrix_structure
+        if shape is None:
+            return fill_with()
+
+        def level(dims):
+            return [fill_with() if len(dims) == 1 else level(dims[1:]) for _ in range(dims[0])]
+        return level(list(shape))
+
     def start_timing(self, matrix_element=None, complex_index=None, time=None):
         self._start[self._key(matrix_element, complex_index)] = \
             time or datetime.now()
@@ -499,15 +542,39 @@ class MaxEntResult(MaxEntResultData):
             self._cache['analyzer_results'] = self._nested_from(self._analysis, dict)
         return self._cache['analyzer_results']
 
+    def _object_array(self, table, per_alpha):
+        """object array in the shape of the matrix structure (+ the alpha axis), NaN where an element has
+        nothing (reference maxent_result.py:720-731 with dtype=object)"""
+        if self.matrix_structure is None or not self.element_wise:
+            val = table.get(None, [] if per_alpha else np.nan)
+            if not per_alpha:
+                return val
+            out = np.empty(len(val), dtype=object)
+            out[:] = list(val)
+            return out
+        ems = tuple(self.effective_matrix_structure)
+        n = max([len(v) for v in table.values()] + [0]) if per_alpha else 0
+        out = np.empty(ems + ((n,) if per_alpha else ()), dtype=object)
+        out[...] = np.nan
+        for key, val in table.items():
+            if per_alpha:
+                for i, t in enumerate(val):
+                    out[key + (i,)] = t
+            else:
+                out[key] = val
+        return out
+
     @property
     def run_times(self):
-        return self._nested_from(
-            {k: list(r.get('run_times', [])) for k, r in self._records.items()}, list)
+        return self._object_array({k: list(r.get('run_times', [])) for k, r in self._records.items()}, True)
 
     @property
     def run_time_total(self):
         tot = {k: self._end[k] - self._start[k] for k in self._end if k in self._start}
-        return self._nested_from(tot, lambda: timedelta(0))
+        if not tot and self._records:
+            # filled alpha by alpha (add_result): the sum of the single times
+            tot = {k: sum(list(r.get('run_times', [])), timedelta(0)) for k, r in self._records.items()}
+        return self._object_array(tot, False)
 
     @property
     def data(self):

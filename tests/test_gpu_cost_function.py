@@ -239,3 +239,59 @@ def test_chi2_and_entropy_do_not_depend_on_the_omega_grid():
             assert abs(c2[-1] - np.sum((np.dot(Kg.K, Ag * om.delta) - G) ** 2)) < 1e-9 * max(1.0, c2[-1])
         assert abs(c2[1] - c2[0]) < 1.e-4, 'chi2 not equal'
         assert abs(s[1] - s[0]) < 1.e-4, 'S not equal'
+
+
+def test_result_filled_alpha_by_alpha_has_the_reference_shapes():
+    """reference test/python/matrix_maxent_result.py:26-140: MaxEntResult.add_result(Q(v)) -- one alpha at a time,
+    with and without matrix structure -- and the shapes of everything that comes out"""
+    rng = np.random.RandomState(658436166)
+    beta = 40
+    tau = np.linspace(0, beta, 100)
+    omega = mx.HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=100)
+    K = mx.TauKernel(tau=tau, omega=omega, beta=beta)
+    K.reduce_singular_space()
+    A = np.exp(-np.asarray(omega) ** 2)
+    A /= np.trapezoid(A, np.asarray(omega))
+    G = np.dot(K.K, A) + 1.e-4 * rng.randn(len(tau))
+    err = 1.e-4 * np.ones(len(G))
+    D = mx.FlatDefaultModel(omega=omega)
+    Q = mx.MaxEntCostFunction(chi2=mx.NormalChi2(K=K, G=G, err=err), S=mx.NormalEntropy(D=D),
+                              H_of_v=mx.NormalH_of_v(D=D, K=K), A_of_H=mx.IdentityA_of_H(omega=D.omega))
+    Q.set_alpha(0.1)
+    ns = len(K.S)
+    v1, v2 = rng.rand(ns), rng.rand(ns)
+
+    mr = mx.MaxEntResult()
+    mr.add_result(Q(v1))
+    with pytest.raises(AssertionError):
+        mr.add_result(Q(v1), matrix_element=(1, 1))
+    assert mr.alpha == [0.1] and mr.alpha.shape == (1,) and mr._n_alphas == 1
+    for name in ('chi2', 'S', 'Q'):
+        assert getattr(mr, name).shape == (1,)
+    assert mr.A.shape == (1, 100) and mr.v.shape == (1, ns) and mr.run_times.shape == (1,)
+    at = Q(v1)
+    assert mr.chi2[0] == at.chi2.f() and mr.Q[0] == at.f()
+    np.testing.assert_array_equal(mr.A[0], at.H_of_v.f() / omega.delta)
+
+    mr = mx.MaxEntResult(matrix_structure=(2, 2))
+    with pytest.raises(AssertionError):
+        mr.add_result(Q(v1))
+    assert mr._get_empty(fill_with=lambda: 1) == [[1, 1], [1, 1]]
+    mr.add_result(Q(v1), matrix_element=(1, 1))
+    mr.add_result(Q(v2), matrix_element=(1, 1))
+    assert np.all(mr.alpha == 0.1) and mr.alpha.shape == (2,)
+    assert np.all(mr._n_alphas == [[0, 0], [0, 2]])
+    for name in ('chi2', 'S', 'Q'):
+        assert getattr(mr, name).shape == (2, 2, 2)
+    assert mr.A.shape == (2, 2, 2, 100) and mr.v.shape == (2, 2, 2, ns)
+    assert mr.run_times.shape == (2, 2, 2) and mr.omega.shape == (100,)
+
+    mr = mx.MaxEntResult(matrix_structure=(2, 2))
+    for elem, v in (((0, 0), v1), ((1, 1), v2), ((0, 1), v1), ((1, 0), v2)):
+        mr.add_result(Q(v), matrix_element=elem)
+    assert mr.alpha == [0.1]
+    for name in ('chi2', 'S', 'Q'):
+        assert getattr(mr, name).shape == (2, 2, 1)
+    assert mr.A.shape == (2, 2, 1, 100) and mr.v.shape == (2, 2, 1, ns) and mr.omega.shape == (100,)
+    assert mr.run_times.shape == (2, 2, 1) and mr.run_time_total.shape == (2, 2)
+    assert mr.chi2[0, 1, 0] == mr.chi2[0, 0, 0] and mr.chi2[1, 0, 0] == mr.chi2[1, 1, 0]
