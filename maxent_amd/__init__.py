@@ -14,7 +14,8 @@ from .default_models import *          # noqa: F401,F403
 from .preblur import get_preblur       # noqa: F401
 from .kernels import (KernelSVD, Kernel, DataKernel, TauKernel,   # noqa: F401
                       PreblurKernel)
-from .functions import (NormalChi2, NormalEntropy, PlusMinusEntropy,   # noqa: F401
+from .functions import (GenericFunction, DoublyDerivableFunction, cached,   # noqa: F401
+                        NormalChi2, NormalEntropy, PlusMinusEntropy,
                         NormalH_of_v, PlusMinusH_of_v, IdentityA_of_H,
                         PreblurA_of_H)
 from .cost_functions import (CostFunction, MaxEntCostFunction,    # noqa: F401

@@ -78,11 +78,15 @@ class GenericFunction(object):
         return bound
 
     def _at(self, x):
-        """argument of this call: the pinned one unless another is given"""
+        """argument of this call: the pinned one unless another is given (the pinned value handed in
+        explicitly -- one memoised method calling another with its own argument -- counts as pinned)"""
+        pinned = getattr(self, '_x', None)
         if x is None:
-            if getattr(self, '_x', None) is None:
+            if pinned is None:
                 raise TypeError('no argument given and none pinned; use fn(x) first')
-            return self._x, True
+            return pinned, True
+        if pinned is not None and (x is pinned or (np.shape(x) == pinned.shape and np.array_equal(x, pinned))):
+            return pinned, True
         return np.asarray(x, dtype=float), False
 
     def _memoized(self, key, x, compute):
@@ -115,6 +119,30 @@ class GenericFunction(object):
 
     def check_derivatives(self, around, renorm=False, prec=1.e-8):
         return bool(self.check_d(around, renorm, prec)) & bool(self.check_dd(around, renorm, prec))
+
+
+def cached(method):
+    """Decorator for the methods of a user-written function object (reference functions.py:46-93): on an object
+    pinned to an argument, ``fn = F(x)``, the method is evaluated once and remembered -- ``fn.f()``, ``fn.d()``
+    --, with any other argument it is evaluated afresh and nothing is remembered."""
+    def method_with_memo(self, x=None):
+        return self._memoized(method.__name__, x, lambda arg: method(self, arg))
+    method_with_memo.__name__ = method.__name__
+    method_with_memo.__doc__ = method.__doc__
+    return method_with_memo
+
+
+class DoublyDerivableFunction(GenericFunction):
+    """base of user-written functions with ``f``, ``d``, ``dd`` (reference functions.py:96-146)"""
+
+    def f(self, x=None):
+        raise NotImplementedError
+
+    def d(self, x=None):
+        raise NotImplementedError
+
+    def dd(self, x=None):
+        raise NotImplementedError
 
 
 class _OnMesh(object):

@@ -386,3 +386,81 @@ def test_logtaker_reproduces_the_reference_test_output(tmp_path, capsys):
     with open(os.path.join(gold, 'logtaker.dat.ref'), newline='') as f, open(logfile, newline='') as mine:
         assert mine.read() == f.read()
     assert log.get_error_messages() == ['This is an error message'] * len(levels)
+
+
+def test_cached_methods_of_a_user_function_follow_the_reference_protocol():
+    """reference test/python/cached_view.py:27-140: evaluation counts of a user-written DoublyDerivableFunction
+    with @cached methods, unpinned and pinned"""
+    from maxent_amd.functions import DoublyDerivableFunction, cached
+    n = dict(f=0, d=0, dd=0, sq=0)
+
+    class Sin(DoublyDerivableFunction):
+        @cached
+        def f(self, v):
+            n['f'] += 1
+            return np.sin(v)[0]
+
+        @cached
+        def d(self, v):
+            n['d'] += 1
+            return np.cos(v)
+
+        @cached
+        def dd(self, v):
+            n['dd'] += 1
+            return -np.diag(np.sin(v))
+
+        @cached
+        def square(self, v):
+            n['sq'] += 1
+            return v ** 2
+
+        @cached
+        def fourth1(self, v):
+            return self.square(v) * self.square(v)
+
+        @cached
+        def fourth2(self, v):
+            return self.square(self.square(v))
+
+    sin = Sin()
+    v = np.random.RandomState(3).rand(1,)
+    f1, d1, dd1 = sin.f(v), sin.d(v), sin.dd(v)
+    assert (n['f'], n['d'], n['dd']) == (1, 1, 1)
+    f1 = sin.f(v)                                 # not pinned: evaluated again
+    assert (n['f'], n['d'], n['dd']) == (2, 1, 1)
+    sin1 = sin(v)
+    f2, d2, dd2 = sin1.f(), sin1.d(), sin1.dd()
+    f2, d2 = sin1.f(), sin1.d()                   # remembered
+    assert f1 == f2 and d1 == d2 and dd1 == dd2
+    assert (n['f'], n['d'], n['dd']) == (3, 2, 2)
+    sin1.f(2 * v)                                 # another argument: evaluated, the memo is untouched
+    assert sin1.f() == f1 and n['f'] == 4
+    sin1.fourth2(); sin1.fourth2(); sin1.fourth1(); sin1.fourth1()
+    assert n['sq'] == 2
+    v[0] += 0.01
+    sin1.f(v)
+    assert n['f'] == 5
+
+
+def test_elementwise_inputs_from_files_and_arrays(tmp_path):
+    """reference test/python/elementwise_set_G.py:62-92: file-name pattern, array of file names, one array"""
+    from itertools import product
+    em = mx.ElementwiseMaxEnt()
+    tau = np.linspace(0, 40, 10)
+    rng = np.random.RandomState(5)
+    G_elems = {}
+    for element in product(range(2), range(2)):
+        G_elems[element] = rng.rand(len(tau))
+        np.savetxt(str(tmp_path / 'g_{}_{}.dat'.format(*element)), np.column_stack((tau, G_elems[element])))
+
+    def check():
+        for element in product(range(2), range(2)):
+            em.set_G_element(em.maxent_diagonal, em.G_mat, element, True)
+            assert np.max(np.abs(em.maxent_diagonal.G - G_elems[element])) < 1e-13
+    em.set_G_tau_filename_pattern(str(tmp_path / 'g_{i}_{j}.dat'), (2, 2))
+    check()
+    em.set_G_tau_filenames([[str(tmp_path / 'g_{}_{}.dat'.format(i, j)) for j in range(2)] for i in range(2)])
+    check()
+    em.set_G_tau_data(tau, np.array([[G_elems[i, j] for j in range(2)] for i in range(2)]))
+    check()
