@@ -46,6 +46,8 @@ class DataAlphaMesh(BaseAlphaMesh):
     def _check(cls, data=None):
         if data is None:
             raise TypeError('DataAlphaMesh needs the alpha values')
+        if np.size(data) > 1 and np.min(data) <= 0:
+            raise Exception('All alpha values must be positive')
 
     @classmethod
     def _points(cls, data):

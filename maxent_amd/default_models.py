@@ -1,8 +1,8 @@
 """Default models.  ``model.D`` is the density times delta-omega, the quantity
 the entropy is written in (reference python/default_models.py:26-115; public
 names and constructor arguments as there).  A model is its density function;
-the product with the mesh weights is formed on demand and dropped whenever the
-mesh changes (``parameter_change``).
+the product with the mesh weights is formed on demand and dropped by
+``parameter_change``.
 """
 
 import numpy as np
@@ -22,9 +22,10 @@ class BaseDefaultModel(object):
 
     @property
     def D(self):
-        if '_D' not in self.__dict__ or self.__dict__.get('_D_for') is not self.omega:
+        # (tabulated on first use and kept until parameter_change(), also across a new ``omega``: the
+        #  reference's protocol, test/python/default_models.py:56-60)
+        if '_D' not in self.__dict__:
             self._D = np.asarray(self.density(self.omega), dtype=float) * self.omega.delta
-            self._D_for = self.omega
         return self._D
 
     def __len__(self):

@@ -487,9 +487,10 @@ def elementwise_cov_case():
 
 
 def logtaker_case():
-    """expected terminal and log-file output of the reference's own logtaker test (test/python/logtaker.py with
-    logtaker.ref / logtaker.dat.ref): data files of the reference's test suite, kept byte for byte"""
-    for name in ('logtaker.ref', 'logtaker.dat.ref'):
+    """expected output files of the reference's own tests (test/python/logtaker.py with logtaker.ref /
+    logtaker.dat.ref, omega_meshes.py with omega_meshes.ref, alpha_meshes.py with alpha_meshes.ref): data files
+    of the reference's test suite, kept byte for byte"""
+    for name in ('logtaker.ref', 'logtaker.dat.ref', 'omega_meshes.ref', 'alpha_meshes.ref'):
         shutil.copyfile(os.path.join(TESTDATA, name), os.path.join(HERE, name))
     print('%-28s' % 'logtaker')
 

@@ -1,0 +1,84 @@
+"""Meshes and default models against the reference's own expected files and assertions (CPU).
+
+Restated from reference test/python/omega_meshes.py, alpha_meshes.py, default_models.py; the ``.ref`` files under
+tests/golden/ are the reference test suite's data files (copied by tests/golden/make_golden.py: logtaker_case)."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+import maxent_amd as mx
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _ref(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return f.read()
+
+
+def _listing(name, mesh):
+    return name + '\n' + ''.join('%.8f\n' % w for w in mesh) + '-' * 80 + '\n'
+
+
+def _old_delta(v):
+    # the formula the reference's test keeps for comparison (omega_meshes.py:28-46)
+    v = np.asarray(v)
+    d = np.empty(len(v))
+    d[1:-1] = (v[2:] - v[:-2]) / 2.0
+    d[0] = (v[1] - v[0]) / 2.0
+    d[-1] = (v[-1] - v[-2]) / 2.0
+    return d
+
+
+def test_omega_meshes_match_the_reference_listing():
+    out = ''
+    rng = np.random.RandomState(0)
+    for cls in (mx.LinearOmegaMesh, mx.LorentzianOmegaMesh, mx.LorentzianSmallerOmegaMesh, mx.HyperbolicOmegaMesh):
+        m = cls(omega_min=-10, omega_max=10, n_points=10)
+        out += _listing(cls.__name__, m)
+        assert np.max(np.abs(_old_delta(m) - m.delta)) < 1.e-15
+        func = rng.rand(len(m))
+        assert abs(np.trapezoid(func, np.asarray(m)) - np.sum(func * m.delta)) < 1.e-14
+        for other in (m.copy(), copy.deepcopy(m)):
+            assert np.all(other == m)
+            assert (other.omega_min, other.omega_max, other.n_points) == (m.omega_min, m.omega_max, m.n_points)
+    assert out == _ref('omega_meshes.ref')
+
+
+def test_alpha_meshes_match_the_reference_listing():
+    out = ''
+    for cls in (mx.LinearAlphaMesh, mx.LogAlphaMesh):
+        out += _listing(cls.__name__, cls(alpha_min=1.e-4, alpha_max=1.e2, n_points=10))
+        with pytest.raises(Exception):
+            cls(alpha_min=2, alpha_max=1)
+        with pytest.raises(Exception):
+            cls(alpha_min=-1, alpha_max=2)
+    out += _listing('DataAlphaMesh', mx.DataAlphaMesh(np.linspace(1.e-3, 100, 10)))
+    with pytest.raises(Exception):
+        mx.DataAlphaMesh(np.linspace(-1, 10))
+    assert out == _ref('alpha_meshes.ref')
+
+
+def test_default_models_follow_the_reference_assertions():
+    # reference test/python/default_models.py:25-62
+    w = mx.HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=100)
+    D1 = mx.FlatDefaultModel(omega=w)
+    assert np.all(np.abs(D1.D / w.delta - 1.0 / 20.0) < 1.e-15)
+    assert np.sum(D1.D) - 1.0 < 2.e-15
+    D2 = mx.DataDefaultModel(D1.D / w.delta, w)
+    assert np.all(D1.D == D2.D)
+    w_lin = mx.LinearOmegaMesh(omega_min=-10, omega_max=10, n_points=50)
+    D3 = mx.DataDefaultModel(D1.D / w.delta, w, w_lin)
+    assert len(D3) == 50
+    assert np.all(np.abs(D3.D / w_lin.delta - 1.0 / 20.0) < 1.e-15)
+    w_2p = mx.DataOmegaMesh([-10, 10])
+    D4 = mx.DataDefaultModel([-10, 10], w_2p, w_lin)
+    assert np.all(np.abs(D4.D / w_lin.delta - np.linspace(-10, 10, 50)) < 1.e-15)
+    D5 = mx.DataDefaultModel([-9, 11], w_2p, w)
+    assert abs(np.sum(D5.D) - 20.0) < 1.e-13          # the trapezoidal rule is exact for a linear function
+    D5.omega = w_2p
+    assert len(D5.D) == len(w)                          # nothing changes before parameter_change()
+    D5.parameter_change()
+    assert len(D5.D) == 2 and abs(np.sum(D5.D) - 20.0) < 1.e-13
