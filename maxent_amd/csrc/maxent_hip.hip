@@ -512,7 +512,13 @@ try {
         int wgpc_guess = (o.wg_per_cu != 1 && ctx->nwp <= 512 && NP == 64 && o.chains_per_wg != 1) ? 2 : 1;
         for (;;) {
             const int n_slots = 4 * wgpc_guess * n_cu;
-            const int want = (2 * n_slots + n_chain - 1) / n_chain;
+            // A piece of a normal-entropy scan costs about twice one of a plus-minus scan of the same length (10-18
+            // against 5 evaluations for the cold start, 3 against 2 per alpha): it counts twice, so that a slot gets
+            // two plus-minus pieces or one normal piece, not three (cfg4: 15 pieces per scan instead of 16 -- of
+            // 4096 pieces 14 % of the slots took a third --, 1.228 -> 1.171 ms; 14: 1.34 ms)
+            long long weight = 0;
+            for (int c = 0; c < n_chain; ++c) weight += (ctx->elem_kind[elem_of_chain[c]] == MXE_ENTROPY_NORMAL) ? 2 : 1;
+            const int want = (int)std::max(1LL, (2LL * n_slots) / std::max(1LL, weight));
             split = std::max(1, std::min(want, n_alpha / 2));
             // (the binary32 streaming variant stops an alpha at its rounding floor, which a cold start reaches
             //  from further away: it keeps pieces of at least six alphas, at most 16 per scan)
@@ -520,7 +526,7 @@ try {
             // two workgroups per CU pay when there is work for two rounds of them; a batch that cannot be cut
             // into that many pieces runs at one per CU, where a round of a workgroup takes 45 k instead of 73 k
             // cycles (the 3 200-problem shard of cfg4 / 8: 0.48 against 0.59 ms)
-            if (wgpc_guess == 2 && o.wg_per_cu == 0 && (long long)n_chain * split < 2LL * n_slots) { wgpc_guess = 1; continue; }
+            if (wgpc_guess == 2 && o.wg_per_cu == 0 && split < want) { wgpc_guess = 1; continue; }
             break;
         }
         ctx->wgpc_auto = wgpc_guess;
