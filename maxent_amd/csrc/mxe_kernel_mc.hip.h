@@ -791,7 +791,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         fac2 = fmin(1.0, fac * fac);
                     }
                     const double relH2_min = fac2 * sdH;            // min(relH, relH_next)^2 * Hn2
-                    const double tol2Hn = p.tol_h * p.tol_h * t.Hn2;
+                    // (a leading alpha is only a starting point for the piece's first alpha: 1e-3 is enough)
+                    const double tol_here = (LEAD && t.ia < 0) ? fmax(p.tol_h, 1e-3) : p.tol_h;
+                    const double tol2Hn = tol_here * tol_here * t.Hn2;
                     vv[q * NP + k] -= dlc[q * NP + k];
                     if (t.niter == 0) t.capp = (t.okprev == 5) ? 2 : (t.okprev == 1 && t.mu == 0.0) ? 1 : 0;
                     else eacc[q * NP + k] -= dlc[q * NP + k];     // what the later iterations add to the first iterate
