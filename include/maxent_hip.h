@@ -94,8 +94,14 @@ typedef struct mxe_opts {
                                 one data set per workgroup in lock-step (shared V loads)   */
     int32_t alpha_split;     /* cut every alpha scan into this many cold-started pieces
                                 (more chains to fill the GPU; results are path independent);
-                                0 = auto (about 2.5 pieces per chain slot of the GPU, at
-                                most 16, none shorter than 6 alphas), 1 = never             */
+                                0 = auto: about two pieces per chain slot of the GPU, a piece
+                                of a normal-entropy scan counting twice, none shorter than two
+                                alphas (binary32 variant: at most 16, none shorter than six);
+                                1 = never.  In either case a piece of a normal-entropy scan
+                                that would start among the scan's smallest alphas (the last 6 %
+                                of its logarithmic range, where a cold start from the default
+                                model can take hundreds of iterations) is started from the last
+                                alpha above that range instead, or joined to the piece before */
     int32_t stop_estimate;   /* 1 (default): after a full (undamped) Newton step the next
                                 correction is estimated as (expm1(max|du|) + decouple_tol) * ||dH||/||H||
                                 (the relative change of the weights w bounds the relative
