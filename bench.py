@@ -465,13 +465,13 @@ def main():
         traffic=traffic, counters=counters,
         definition='The kernel is bound by the instruction issue of the four SIMDs of a CU: on gfx950 the binary64 and '
                    'binary32 MFMAs run at the rate of -- and instead of -- the vector instructions (profiles/'
-                   'r01_f_microbench_mfma_shadow.txt), so the solve of the home waves (v_readlane + v_fma_f64), the '
+                   'r01_f_microbench_mfma_shadow.txt), so the solve of the home waves (v_fma_f64 behind ds_swizzle / v_permlane32_swap broadcasts), the '
                    'exp / entropy arithmetic, the binary64 matrix products and the operand splitting of the Gram '
                    'tiles all queue for the same pipe; only the binary16 Gram MFMAs have a pipe of their own.  achieved = '
                    '(4 SQ_ACTIVE_INST_VALU + SQ_VALU_MFMA_BUSY_CYCLES - SQ_VALU_MFMA_COEXEC_CYCLES) per launch '
                    '(rocprofv3 --pmc on this command, %s) / the kernel time measured here with HIP events; peak = 1024 '
                    'SIMDs x 2.4 GHz.  Two workgroups per CU run the serial and the streaming phases of different '
-                   'workgroups side by side (8 %% over one per CU); what is left idle is waiting on L2 latency and '
+                   'workgroups side by side (a round of four chains: 34.5 k cycles against 47 k with one per CU); what is left idle is waiting on L2 latency and '
                    'barriers inside phases that are too short to fill from elsewhere.  HBM and L2 are far from binding '
                    '(hbm_frac, l2_frac); traffic = 2 FETCH_SIZE + WRITE_SIZE per launch, of which 117 MB are the '
                    'compulsory per-alpha results.' % pmc.get('source', 'counters not collected for this workload / kernel'),
