@@ -155,6 +155,8 @@ class ElementwiseMaxEnt(object):
             if per_job_D is not None:
                 worker.set_D(per_job_D[n])
             self._load_element(worker, element, re)
+            if n == 0:
+                self._share_decomposition()      # (the worker has its tau grid now)
             if loop.below_threshold():
                 key = tuple(element) + ((cidx,) if self.use_complex else ())
                 res._zero_elements.append(key)
