@@ -734,7 +734,6 @@ try {
         mxe::MCExtra ex; ex.wg_chains = ctx->dwg_chains.p; ex.n_wg = ctx->n_wg;
         ex.queue = ctx->dqueue.p; ex.n_queue = ctx->n_queue; ex.counter = ctx->dcounter.p;
         ex.stagger = 5;
-        if (const char* sg = getenv("MXE_X_STAGGER")) ex.stagger = atoi(sg);
         HIPCHK(ctx, hipMemsetAsync(ctx->dcounter.p, 0, sizeof(int), ctx->stream));
         ctx->last_nw = NWV; ctx->last_lds = (int)lds;
         const bool lead = kp.chain_lead != nullptr;
