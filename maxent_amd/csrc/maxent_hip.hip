@@ -734,7 +734,29 @@ try {
         mxe::MCExtra ex; ex.wg_chains = ctx->dwg_chains.p; ex.n_wg = ctx->n_wg;
         ex.queue = ctx->dqueue.p; ex.n_queue = ctx->n_queue; ex.counter = ctx->dcounter.p;
         ex.stagger = 5;
-        HIPCHK(ctx, hipMemsetAsync(ctx->dcounter.p, 0, sizeof(int), ctx->stream));
+        ex.n_solo = 0;
+        int counter0 = 0;
+        const bool o_launch_solo = ctx->opts.alpha_split == 0;      // the library's own schedule only
+        if (ex.n_queue > 0 && WGPC == 2) {
+            hipDeviceProp_t prop_s;
+            HIPCHK(ctx, hipGetDeviceProperties(&prop_s, ctx->device));
+            // The launch ends with its longest pieces: the last pieces of the normal-entropy scans (the most expensive
+            // cold start, the most evaluations per alpha).  They are at the head of the queue; the workgroups that take
+            // them get a CU to themselves, where a round takes 47 k instead of 69 k cycles (cfg4, 16 such pieces in
+            // four workgroups: kernel 1.150 -> 1.123 ms; 16 workgroups 1.130, 64: 1.21)
+            int n_tail = 0;
+            for (int sc = 0; sc < ctx->n_sub; ++sc) {
+                const int c = ctx->sub_v0[sc];
+                if (ctx->elem_kind[ctx->sub_elem[sc]] == MXE_ENTROPY_NORMAL &&
+                    ctx->sub_prob0[sc] + ctx->sub_len[sc] == (c + 1) * ctx->n_alpha) ++n_tail;
+            }
+            const int want_solo = std::min((n_tail + 3) / 4, prop_s.multiProcessorCount / 32);
+            if (o_launch_solo && want_solo > 0 && ctx->n_wg == 2 * prop_s.multiProcessorCount) {
+                ex.n_solo = want_solo;
+                counter0 = (ctx->n_wg - ex.n_solo) * 4;
+            }
+        }
+        HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->dcounter.p, counter0, 1, ctx->stream));
         ctx->last_nw = NWV; ctx->last_lds = (int)lds;
         const bool lead = kp.chain_lead != nullptr;
         ctx->last_kernel = "mxe::chain_kernel_mc<" + std::to_string(NA) + ", " + std::to_string(WGPC) + (lead ? ", lead>" : ">");

@@ -38,6 +38,9 @@ struct MCExtra {
     int n_queue;                  //   (0 = static layout)
     int* counter;                 //   next queue position (zeroed before every launch)
     int stagger;                  // WGPC = 2: the second half of the grid starts this many units of 4096 cycles late
+    int n_solo;                   // WGPC = 2, dynamic layout, gridDim = 2 x CUs: workgroups b and b + gridDim / 2 share a CU
+                                  //   (tools/wg_placement.hip); the first n_solo workgroups get their CU to themselves --
+                                  //   their partners leave at once -- and the first pieces of the queue (the most expensive)
 };
 
 // NA    capacity of the active block: 32 or 48
@@ -82,6 +85,8 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     typedef double d4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if ((int)blockIdx.x >= x.n_wg) return;
+    const int half_grid = (int)gridDim.x / 2;
+    if (WGPC == 2 && x.n_solo > 0 && (int)blockIdx.x >= half_grid && (int)blockIdx.x < half_grid + x.n_solo) return;
     const int ns = p.n_s, nw = p.n_omega, nwp = p.n_omega_pad;
     const bool dynamic = x.n_queue > 0;
 
@@ -180,7 +185,13 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     if (wave < MCC) {
         Slot t;
         int c;
-        if (dynamic) {
+        if (dynamic && WGPC == 2 && x.n_solo > 0) {
+            // first pieces by position in the grid, so that the head of the queue lands in the workgroups that are
+            // alone on their CU (the counter starts behind these entries)
+            const int b = (int)blockIdx.x < half_grid ? (int)blockIdx.x : (int)blockIdx.x - x.n_solo;
+            const int idx = b * MCC + wave;
+            c = (idx < x.n_queue) ? x.queue[idx] : -1;
+        } else if (dynamic) {
             int idx = 0;
             if (lane == 0) idx = atomicAdd(x.counter, 1);
             idx = __builtin_amdgcn_readfirstlane(idx);
