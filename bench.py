@@ -38,19 +38,19 @@ L2_PEAK_GBS = 34500.0          # ... aggregate L2
 N_EVAL_NOMINAL = {'normal': 160, 'plusminus': 84}   # the reference's passes per alpha-solve
 
 # Counter values per launch of the default workload (rocprofv3 --pmc on this very command, summaries under
-# profiles/r02_h_pmc_*.csv; they count events, not time, and do not depend on the clock):
+# profiles/r02_i_pmc_*.csv; they count events, not time, and do not depend on the clock):
 PMC_DEFAULT = dict(
-    source='profiles/r02_h_pmc_summary.csv',
+    source='profiles/r02_i_pmc_summary.csv',
     # mean per dispatch of mxe::chain_kernel_mc<32, 2> over ~220 dispatches
-    valu_active_quadcycles=3.14654e8,      # SQ_ACTIVE_INST_VALU (counts quad-cycles: MI355X_MICROARCH.md, cycle constants)
-    mfma_busy_cycles=4.55551e8,           # SQ_VALU_MFMA_BUSY_CYCLES (cycles)
-    coexec_cycles=3.10844e7,               # SQ_VALU_MFMA_COEXEC_CYCLES: both at once, counted once below
-    any_active_quadcycles=4.63214e8,       # SQ_ACTIVE_INST_ANY
-    wave_quadcycles=1.22789e9,            # SQ_WAVE_CYCLES
-    wait_inst_quadcycles=3.13269e8, wait_any_quadcycles=4.51412e8,
-    gui_active_cycles_all_xcd=2.1999e7,   # GRBM_GUI_ACTIVE (sum over the 8 XCDs)
-    fetch_kb=43256.6, write_kb=138634.0, # FETCH_SIZE (x 2 on gfx950, MI355X_MICROARCH.md section HBM), WRITE_SIZE
-    l2_hit=8.55128e7, l2_miss=1.68975e6)
+    valu_active_quadcycles=3.10033e8,      # SQ_ACTIVE_INST_VALU (counts quad-cycles: MI355X_MICROARCH.md, cycle constants)
+    mfma_busy_cycles=4.46647e8,           # SQ_VALU_MFMA_BUSY_CYCLES (cycles)
+    coexec_cycles=3.04148e7,               # SQ_VALU_MFMA_COEXEC_CYCLES: both at once, counted once below
+    any_active_quadcycles=4.57153e8,       # SQ_ACTIVE_INST_ANY
+    wave_quadcycles=1.15722e9,            # SQ_WAVE_CYCLES
+    wait_inst_quadcycles=3.11039e8, wait_any_quadcycles=3.89028e8,
+    gui_active_cycles_all_xcd=2.13752e7,   # GRBM_GUI_ACTIVE (sum over the 8 XCDs)
+    fetch_kb=32560.0, write_kb=139043.0, # FETCH_SIZE (x 2 on gfx950, MI355X_MICROARCH.md section HBM), WRITE_SIZE
+    l2_hit=8.32901e7, l2_miss=1.47357e6)
 N_SIMD = 256 * 4
 CLOCK_PEAK_GHZ = 2.4                      # MI355X_MICROARCH.md: max clock
 
