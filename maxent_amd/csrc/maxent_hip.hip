@@ -63,7 +63,7 @@ struct mxe_ctx {
     int n_chain = 0, n_alpha = 0;
     std::vector<int> chain_elem;      // per parent chain
     std::vector<int> sub_elem, sub_prob0, sub_len, sub_v0, wg_chains;   // per launched (sub-)chain
-    int n_sub = 0, n_wg = 0, mc_na = 0, mc_wgpc = 1, wgpc_auto = 2, n_queue = 0;
+    int n_sub = 0, n_wg = 0, mc_na = 0, mc_wgpc = 1, wgpc_auto = 2, n_queue = 0, n_solo = 0;
     std::vector<int> queue;
     std::vector<int> sub_pre;                                           // leading alpha of a piece: entries before its first alpha (0: none)
     bool has_pre = false;
@@ -617,7 +617,7 @@ try {
         ctx->sub_pre.assign(w, 0); ctx->has_pre = false;
         ctx->n_sub = (int)w;
     }
-    ctx->wg_chains.clear(); ctx->queue.clear(); ctx->n_queue = 0;
+    ctx->wg_chains.clear(); ctx->queue.clear(); ctx->n_queue = 0; ctx->n_solo = 0;
     if (layout == 4) {
         bool one_ds = true;
         for (int sc = 1; sc < ctx->n_sub; ++sc)
@@ -641,6 +641,19 @@ try {
             HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
             const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
             ctx->n_wg = std::min((ctx->n_sub + 3) / 4, n_cu * ctx->mc_wgpc);
+            // The launch ends with its longest pieces: the last pieces of the normal-entropy scans (the most expensive
+            // cold start, the most evaluations per alpha).  They are at the head of the queue; with two workgroups per
+            // CU, the workgroups that take them get a CU to themselves -- workgroups b and b + n_wg / 2 share one
+            // (tools/wg_placement.hip), the partners leave at once --, where a round takes 47 k instead of 69 k cycles
+            // (cfg4, 16 such pieces in four workgroups: kernel 1.150 -> 1.123 ms; 16 workgroups 1.130, 64: 1.21).
+            // The library's own schedule only.
+            if (o.alpha_split == 0 && ctx->mc_wgpc == 2 && ctx->n_wg == 2 * n_cu) {
+                int n_tail = 0;
+                for (int sc = 0; sc < ctx->n_sub; ++sc)
+                    if (ctx->elem_kind[ctx->sub_elem[sc]] == MXE_ENTROPY_NORMAL &&
+                        ctx->sub_prob0[sc] + ctx->sub_len[sc] == (ctx->sub_v0[sc] + 1) * n_alpha) ++n_tail;
+                ctx->n_solo = std::min((n_tail + 3) / 4, n_cu / 32);
+            }
         } else {
             // static layout: group by data set, four per workgroup, -1 pads
             std::vector<std::vector<int>> by_ds(ctx->ds.size());
@@ -736,25 +749,9 @@ try {
         ex.stagger = 5;
         ex.n_solo = 0;
         int counter0 = 0;
-        const bool o_launch_solo = ctx->opts.alpha_split == 0;      // the library's own schedule only
-        if (ex.n_queue > 0 && WGPC == 2) {
-            hipDeviceProp_t prop_s;
-            HIPCHK(ctx, hipGetDeviceProperties(&prop_s, ctx->device));
-            // The launch ends with its longest pieces: the last pieces of the normal-entropy scans (the most expensive
-            // cold start, the most evaluations per alpha).  They are at the head of the queue; the workgroups that take
-            // them get a CU to themselves, where a round takes 47 k instead of 69 k cycles (cfg4, 16 such pieces in
-            // four workgroups: kernel 1.150 -> 1.123 ms; 16 workgroups 1.130, 64: 1.21)
-            int n_tail = 0;
-            for (int sc = 0; sc < ctx->n_sub; ++sc) {
-                const int c = ctx->sub_v0[sc];
-                if (ctx->elem_kind[ctx->sub_elem[sc]] == MXE_ENTROPY_NORMAL &&
-                    ctx->sub_prob0[sc] + ctx->sub_len[sc] == (c + 1) * ctx->n_alpha) ++n_tail;
-            }
-            const int want_solo = std::min((n_tail + 3) / 4, prop_s.multiProcessorCount / 32);
-            if (o_launch_solo && want_solo > 0 && ctx->n_wg == 2 * prop_s.multiProcessorCount) {
-                ex.n_solo = want_solo;
-                counter0 = (ctx->n_wg - ex.n_solo) * 4;
-            }
+        if (ex.n_queue > 0 && WGPC == 2 && ctx->n_solo > 0) {
+            ex.n_solo = ctx->n_solo;
+            counter0 = (ctx->n_wg - ex.n_solo) * 4;
         }
         HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->dcounter.p, counter0, 1, ctx->stream));
         ctx->last_nw = NWV; ctx->last_lds = (int)lds;
