@@ -1,0 +1,45 @@
+"""Random shapes, alpha meshes (descending and ascending) and matrix sizes through the DEFAULT schedule -- pieces
+counted by entropy kind, led / joined tail pieces, workgroups alone on their CU -- checked with the device audit:
+the exact Newton correction at the returned v of EVERY problem (mxe_audit).  tools/stress.py is the long version."""
+import numpy as np
+import pytest
+
+import maxent_amd as mx
+from maxent_amd import device, synthetic, hostprep
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('seed', [3, 11, 29])
+def test_default_schedule_on_random_batches(seed):
+    rng = np.random.RandomState(seed)
+    for _ in range(4):
+        n_orb = int(rng.choice([1, 3, 6, 12, 16]))
+        n_tau = int(rng.choice([40, 100, 200]))
+        n_omega = int(rng.choice([60, 100, 257, 500]))
+        n_alpha = int(rng.choice([3, 8, 20, 50, 100, 150]))
+        lo, hi = 10.0 ** rng.uniform(-2, 0), 10.0 ** rng.uniform(2, 5)
+        ascending = rng.rand() < 0.25
+        tau, omega, K, Gmat, _ = synthetic.matrix_G(n_orb, n_tau, n_omega, seed=int(rng.randint(1 << 30)))
+        K.reduce_singular_space(1e-14)
+        D = synthetic.flat_D(omega)
+        err = synthetic.SIGMA * np.ones(n_tau)
+        alphas = np.array(mx.LogAlphaMesh(alpha_min=lo, alpha_max=hi, n_points=n_alpha)) * n_tau
+        if ascending:
+            alphas = alphas[::-1].copy()
+        elems = [(i, j) for i in range(n_orb) for j in range(n_orb)]
+        kinds = [device.ENTROPY_NORMAL if i == j else device.ENTROPY_PLUSMINUS for i, j in elems]
+        v0 = np.stack([hostprep.initial_v(K.V, D, omega.delta, k) for k in kinds])
+        ctx = device.DeviceContext(K.U, K.S, K.V)
+        ds = ctx.add_dataset(err)
+        n = len(elems)
+        ctx.set_elements([ds] * n, [Gmat[i, j] for i, j in elems], np.tile(D, (n, 1)), kinds)
+        out = ctx.solve_chains(np.arange(n), alphas, v0, want_v=False)
+        what = (n_orb, n_tau, n_omega, n_alpha, lo, hi, ascending, ctx.last_launch_info()['kernel'])
+        audit = ctx.audit()
+        ctx.close()
+        assert out['converged'].all(), what
+        assert np.all(np.isfinite(out['H'])), what
+        assert audit['corr'].max() < 1e-6, (what, audit['corr'].max())
+        if n_alpha >= 50:          # (steps of decades in alpha -- three alphas over five decades -- take hundreds of iterations)
+            assert out['n_evals'].max() < 400, (what, out['n_evals'].max())
