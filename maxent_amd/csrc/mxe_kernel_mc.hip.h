@@ -225,7 +225,11 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long prof_t = clock64();
     long long prof_rounds = 0;
-#ifdef MXE_PROFILE_HOME          // split the home phase instead: everything else goes to slot 5
+#if defined(MXE_PROFILE_ACCEPT)   // split the accept step: everything else goes to slot 5
+#define MXE_STAMPW(idx) do { const long long t__ = clock64(); prof_acc[5] += t__ - prof_t; prof_t = t__; } while (0)
+#define MXE_STAMPH(idx) do {} while (0)
+#define MXE_STAMPA(idx) do { const long long t__ = clock64(); prof_acc[idx] += t__ - prof_t; prof_t = t__; } while (0)
+#elif defined(MXE_PROFILE_HOME)  // split the home phase instead: everything else goes to slot 5
 #define MXE_STAMPW(idx) do { const long long t__ = clock64(); prof_acc[(idx) == 2 ? 2 : 5] += t__ - prof_t; prof_t = t__; } while (0)
 #define MXE_STAMPH(idx) do { const long long t__ = clock64(); prof_acc[idx] += t__ - prof_t; prof_t = t__; } while (0)
 #else
@@ -235,6 +239,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 #else
 #define MXE_STAMPW(idx) do {} while (0)
 #define MXE_STAMPH(idx) do {} while (0)
+#endif
+#ifndef MXE_STAMPA
+#define MXE_STAMPA(idx) do {} while (0)
 #endif
 
     // ------------------------------------------------------------------
@@ -735,6 +742,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         // ---- 4. home wave: rho, sums, accept / converge / advance, results ----
         if (wave < MCC) {
             const int q = wave, k = lane;
+            MXE_STAMPA(5);
             double h = 0.0;
 #pragma unroll
             for (int wv = 0; wv < HPW; ++wv) h += hpart[(wv * MCC + q) * NP + k];
@@ -747,8 +755,10 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 sHn += red[wv * 32 + q * 8 + 2]; swm = fmax(swm, red[wv * 32 + q * 8 + 3]);
                 sdu = fmax(sdu, red[wv * 32 + q * 8 + 4]);
             }
+            MXE_STAMPA(0);
             Slot t;
             load_slot(t);
+            MXE_STAMPA(1);
             if (t.active) {
                 rho[q * NP + k] = r;
                 const double chi2t = r2 + t.cperp, St = sS;
@@ -817,6 +827,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     else if (p.tol_relq > 0.0 && fabs(fabs(t.Qprev - t.Q) / t.Q) < p.tol_relq && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                     else if (t.niter >= p.maxiter) finish_alpha = true;
                 }
+                MXE_STAMPA(2);
                 if (finish_alpha) {
                     // (the leading alpha of a piece, number -1, writes its record where the piece's first alpha will
                     //  write its own over it -- no branch; where it fails, the first alpha starts from the state it
@@ -835,6 +846,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         p.out_niter[prob] = t.niter; p.out_conv[prob] = conv;
                         p.out_nevals[prob] = t.nevals; p.out_nact[prob] = t.nact;
                     }
+                    MXE_STAMPA(3);
                     {
                         // defect of this alpha's first Newton iterate -> predictor of the next alpha, scaled
                         // with the square of the ratio of the steps in log alpha
@@ -868,7 +880,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         t.Q = 0.5 * t.chi2 - t.alpha * t.S;
                     }
                 }
+                MXE_STAMPA(4);
                 store_slot(t);
+                MXE_STAMPA(6);
             }
         }
         // No barrier here: steps 4 and 1 are ONE serial section of the home wave.  Everything step 1 reads

@@ -28,6 +28,7 @@ ap.add_argument('--split', type=int, default=1)
 ap.add_argument('--n-omega', type=int, default=500)
 ap.add_argument('--wgpc', type=int, default=0)
 ap.add_argument('--home', action='store_true', help='library built with -DMXE_PROFILE_HOME: split the home phase')
+ap.add_argument('--accept', action='store_true', help='library built with -DMXE_PROFILE_ACCEPT: split the accept step')
 args = ap.parse_args()
 batch = bench.build_batch(args.n_orb, 200, args.n_omega, 100, 0)
 ctx = bench.stage(batch, 0)
@@ -53,7 +54,10 @@ if args.layout == 4:
     rounds = pw[:, 0, 7].astype(float)
     names = ['row:matvec', 'fused:loop', 'home', 'row:exp+sums', 'fused:accum', 'accept', 'fused:shuffle', 'row:barrier']
     order = (2, 0, 3, 7, 1, 6, 4, 5)
-    if args.home:
+    if args.accept:
+        names = ['acc:h+rho+sums', 'acc:load slot', 'acc:decide', 'acc:outputs', 'acc:predictor+next', 'everything else', 'acc:store slot', 'row:barrier']
+        order = (0, 1, 2, 3, 4, 6, 5)
+    elif args.home:
         names = ['home:refill+rhs', 'home:load A', 'home:barrier', 'home:factor', 'home:solve', 'all passes', '#factorisations', 'row:barrier']
         order = (0, 1, 3, 4, 6, 2, 5)
     print('workgroups %d, rounds per workgroup: mean %.1f (min %d, median %d, max %d)' %
