@@ -193,6 +193,9 @@ def kat_tau_maxent():
                         n_iter_ref=np.array(its), converged_ref=np.array(conv),
                         v_ref=np.array(vs), H_truth=Htruth,
                         probability_ref=np.array(res.probability), probability_kat=np.array(kat),
+                        bryan_A_out=np.array(res.analyzer_results['BryanAnalyzer']['A_out']),
+                        classic_A_out=np.array(res.analyzer_results['ClassicAnalyzer']['A_out']),
+                        classic_alpha_index=int(res.analyzer_results['ClassicAnalyzer']['alpha_index']),
                         G_clean_file=np.loadtxt(os.path.join(TESTDATA, 'g_tau_semicircular.dat')))
 
 

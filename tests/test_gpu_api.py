@@ -108,8 +108,12 @@ def test_known_answer_log_probability():
     assert rel_l2(res.H, g['H_truth']).max() < GATE
     np.testing.assert_almost_equal(res.probability, g['probability_kat'], 4)
     np.testing.assert_allclose(res.probability, g['probability_ref'], rtol=1e-7)
-    assert 'BryanAnalyzer' in res.analyzer_results
-    assert 'alpha_index' in res.analyzer_results['ClassicAnalyzer']
+    # the probability-weighted analyzers (reference analyzers/bryan_analyzer.py:106-154, classic_analyzer.py:50-82)
+    # give the reference's own spectra
+    ar = res.analyzer_results
+    assert ar['ClassicAnalyzer']['alpha_index'] == int(g['classic_alpha_index'])
+    assert rel_l2(ar['ClassicAnalyzer']['A_out'], g['classic_A_out']) < REF_SPREAD
+    assert rel_l2(ar['BryanAnalyzer']['A_out'], g['bryan_A_out']) < REF_SPREAD
 
 
 def test_srvo3_bryan_matches_alps():
