@@ -82,3 +82,32 @@ def test_default_models_follow_the_reference_assertions():
     assert len(D5.D) == len(w)                          # nothing changes before parameter_change()
     D5.parameter_change()
     assert len(D5.D) == 2 and abs(np.sum(D5.D) - 20.0) < 1.e-13
+
+
+def test_tau_kernel_follows_the_reference_assertions():
+    # reference test/python/tau_kernel.py:26-85
+    def old_kernel(tau, omega, beta):
+        oomega, ttau = np.meshgrid(omega, tau)
+        K = np.empty(oomega.shape)
+        L = oomega >= 0.0
+        iL, nL = np.where(L), np.where(np.logical_not(L))
+        K[iL] = -np.exp(-oomega[iL] * ttau[iL]) / (np.exp(-beta * oomega[iL]) + 1.0)
+        K[nL] = -np.exp(oomega[nL] * (beta - ttau[nL])) / (1.0 + np.exp(beta * oomega[nL]))
+        return K
+    rng = np.random.RandomState(12)
+    tau = 10 * rng.rand(10)
+    omega = mx.DataOmegaMesh(rng.rand(20))
+    beta = 10.0
+    K1 = mx.TauKernel(tau=tau, omega=omega, beta=beta)
+    K2 = old_kernel(tau, np.asarray(omega), beta)
+    assert np.max(np.abs(K1.K - K2)) < 1.e-15
+    assert np.max(np.abs(K1.K - np.dot(K1.U, np.dot(np.diag(K1.S), K1.V.transpose())))) < 1.e-13
+    L1 = len(K1.S)
+    K1.reduce_singular_space(np.median(K1.S))
+    assert len(K1.S) == L1 // 2
+    K3 = mx.TauKernel(tau=tau, omega=omega, beta=beta)
+    K3.omega = omega[::2]
+    assert np.max(np.abs(K2 - K3.K)) < 1.e-15            # nothing changes before parameter_change()
+    K3.parameter_change()
+    assert K3.K.shape == (10, 10)
+    assert np.max(np.abs(K3.K - old_kernel(tau, np.asarray(omega)[::2], beta))) < 1.e-15
