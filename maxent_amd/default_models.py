@@ -1,31 +1,33 @@
 """Default models.  ``model.D`` is the density times delta-omega, the quantity
 the entropy is written in (reference python/default_models.py:26-115; public
-names and constructor arguments as there).  A model is its density function;
-the product with the mesh weights is formed on demand and dropped by
-``parameter_change``.
+names and constructor arguments as there).
 """
 
 import numpy as np
 
 
 class BaseDefaultModel(object):
+    """``D`` is tabulated by ``_fill_values`` -- on first use and on ``parameter_change()`` -- and kept in
+    between, also across a new ``omega`` (the reference's protocol, test/python/default_models.py:56-60).  A
+    model is written either as a ``density(omega)`` or, like in the reference (doc/guide/customization.rst),
+    by overriding ``_fill_values`` to set ``self._D``."""
+
     def __init__(self, omega):
         self.omega = omega
 
     def density(self, omega):
         raise NotImplementedError('Use a subclass of BaseDefaultModel')
 
-    def parameter_change(self):
-        self.__dict__.pop('_D', None)
+    def _fill_values(self):
+        self._D = np.asarray(self.density(self.omega), dtype=float) * self.omega.delta
 
-    _fill_values = parameter_change
+    def parameter_change(self):
+        self._fill_values()
 
     @property
     def D(self):
-        # (tabulated on first use and kept until parameter_change(), also across a new ``omega``: the
-        #  reference's protocol, test/python/default_models.py:56-60)
         if '_D' not in self.__dict__:
-            self._D = np.asarray(self.density(self.omega), dtype=float) * self.omega.delta
+            self._fill_values()
         return self._D
 
     def __len__(self):

@@ -111,3 +111,45 @@ def test_tau_kernel_follows_the_reference_assertions():
     K3.parameter_change()
     assert K3.K.shape == (10, 10)
     assert np.max(np.abs(K3.K - old_kernel(tau, np.asarray(omega)[::2], beta))) < 1.e-15
+
+
+def test_user_written_mesh_and_default_model_as_in_the_customization_guide():
+    """reference doc/guide/customization.rst: a mesh class with its own __init__ on top of BaseOmegaMesh, a default
+    model that fills ``_D`` in ``_fill_values``, both handed to TauMaxEnt"""
+    import pickle
+    from maxent_amd.omega_meshes import BaseOmegaMesh
+    from maxent_amd.default_models import BaseDefaultModel
+
+    class MyLogOmegaMesh(BaseOmegaMesh):
+        def __init__(self, order_min=-5, order_max=1, n_points=100):
+            super(MyLogOmegaMesh, self).__init__(omega_min=-10 ** order_max, omega_max=10 ** order_max, n_points=n_points)
+            if n_points % 2 != 0:
+                raise Exception('MyLogOmegaMesh needs an even number of n_points.')
+            mesh_p = -np.logspace(order_min, order_max, n_points // 2)
+            self[:] = np.append(mesh_p[::-1], -mesh_p)
+
+    class MyGaussianDefaultModel(BaseDefaultModel):
+        def __init__(self, omega, sigma=0.5):
+            super(MyGaussianDefaultModel, self).__init__(omega)
+            self.sigma = sigma
+            self._fill_values()
+
+        def _fill_values(self):
+            self._D = 1.0 / np.sqrt(2.0 * np.pi * self.sigma ** 2) * np.exp(-self.omega ** 2 / (2.0 * self.sigma ** 2))
+
+    m = MyLogOmegaMesh(order_max=1, n_points=400)
+    assert m.shape == (400,) and m[0] == -10.0 and m[-1] == 10.0 and (m.omega_min, m.omega_max, m.n_points) == (-10, 10, 400)
+    assert np.all(np.diff(np.asarray(m)) > 0) and m.delta.shape == (400,)
+    assert isinstance(m[::2], MyLogOmegaMesh) and m[::2].omega_max == 10
+    back = pickle.loads(pickle.dumps(m))
+    assert np.array_equal(back, m) and back.n_points == 400
+    with pytest.raises(Exception):
+        MyLogOmegaMesh(n_points=3)
+    tm = mx.TauMaxEnt()
+    tm.omega = m
+    tm.D = MyGaussianDefaultModel(tm.omega)
+    assert tm.D.D.shape == (400,) and tm.maxent_loop.D is tm.D
+    tm.D.sigma = 1.0
+    before = tm.D.D.copy()
+    tm.D.parameter_change()
+    assert not np.array_equal(before, tm.D.D)
