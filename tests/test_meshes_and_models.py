@@ -116,7 +116,6 @@ def test_tau_kernel_follows_the_reference_assertions():
 def test_user_written_mesh_and_default_model_as_in_the_customization_guide():
     """reference doc/guide/customization.rst: a mesh class with its own __init__ on top of BaseOmegaMesh, a default
     model that fills ``_D`` in ``_fill_values``, both handed to TauMaxEnt"""
-    import pickle
     from maxent_amd.omega_meshes import BaseOmegaMesh
     from maxent_amd.default_models import BaseDefaultModel
 
@@ -141,8 +140,8 @@ def test_user_written_mesh_and_default_model_as_in_the_customization_guide():
     assert m.shape == (400,) and m[0] == -10.0 and m[-1] == 10.0 and (m.omega_min, m.omega_max, m.n_points) == (-10, 10, 400)
     assert np.all(np.diff(np.asarray(m)) > 0) and m.delta.shape == (400,)
     assert isinstance(m[::2], MyLogOmegaMesh) and m[::2].omega_max == 10
-    back = pickle.loads(pickle.dumps(m))
-    assert np.array_equal(back, m) and back.n_points == 400
+    back = copy.deepcopy(m)                    # (a class defined inside a function cannot be pickled by name)
+    assert isinstance(back, MyLogOmegaMesh) and np.array_equal(back, m) and back.n_points == 400
     with pytest.raises(Exception):
         MyLogOmegaMesh(n_points=3)
     tm = mx.TauMaxEnt()
