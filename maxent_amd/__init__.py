@@ -36,5 +36,7 @@ from .tau_maxent import TauMaxEnt                   # noqa: F401
 from .elementwise_maxent import (ElementwiseMaxEnt, DiagonalMaxEnt,   # noqa: F401
                                  PoormanMaxEnt)
 from .device import MaxEntDeviceError, device_count  # noqa: F401
+from . import _layout as _layout        # the reference's sub-module paths (analyzers.linefit_analyzer, ...)
+_layout.register(__name__)
 
 __version__ = '0.1.0'

@@ -464,3 +464,22 @@ def test_elementwise_inputs_from_files_and_arrays(tmp_path):
     check()
     em.set_G_tau_data(tau, np.array([[G_elems[i, j] for j in range(2)] for i in range(2)]))
     check()
+
+
+def test_the_reference_import_paths_exist():
+    """scripts written against the reference import from its sub-packages (doc/guide/preblur_example.py,
+    test/python/*.py); the same paths under this package give the same objects"""
+    from maxent_amd.analyzers.linefit_analyzer import fit_piecewise, LineFitAnalyzer
+    from maxent_amd.analyzers.chi2_curvature_analyzer import curv, Chi2CurvatureAnalyzer
+    from maxent_amd.analyzers.analyzer import Analyzer, AnalyzerResult
+    from maxent_amd.cost_functions.maxent_cost_function import MaxEntCostFunction
+    from maxent_amd.cost_functions.bryan_cost_function import BryanCostFunction
+    from maxent_amd.minimizers.levenberg_minimizer import LevenbergMinimizer
+    from maxent_amd.minimizers.convergence_methods import MaxDerivativeConvergenceMethod
+    from maxent_amd.triqs_support import if_no_triqs, if_triqs_1, if_triqs_2, assert_text_files_equal
+    assert LineFitAnalyzer is mx.LineFitAnalyzer and Chi2CurvatureAnalyzer is mx.Chi2CurvatureAnalyzer
+    assert MaxEntCostFunction is mx.MaxEntCostFunction and BryanCostFunction is mx.BryanCostFunction
+    assert LevenbergMinimizer is mx.LevenbergMinimizer and Analyzer is mx.Analyzer and AnalyzerResult is mx.AnalyzerResult
+    assert MaxDerivativeConvergenceMethod is mx.MaxDerivativeConvergenceMethod
+    assert if_no_triqs() and not if_triqs_1() and not if_triqs_2()
+    assert callable(fit_piecewise) and callable(curv) and callable(assert_text_files_equal)
