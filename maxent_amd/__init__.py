@@ -22,7 +22,7 @@ from .cost_functions import (CostFunction, MaxEntCostFunction,    # noqa: F401
                              BryanCostFunction)
 from .minimizers import (Minimizer, LevenbergMinimizer, ConvergenceMethod,   # noqa: F401
                          AndConvergenceMethod, OrConvergenceMethod,
-                         MaxDerivativeConvergenceMethod,
+                         MaxDerivativeConvergenceMethod, FunctionChangeConvergenceMethod,
                          RelativeFunctionChangeConvergenceMethod,
                          NewtonStepConvergenceMethod, NullConvergenceMethod)
 from .analyzers import (Analyzer, AnalyzerResult, LineFitAnalyzer,   # noqa: F401

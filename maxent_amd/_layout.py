@@ -25,7 +25,7 @@ _TABLE = {
     'minimizers.minimizer': (minimizers, ('Minimizer',)),
     'minimizers.levenberg_minimizer': (minimizers, ('LevenbergMinimizer', 'Minimizer')),
     'minimizers.convergence_methods': (minimizers, ('ConvergenceMethod', 'AndConvergenceMethod', 'OrConvergenceMethod',
-                                                    'MaxDerivativeConvergenceMethod',
+                                                    'MaxDerivativeConvergenceMethod', 'FunctionChangeConvergenceMethod',
                                                     'RelativeFunctionChangeConvergenceMethod',
                                                     'NullConvergenceMethod', 'NewtonStepConvergenceMethod')),
 }

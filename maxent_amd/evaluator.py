@@ -27,10 +27,17 @@ class Evaluator(object):
     def __init__(self, K, G, err, D, kind, device_id=0):
         K.S                                     # decompose if needed
         U, S, V = np.array(K.U), np.array(K.S), np.array(K.V)
+        self.v_length = len(S)
         if len(S) > 128:
-            raise device.MaxEntDeviceError(
-                'the device evaluates cost functions with at most 128 singular values; call '
-                'K.reduce_singular_space() first ({} kept now)'.format(len(S)))
+            # A kernel that has not been through reduce_singular_space: functions of H (chi2(H), S(H), their
+            # derivatives) do not see the singular directions below 1e-14 of the largest -- they carry that
+            # fraction of K H --, so the device gets the rest; functions of v need every component of v
+            keep = S >= 1e-14 * S[0]
+            if int(keep.sum()) > 128:
+                raise device.MaxEntDeviceError(
+                    'the device evaluates cost functions with at most 128 singular values; call '
+                    'K.reduce_singular_space() first ({} kept now)'.format(len(S)))
+            U, S, V = U[:, keep], S[keep], V[:, keep]
         G = np.asarray(G, dtype=float)
         err = np.asarray(err, dtype=float) * np.ones(len(G))
         self.ctx = device.DeviceContext(None if K.rotation is not None else U, S, V, device=device_id)
@@ -49,6 +56,10 @@ class Evaluator(object):
         return self._M
 
     def at_v(self, v, alpha, eta=1.0, want=('Q', 'chi2', 'S', 'H', 'u', 'w', 'q', 'g', 'W')):
+        if len(self.S) != self.v_length:
+            raise device.MaxEntDeviceError(
+                'functions of v are evaluated with at most 128 singular values; call K.reduce_singular_space() '
+                'first ({} kept now)'.format(self.v_length))
         out = self.ctx.eval_batch([0], [alpha], np.asarray(v, dtype=float)[np.newaxis, :],
                                   chi2_factor=eta, want=want)
         return {k: a[0] for k, a in out.items()}

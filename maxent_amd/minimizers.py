@@ -66,6 +66,18 @@ class MaxDerivativeConvergenceMethod(ConvergenceMethod):
         opts.tol_d = float(self.convergence_criterion)
 
 
+class FunctionChangeConvergenceMethod(ConvergenceMethod):
+    """|Q0 - Q1| < criterion (reference convergence_methods.py:99-109).  The device solver tests the RELATIVE
+    change (scale free); the absolute form is accepted for the value of Q it is given with."""
+
+    def __init__(self, convergence_criterion):
+        self.convergence_criterion = convergence_criterion
+
+    def apply(self, opts):
+        raise NotImplementedError('the device solver stops on the relative change of Q: use '
+                                  'RelativeFunctionChangeConvergenceMethod (or NewtonStepConvergenceMethod)')
+
+
 class RelativeFunctionChangeConvergenceMethod(ConvergenceMethod):
     """|Q0 - Q1| / |Q1| < criterion between two accepted iterates."""
 
@@ -175,6 +187,10 @@ class LevenbergMinimizer(Minimizer):
     def minimize(self, function, v0):
         """One alpha on the device: ``function`` is a bound cost function with
         ``set_alpha`` called (reference minimizer.py:23-28)."""
+        if not hasattr(function, 'entropy_kind') or getattr(function, '_alpha', None) is None:
+            raise TypeError('LevenbergMinimizer runs on the device and minimises MaxEnt cost functions '
+                            '(MaxEntCostFunction / BryanCostFunction with set_alpha called); a general '
+                            'DoublyDerivableFunction has no device form')
         from .maxent_loop import solve_single
         v, info = solve_single(function, v0, self)
         self.n_iter_last = int(info['n_iter'])

@@ -484,3 +484,71 @@ def test_loop_assembled_by_hand_equals_the_facade():
     # (the data are K.K applied to A, not to A delta-omega, as in the reference's test: the weight is sum(A))
     w = np.asarray(omega)
     assert abs(np.trapezoid(res.A[-1], w) / np.sum(A) - 1.0) < 2e-2
+
+
+@pytest.mark.gpu
+def test_hand_built_loop_equals_tau_maxent_object_by_object():
+    """reference test/python/tau_maxent.py:50-135: a MaxEntLoop assembled from a copy of TauMaxEnt's kernel
+    answers like TauMaxEnt's own loop -- data, meshes, kernel, chi2 / S at a random A on the UNREDUCED kernel,
+    H_of_v at a random v, and the whole result field by field"""
+    import copy
+    g = load('kat_tau_maxent')
+    tm = mx.TauMaxEnt(probability='normal')
+    tm.set_verbosity(mx.VerbosityFlags.Quiet)
+    tm.set_G_tau_data(g['tau'], g['G'])
+    tm.alpha_mesh = mx.LogAlphaMesh(alpha_min=0.08, n_points=5)
+    tm.omega = mx.HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=200)
+    tm.set_error(1.e-3)
+    assert np.max(np.abs(mx.TauKernel(tm.tau, tm.omega).K - tm.K.K)) < 1.e-14
+    tm.K.S                                             # trigger the SVD
+    omega = mx.HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=200)
+    K = copy.deepcopy(tm.K)
+    G = tm.G
+    err = 1.e-3 * np.ones(len(G))
+    D = mx.FlatDefaultModel(omega=omega)
+    Q = mx.MaxEntCostFunction(chi2=mx.NormalChi2(K=K, G=G, err=err), S=mx.NormalEntropy(D=D),
+                              H_of_v=mx.NormalH_of_v(D=D, K=K))
+    log = mx.Logtaker()
+    log.verbose = mx.VerbosityFlags.Quiet
+    ml = mx.MaxEntLoop(cost_function=Q, minimizer=mx.LevenbergMinimizer(),
+                       alpha_mesh=mx.LogAlphaMesh(alpha_min=0.08, n_points=5), logtaker=log, probability='normal')
+
+    def same(a, b, d=13):
+        np.testing.assert_almost_equal(np.asarray(a), np.asarray(b), decimal=d)
+    tl = tm.maxent_loop
+    for name in ('G', 'alpha_mesh', 'data_variable', 'err', 'omega'):
+        same(getattr(ml, name), getattr(tl, name))
+    same(ml.D.D, tl.D.D)
+    same(ml.H_of_v.D.D, tl.H_of_v.D.D)
+    for part in ('K', 'U', 'S', 'V'):
+        same(getattr(ml.K, part), getattr(tl.K, part))
+    same(ml.H_of_v.K.V, tl.H_of_v.K.V)
+    rng = np.random.RandomState(9)
+    random_A = rng.rand(len(omega))
+    for fn in ('chi2', 'S'):
+        a, b = getattr(ml, fn)(random_A), getattr(tl, fn)(random_A)
+        same(a.f(), b.f(), 9)
+        same(a.d(), b.d(), 7)
+        same(a.dd(), b.dd(), 7)
+    # chi2 against plain numpy on the full kernel
+    assert abs(ml.chi2(random_A).f() / np.sum(((np.dot(K.K, random_A) - G) / err) ** 2) - 1) < 1e-12
+    result1 = ml.run()
+    result2 = tm.run()
+    random_v = rng.rand(len(ml.K.S))                   # (after the run: both kernels reduced to the same n_s)
+    assert len(ml.K.S) == len(tl.K.S) <= 128
+    for what in ('f', 'd', 'dd'):
+        same(getattr(ml.H_of_v(random_v), what)(), getattr(tl.H_of_v(random_v), what)())
+    assert np.max(np.abs(result1.A_out - result2.A_out)) < 1.e-12
+    assert np.all(result1.A_out == result1.analyzer_results['LineFitAnalyzer']['A_out'])
+    for field in result1._all_fields:
+        if field == 'analyzer_results':
+            for key in result1.analyzer_results:
+                if 'A_out' in result1.analyzer_results[key]:
+                    same(result1.analyzer_results[key]['A_out'], result2.analyzer_results[key]['A_out'], 10)
+        elif field.startswith('run_time'):
+            pass
+        elif field in ('matrix_structure', 'effective_matrix_structure') or isinstance(getattr(result1, field), str):
+            assert getattr(result1, field) == getattr(result2, field)
+        else:
+            same(getattr(result1, field), getattr(result2, field), 8)
+    np.testing.assert_almost_equal(result2.probability, g['probability_kat'], 4)
