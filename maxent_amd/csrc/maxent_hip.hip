@@ -88,6 +88,8 @@ struct mxe_ctx {
     // mxe_eval_batch / mxe_audit scratch
     DevBuf<double> ev_x, ev_alpha, ev_scal, ev_vecw, ev_vecs, ev_mat;
     DevBuf<int> ev_elem;
+    DevBuf<double> rows_out;        // mxe_fetch_rows: the selected rows, gathered on the device
+    DevBuf<int> rows_idx;
     double chi2_factor = 1.0;     // of the staged chains (mxe_opts.chi2_factor)
     struct mxe_comm_state* comm = nullptr;      // gather between GPUs (mxe_comm_*)
     std::string hip_err;
@@ -359,6 +361,7 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
     ctx->dchain_elem.release(); ctx->dsub_prob0.release(); ctx->dsub_len.release(); ctx->dsub_v0.release(); ctx->dwg_chains.release(); ctx->dqueue.release(); ctx->dcounter.release(); ctx->dsub_pre.release(); ctx->dout_v.release(); ctx->dout_pack.release(); ctx->dout_pack2.release();
     ctx->dout_niter.release(); ctx->dout_conv.release(); ctx->dout_nevals.release(); ctx->dout_nact.release();
     ctx->dB.release(); ctx->dA.release(); ctx->dprof.release();
+    ctx->rows_out.release(); ctx->rows_idx.release();
     ctx->ev_x.release(); ctx->ev_alpha.release(); ctx->ev_scal.release(); ctx->ev_vecw.release(); ctx->ev_vecs.release();
     ctx->ev_mat.release(); ctx->ev_elem.release();
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -1350,19 +1353,35 @@ try {
 }
 MXE_CATCH_ALL
 
+namespace {
+// one workgroup per requested row: out[r][:] = H[idx[r]][:]
+__global__ __launch_bounds__(256)
+void rows_gather_kernel(const double* __restrict__ H, const int* __restrict__ idx, int n_omega, double* __restrict__ out)
+{
+    const double* src = H + (size_t)idx[blockIdx.x] * n_omega;
+    double* dst = out + (size_t)blockIdx.x * n_omega;
+    for (int i = threadIdx.x; i < n_omega; i += 256) dst[i] = src[i];
+}
+}  // namespace
+
 extern "C" int mxe_fetch_rows(mxe_ctx* ctx, int n_rows, const int32_t* problem_index, double* out_H)
 try {
     if (!ctx || n_rows < 1 || !problem_index || !out_H) return MXE_ERR_ARG;
     if (!ctx->launched) return MXE_ERR_STATE;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t P = (size_t)ctx->n_chain * ctx->n_alpha, nw = ctx->n_omega;
-    HIPCHK(ctx, stream_wait(ctx->stream));
-    for (int r = 0; r < n_rows; ++r) {
+    for (int r = 0; r < n_rows; ++r)
         if (problem_index[r] < 0 || (size_t)problem_index[r] >= P) return MXE_ERR_ARG;
-        HIPCHK(ctx, hipMemcpyAsync(out_H + (size_t)r * nw, ctx->dout_H.p + (size_t)problem_index[r] * nw, nw * 8,
-                                   hipMemcpyDeviceToHost, ctx->stream));
-    }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // the rows are collected on the device and come over in ONE copy (a copy per row cost 7 us each: 5 ms for the
+    // 768 rows the analyzers of a 16 x 16 job pick)
+    HIPCHK(ctx, ctx->rows_idx.ensure(n_rows));
+    HIPCHK(ctx, ctx->rows_out.ensure((size_t)n_rows * nw));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->rows_idx.p, problem_index, (size_t)n_rows * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(rows_gather_kernel, dim3(n_rows), dim3(256), 0, ctx->stream,
+                       (const double*)ctx->dout_H.p, (const int*)ctx->rows_idx.p, (int)nw, ctx->rows_out.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out_H, ctx->rows_out.p, (size_t)n_rows * nw * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));
     return MXE_OK;
 }
 MXE_CATCH_ALL
