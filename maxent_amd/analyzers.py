@@ -216,20 +216,21 @@ def fit_piecewise_many(logx, logY, p2_deg=0, max_candidates=6):
                 good = valid & (n1 >= 1) & (n2 >= 1)
                 mis[:, k] = np.where(good, e1 + e2, np.nan)
                 keep.append((bi, s1, c1, s2, c2))
-            for q, r in enumerate(rows):
-                if np.all(np.isnan(mis[q])):
-                    continue
-                k = int(np.nanargmin(mis[q]))
-                bi, s1, c1, s2, c2 = [a[q] for a in keep[k]]
-                p1 = np.array([s1, c1])
-                p2 = np.array([s2, c2]) if p2_deg == 1 else np.array([c2])
-                with np.errstate(all='ignore'):
-                    x_cross = (c2 - c1) / (s1 - (s2 if p2_deg == 1 else 0.0))
-                    dist = np.abs(logx - x_cross)
-                if np.all(np.isnan(dist)):
-                    continue
-                out_idx[r] = int(np.nanargmin(dist))
-                out_par[r] = (p1, p2)
+            # every row's best candidate and the alpha nearest to where its two lines cross, for all rows at once
+            has = ~np.all(np.isnan(mis), axis=1)
+            kbest = np.argmin(np.where(np.isnan(mis), np.inf, mis), axis=1)           # (first minimum, like nanargmin)
+            pick = [np.stack([kp[i] for kp in keep], axis=1)[np.arange(len(rows)), kbest] for i in range(5)]
+            bi_b, s1_b, c1_b, s2_b, c2_b = pick
+            with np.errstate(all='ignore'):
+                x_cross = (c2_b - c1_b) / (s1_b - (s2_b if p2_deg == 1 else 0.0))
+                dist = np.abs(logx[None, :] - x_cross[:, None])
+            has &= ~np.all(np.isnan(dist), axis=1)
+            nearest = np.argmin(np.where(np.isnan(dist), np.inf, dist), axis=1)
+            for q in np.where(has)[0]:
+                r = rows[q]
+                out_idx[r] = int(nearest[q])
+                out_par[r] = (np.array([s1_b[q], c1_b[q]]),
+                              np.array([s2_b[q], c2_b[q]]) if p2_deg == 1 else np.array([c2_b[q]]))
     for r in np.where(todo_scalar)[0]:
         try:
             out_idx[r], out_par[r] = fit_piecewise(logx, Y[r], p2_deg)
@@ -324,19 +325,22 @@ class Chi2CurvatureAnalyzer(Analyzer):
             der1 = ((Y[:, 2:] - Y[:, 1:-1]) / hp + (Y[:, 1:-1] - Y[:, :-2]) / hm) / 2
             c = np.full(Y.shape, np.nan)
             c[:, 1:-1] = der2 / (1 + der1 * der1) ** 1.5
-        for k, row in zip(keys, c):
+        best = np.argmax(np.where(np.isnan(c), -np.inf, c), axis=1)        # (first maximum, like nanargmax)
+        empty = np.all(np.isnan(c), axis=1)
+        for k, row, i, e in zip(keys, c, best, empty):
             res = AnalyzerResult()
             res['curvature'] = row
             try:
-                out.append(self._finish(res, maxent_result, k, alpha))
-            except ValueError as e:
-                out.append(str(e))
+                out.append(self._finish(res, maxent_result, k, alpha, None if e else int(i)))
+            except ValueError as err:
+                out.append(str(err))
         return out
 
-    def _finish(self, res, maxent_result, matrix_element, alpha):
-        if np.all(np.isnan(res['curvature'])):
-            raise ValueError('curvature is all NaN')
-        idx = int(np.nanargmax(res['curvature']))
+    def _finish(self, res, maxent_result, matrix_element, alpha, idx=None):
+        if idx is None:
+            if np.all(np.isnan(res['curvature'])):
+                raise ValueError('curvature is all NaN')
+            idx = int(np.nanargmax(res['curvature']))
         res['alpha_index'] = idx
         res['A_out'] = maxent_result.element_row('A', matrix_element, idx)
         res['gamma'] = self.gamma
@@ -364,20 +368,23 @@ class EntropyAnalyzer(Analyzer):
         D = np.full(S.shape, np.nan)
         D[:, 1:-1] = (S[:, 2:] - S[:, :-2]) / (np.log(alpha[2:]) - np.log(alpha[:-2]))
         out = []
-        for k, row in zip(keys, D):
+        best = np.argmin(np.where(np.isnan(D), np.inf, D ** 2), axis=1)       # (first minimum, like nanargmin)
+        empty = np.all(np.isnan(D), axis=1)
+        for k, row, i, e in zip(keys, D, best, empty):
             res = AnalyzerResult()
             res['dS_dalpha'] = row
             try:
-                out.append(self._finish(res, maxent_result, k, alpha))
-            except ValueError as e:
-                out.append(str(e))
+                out.append(self._finish(res, maxent_result, k, alpha, None if e else int(i)))
+            except ValueError as err:
+                out.append(str(err))
         return out
 
-    def _finish(self, res, maxent_result, matrix_element, alpha):
+    def _finish(self, res, maxent_result, matrix_element, alpha, idx=None):
         d = res['dS_dalpha']
-        if np.all(np.isnan(d)):
-            raise ValueError('dS_dalpha is all NaN')
-        idx = int(np.nanargmin(d ** 2))
+        if idx is None:
+            if np.all(np.isnan(d)):
+                raise ValueError('dS_dalpha is all NaN')
+            idx = int(np.nanargmin(d ** 2))
         res['alpha_index'] = idx
         res['A_out'] = maxent_result.element_row('A', matrix_element, idx)
         res['name'] = self.name
