@@ -134,6 +134,7 @@ class ElementwiseMaxEnt(object):
         specs, live = [], []
         self._share_decomposition()
         direct = self._direct_input(worker) and per_job_D is None
+        template = None
         for n, (element, re) in enumerate(jobs):
             cidx = 0 if re else 1
             if direct and n > 0:
@@ -145,8 +146,12 @@ class ElementwiseMaxEnt(object):
                     res._zero_elements.append(tuple(element) + ((cidx,) if self.use_complex else ()))
                     worker.logtaker.error_message('G below threshold, not performing the calculation.')
                     continue
-                spec = loop.make_spec(G=g, err=self.get_error(tuple(element)))
-                spec['A_map'] = loop.A_of_H
+                if template is None:
+                    template = loop.make_spec(G=g, err=self.get_error(tuple(element)))
+                    template['A_map'] = loop.A_of_H
+                    spec = template
+                else:
+                    spec = loop.spec_like(template, g, self.get_error(tuple(element)))
                 specs.append(spec)
                 live.append((element, cidx))
                 if n == len(jobs) - 1:

@@ -197,6 +197,16 @@ class MaxEntLoop(object):
                     A_matrix=self.A_of_H.matrix(),
                     T=K.rotation)
 
+    @staticmethod
+    def spec_like(template, G, err):
+        """the spec of another data vector of the problem ``template`` was made for (``make_spec(G=..., err=...)``):
+        everything but G and err is shared with it"""
+        spec = dict(template)
+        G_use = np.array(G, dtype=float)
+        spec['G'] = spec['G_orig'] = G_use
+        spec['err'] = np.asarray(err, dtype=float) * np.ones(len(G_use))
+        return spec
+
     def make_record(self, spec, sol):
         """MaxEntResult arrays of one finished scan (maxent_result.py:835-967)."""
         A = sol.get('A')
