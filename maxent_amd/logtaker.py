@@ -16,13 +16,8 @@ from datetime import datetime
 
 
 class VerbosityFlags(object):
-    Quiet = 0
-    Header = 1
-    ElementInfo = 2
-    Timing = 4
-    AlphaLoop = 8
-    SolverDetails = 16
-    Errors = 32
+    """bit flags of the message kinds (reference logtaker.py:64-79)"""
+    Quiet, Header, ElementInfo, Timing, AlphaLoop, SolverDetails, Errors = 0, 1, 2, 4, 8, 16, 32
     Default = Header | ElementInfo | Timing | AlphaLoop | Errors
 
 
@@ -59,12 +54,12 @@ class Logtaker(object):
     # ---- where messages go ---------------------------------------------------
     def open_logfile(self, name, append=True):
         self.close_logfile()
-        self.logfile = open(name, 'a' if append else 'w')
+        self.logfile = open(name, {True: 'a', False: 'w'}[bool(append)])
 
     def close_logfile(self):
-        if self.logfile is not None:
-            self.logfile.close()
-        self.logfile = None
+        handle, self.logfile = self.logfile, None
+        if handle is not None:
+            handle.close()
 
     @staticmethod
     def _passes(level, flags):

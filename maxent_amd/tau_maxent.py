@@ -9,25 +9,22 @@ rotated into the covariance eigenbasis).  ``set_G_tau`` / ``set_G_iw`` need
 TRIQS Green-function objects and are not provided.
 """
 
-import copy
+from copy import deepcopy
 
 import numpy as np
 
-from .default_models import FlatDefaultModel
-from .kernels import TauKernel
-from .maxent_loop import MaxEntLoop
-from .omega_meshes import HyperbolicOmegaMesh
+from . import default_models, kernels, maxent_loop as loop_module, omega_meshes
 
 
 class TauMaxEnt(object):
     maxent_loop = None      # needed by the attribute shadowing below
 
     def __init__(self, cov_threshold=1.e-14, svd_backend='host', **kwargs):
-        self.maxent_loop = MaxEntLoop(**kwargs)
-        omega = HyperbolicOmegaMesh()
-        self.D = FlatDefaultModel(omega)
+        self.maxent_loop = loop_module.MaxEntLoop(**kwargs)
+        omega = omega_meshes.HyperbolicOmegaMesh()
+        self.D = default_models.FlatDefaultModel(omega)
         # svd_backend='device': kernel fill + SVD on the GPU (mxe_kernel_svd)
-        self.K = TauKernel([0, 1], omega, svd_backend=svd_backend)      # placeholder tau grid
+        self.K = kernels.TauKernel([0, 1], omega, svd_backend=svd_backend)      # placeholder tau grid
         self.omega = omega
         self.cov_threshold = cov_threshold
 
@@ -70,7 +67,7 @@ class TauMaxEnt(object):
 
     def _adopt_data(self, keep_rotation=True):
         T = self._T if keep_rotation else None
-        self.cost_function._G_orig = copy.deepcopy(self.G)
+        self.cost_function._G_orig = deepcopy(self.G)
         self._move_data(T, None)
         self._announce_kernel(T)
 
@@ -81,7 +78,7 @@ class TauMaxEnt(object):
     def _transform(self, T_, G_original_basis=False):
         """the reference's name for the two moves (tau_maxent.py:303-325)"""
         if G_original_basis:
-            self.cost_function._G_orig = copy.deepcopy(self.G)
+            self.cost_function._G_orig = deepcopy(self.G)
             self._move_data(T_, None)
             self._announce_kernel(T_)
         else:
