@@ -58,7 +58,7 @@ struct mxe_ctx {
     // elements (host)
     int n_elem = 0;
     std::vector<int> elem_ds, elem_kind;
-    std::vector<double> h_sumD;
+    std::vector<double> h_sumD, h_D;           // h_D: [n_elem][nwp], for the classes of the start-state table
     // chains
     int n_chain = 0, n_alpha = 0;
     std::vector<int> chain_elem;      // per parent chain
@@ -84,7 +84,9 @@ struct mxe_ctx {
     DevBuf<int> dout_niter, dout_conv, dout_nevals, dout_nact;
     DevBuf<long long> dprof;
     DevBuf<int> dqueue, dcounter;
-    DevBuf<int> dsub_pre;
+    DevBuf<int> dsub_pre, dsub_init;
+    DevBuf<double> dinit_tab;           // start states per class of pieces (KParams::init_tab)
+    bool has_init = false;
     // mxe_eval_batch / mxe_audit scratch
     DevBuf<double> ev_x, ev_alpha, ev_scal, ev_vecw, ev_vecs, ev_mat;
     DevBuf<int> ev_elem;
@@ -358,7 +360,7 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
     ctx->dlogdet.release(); ctx->dparent_elem.release(); ctx->dV.release(); ctx->dVt.release(); ctx->dVf.release(); ctx->dVtf.release(); ctx->dc.release(); ctx->dcinv.release();
     ctx->dghat.release(); ctx->dcperp.release(); ctx->dD.release(); ctx->dsumD.release();
     ctx->dalpha.release(); ctx->dv0.release(); ctx->delem_ds.release(); ctx->delem_kind.release();
-    ctx->dchain_elem.release(); ctx->dsub_prob0.release(); ctx->dsub_len.release(); ctx->dsub_v0.release(); ctx->dwg_chains.release(); ctx->dqueue.release(); ctx->dcounter.release(); ctx->dsub_pre.release(); ctx->dout_v.release(); ctx->dout_pack.release(); ctx->dout_pack2.release();
+    ctx->dchain_elem.release(); ctx->dsub_prob0.release(); ctx->dsub_len.release(); ctx->dsub_v0.release(); ctx->dwg_chains.release(); ctx->dqueue.release(); ctx->dcounter.release(); ctx->dsub_pre.release(); ctx->dsub_init.release(); ctx->dinit_tab.release(); ctx->dout_v.release(); ctx->dout_pack.release(); ctx->dout_pack2.release();
     ctx->dout_niter.release(); ctx->dout_conv.release(); ctx->dout_nevals.release(); ctx->dout_nact.release();
     ctx->dB.release(); ctx->dA.release(); ctx->dprof.release();
     ctx->rows_out.release(); ctx->rows_idx.release();
@@ -434,6 +436,7 @@ try {
     }
     ctx->n_elem = n_elem;
     ctx->h_sumD = hsumD;
+    ctx->h_D = hD;
     HIPCHK(ctx, ctx->dghat.ensure(hghat.size()));
     HIPCHK(ctx, ctx->dcperp.ensure(n_elem));
     HIPCHK(ctx, ctx->dD.ensure(hD.size()));
@@ -452,6 +455,106 @@ try {
     return MXE_OK;
 }
 MXE_CATCH_ALL
+
+namespace {
+int launch_eval(mxe_ctx* ctx, const mxe::EvalParams& ep, size_t P);
+void eval_params_base(mxe_ctx* ctx, mxe::EvalParams& ep);
+
+// Start states of the lock-step kernel (KParams::init_tab): every piece of a scan starts from the scan's v0, and
+// scans of one class -- same data set, entropy, default model, v0 -- share what the evaluation of that vector
+// gives: H, S, h = V^T H, the Gram matrix.  They are evaluated ONCE per class with the device's own evaluation
+// kernel (eval_kernel, the one behind mxe_eval_batch) when the chains are uploaded, and a piece begins with a
+// Newton step instead of the evaluation of its start vector (one round of the kernel per piece).  At most
+// eight classes; scans beyond that start the old way.
+int build_init_table(mxe_ctx* ctx, int n_chain, const int32_t* elem_of_chain, const std::vector<double>& hv0)
+{
+    ctx->has_init = false;
+    const int NP = ctx->NP, nw = ctx->n_omega, nwp = ctx->nwp;
+    if (NP != 64 || ctx->mc_na != 32) return MXE_OK;
+    std::vector<int> rep, class_of(n_chain, -1);
+    for (int c = 0; c < n_chain; ++c) {
+        const int e = elem_of_chain[c];
+        int k = -1;
+        for (size_t q = 0; q < rep.size() && k < 0; ++q) {
+            const int c0 = rep[q], e0 = elem_of_chain[c0];
+            if (ctx->elem_kind[e0] == ctx->elem_kind[e] && ctx->elem_ds[e0] == ctx->elem_ds[e] &&
+                std::memcmp(&hv0[(size_t)c0 * NP], &hv0[(size_t)c * NP], (size_t)NP * 8) == 0 &&
+                (e0 == e || std::memcmp(&ctx->h_D[(size_t)e0 * nwp], &ctx->h_D[(size_t)e * nwp], (size_t)nwp * 8) == 0)) k = (int)q;
+        }
+        if (k < 0 && rep.size() < 8) { k = (int)rep.size(); rep.push_back(c); }
+        class_of[c] = k;
+    }
+    const int P = (int)rep.size();
+    if (P == 0) return MXE_OK;
+    std::vector<double> hx((size_t)P * NP), halpha(P, 1.0);
+    std::vector<int> helem(P);
+    for (int q = 0; q < P; ++q) {
+        std::copy(hv0.begin() + (size_t)rep[q] * NP, hv0.begin() + (size_t)(rep[q] + 1) * NP, hx.begin() + (size_t)q * NP);
+        helem[q] = elem_of_chain[rep[q]];
+    }
+    HIPCHK(ctx, ctx->ev_x.ensure(hx.size()));
+    HIPCHK(ctx, ctx->ev_alpha.ensure(P));
+    HIPCHK(ctx, ctx->ev_elem.ensure(P));
+    HIPCHK(ctx, ctx->ev_scal.ensure((size_t)5 * P));
+    HIPCHK(ctx, ctx->ev_vecw.ensure((size_t)4 * P * nw));
+    HIPCHK(ctx, ctx->ev_vecs.ensure((size_t)2 * P * NP));
+    HIPCHK(ctx, ctx->ev_mat.ensure((size_t)P * NP * NP));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ev_x.p, hx.data(), hx.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ev_alpha.p, halpha.data(), (size_t)P * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ev_elem.p, helem.data(), (size_t)P * 4, hipMemcpyHostToDevice, ctx->stream));
+    mxe::EvalParams ep;
+    eval_params_base(ctx, ep);
+    ep.elem = ctx->ev_elem.p; ep.alpha = ctx->ev_alpha.p; ep.x = ctx->ev_x.p; ep.x_stride = NP;
+    ep.input_is_H = 0; ep.eta = 1.0; ep.want_gram = 1;
+    ep.Q = ctx->ev_scal.p; ep.chi2 = ep.Q + P; ep.S = ep.chi2 + P;
+    ep.H = ctx->ev_vecw.p; ep.u = ep.H + (size_t)P * nw; ep.w = ep.u + (size_t)P * nw;
+    ep.h = ctx->ev_vecs.p; ep.g = ep.h + (size_t)P * NP;
+    ep.W = ctx->ev_mat.p;
+    int rc = launch_eval(ctx, ep, (size_t)P);
+    if (rc != MXE_OK) return rc;
+    std::vector<double> hS(P), hH((size_t)P * nw), hw((size_t)P * nw), hh((size_t)P * NP), hW((size_t)P * NP * NP);
+    HIPCHK(ctx, hipMemcpyAsync(hS.data(), ep.S, (size_t)P * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hH.data(), ep.H, hH.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hw.data(), ep.w, hw.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hh.data(), ep.h, hh.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hW.data(), ep.W, hW.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int STR = mxe::MC_INIT_STRIDE;
+    std::vector<double> tab((size_t)P * STR, 0.0);
+    for (int q = 0; q < P; ++q) {
+        double Hn2 = 0.0, wmax = 0.0;
+        for (int i = 0; i < nw; ++i) { Hn2 += hH[(size_t)q * nw + i] * hH[(size_t)q * nw + i]; wmax = std::max(wmax, hw[(size_t)q * nw + i]); }
+        if (!(wmax > 1e-290 && wmax < 1e290) || !std::isfinite(Hn2) || !std::isfinite(hS[q])) {       // nothing to tabulate: these scans start the old way
+            for (int c = 0; c < n_chain; ++c) if (class_of[c] == q) class_of[c] = -1;
+            continue;
+        }
+        const double sc2 = std::ldexp(1.0, 8 - std::ilogb(wmax));       // as the kernel scales the operands of its Gram tiles
+        double* T = &tab[(size_t)q * STR];
+        const double* W = &hW[(size_t)q * NP * NP];
+        int pr = 0;
+        for (int mt = 0; mt < 2; ++mt)
+            for (int nt = mt; nt < 2; ++nt, ++pr)
+                for (int r = 0; r < 4; ++r)
+                    for (int l = 0; l < 64; ++l) {
+                        const int a = 16 * mt + 4 * (l >> 4) + r, b = 16 * nt + (l & 15);      // accumulator layout of the 16 x 16 tile
+                        T[(pr * 4 + r) * 64 + l] = sc2 * W[(size_t)a * NP + b];
+                    }
+        for (int k = 0; k < NP; ++k) T[3 * 256 + k] = hh[(size_t)q * NP + k];
+        T[3 * 256 + NP + 0] = hS[q]; T[3 * 256 + NP + 1] = Hn2; T[3 * 256 + NP + 2] = wmax; T[3 * 256 + NP + 3] = sc2;
+    }
+    std::vector<int> sub_init(std::max(ctx->n_sub, 1), -1);
+    bool any = false;
+    for (int sc = 0; sc < ctx->n_sub; ++sc) { sub_init[sc] = class_of[ctx->sub_v0[sc]]; any = any || sub_init[sc] >= 0; }
+    if (!any) return MXE_OK;
+    HIPCHK(ctx, ctx->dinit_tab.ensure(tab.size()));
+    HIPCHK(ctx, ctx->dsub_init.ensure(sub_init.size()));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dinit_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_init.p, sub_init.data(), sub_init.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->has_init = true;
+    return MXE_OK;
+}
+}  // namespace
 
 int mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
                       const int32_t* elem_of_chain, const double* alpha_scaled,
@@ -706,6 +809,8 @@ try {
     HIPCHK(ctx, hipMemcpyAsync(ctx->dv0.p, hv0.data(), hv0.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_chain = n_chain; ctx->n_alpha = n_alpha;
+    ctx->has_init = false;
+    { const int rc_init = build_init_table(ctx, n_chain, elem_of_chain, hv0); if (rc_init != MXE_OK) return rc_init; }
     ctx->chains_ready = true; ctx->launched = false;
     return MXE_OK;
 }
@@ -727,6 +832,8 @@ try {
     kp.chain_elem = ctx->dchain_elem.p; kp.alpha = ctx->dalpha.p; kp.v0 = ctx->dv0.p;
     kp.chain_prob0 = ctx->dsub_prob0.p; kp.chain_len = ctx->dsub_len.p; kp.chain_v0 = ctx->dsub_v0.p;
     kp.chain_lead = (ctx->has_pre && ctx->mc_na > 0) ? ctx->dsub_pre.p : nullptr;
+    kp.init_tab = (ctx->has_init && ctx->mc_na > 0) ? ctx->dinit_tab.p : nullptr;
+    kp.chain_init = ctx->dsub_init.p;
     kp.n_chain = ctx->n_sub;
     kp.out_v = ctx->dout_v.p; kp.out_H = ctx->dout_H.p; kp.out_chi2 = ctx->dout_chi2.p;
     kp.out_S = ctx->dout_S.p; kp.out_Q = ctx->dout_Q.p; kp.out_niter = ctx->dout_niter.p;

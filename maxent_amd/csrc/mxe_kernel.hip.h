@@ -59,6 +59,11 @@ struct KParams {
     const int* chain_prob0; // [n_chain] first problem (index into alpha[] and the outputs)
     const int* chain_len;   // [n_chain] number of alphas of the (sub-)chain
     const int* chain_v0;    // [n_chain] row of v0[] to start from
+    // (lock-step kernel) the state of a piece after the evaluation of its start vector, tabulated per class of
+    // pieces that start from the same (v0, default model, entropy): the Gram tiles in accumulator layout times
+    // sc2 [NPAIR * 256], h = V^T H [NP], then S, sum H^2, max w, sc2 -- the first round of a piece is a Newton step
+    const double* init_tab;     // [n_class][MC_INIT_STRIDE] or nullptr
+    const int* chain_init;      // [n_chain] class of the piece, -1: none
     const int* chain_lead;  // [n_chain] or nullptr: solve alpha[chain_prob0 - chain_lead] BEFORE the piece's first one (no record; 0 = none); lock-step kernel only
     const double* alpha;    // [P]
     const double* v0;       // [n_parent][NP]   whitened basis

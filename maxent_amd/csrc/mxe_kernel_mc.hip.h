@@ -54,6 +54,7 @@ struct MCExtra {
 // rows of V behind the last omega row (and LDS entries behind H / sw) that the look-ahead of the
 // fused pass may read without using them: (DEPTH + 2) groups * 4 waves * 4 rows, rounded up
 constexpr double MC_GRAM_ERR = 0.0;              // allowance for the inexact Gram tiles in the stopping estimate
+constexpr int MC_INIT_STRIDE = 3 * 256 + 64 + 8;       // KParams::init_tab, NA = 32: three tile pairs, h, four scalars (+ pad)
 constexpr int MC_LOOKAHEAD_ROWS = 512;
 constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
 // f(integral_constant<int, J>) for every J of the sequence, in order
@@ -175,6 +176,25 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         vv[wave * NP + lane] = p.v0[(size_t)p.chain_v0[c] * NP + lane];
         ecor[wave * NP + lane] = 0.0; eacc[wave * NP + lane] = 0.0;
         if (lane == 0) { s_elem[wave] = t.elem; s_kind[wave] = p.elem_kind[t.elem]; }
+        // Every piece of a class starts from the same vector: what its evaluation gives -- H, S, h, the Gram
+        // tiles -- is tabulated, only rho = c h - ghat is the piece's own.  The slot is in the state "evaluated at v0"
+        // right away (scratch = 2): its first round is a Newton step, not the evaluation of the start vector.
+        if (NA == 32 && p.init_tab) {
+            const int ic = p.chain_init[c];
+            if (ic >= 0) {
+                const double* T = p.init_tab + (size_t)ic * MC_INIT_STRIDE;
+                double* Wq = Wt + (size_t)wave * NPAIR * 256;
+                for (int i = lane; i < NPAIR * 256; i += 64) Wq[i] = T[i];
+                const double r = (lane < ns) ? p.c[p.elem_ds[t.elem] * NP + lane] * T[NPAIR * 256 + lane] - gh[wave * NP + lane] : 0.0;
+                rho[wave * NP + lane] = r;
+                const double r2 = wave_sum(r * r);
+                const double* sc = T + NPAIR * 256 + NP;
+                t.S = sc[0]; t.Hn2 = sc[1]; t.wmax = sc[2]; t.sc2 = sc[3];
+                t.chi2 = r2 + t.cperp;
+                t.Q = 0.5 * t.chi2 - t.alpha * t.S;
+                t.scratch = 2;
+            }
+        }
     };
 
     auto alpha_at = [&](const Slot& t, int i) -> double {
@@ -389,7 +409,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 if (lane == 0) { s_scw[q][0] = isc2; s_scw[q][1] = sc2n; }
                 t.sc2 = sc2n;
             }
-            if (t.active && t.scratch) {
+            if (t.active && t.scratch == 1) {
                 dk = vv[q * NP + k];                 // evaluation from scratch: the operand is v
             } else if (t.active && t.okprev == 3) {
                 // backtracking: the last trial v - delta made Q worse; the next one is v - delta / 2,
@@ -457,6 +477,12 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     if (!(t.mu <= p.mu_max * t.alpha)) break;
                 }
             }
+            if (t.active && t.scratch == 2) {
+                // the first step of a piece whose start state came from the table: the row pass evaluates
+                // v - delta from scratch (u is not in the other waves' registers yet)
+                dtot = okflag ? dk : 0.0;
+                dk = vv[q * NP + k] - dtot;
+            } else
             if (okflag != 4) dtot = okflag ? dk : 0.0;
             dlc[q * NP + k] = dtot;
             vecI[k * MCC + q] = dk;
@@ -765,7 +791,11 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 const double Qt = 0.5 * chi2t - t.alpha * St;
                 const bool finite = fabs(Qt) <= 1.7e308;
                 bool finish_alpha = false, failed = false; int conv = 0;
-                if (t.scratch) {
+                // (fresh: the piece's start state came from the table and this round evaluated its first Newton step
+                //  v0 - delta from scratch: a trial point like any other, except that the row pass has no old state to
+                //  measure the step against -- no convergence test on it)
+                const bool fresh = t.scratch == 2;
+                if (t.scratch == 1 || (fresh && !t.okprev)) {
                     // state restored from v (or first evaluation of the piece); damping kept
                     ++t.nevals;
                     if (finite) { t.scratch = 0; t.chi2 = chi2t; t.S = St; t.Hn2 = sHn; t.wmax = swm; t.Q = Qt; }
@@ -821,13 +851,14 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     t.chi2 = chi2t; t.S = St; t.Hn2 = sHn; t.wmax = swm;
                     t.Qprev = t.Q; t.Q = Qt; t.muh = t.mu; t.mu = 0.0;
                     ++t.niter;
-                    const bool newton_step = t.okprev != 4;       // a halved step says nothing about convergence
+                    const bool newton_step = t.okprev != 4 && !fresh;       // a halved step says nothing about convergence
                     t.bt = 0;
                     if (newton_step && p.tol_h > 0.0 && relH2_min < tol2Hn && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                     else if (p.tol_relq > 0.0 && fabs(fabs(t.Qprev - t.Q) / t.Q) < p.tol_relq && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                     else if (t.niter >= p.maxiter) finish_alpha = true;
                 }
                 MXE_STAMPA(2);
+                if (fresh && t.scratch == 2) t.scratch = 0;     // accepted or to be halved: the state in LDS is that trial point
                 if (finish_alpha) {
                     // (the leading alpha of a piece, number -1, writes its record where the piece's first alpha will
                     //  write its own over it -- no branch; where it fails, the first alpha starts from the state it
