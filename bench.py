@@ -38,19 +38,19 @@ L2_PEAK_GBS = 34500.0          # ... aggregate L2
 N_EVAL_NOMINAL = {'normal': 160, 'plusminus': 84}   # the reference's passes per alpha-solve
 
 # Counter values per launch of the default workload (rocprofv3 --pmc on this very command, summaries under
-# profiles/r02_i_pmc_*.csv; they count events, not time, and do not depend on the clock):
+# profiles/r02_j_pmc_*.csv; they count events, not time, and do not depend on the clock):
 PMC_DEFAULT = dict(
-    source='profiles/r02_i_pmc_summary.csv',
+    source='profiles/r02_j_pmc_summary.csv',
     # mean per dispatch of mxe::chain_kernel_mc<32, 2> over ~220 dispatches
-    valu_active_quadcycles=3.10033e8,      # SQ_ACTIVE_INST_VALU (counts quad-cycles: MI355X_MICROARCH.md, cycle constants)
-    mfma_busy_cycles=4.46647e8,           # SQ_VALU_MFMA_BUSY_CYCLES (cycles)
-    coexec_cycles=3.04148e7,               # SQ_VALU_MFMA_COEXEC_CYCLES: both at once, counted once below
-    any_active_quadcycles=4.57153e8,       # SQ_ACTIVE_INST_ANY
-    wave_quadcycles=1.15722e9,            # SQ_WAVE_CYCLES
-    wait_inst_quadcycles=3.11039e8, wait_any_quadcycles=3.89028e8,
-    gui_active_cycles_all_xcd=2.13752e7,   # GRBM_GUI_ACTIVE (sum over the 8 XCDs)
-    fetch_kb=32560.0, write_kb=139043.0, # FETCH_SIZE (x 2 on gfx950, MI355X_MICROARCH.md section HBM), WRITE_SIZE
-    l2_hit=8.32901e7, l2_miss=1.47357e6)
+    valu_active_quadcycles=3.0024e8,      # SQ_ACTIVE_INST_VALU (counts quad-cycles: MI355X_MICROARCH.md, cycle constants)
+    mfma_busy_cycles=4.23477e8,           # SQ_VALU_MFMA_BUSY_CYCLES (cycles)
+    coexec_cycles=2.90309e7,               # SQ_VALU_MFMA_COEXEC_CYCLES: both at once, counted once below
+    any_active_quadcycles=4.40557e8,       # SQ_ACTIVE_INST_ANY
+    wave_quadcycles=1.13646e9,            # SQ_WAVE_CYCLES
+    wait_inst_quadcycles=3.11661e8, wait_any_quadcycles=3.84242e8,
+    gui_active_cycles_all_xcd=2.09159e7,   # GRBM_GUI_ACTIVE (sum over the 8 XCDs)
+    fetch_kb=40278.9, write_kb=194818.0, # FETCH_SIZE (x 2 on gfx950, MI355X_MICROARCH.md section HBM), WRITE_SIZE
+    l2_hit=8.03487e7, l2_miss=1.77573e6)
 N_SIMD = 256 * 4
 CLOCK_PEAK_GHZ = 2.4                      # MI355X_MICROARCH.md: max clock
 
@@ -474,7 +474,7 @@ def main():
                    'workgroups side by side (a round of four chains: 34.5 k cycles against 47 k with one per CU); what is left idle is waiting on L2 latency and '
                    'barriers inside phases that are too short to fill from elsewhere.  HBM and L2 are far from binding '
                    '(hbm_frac, l2_frac); traffic = 2 FETCH_SIZE + WRITE_SIZE per launch, of which 117 MB are the '
-                   'compulsory per-alpha results.' % pmc.get('source', 'counters not collected for this workload / kernel'),
+                   'compulsory per-alpha results and ~56 MB five spilled dwords per lane and round.' % pmc.get('source', 'counters not collected for this workload / kernel'),
         hbm_frac=(None if traffic is None else traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS),
         l2_frac=(rounds / 4.0 * (2 * nwp * 64 * 8) / (k_ms * 1e-3) / 1e9 / L2_PEAK_GBS),
         l2_definition='V^T + V (2 x %d KB) streamed once per round of a workgroup of four chains / kernel time, against '
