@@ -552,3 +552,46 @@ def test_hand_built_loop_equals_tau_maxent_object_by_object():
         else:
             same(getattr(result1, field), getattr(result2, field), 8)
     np.testing.assert_almost_equal(result2.probability, g['probability_kat'], 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_alpha', [1, 2])
+def test_scans_of_one_and_two_alphas(n_alpha):
+    """the shortest scans: one alpha (nothing to cut into pieces, analyzers that need a curve say so), two alphas"""
+    g = load('cfg1_normal')
+    tm = make_tm(g, 'normal')
+    alphas = g['alpha'][:n_alpha] / len(g['tau'])
+    tm.alpha_mesh = mx.DataAlphaMesh(alphas)
+    res = tm.run()
+    assert res.A.shape == (n_alpha, len(g['omega'])) and np.all(res.converged)
+    e = rel_l2(res.H, g['H_truth'][:n_alpha]) if set(range(n_alpha)) <= set(int(r) for r in g['rows']) else None
+    if e is not None:
+        assert e.max() < GATE
+    np.testing.assert_allclose(res.chi2, g['chi2_ref'][:n_alpha], rtol=REF_SPREAD)
+    # analyzers answer or explain, never crash
+    for name, out in res.analyzer_results.items():
+        assert isinstance(out, (dict, str))
+
+
+@pytest.mark.gpu
+def test_tiny_grids():
+    """8 tau points, 16 omega points, 5 alphas: fewer singular values than a tile, one workgroup"""
+    rng = np.random.RandomState(4)
+    tau = np.linspace(0, 10, 8)
+    omega = mx.LinearOmegaMesh(omega_min=-4, omega_max=4, n_points=16)
+    K = mx.TauKernel(tau=tau, omega=omega, beta=10.0)
+    A = np.exp(-(np.asarray(omega) - 0.5) ** 2)
+    A /= np.trapezoid(A, np.asarray(omega))
+    G = np.dot(K.K_delta, A) + 1e-4 * rng.randn(len(tau))
+    tm = mx.TauMaxEnt()
+    tm.set_verbosity(mx.VerbosityFlags.Quiet)
+    tm.omega = omega
+    tm.set_G_tau_data(tau, G)
+    tm.set_error(1e-4)
+    tm.alpha_mesh = mx.LogAlphaMesh(alpha_min=1e-1, alpha_max=1e3, n_points=5)
+    res = tm.run()
+    assert res.A.shape == (5, 16) and np.all(res.converged) and np.all(np.isfinite(res.A))
+    assert abs(np.trapezoid(res.A[-1], np.asarray(omega)) - 1.0) < 0.05
+    at = tm.cost_function
+    at.set_alpha(float(res.alpha[-1]))
+    assert abs(at(res.v[-1]).f() / res.Q[-1] - 1.0) < 1e-9        # the device cost function at the returned v
