@@ -53,7 +53,9 @@ extern "C" {
 #define MXE_ERR_HIP         -2   /* a HIP runtime call failed (mxe_last_hip_error) */
 #define MXE_ERR_NODEVICE    -3   /* no usable gfx950 device                   */
 #define MXE_ERR_STATE       -4   /* call order (e.g. solve before elements)   */
-#define MXE_ERR_LIMIT       -5   /* n_s > 128 (fp32: > 64) or LDS budget exceeded */
+#define MXE_ERR_LIMIT       -5   /* n_s > 128 (fp32: > 64); mxe_eval_batch / mxe_audit: w and H of a problem
+                                     exceed the LDS (n_omega > ~7900); the alpha scans themselves take any
+                                     n_omega (state in device memory where the LDS does not hold it) */
 #define MXE_ERR_NUMERIC     -6   /* whitening failed (non-positive error bar) / SVD sweeps exhausted */
 #define MXE_ERR_NOMEM       -7   /* host allocation failed                     */
 

@@ -86,6 +86,7 @@ struct mxe_ctx {
     DevBuf<int> dqueue, dcounter;
     DevBuf<int> dsub_pre, dsub_init;
     DevBuf<double> dinit_tab;           // start states per class of pieces (KParams::init_tab)
+    DevBuf<double> dgstate;             // omega-space state of the chains when it does not fit LDS (KParams::gstate)
     bool has_init = false;
     // mxe_eval_batch / mxe_audit scratch
     DevBuf<double> ev_x, ev_alpha, ev_scal, ev_vecw, ev_vecs, ev_mat;
@@ -253,22 +254,23 @@ size_t mc_lds_bytes(int NA, int nwp, int wgpc)
 
 // LDS bytes of chain_kernel<NW, NAB, TS>: stream arrays (u, ut, w, wt, Hs, vecs) in the stream
 // type, the Gram staging area only in the binary64 build
-size_t lds_bytes(int NP, int nwp, int NW, bool f32)
+// (gst: the five omega arrays live in device memory, KParams::gstate)
+size_t lds_bytes(int NP, int nwp, int NW, bool f32, bool gst = false)
 {
     const int SROW = (NP / 4) * mxe::GBLK;
     const size_t fixed = (size_t)NP * (NP + 1) + (NP == 64 ? 13 : 11) * (size_t)NP + (size_t)NW * NP + (size_t)NW * 8;
-    const size_t stream = 5 * (size_t)nwp + NP;
+    const size_t stream = (gst ? 0 : 5 * (size_t)nwp) + NP;
     const size_t stage = f32 ? 0 : (size_t)NW * 2 * mxe::GRAM_R * SROW;
     return (fixed + stage) * 8 + stream * (f32 ? 4 : 8);
 }
 
-template <int NW, int NAB, typename TS = double>
+template <int NW, int NAB, typename TS = double, bool GST = false>
 hipError_t launch_t(const KParams& kp, size_t lds, hipStream_t s)
 {
-    hipError_t e = hipFuncSetAttribute((const void*)mxe::chain_kernel<NW, NAB, TS>,
+    hipError_t e = hipFuncSetAttribute((const void*)mxe::chain_kernel<NW, NAB, TS, GST>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mxe::chain_kernel<NW, NAB, TS>), dim3(kp.n_chain), dim3(64 * NW), lds, s, kp);
+    hipLaunchKernelGGL((mxe::chain_kernel<NW, NAB, TS, GST>), dim3(kp.n_chain), dim3(64 * NW), lds, s, kp);
     return hipGetLastError();
 }
 
@@ -843,6 +845,7 @@ try {
     kp.step_max = o.step_max; kp.mu_first = o.mu_first; kp.mu_grow = o.mu_grow; kp.mu_max = o.mu_max;
     kp.theta = o.decouple_tol; kp.out_nact = ctx->dout_nact.p;
     kp.prof = nullptr;
+    kp.gstate = nullptr;
 #ifdef MXE_PROFILE
     HIPCHK(ctx, ctx->dprof.ensure(((size_t)ctx->n_sub + 8 * 1024) * 8));   // rows: chain (v2) or workgroup*8 + wave (lock-step)
     HIPCHK(ctx, hipMemsetAsync(ctx->dprof.p, 0, ((size_t)ctx->n_sub + 8 * 1024) * 64, ctx->stream));
@@ -888,10 +891,23 @@ try {
         const bool f32 = (o.precision == MXE_PRECISION_F32);
         size_t lds = lds_bytes(ctx->NP, ctx->nwp, NW, f32);
         while (lds > 160 * 1024 && NW > 1) { NW /= 2; lds = lds_bytes(ctx->NP, ctx->nwp, NW, f32); }
-        if (lds > 160 * 1024) return MXE_ERR_LIMIT;
+        // a frequency mesh whose omega-space state (five arrays per chain) does not fit the LDS: the state goes to
+        // device memory (four waves per chain; one where the 128 x 128 Newton matrix leaves no room for more)
+        const bool gst = lds > 160 * 1024;
+        if (gst) {
+            NW = (ctx->NP == 64) ? 4 : 1;
+            lds = lds_bytes(ctx->NP, ctx->nwp, NW, f32, true);
+            if (lds > 160 * 1024) return MXE_ERR_LIMIT;
+            HIPCHK(ctx, ctx->dgstate.ensure((size_t)ctx->n_sub * 5 * ctx->nwp));     // (binary32 build: half of it used)
+            kp.gstate = ctx->dgstate.p;
+        }
         ctx->last_nw = NW; ctx->last_lds = (int)lds;
-        ctx->last_kernel = "mxe::chain_kernel<" + std::to_string(NW) + ", " + std::to_string(ctx->NP / 32) + (f32 ? ", float>" : ", double>");
+        ctx->last_kernel = "mxe::chain_kernel<" + std::to_string(NW) + ", " + std::to_string(ctx->NP / 32) + (f32 ? ", float" : ", double") + (gst ? ", device-memory state>" : ">");
         HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        if (gst) {
+            if (f32) e = launch_t<4, 2, float, true>(kp, lds, ctx->stream);
+            else e = (ctx->NP == 64) ? launch_t<4, 2, double, true>(kp, lds, ctx->stream) : launch_t<1, 4, double, true>(kp, lds, ctx->stream);
+        } else
         if (f32) {
             switch (NW) {
                 case 1: e = launch_t<1, 2, float>(kp, lds, ctx->stream); break;

@@ -85,6 +85,9 @@ struct KParams {
     // binary32 copies of V / Vt (same shapes) for the fp32 streaming variant (mxe_opts.precision)
     const float* Vf;
     const float* Vtf;
+    // (one-chain kernel, GST build) the omega-space state of every chain -- u, trial u, w, trial w, H: 5 x n_omega_pad
+    // of the stream type each -- in device memory, for frequency meshes whose state does not fit the 160 KB of LDS
+    void* gstate;
 };
 
 #if defined(MXE_PROFILE) && defined(MXE_PROFILE_EVAL)
@@ -326,10 +329,14 @@ __device__ __forceinline__ void block_reduce2(double (&x)[NV], double& mx, doubl
 // NW  wavefronts per chain
 // NAB padded singular dimension in units of 32 (2 -> NP = 64, 4 -> NP = 128)
 // TS  stream type (double; float = the fp32 variant, NAB = 2 only)
-template <int NW, int NAB, typename TS = double>
+// GST the omega-space state (u, w, H and their trial copies) lives in device memory (KParams::gstate) instead of
+//     LDS: any n_omega; the waves exchange it behind __syncthreads (also with one wave per chain: its fences
+//     order global memory inside the workgroup)
+template <int NW, int NAB, typename TS = double, bool GST = false>
 __global__ __launch_bounds__(64 * NW)
 void chain_kernel(const KParams p)
 {
+    constexpr int SYNCW = GST ? 4 : NW;        // (device-memory state: always the workgroup barrier, whose fences order global memory)
     typedef Stream<TS> ST;
     typedef typename ST::vec2 TS2;
     constexpr bool F64 = std::is_same<TS, double>::value;
@@ -367,12 +374,13 @@ void chain_kernel(const KParams p)
     double* eacc = ecor + (PRED ? NP : 0);   // [NP] ... of this alpha, being accumulated
     double* hpart = eacc + (PRED ? NP : 0);  // [NW][NP]
     double* red  = hpart + NW * NP;          // [NW*8]
-    TS* u    = reinterpret_cast<TS*>(red + NW * 8);   // [nwp]
+    TS* u    = GST ? reinterpret_cast<TS*>(p.gstate) + (size_t)chain * 5 * nwp
+                   : reinterpret_cast<TS*>(red + NW * 8);   // [nwp]
     TS* ut   = u + nwp;
     TS* w    = ut + nwp;
     TS* wt   = w + nwp;
     TS* Hs   = wt + nwp;
-    TS* vecs = Hs + nwp;                     // [NP] stream-type copy of the vector of a pass
+    TS* vecs = GST ? reinterpret_cast<TS*>(red + NW * 8) : Hs + nwp;   // [NP] stream-type copy of the vector of a pass
     double* stage = reinterpret_cast<double*>(vecs + NP);   // [NW][2 (x,y)][GRAM_R][SROW] (fp64 VALU Gram only)
 
     const int elem = p.chain_elem[chain];
@@ -396,7 +404,7 @@ void chain_kernel(const KParams p)
         dl[k] = 0.0;
         if (PRED) { ecor[k] = 0.0; eacc[k] = 0.0; }
     }
-    block_sync<NW>();
+    block_sync<SYNCW>();
 
     // ------------------------------------------------------------------
     // evaluation pass: trial u = u - V*vec (from_scratch: u = V*vec).
@@ -410,7 +418,7 @@ void chain_kernel(const KParams p)
         if constexpr (F64) vs = vec;
         else {
             for (int k = tid; k < NP; k += T) vecs[k] = (TS)vec[k];
-            block_sync<NW>();
+            block_sync<SYNCW>();
             vs = vecs;
         }
         for (int i = 2 * tid; i < nwp; i += 2 * T) {
@@ -461,7 +469,7 @@ void chain_kernel(const KParams p)
                 pwm = fmax(pwm, (double)wi);     // NaN-ignoring; non-finite states are caught through Q
             }
         }
-        block_sync<NW>();                    // Hs complete
+        block_sync<SYNCW>();                    // Hs complete
         MXE_STAMP_E(3);
         // h = V^T H : rows split over the waves; lanes 0-31 take even rows,
         // lanes 32-63 odd rows, each lane two adjacent singular columns
@@ -498,7 +506,7 @@ void chain_kernel(const KParams p)
                 }
             }
         }
-        block_sync<NW>();
+        block_sync<SYNCW>();
         MXE_STAMP_E(4);
         double r2 = 0.0;
         for (int k = tid; k < NP; k += T) {
@@ -518,7 +526,7 @@ void chain_kernel(const KParams p)
     auto accept_trial = [&]() {
         for (int i = tid; i < nwp; i += T) { u[i] = ut[i]; w[i] = wt[i]; }
         for (int k = tid; k < NP; k += T) { v[k] -= dl[k]; rho[k] = rhot[k]; }
-        block_sync<NW>();
+        block_sync<SYNCW>();
     };
 
     // ------------------------------------------------------------------
@@ -605,7 +613,7 @@ void chain_kernel(const KParams p)
                         }
                 }
             }
-            block_sync<NW>();
+            block_sync<SYNCW>();
         }
     };
 
@@ -685,7 +693,7 @@ void chain_kernel(const KParams p)
                         ++q;
                     }
             }
-            block_sync<NW>();
+            block_sync<SYNCW>();
         }
     };
 
@@ -963,7 +971,7 @@ void chain_kernel(const KParams p)
                 if (n_act0 < 1) n_act0 = 1;
                 if (n_act0 > NP) n_act0 = NP;
             }
-            block_sync<NW>();
+            block_sync<SYNCW>();
             MXE_STAMP(0);
             gram(n_act0);               // ends with a block sync
             MXE_STAMP(1);
@@ -972,13 +980,13 @@ void chain_kernel(const KParams p)
             bool stop = false;
             if (p.tol_d > 0.0) {
                 symv(g, zz, n_act0);
-                block_sync<NW>();
+                block_sync<SYNCW>();
                 double mx = 0.0;
                 for (int k = tid; k < n_act0; k += T) mx = fmax(mx, fabs(zz[k]));
                 double none[1] = {0.0};
                 block_reduce<NW, 1>(none, mx, red);
                 if (mx < p.tol_d) stop = true;
-                block_sync<NW>();
+                block_sync<SYNCW>();
             }
             if (p.tol_relq > 0.0 && it > 0) {
                 if (fabs(fabs(Qprev - Q) / Q) < p.tol_relq) stop = true;
@@ -1014,7 +1022,7 @@ void chain_kernel(const KParams p)
                     double x1[1] = {nrm};
                     double dummy = 0.0;
                     block_reduce<NW, 1>(x1, dummy, red);
-                    block_sync<NW>();
+                    block_sync<SYNCW>();
                     scaled = false;
                     if (!(x1[0] <= step_lim)) {
                         // an undamped Newton step beyond Bryan's bound is shortened onto it (same
@@ -1023,7 +1031,7 @@ void chain_kernel(const KParams p)
                         if (mu == 0.0 && x1[0] < 1e300) {
                             const double sc = sqrt(step_lim / x1[0]);
                             for (int k = tid; k < NP; k += T) dl[k] *= sc;
-                            block_sync<NW>();
+                            block_sync<SYNCW>();
                             scaled = true;
                         } else good = false;
                     }
@@ -1039,10 +1047,10 @@ void chain_kernel(const KParams p)
                         for (int k = tid; k < NP; k += T) { n2[0] = fma(ecor[k], ecor[k], n2[0]); n2[1] = fma(dl[k], dl[k], n2[1]); }
                         double dummy2 = 0.0;
                         block_reduce<NW, 2>(n2, dummy2, red);
-                        block_sync<NW>();
+                        block_sync<SYNCW>();
                         if (n2[0] > 0.0 && n2[0] <= 0.25 * n2[1]) {
                             for (int k = tid; k < NP; k += T) dl[k] -= ecor[k];
-                            block_sync<NW>();
+                            block_sync<SYNCW>();
                             predicted = true;
                         }
                     }
@@ -1106,7 +1114,7 @@ void chain_kernel(const KParams p)
                 if (!(fabs(e) < 1e300)) e = 0.0;
                 ecor[k] = e; eacc[k] = 0.0;
             }
-            block_sync<NW>();
+            block_sync<SYNCW>();
         }
         // ---- results of this alpha (MaxEntResult fields, maxent_result.py:835-967)
         const size_t prob = (size_t)prob0 + ia;

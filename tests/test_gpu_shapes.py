@@ -60,3 +60,66 @@ def test_layouts_agree_on_odd_shapes(n_orb, n_tau, n_omega, n_alpha, split):
         for ia in (0, n_alpha - 1):
             assert np.linalg.norm(b['H'][c, ia] - truth[ia]) / np.linalg.norm(truth[ia]) < 1e-6
     ctx.close()
+
+
+@pytest.mark.parametrize('n_omega,precision', [(3100, device.PRECISION_F64), (7000, device.PRECISION_F32)])
+def test_frequency_mesh_beyond_the_lds(n_omega, precision):
+    """A frequency mesh whose omega-space state does not fit the 160 KB of LDS: the one-chain kernel keeps
+    the state in device memory.  binary64: against the extended-precision fixed point reached from the
+    reference's iterates (the oracle runs the three largest alphas only: its dense n_omega x n_omega algebra
+    takes a minute there) and the all-problem audit; binary32: against the binary64 run."""
+    n_orb, n_tau, n_alpha = 2, 40, 6
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(n_orb, n_tau, n_omega)
+    K.reduce_singular_space(1e-14)
+    D = synthetic.flat_D(omega)
+    err = synthetic.SIGMA * np.ones(n_tau)
+    alphas = np.array(synthetic.alpha_mesh(n_alpha)) * n_tau
+    elems = [(i, j) for i in range(n_orb) for j in range(n_orb)]
+    kinds = [device.ENTROPY_NORMAL if i == j else device.ENTROPY_PLUSMINUS for i, j in elems]
+    v0 = np.stack([hostprep.initial_v(K.V, D, omega.delta, k) for k in kinds])
+    ctx = device.DeviceContext(K.U, K.S, K.V)
+    ds = ctx.add_dataset(err)
+    n = len(elems)
+    ctx.set_elements([ds] * n, [Gmat[i, j] for i, j in elems], np.tile(D, (n, 1)), kinds)
+    out = ctx.solve_chains(np.arange(n), alphas, v0, device.default_opts(precision=device.PRECISION_F64))
+    assert 'device-memory state' in ctx.last_launch_info()['kernel']
+    assert out['converged'].all() and np.all(np.isfinite(out['H']))
+    assert ctx.audit()['corr'].max() < 1e-6
+    if precision == device.PRECISION_F64:
+        for c in (0, 1):
+            i, j = elems[c]
+            ent = 'normal' if kinds[c] == device.ENTROPY_NORMAL else 'plusminus'
+            p = R.Problem(np.array(K.K), K.U, K.S, K.V, Gmat[i, j], err, D, entropy=ent)
+            truth, _ = anchor.truth_rows(p, omega.delta, alphas[:3], n_tau, (0, 2), ent)
+            for ia in (0, 2):
+                assert np.linalg.norm(out['H'][c, ia] - truth[ia]) / np.linalg.norm(truth[ia]) < 1e-6
+    else:
+        o32 = ctx.solve_chains(np.arange(n), alphas, v0, device.default_opts(precision=precision))
+        assert 'float, device-memory state' in ctx.last_launch_info()['kernel']
+        assert o32['converged'].all()
+        assert rel_l2(o32['H'], out['H']).max() < 1e-3
+    ctx.close()
+
+
+def test_more_than_64_singular_values_on_a_long_mesh():
+    """n_s > 64 (the 128 x 128 Newton matrix takes 132 KB of LDS) with a frequency mesh that no longer fits
+    beside it: one wave per chain, state in device memory; checked by the all-problem audit and against the
+    mesh cut to the size that does fit (same grid spacing is not needed: the fixed point of each run is
+    audited on its own)."""
+    n_tau, n_omega, n_alpha = 110, 700, 5
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(2, n_tau, n_omega)
+    K.reduce_singular_space(1e-18)
+    assert len(K.S) > 64
+    D = synthetic.flat_D(omega)
+    err = synthetic.SIGMA * np.ones(n_tau)
+    alphas = np.array(synthetic.alpha_mesh(n_alpha)) * n_tau
+    kinds = [device.ENTROPY_NORMAL, device.ENTROPY_PLUSMINUS]
+    v0 = np.stack([hostprep.initial_v(K.V, D, omega.delta, k) for k in kinds])
+    ctx = device.DeviceContext(K.U, K.S, K.V)
+    ds = ctx.add_dataset(err)
+    ctx.set_elements([ds] * 2, [Gmat[0, 0], Gmat[0, 1]], np.tile(D, (2, 1)), kinds)
+    out = ctx.solve_chains(np.arange(2), alphas, v0)
+    assert ctx.last_launch_info()['kernel'] == 'mxe::chain_kernel<1, 4, double, device-memory state>'
+    assert out['converged'].all() and np.all(np.isfinite(out['H']))
+    assert ctx.audit()['corr'].max() < 1e-6
+    ctx.close()
