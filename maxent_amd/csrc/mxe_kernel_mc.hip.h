@@ -330,6 +330,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             }
         }
         double b = live ? rq[i] : 0.0;
+#ifdef MXE_X_GJ_SINGLE
         double dinv_i = 1.0;
         MXE_STAMPH(1);
         auto pivot = [&](auto JTag) {
@@ -366,6 +367,64 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         static_for_seq(std::make_integer_sequence<int, N>{}, pivot);
         MXE_STAMPH(3);
         if (ok && live && h == 0) zz[q * NP + i] = b * dinv_i;
+#else
+        // Two pivots per step.  Columns j (even: kept by the lower half) and j + 1 (upper half) are BOTH the
+        // register A[j / 2] -- one pair of v_permlane32_swap hands the two columns to every lane --, the 2 x 2
+        // pivot block P = [[a, b], [b, d]] (rows j, j + 1: three broadcasts) is inverted in closed form, and every
+        // other row subtracts (f0, f1) = (A_ij, A_i,j+1) P^-1 times rows j and j + 1 from its columns k > j + 1
+        // and from its right-hand side.  The two pivot rows stay as they are; when the elimination ends the
+        // matrix is block diagonal and z of a row pair is P^-1 (b_j, b_j+1) with the P of its pivot step.  Same
+        // multiply-adds and swizzles as one pivot at a time, but ONE dependent chain (swap, broadcasts, determinant,
+        // reciprocal, multipliers, row broadcasts) per two pivots instead of two.
+        double ps = 1.0, pc = 0.0;                 // z_i = ps b_i + pc b_(i ^ 1)
+        MXE_STAMPH(1);
+        auto pivot2 = [&](auto KTag) {
+            constexpr int kj = decltype(KTag)::value, j = 2 * kj;
+            double c0, c1;
+            {
+                const unsigned xlo = (unsigned)__double2loint(A[kj]), xhi = (unsigned)__double2hiint(A[kj]);
+                const auto slo = __builtin_amdgcn_permlane32_swap(xlo, xlo, false, false);
+                const auto shi = __builtin_amdgcn_permlane32_swap(xhi, xhi, false, false);
+                // [0]: the lower half's values in both halves (column j), [1]: the upper half's (column j + 1)
+                c0 = __hiloint2double((int)shi[0], (int)slo[0]);
+                c1 = __hiloint2double((int)shi[1], (int)slo[1]);
+            }
+            const double pa = wave_bcast(c0, j), pb = wave_bcast(c1, j), pd = wave_bcast(c1, j + 1);
+            const double det = fma(pa, pd, -pb * pb);
+            if (!(pa > 0.0) || !(det > 0.0)) ok = false;
+            double inv = __builtin_amdgcn_rcp(det);
+            inv = fma(fma(-det, inv, 1.0), inv, inv);
+            const double qa = pa * inv, qb = pb * inv, qd = pd * inv;       // P^-1 = [[qd, -qb], [-qb, qa]]
+            const bool prow = (i >> 1) == kj;
+            if (prow) { ps = (i & 1) ? qa : qd; pc = -qb; }
+            const double f0 = prow ? 0.0 : fma(c0, qd, -c1 * qb);
+            const double f1 = prow ? 0.0 : fma(c1, qa, -c0 * qb);
+            {
+                const double b0 = wave_bcast(b, j), b1 = wave_bcast(b, j + 1);
+                b = fma(-f1, b1, fma(-f0, b0, b));
+            }
+            constexpr int K0 = kj + 1;
+#pragma unroll
+            for (int k0 = K0; k0 < NHALF; k0 += 4) {
+                double r0[4], r1[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (k0 + r < NHALF) {
+                    r0[r] = half_bcast(A[k0 + r], std::integral_constant<int, j>{});          // row j, column k
+                    r1[r] = half_bcast(A[k0 + r], std::integral_constant<int, j + 1>{});      // row j + 1
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (k0 + r < NHALF) A[k0 + r] = fma(-f1, r1[r], fma(-f0, r0[r], A[k0 + r]));
+            }
+        };
+        static_for_seq(std::make_integer_sequence<int, NHALF>{}, pivot2);
+        MXE_STAMPH(3);
+        {
+            const int plo = __builtin_amdgcn_ds_swizzle(__double2loint(b), (1 << 10) | 0x1f);     // lane ^ 1
+            const int phi = __builtin_amdgcn_ds_swizzle(__double2hiint(b), (1 << 10) | 0x1f);
+            const double bp = __hiloint2double(phi, plo);
+            if (ok && live && h == 0) zz[q * NP + i] = fma(ps, b, pc * bp);
+        }
+#endif
         MXE_STAMPH(4);
 #ifdef MXE_PROFILE_HOME
         prof_acc[6] += 1;                        // solves (slot 6 is a count in this build)
