@@ -199,6 +199,15 @@ int  mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
                        const double* v0, const mxe_opts* opts);
 int  mxe_chains_launch(mxe_ctx* ctx);
 int  mxe_sync(mxe_ctx* ctx);
+/* Blocking.  After a launch in the lock-step layout: the alphas that did not converge there are solved again in
+ * the one-chain layout, from the state they were left in, and their records are overwritten (iteration and
+ * evaluation counts: both passes).  The lock-step kernel forms its Gram matrices from binary16 products (21 bits):
+ * an inexact Newton matrix that is harmless where the system is well conditioned and stalls where it is not (few
+ * data points, small alpha); it gives an alpha up after 32 iterations, and the one-chain kernel (binary64 Gram
+ * matrix) takes it from there with the rest of mxe_opts.maxiter.  n_resolved (may be NULL): how many alphas that
+ * was.  A no-op after a launch in the one-chain layout or when everything converged.  mxe_solve_chains calls it;
+ * what it replaces in the reference is nothing but the remaining iterations of levenberg_minimizer.py:155-243. */
+int  mxe_chains_finish(mxe_ctx* ctx, int32_t* n_resolved);
 int  mxe_chains_fetch(mxe_ctx* ctx, double* out_v, double* out_H,
                       double* out_chi2, double* out_S, double* out_Q,
                       int32_t* out_niter, int32_t* out_converged,

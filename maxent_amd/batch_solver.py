@@ -151,6 +151,8 @@ class BatchSolver(object):
             self._stage(self.ctxs[r], K, [specs[i] for i in per_rank[r]], opts)
         for r in active:
             self.ctxs[r].launch()
+        for r in active:
+            self.ctxs[r].finish()                   # (alphas the lock-step layout gave up on: one-chain layout)
         info = None
         outs = [None] * N
         if len(active) == N and N > 1:

@@ -87,6 +87,9 @@ struct mxe_ctx {
     DevBuf<int> dsub_pre, dsub_init;
     DevBuf<double> dinit_tab;           // start states per class of pieces (KParams::init_tab)
     DevBuf<double> dgstate;             // omega-space state of the chains when it does not fit LDS (KParams::gstate)
+    DevBuf<int> dfin_elem, dfin_prob0, dfin_len, dfin_v0;       // mxe_chains_finish: one piece per alpha that is solved again
+    DevBuf<double> dfin_start;          //   and its start vector (the state the lock-step kernel left)
+    int last_finished = 0;              // alphas the last mxe_chains_finish solved again
     bool has_init = false;
     // mxe_eval_batch / mxe_audit scratch
     DevBuf<double> ev_x, ev_alpha, ev_scal, ev_vecw, ev_vecs, ev_mat;
@@ -684,10 +687,13 @@ try {
         }
     }
     ctx->n_sub = (int)ctx->sub_elem.size();
-    // ---- layout: four chains of one data set per workgroup when there are enough
+    // ---- layout: four chains of one data set per workgroup wherever the lock-step kernel has a build for the
+    //      problem -- also for a handful of pieces: its round (four chains) takes no longer than an iteration of the
+    //      one-chain kernel (one), and a single scan of 100 alphas in 50 pieces runs in 0.45 ms against 0.94 ms
+    //      (profiles/r02_k_small_batches.txt; until r02_j: only from 768 pieces on)
     int layout = o.chains_per_wg;
     ctx->mc_na = 0;
-    if (layout == 0) layout = (ctx->n_sub >= 768) ? 4 : 1;
+    if (layout == 0) layout = 4;
     if (layout == 4 && (NP != 64 || o.tol_d > 0.0 || o.decouple_tol <= 0.0 || o.precision != MXE_PRECISION_F64)) layout = 1;
     if (layout == 4) {
         // capacity of the active block: the kernel clamps n_act to NA, and the
@@ -818,13 +824,11 @@ try {
 }
 MXE_CATCH_ALL
 
-int mxe_chains_launch(mxe_ctx* ctx)
-try {
-    if (!ctx) return MXE_ERR_ARG;
-    if (!ctx->chains_ready) return MXE_ERR_STATE;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+// the kernel parameters of the staged chains (mxe_chains_launch; mxe_chains_finish replaces the chain arrays)
+constexpr int MC_MAXITER = 32;       // iterations the lock-step kernel spends on one alpha before it gives it up (mxe_chains_finish)
+static void fill_kparams(mxe_ctx* ctx, KParams& kp)
+{
     const mxe_opts& o = ctx->opts;
-    KParams kp;
     kp.n_omega = ctx->n_omega; kp.n_omega_pad = ctx->nwp; kp.n_s = ctx->n_s; kp.NP = ctx->NP;
     kp.n_alpha = ctx->n_alpha; kp.n_chain = ctx->n_chain;
     kp.Vf = ctx->dVf.p; kp.Vtf = ctx->dVtf.p;
@@ -846,6 +850,17 @@ try {
     kp.theta = o.decouple_tol; kp.out_nact = ctx->dout_nact.p;
     kp.prof = nullptr;
     kp.gstate = nullptr;
+    kp.mc_maxiter = std::min(o.maxiter, MC_MAXITER);
+}
+
+int mxe_chains_launch(mxe_ctx* ctx)
+try {
+    if (!ctx) return MXE_ERR_ARG;
+    if (!ctx->chains_ready) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const mxe_opts& o = ctx->opts;
+    KParams kp;
+    fill_kparams(ctx, kp);
 #ifdef MXE_PROFILE
     HIPCHK(ctx, ctx->dprof.ensure(((size_t)ctx->n_sub + 8 * 1024) * 8));   // rows: chain (v2) or workgroup*8 + wave (lock-step)
     HIPCHK(ctx, hipMemsetAsync(ctx->dprof.p, 0, ((size_t)ctx->n_sub + 8 * 1024) * 64, ctx->stream));
@@ -952,6 +967,76 @@ int mxe_sync(mxe_ctx* ctx)
     return MXE_OK;
 }
 
+// Alphas that the lock-step layout gave up on are solved again in the one-chain layout, from the state they were
+// left in.  The lock-step kernel forms its Gram matrices from binary16 products (21 bits): an inexact
+// Newton matrix that costs nothing where the system is well conditioned and stalls the iteration where it is not
+// (few data points, small alpha: tens to hundreds of iterations per alpha where the binary64 Gram matrix of the
+// one-chain kernel takes five); it stops an alpha after MC_MAXITER iterations.  Blocking; a no-op after a launch of
+// the one-chain layout and when everything converged.
+int mxe_chains_finish(mxe_ctx* ctx, int32_t* n_resolved)
+try {
+    if (n_resolved) *n_resolved = 0;
+    if (!ctx) return MXE_ERR_ARG;
+    if (!ctx->launched) return MXE_ERR_STATE;
+    ctx->last_finished = 0;
+    if (ctx->mc_na == 0) return MXE_OK;                       // the launch was in the one-chain layout
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, stream_wait(ctx->stream));
+    const mxe_opts& o = ctx->opts;
+    const size_t P = (size_t)ctx->n_chain * ctx->n_alpha;
+    std::vector<int> conv(P), nit(P), nev(P);
+    HIPCHK(ctx, hipMemcpy(conv.data(), ctx->dout_conv.p, P * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<int> todo;
+    for (size_t i = 0; i < P; ++i) if (!conv[i]) todo.push_back((int)i);
+    if (todo.empty()) return MXE_OK;
+    HIPCHK(ctx, hipMemcpy(nit.data(), ctx->dout_niter.p, P * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(nev.data(), ctx->dout_nevals.p, P * sizeof(int), hipMemcpyDeviceToHost));
+    // (an alpha that used up the caller's own maxiter stays as it is)
+    std::vector<int> keep;
+    for (int i : todo) if (nit[i] < o.maxiter) keep.push_back(i);
+    todo.swap(keep);
+    if (todo.empty()) return MXE_OK;
+    const int n = (int)todo.size(), NP = ctx->NP;
+    std::vector<int> f_elem(n), f_len(n, 1), f_v0(n);
+    for (int k = 0; k < n; ++k) { f_elem[k] = ctx->chain_elem[todo[k] / ctx->n_alpha]; f_v0[k] = k; }
+    HIPCHK(ctx, ctx->dfin_elem.ensure(n)); HIPCHK(ctx, ctx->dfin_prob0.ensure(n));
+    HIPCHK(ctx, ctx->dfin_len.ensure(n)); HIPCHK(ctx, ctx->dfin_v0.ensure(n));
+    HIPCHK(ctx, ctx->dfin_start.ensure((size_t)n * NP));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_elem.p, f_elem.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_prob0.p, todo.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_len.p, f_len.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_v0.p, f_v0.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    for (int k = 0; k < n; ++k)          // start vectors: the v of the record (whitened basis, row stride NP)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_start.p + (size_t)k * NP, ctx->dout_v.p + (size_t)todo[k] * NP, NP * sizeof(double),
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+    KParams kp;
+    fill_kparams(ctx, kp);
+    kp.chain_elem = ctx->dfin_elem.p; kp.chain_prob0 = ctx->dfin_prob0.p; kp.chain_len = ctx->dfin_len.p;
+    kp.chain_v0 = ctx->dfin_v0.p; kp.v0 = ctx->dfin_start.p;
+    kp.chain_lead = nullptr; kp.init_tab = nullptr; kp.chain_init = nullptr;
+    kp.n_chain = n;
+    kp.maxiter = std::max(1, o.maxiter - MC_MAXITER);
+    const int NW = 4;
+    const size_t lds = lds_bytes(NP, ctx->nwp, NW, false);
+    if (lds > 160 * 1024) return MXE_ERR_LIMIT;               // (the lock-step layout holds less than this one)
+    hipError_t e = launch_t<4, 2>(kp, lds, ctx->stream);
+    HIPCHK(ctx, e);
+    HIPCHK(ctx, stream_wait(ctx->stream));
+    // the counters of the record: both passes
+    std::vector<int> nit2(n), nev2(n);
+    for (int k = 0; k < n; ++k) {
+        HIPCHK(ctx, hipMemcpy(&nit2[k], ctx->dout_niter.p + todo[k], sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(&nev2[k], ctx->dout_nevals.p + todo[k], sizeof(int), hipMemcpyDeviceToHost));
+        nit2[k] += nit[todo[k]]; nev2[k] += nev[todo[k]];
+        HIPCHK(ctx, hipMemcpy(ctx->dout_niter.p + todo[k], &nit2[k], sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(ctx->dout_nevals.p + todo[k], &nev2[k], sizeof(int), hipMemcpyHostToDevice));
+    }
+    ctx->last_finished = n;
+    if (n_resolved) *n_resolved = n;
+    return MXE_OK;
+}
+MXE_CATCH_ALL
+
 int mxe_chains_fetch(mxe_ctx* ctx, double* out_v, double* out_H, double* out_chi2,
                      double* out_S, double* out_Q, int32_t* out_niter,
                      int32_t* out_converged, int32_t* out_nevals)
@@ -1014,6 +1099,8 @@ int mxe_solve_chains(mxe_ctx* ctx, int n_chain, int n_alpha,
     int rc = mxe_chains_upload(ctx, n_chain, n_alpha, elem_of_chain, alpha_scaled, v0, opts);
     if (rc != MXE_OK) return rc;
     rc = mxe_chains_launch(ctx);
+    if (rc != MXE_OK) return rc;
+    rc = mxe_chains_finish(ctx, nullptr);
     if (rc != MXE_OK) return rc;
     return mxe_chains_fetch(ctx, out_v, out_H, out_chi2, out_S, out_Q, out_niter, out_converged, out_nevals);
 }

@@ -88,6 +88,10 @@ struct KParams {
     // (one-chain kernel, GST build) the omega-space state of every chain -- u, trial u, w, trial w, H: 5 x n_omega_pad
     // of the stream type each -- in device memory, for frequency meshes whose state does not fit the 160 KB of LDS
     void* gstate;
+    // (lock-step kernel) an alpha is given up after this many iterations: its Gram matrices are binary16 products
+    // (21 bits), which stalls the iteration where the Newton matrix is very ill conditioned; mxe_chains_finish hands
+    // those alphas to the one-chain kernel (binary64 Gram matrix)
+    int mc_maxiter;
 };
 
 #if defined(MXE_PROFILE) && defined(MXE_PROFILE_EVAL)

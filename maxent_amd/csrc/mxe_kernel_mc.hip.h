@@ -66,6 +66,9 @@ __device__ __forceinline__ void static_for_seq(std::integer_sequence<int, J...>,
 #ifndef MXE_X_DEPTH2
 #define MXE_X_DEPTH2 2        // V ring of the fused pass at two workgroups per CU (4: 1.33 ms and 300 MB of spill stores per launch; 2: 1.29 ms, none)
 #endif
+#ifndef MXE_X_GJB
+#define MXE_X_GJB 4        // entries of the two pivot rows broadcast per batch of the elimination
+#endif
 #ifndef MXE_X_UL
 #define MXE_X_UL 0            // u elements per lane kept in LDS instead of registers (0: all eight in registers)
 #endif
@@ -405,15 +408,15 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             }
             constexpr int K0 = kj + 1;
 #pragma unroll
-            for (int k0 = K0; k0 < NHALF; k0 += 4) {
-                double r0[4], r1[4];
+            for (int k0 = K0; k0 < NHALF; k0 += MXE_X_GJB) {
+                double r0[MXE_X_GJB], r1[MXE_X_GJB];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (k0 + r < NHALF) {
+                for (int r = 0; r < MXE_X_GJB; ++r) if (k0 + r < NHALF) {
                     r0[r] = half_bcast(A[k0 + r], std::integral_constant<int, j>{});          // row j, column k
                     r1[r] = half_bcast(A[k0 + r], std::integral_constant<int, j + 1>{});      // row j + 1
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (k0 + r < NHALF) A[k0 + r] = fma(-f1, r1[r], fma(-f0, r0[r], A[k0 + r]));
+                for (int r = 0; r < MXE_X_GJB; ++r) if (k0 + r < NHALF) A[k0 + r] = fma(-f1, r1[r], fma(-f0, r0[r], A[k0 + r]));
             }
         };
         static_for_seq(std::make_integer_sequence<int, NHALF>{}, pivot2);
@@ -461,7 +464,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             // sc2 = 2^(8 - exponent of the largest w of the accepted point), so that sw <= 16 while w stays
             // below that maximum and a w that grows 2^24-fold still converts to a finite binary16 (the
             // conversion saturates beyond; such a trial point does not survive the test on Q)
-            const double isc2 = 1.0 / t.sc2;
+            const double isc2 = ldexp(1.0, -ilogb(t.sc2));      // sc2 is a power of two: no division in this serial section
             {
                 const double wm = (t.wmax > 1e-290 && t.wmax < 1e290) ? t.wmax : 1.0;
                 const double sc2n = ldexp(1.0, 8 - ilogb(wm));
@@ -479,8 +482,8 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 okflag = 4;
             } else if (t.active) {
                 rhs[q * NP + k] = (k < ns) ? fma(t.alpha * vv[q * NP + k], ci[k], rho[q * NP + k]) : 0.0;
-                const double thr = p.theta * t.alpha / fmax(t.wmax, 1e-300);
-                const unsigned long long m = __ballot(k < ns && cc[k] * cc[k] > thr);
+                const double thr = p.theta * t.alpha, wmx = fmax(t.wmax, 1e-300);
+                const unsigned long long m = __ballot(k < ns && cc[k] * cc[k] * wmx > thr);
                 int na = (p.theta > 0.0) ? __popcll(m) : ns;
                 na = max(1, min(na, NA));
                 t.nact = na;
@@ -489,6 +492,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 // damping loop: raise mu until the factorisation succeeds and Bryan's bound holds
                 while (true) {
                     const double a = t.alpha + t.mu;
+                    double ia = __builtin_amdgcn_rcp(a);             // (the decoupled directions: z = rhs / a)
+                    ia = fma(fma(-a, ia, 1.0), ia, ia);
+                    ia = fma(fma(-a, ia, 1.0), ia, ia);
                     bool ok;
                     if (na <= 16) ok = gj_home(std::integral_constant<int, 16>{}, a, na, isc2);
                     else if (na <= 20) ok = gj_home(std::integral_constant<int, 20>{}, a, na, isc2);
@@ -499,7 +505,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     if (ok) {
                         double z = 0.0, nrm = 0.0;
                         if (k < na) { z = zz[q * NP + k]; nrm = z * (rhs[q * NP + k] - a * z); }
-                        else if (k < ns) z = rhs[q * NP + k] / a;
+                        else if (k < ns) z = rhs[q * NP + k] * ia;
                         nrm = wave_sum(nrm);
                         if (nrm <= t.steplim) {
                             okflag = 1; dk = (k < ns) ? cc[k] * z : 0.0;
@@ -914,7 +920,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     t.bt = 0;
                     if (newton_step && p.tol_h > 0.0 && relH2_min < tol2Hn && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                     else if (p.tol_relq > 0.0 && fabs(fabs(t.Qprev - t.Q) / t.Q) < p.tol_relq && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
-                    else if (t.niter >= p.maxiter) finish_alpha = true;
+                    else if (t.niter >= p.mc_maxiter) finish_alpha = true;
                 }
                 MXE_STAMPA(2);
                 if (fresh && t.scratch == 2) t.scratch = 0;     // accepted or to be halved: the state in LDS is that trial point

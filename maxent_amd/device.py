@@ -78,6 +78,7 @@ SYMBOLS = [
     ('mxe_sync', ctypes.c_int, [_vp]),
     ('mxe_logdet', ctypes.c_int, [_vp, _dp]),
     ('mxe_chains_fetch_nact', ctypes.c_int, [_vp, _ip]),
+    ('mxe_chains_finish', ctypes.c_int, [_vp, _ip]),
     ('mxe_chains_fetch', ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _ip, _ip,
                                         _ip]),
     ('mxe_result_device_ptrs', ctypes.c_int, [_vp] + [ctypes.POINTER(_vp)] * 7),
@@ -386,6 +387,13 @@ class DeviceContext(object):
     def sync(self):
         self._check(self._lib.mxe_sync(self._h), 'mxe_sync')
 
+    def finish(self):
+        """``mxe_chains_finish``: the alphas the lock-step layout gave up on, solved again in the one-chain
+        layout (blocking); returns how many that was"""
+        n = ctypes.c_int32(0)
+        self._check(self._lib.mxe_chains_finish(self._h, ctypes.byref(n)), 'mxe_chains_finish')
+        return int(n.value)
+
     def fetch(self, want_v=True, want_H=True):
         nc, na = self._n_chain, self._n_alpha
         out = dict(
@@ -420,6 +428,7 @@ class DeviceContext(object):
         """Blocking solve: upload, one launch, fetch (``mxe_solve_chains``)."""
         self.upload_chains(elem_of_chain, alpha_scaled, v0, opts)
         self.launch()
+        self.finish()
         return self.fetch(want_v, want_H)
 
     def eval_batch(self, elem_of_problem, alpha_scaled, x, input_is_H=False, chi2_factor=1.0,

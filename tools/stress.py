@@ -34,16 +34,19 @@ for case in range(n_cases):
     n = len(elems)
     ctx.set_elements([ds] * n, [Gmat[i, j] for i, j in elems], np.tile(D, (n, 1)), kinds)
     t0 = time.perf_counter()
-    out = ctx.solve_chains(np.arange(n), alphas, v0, want_v=False, want_H=True)
+    ctx.upload_chains(np.arange(n), alphas, v0)
+    ctx.launch()
+    n_fin = ctx.finish()
+    out = ctx.fetch(want_v=False, want_H=True)
     dt = time.perf_counter() - t0
     info = ctx.last_launch_info()
     au = ctx.audit()
     conv = out['converged']
     corr = np.where(conv, au['corr'], 0.0)
-    line = ('case %2d: %2dx%-2d n_tau %3d n_omega %3d n_s %2d n_alpha %3d alpha %.1e..%.1e%s sigma %.0e | %s | kernel %.2f ms | '
+    line = ('case %2d: %2dx%-2d n_tau %3d n_omega %3d n_s %2d n_alpha %3d alpha %.1e..%.1e%s sigma %.0e | %s | kernel %.2f ms (solve incl. upload / finish / fetch %.1f ms, %d alphas finished in the one-chain layout) | '
             'converged %d/%d, audit max %.1e, evals/alpha max %d, H finite %s' % (
                 case, n_orb, n_orb, n_tau, n_omega, len(K.S), n_alpha, lo, hi, ' asc' if ascending else '', sigma,
-                info['kernel'].replace('mxe::', ''), ctx.last_kernel_ms(), conv.sum(), conv.size, corr.max(),
+                info['kernel'].replace('mxe::', ''), ctx.last_kernel_ms(), 1e3 * dt, n_fin, conv.sum(), conv.size, corr.max(),
                 out['n_evals'].max(), bool(np.all(np.isfinite(out['H'][conv.astype(bool)])))))
     print(line, flush=True)
     worst['corr'] = max(worst['corr'], corr.max()); worst['evals'] = max(worst['evals'], int(out['n_evals'].max()))
