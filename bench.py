@@ -38,19 +38,19 @@ L2_PEAK_GBS = 34500.0          # ... aggregate L2
 N_EVAL_NOMINAL = {'normal': 160, 'plusminus': 84}   # the reference's passes per alpha-solve
 
 # Counter values per launch of the default workload (rocprofv3 --pmc on this very command, summaries under
-# profiles/r02_j_pmc_*.csv; they count events, not time, and do not depend on the clock):
+# profiles/r02_k_pmc_*.csv; they count events, not time, and do not depend on the clock):
 PMC_DEFAULT = dict(
     source='profiles/r02_k_pmc_summary.csv',
     # mean per dispatch of mxe::chain_kernel_mc<32, 2> over ~200 dispatches
-    valu_active_quadcycles=2.66788e8,      # SQ_ACTIVE_INST_VALU (counts quad-cycles: MI355X_MICROARCH.md, cycle constants)
-    mfma_busy_cycles=4.2498e8,            # SQ_VALU_MFMA_BUSY_CYCLES (cycles)
-    coexec_cycles=3.18699e7,               # SQ_VALU_MFMA_COEXEC_CYCLES: both at once, counted once below
-    any_active_quadcycles=3.94375e8,       # SQ_ACTIVE_INST_ANY
-    wave_quadcycles=9.71851e8,            # SQ_WAVE_CYCLES
-    wait_inst_quadcycles=3.16418e8, wait_any_quadcycles=2.61058e8,
-    gui_active_cycles_all_xcd=1.80356e7,   # GRBM_GUI_ACTIVE (sum over the 8 XCDs)
-    fetch_kb=12812.7, write_kb=132659.0,  # FETCH_SIZE (x 2 on gfx950, MI355X_MICROARCH.md section HBM), WRITE_SIZE
-    l2_hit=7.58988e7, l2_miss=1.20911e6)
+    valu_active_quadcycles=2.66584e8,      # SQ_ACTIVE_INST_VALU (counts quad-cycles: MI355X_MICROARCH.md, cycle constants)
+    mfma_busy_cycles=4.25153e8,            # SQ_VALU_MFMA_BUSY_CYCLES (cycles)
+    coexec_cycles=3.18031e7,               # SQ_VALU_MFMA_COEXEC_CYCLES: both at once, counted once below
+    any_active_quadcycles=3.94147e8,       # SQ_ACTIVE_INST_ANY
+    wave_quadcycles=9.70495e8,            # SQ_WAVE_CYCLES
+    wait_inst_quadcycles=3.15671e8, wait_any_quadcycles=2.60677e8,
+    gui_active_cycles_all_xcd=1.80296e7,   # GRBM_GUI_ACTIVE (sum over the 8 XCDs)
+    fetch_kb=12637.1, write_kb=132701.0,  # FETCH_SIZE (x 2 on gfx950, MI355X_MICROARCH.md section HBM), WRITE_SIZE
+    l2_hit=7.59391e7, l2_miss=1.21157e6)
 N_SIMD = 256 * 4
 CLOCK_PEAK_GHZ = 2.4                      # MI355X_MICROARCH.md: max clock
 

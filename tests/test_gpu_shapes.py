@@ -9,6 +9,7 @@ import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import anchor                                                # noqa: E402
+import maxent_amd as mx                                     # noqa: E402
 from maxent_amd import device, synthetic, hostprep           # noqa: E402
 from oracle import ref_numpy as R                            # noqa: E402
 
@@ -122,4 +123,38 @@ def test_more_than_64_singular_values_on_a_long_mesh():
     assert ctx.last_launch_info()['kernel'] == 'mxe::chain_kernel<1, 4, double, device-memory state>'
     assert out['converged'].all() and np.all(np.isfinite(out['H']))
     assert ctx.audit()['corr'].max() < 1e-6
+    ctx.close()
+
+
+def test_alphas_the_lock_step_layout_gives_up_on_are_finished_in_the_one_chain_layout():
+    """Few data points, small alpha: the Newton matrix is so ill conditioned that the binary16 Gram products of
+    the lock-step kernel stall the iteration (hundreds of iterations per alpha where the binary64 Gram matrix
+    takes five).  The kernel gives such an alpha up after 32 iterations and mxe_chains_finish solves it again
+    in the one-chain layout: every alpha converges, to the result of the one-chain layout."""
+    n_tau, n_omega, n_alpha = 40, 257, 20
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(1, n_tau, n_omega, seed=275795323)
+    K.reduce_singular_space(1e-14)
+    D = synthetic.flat_D(omega)
+    err = synthetic.SIGMA * np.ones(n_tau)
+    alphas = np.array(mx.LogAlphaMesh(alpha_min=0.011225438059035777, alpha_max=160.6748373405088, n_points=n_alpha)) * n_tau
+    kinds = [device.ENTROPY_NORMAL]
+    v0 = np.stack([hostprep.initial_v(K.V, D, omega.delta, k) for k in kinds])
+    ctx = device.DeviceContext(K.U, K.S, K.V)
+    ds = ctx.add_dataset(err)
+    ctx.set_elements([ds], [Gmat[0, 0]], np.tile(D, (1, 1)), kinds)
+    ref = ctx.solve_chains(np.arange(1), alphas, v0, device.default_opts(chains_per_wg=1, alpha_split=1))
+    assert ref['converged'].all()
+    ctx.upload_chains(np.arange(1), alphas, v0, device.default_opts(alpha_split=1))
+    ctx.launch()
+    assert ctx.last_launch_info()['kernel'].startswith('mxe::chain_kernel_mc<')
+    ctx.sync()
+    first = ctx.fetch(want_v=False, want_H=False)
+    n_fin = ctx.finish()
+    out = ctx.fetch()
+    assert n_fin == int((first["converged"] == 0).sum()) and n_fin > 0
+    assert out['converged'].all() and np.all(np.isfinite(out['H']))
+    assert rel_l2(out['H'], ref['H']).max() < 1e-7
+    assert np.all(out['n_iter'] >= first['n_iter'])
+    assert ctx.audit()['corr'].max() < 1e-6
+    assert ctx.finish() == 0                      # nothing left to do
     ctx.close()
