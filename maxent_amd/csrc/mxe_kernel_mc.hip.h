@@ -66,6 +66,9 @@ __device__ __forceinline__ void static_for_seq(std::integer_sequence<int, J...>,
 #ifndef MXE_X_DEPTH2
 #define MXE_X_DEPTH2 2        // V ring of the fused pass at two workgroups per CU (4: 1.33 ms and 300 MB of spill stores per launch; 2: 1.29 ms, none)
 #endif
+#ifndef MXE_X_RD1
+#define MXE_X_RD1 4        // (8: the shards of an 8-GPU job 0.593 / 0.653 -> 0.617 / 0.688 ms)
+#endif
 #ifndef MXE_X_GJB
 #define MXE_X_GJB 4        // entries of the two pivot rows broadcast per batch of the elimination
 #endif
@@ -587,7 +590,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             const int nblk = nwp >> 5;                           // blocks of 32 omega rows = two 16-row tiles
             const int nchunk = (ns + 3) >> 2;                    // chunks of four singular directions
             constexpr int TB = 8;                                // tiles per batch (accumulators)
-            constexpr int RD = 4;                                // ring depth in chunks
+            constexpr int RD = (WGPC == 1) ? MXE_X_RD1 : 4;           // ring depth in chunks (one workgroup per CU: registers to spare)
             constexpr int NCHK = NP / 4;
             // The two tiles of a block interleave: tile parity = omega parity, so that a lane's operands of
             // both come from ONE 16-byte load (V^T[4 kc + ak][32 blk + 2 (lane & 15) .. + 1]).  The loads of
