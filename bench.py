@@ -274,7 +274,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     # a step is ~1.3 ms: 200 of them keep the timed region long enough (0.27 s) for the tens of milliseconds
     # by which a fresh submission is sometimes picked up late on the MI355X boxes
-    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--steps', type=int, default=1000)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--scaling', choices=('strong', 'weak'), default='strong')
     ap.add_argument('--gather', choices=('compact', 'full'), default='compact')

@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include <utility>
 
 namespace mxe {
 
@@ -272,6 +273,70 @@ __device__ __forceinline__ double wave_bcast(double x, int src) {
 
 template <int NW> __device__ __forceinline__ void block_sync() {
     if (NW == 1) wave_sync(); else __syncthreads();
+}
+
+// f(integral_constant<int, J>) for every J of the sequence, in order
+template <int... J, class F>
+__device__ __forceinline__ void static_for_seq(std::integer_sequence<int, J...>, F&& f) {
+    (f(std::integral_constant<int, J>{}), ...);
+}
+
+// lane J of the lane's own group of 32 (ds_swizzle_b32, bit-mask mode: and 0, or J, xor 0 -- the LDS crossbar, no memory)
+template <int J> __device__ __forceinline__ double half_bcast(double x) {
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(x), J << 5);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), J << 5);
+    return __hiloint2double(hi, lo);
+}
+
+// Gauss-Jordan elimination of an N x N positive definite system (N <= 32, even) on the 64 lanes of one wavefront,
+// two pivots per step (the solve of the lock-step kernel, mxe_kernel_mc.hip.h: gj_home, explains the layout): lane
+// (h = lane >> 5, i = lane & 31) holds of row i the columns of parity h -- A[kk] = column 2 kk + h -- and the
+// right-hand side b_i (both halves carry it).  Returns false where a pivot block is not positive definite; z = the
+// lane's solution component.
+template <int N>
+__device__ __forceinline__ bool gj2_solve64(double (&A)[N / 2], double b, int i, double& z)
+{
+    constexpr int NHALF = N / 2;
+    bool ok = true;
+    double ps = 1.0, pc = 0.0;                 // z_i = ps b_i + pc b_(i ^ 1)
+    auto pivot2 = [&](auto KTag) {
+        constexpr int kj = decltype(KTag)::value, j = 2 * kj;
+        double c0, c1;
+        {
+            const unsigned xlo = (unsigned)__double2loint(A[kj]), xhi = (unsigned)__double2hiint(A[kj]);
+            const auto slo = __builtin_amdgcn_permlane32_swap(xlo, xlo, false, false);
+            const auto shi = __builtin_amdgcn_permlane32_swap(xhi, xhi, false, false);
+            c0 = __hiloint2double((int)shi[0], (int)slo[0]);      // column j (the lower half's values in both halves)
+            c1 = __hiloint2double((int)shi[1], (int)slo[1]);      // column j + 1
+        }
+        const double pa = wave_bcast(c0, j), pb = wave_bcast(c1, j), pd = wave_bcast(c1, j + 1);
+        const double det = fma(pa, pd, -pb * pb);
+        if (!(pa > 0.0) || !(det > 0.0)) ok = false;
+        double inv = __builtin_amdgcn_rcp(det);
+        inv = fma(fma(-det, inv, 1.0), inv, inv);
+        const double qa = pa * inv, qb = pb * inv, qd = pd * inv;       // P^-1 = [[qd, -qb], [-qb, qa]]
+        const bool prow = (i >> 1) == kj;
+        if (prow) { ps = (i & 1) ? qa : qd; pc = -qb; }
+        const double f0 = prow ? 0.0 : fma(c0, qd, -c1 * qb);
+        const double f1 = prow ? 0.0 : fma(c1, qa, -c0 * qb);
+        {
+            const double b0 = wave_bcast(b, j), b1 = wave_bcast(b, j + 1);
+            b = fma(-f1, b1, fma(-f0, b0, b));
+        }
+#pragma unroll
+        for (int k0 = kj + 1; k0 < NHALF; k0 += 4) {
+            double r0[4], r1[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (k0 + r < NHALF) { r0[r] = half_bcast<j>(A[k0 + r]); r1[r] = half_bcast<j + 1>(A[k0 + r]); }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (k0 + r < NHALF) A[k0 + r] = fma(-f1, r1[r], fma(-f0, r0[r], A[k0 + r]));
+        }
+    };
+    static_for_seq(std::make_integer_sequence<int, NHALF>{}, pivot2);
+    const int plo = __builtin_amdgcn_ds_swizzle(__double2loint(b), (1 << 10) | 0x1f);     // lane ^ 1
+    const int phi = __builtin_amdgcn_ds_swizzle(__double2hiint(b), (1 << 10) | 0x1f);
+    z = fma(ps, b, pc * __hiloint2double(phi, plo));
+    return ok;
 }
 
 // block-wide reduction of NV sums and one max; results valid in every thread.
@@ -871,50 +936,27 @@ void chain_kernel(const KParams p)
         constexpr int N = decltype(NTag)::value;
         bool ok = true;
         if (wave == 0) {
-            // Gauss-Jordan elimination of the full symmetric rows (lane i = row i) instead of a Cholesky
-            // factorisation with a transposed solve: the wave issues the same instructions for the lanes
-            // above the pivot as the factorisation does for the lanes below it, and the solution falls out
-            // of the right-hand-side column (see the lock-step kernel, home phase)
-            const int i = lane;
+            // Gauss-Jordan elimination on all 64 lanes, two pivots per step (gj2_solve64): the solution falls
+            // out of the right-hand-side column, no transposed solve
+            const int i = lane & 31, h = lane >> 5;
             const bool live = i < n_act;
             const double ci_ = live ? cc[i] : 0.0;
-            double A[N];
+            double A[N / 2];
             {
                 const int ic = min(i, N - 1);
 #pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    // W is kept as upper triangle + diagonal: entry (i, j) sits at [min][max]
+                for (int kk = 0; kk < N / 2; ++kk) {
+                    // W is kept as upper triangle + diagonal: entry (i, k) sits at [min][max]
+                    const int k = 2 * kk + h;
                     double x = 0.0;
-                    if (live && j < n_act) x = ci_ * Wm[min(j, ic) * LD + max(j, ic)] * cc[j];
-                    if (j == i) x = live ? x + a : 1.0;
-                    A[j] = x;
+                    if (live && k < n_act) x = ci_ * Wm[min(k, ic) * LD + max(k, ic)] * cc[k];
+                    if (k == i) x = live ? x + a : 1.0;
+                    A[kk] = x;
                 }
             }
-            double b = live ? rhs[i] : 0.0;
-            double dinv_i = 1.0;
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                const double piv = wave_bcast(A[j], j);
-                if (!(piv > 0.0)) ok = false;
-                double inv = __builtin_amdgcn_rcp(piv);
-                inv = fma(fma(-piv, inv, 1.0), inv, inv);
-                if (i == j) dinv_i = inv;
-                const double f = (i != j) ? A[j] * inv : 0.0;     // multiplier of row j for this lane's row
-                b = fma(-f, wave_bcast(b, j), b);
-                // broadcasts batched eight at a time so that the v_readlane -> v_fma SGPR hazard
-                // slots are filled with work
-#pragma unroll
-                for (int k0 = j + 1; k0 < N; k0 += 8) {
-                    double rk[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) if (k0 + q < N) rk[q] = wave_bcast(A[k0 + q], j);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) if (k0 + q < N) A[k0 + q] = fma(-f, rk[q], A[k0 + q]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            if (ok && live) zz[i] = b * dinv_i;
+            double z;
+            ok = gj2_solve64<N>(A, live ? rhs[i] : 0.0, i, z);
+            if (ok && live && h == 0) zz[i] = z;
         }
         if (NW > 1) {
             if (tid == 0) red[0] = ok ? 1.0 : 0.0;

@@ -57,11 +57,6 @@ constexpr double MC_GRAM_ERR = 0.0;              // allowance for the inexact Gr
 constexpr int MC_INIT_STRIDE = 3 * 256 + 64 + 8;       // KParams::init_tab, NA = 32: three tile pairs, h, four scalars (+ pad)
 constexpr int MC_LOOKAHEAD_ROWS = 512;
 constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
-// f(integral_constant<int, J>) for every J of the sequence, in order
-template <int... J, class F>
-__device__ __forceinline__ void static_for_seq(std::integer_sequence<int, J...>, F&& f) {
-    (f(std::integral_constant<int, J>{}), ...);
-}
 
 #ifndef MXE_X_DEPTH2
 #define MXE_X_DEPTH2 2        // V ring of the fused pass at two workgroups per CU (4: 1.33 ms and 300 MB of spill stores per launch; 2: 1.29 ms, none)
