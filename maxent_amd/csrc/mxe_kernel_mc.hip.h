@@ -64,9 +64,6 @@ constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
 #ifndef MXE_X_RD1
 #define MXE_X_RD1 4        // (8: the shards of an 8-GPU job 0.593 / 0.653 -> 0.617 / 0.688 ms)
 #endif
-#ifndef MXE_X_GJB
-#define MXE_X_GJB 4        // entries of the two pivot rows broadcast per batch of the elimination
-#endif
 #ifndef MXE_X_UL
 #define MXE_X_UL 0            // u elements per lane kept in LDS instead of registers (0: all eight in registers)
 #endif
@@ -269,22 +266,19 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     // home wave: the slot's Newton system  (c W c + a I) z = rhs  on the active block, in registers.
     // All 64 lanes work on the one N x N system (N <= 32): lane (h = lane >> 5, i = lane & 31) holds of
     // row i the columns of parity h -- A[kk] = column 2 kk + h, N / 2 doubles -- and the right-hand side b_i
-    // (both halves carry it).  Gauss-Jordan elimination without pivoting (positive definite matrix): for
-    // pivot j every row subtracts f_i = A_ij / A_jj times row j from its columns k > j and from b_i.
-    //   * row j, as far as a lane needs it, sits in the lane of ITS OWN half that holds row j: a broadcast
-    //     inside the groups of 32 lanes, ds_swizzle_b32 (the LDS crossbar; no memory, static pattern);
-    //   * column j sits in one half (parity of j); v_permlane32_swap hands it to the other.
-    // Per pivot a wave issues (N - j) / 2 fused multiply-adds and N - j swizzles where the one-half layout
-    // (lane = row, v_readlane broadcasts) issued N - j and 2 (N - j) readlanes: a third of the vector
-    // instructions.  When the elimination ends z_i = b_i / A_ii: no back substitution.
+    // (both halves carry it).  Gauss-Jordan elimination without pivoting (positive definite matrix), two pivots
+    // per step (gj2_solve64, mxe_kernel.hip.h): every row subtracts (f0, f1) = (A_ij, A_i,j+1) P^-1 times rows j
+    // and j + 1 -- P the 2 x 2 pivot block, inverted in closed form -- from its columns k > j + 1 and from b_i.
+    //   * rows j, j + 1, as far as a lane needs them, sit in lanes of ITS OWN half: a broadcast inside the
+    //     groups of 32 lanes, ds_swizzle_b32 (the LDS crossbar; no memory, static pattern);
+    //   * columns j (even: lower half) and j + 1 (upper half) are the same register A[j / 2]: one pair of
+    //     v_permlane32_swap hands both to every lane.
+    // Per pair a wave issues N - j - 2 fused multiply-adds and 2 (N - j - 2) swizzles behind ONE dependent chain
+    // (swap, three broadcasts, determinant, reciprocal, multipliers); the one-half layout of round 1 (lane = row,
+    // v_readlane broadcasts) issued three times the vector instructions.  The pivot rows stay untouched and the
+    // matrix ends block diagonal: z of a row pair is P^-1 (b_j, b_j+1), no back substitution.
     // The solve only preconditions the (inexact) Newton step; rows >= n_act are identity rows.
     // ------------------------------------------------------------------
-    auto half_bcast = [&](double x, auto JTag) -> double {       // lane j of the lane's own group of 32
-        constexpr int pat = decltype(JTag)::value << 5;            // bit-mask mode: and 0, or j, xor 0
-        const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(x), pat);
-        const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), pat);
-        return __hiloint2double(hi, lo);
-    };
     auto gj_home = [&](auto NTag, double a, int n_act, double isc2) -> bool {
         constexpr int N = decltype(NTag)::value;
         static_assert(N <= 32 && N % 2 == 0, "two half-waves of 32 rows");
@@ -331,101 +325,12 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             }
         }
         double b = live ? rq[i] : 0.0;
-#ifdef MXE_X_GJ_SINGLE
-        double dinv_i = 1.0;
+        // two pivots per step: gj2_solve64 (mxe_kernel.hip.h)
         MXE_STAMPH(1);
-        auto pivot = [&](auto JTag) {
-            constexpr int j = decltype(JTag)::value;
-            constexpr int kj = j >> 1, hj = j & 1;
-            // column j for both halves
-            double cj;
-            {
-                const unsigned xlo = (unsigned)__double2loint(A[kj]), xhi = (unsigned)__double2hiint(A[kj]);
-                const auto slo = __builtin_amdgcn_permlane32_swap(xlo, xlo, false, false);
-                const auto shi = __builtin_amdgcn_permlane32_swap(xhi, xhi, false, false);
-                // [0]: the lower half's values in both halves, [1]: the upper half's
-                cj = __hiloint2double((int)shi[hj], (int)slo[hj]);
-            }
-            const double piv = wave_bcast(cj, j);
-            if (!(piv > 0.0)) ok = false;
-            double inv = __builtin_amdgcn_rcp(piv);
-            inv = fma(fma(-piv, inv, 1.0), inv, inv);
-            if (i == j) dinv_i = inv;
-            const double f = (i != j) ? cj * inv : 0.0;      // multiplier of row j for this lane's row
-            b = fma(-f, wave_bcast(b, j), b);
-            // columns k = 2 kk + h > j: kk >= (j + 1) >> 1 (for even j the lower half also "updates" column j
-            // itself, which nobody reads again)
-            constexpr int K0 = (j + 1) >> 1;
-#pragma unroll
-            for (int k0 = K0; k0 < NHALF; k0 += 8) {
-                double rk[8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) if (k0 + r < NHALF) rk[r] = half_bcast(A[k0 + r], JTag);     // row j, column k
-#pragma unroll
-                for (int r = 0; r < 8; ++r) if (k0 + r < NHALF) A[k0 + r] = fma(-f, rk[r], A[k0 + r]);
-            }
-        };
-        static_for_seq(std::make_integer_sequence<int, N>{}, pivot);
+        double z;
+        ok = gj2_solve64<N>(A, b, i, z);
         MXE_STAMPH(3);
-        if (ok && live && h == 0) zz[q * NP + i] = b * dinv_i;
-#else
-        // Two pivots per step.  Columns j (even: kept by the lower half) and j + 1 (upper half) are BOTH the
-        // register A[j / 2] -- one pair of v_permlane32_swap hands the two columns to every lane --, the 2 x 2
-        // pivot block P = [[a, b], [b, d]] (rows j, j + 1: three broadcasts) is inverted in closed form, and every
-        // other row subtracts (f0, f1) = (A_ij, A_i,j+1) P^-1 times rows j and j + 1 from its columns k > j + 1
-        // and from its right-hand side.  The two pivot rows stay as they are; when the elimination ends the
-        // matrix is block diagonal and z of a row pair is P^-1 (b_j, b_j+1) with the P of its pivot step.  Same
-        // multiply-adds and swizzles as one pivot at a time, but ONE dependent chain (swap, broadcasts, determinant,
-        // reciprocal, multipliers, row broadcasts) per two pivots instead of two.
-        double ps = 1.0, pc = 0.0;                 // z_i = ps b_i + pc b_(i ^ 1)
-        MXE_STAMPH(1);
-        auto pivot2 = [&](auto KTag) {
-            constexpr int kj = decltype(KTag)::value, j = 2 * kj;
-            double c0, c1;
-            {
-                const unsigned xlo = (unsigned)__double2loint(A[kj]), xhi = (unsigned)__double2hiint(A[kj]);
-                const auto slo = __builtin_amdgcn_permlane32_swap(xlo, xlo, false, false);
-                const auto shi = __builtin_amdgcn_permlane32_swap(xhi, xhi, false, false);
-                // [0]: the lower half's values in both halves (column j), [1]: the upper half's (column j + 1)
-                c0 = __hiloint2double((int)shi[0], (int)slo[0]);
-                c1 = __hiloint2double((int)shi[1], (int)slo[1]);
-            }
-            const double pa = wave_bcast(c0, j), pb = wave_bcast(c1, j), pd = wave_bcast(c1, j + 1);
-            const double det = fma(pa, pd, -pb * pb);
-            if (!(pa > 0.0) || !(det > 0.0)) ok = false;
-            double inv = __builtin_amdgcn_rcp(det);
-            inv = fma(fma(-det, inv, 1.0), inv, inv);
-            const double qa = pa * inv, qb = pb * inv, qd = pd * inv;       // P^-1 = [[qd, -qb], [-qb, qa]]
-            const bool prow = (i >> 1) == kj;
-            if (prow) { ps = (i & 1) ? qa : qd; pc = -qb; }
-            const double f0 = prow ? 0.0 : fma(c0, qd, -c1 * qb);
-            const double f1 = prow ? 0.0 : fma(c1, qa, -c0 * qb);
-            {
-                const double b0 = wave_bcast(b, j), b1 = wave_bcast(b, j + 1);
-                b = fma(-f1, b1, fma(-f0, b0, b));
-            }
-            constexpr int K0 = kj + 1;
-#pragma unroll
-            for (int k0 = K0; k0 < NHALF; k0 += MXE_X_GJB) {
-                double r0[MXE_X_GJB], r1[MXE_X_GJB];
-#pragma unroll
-                for (int r = 0; r < MXE_X_GJB; ++r) if (k0 + r < NHALF) {
-                    r0[r] = half_bcast(A[k0 + r], std::integral_constant<int, j>{});          // row j, column k
-                    r1[r] = half_bcast(A[k0 + r], std::integral_constant<int, j + 1>{});      // row j + 1
-                }
-#pragma unroll
-                for (int r = 0; r < MXE_X_GJB; ++r) if (k0 + r < NHALF) A[k0 + r] = fma(-f1, r1[r], fma(-f0, r0[r], A[k0 + r]));
-            }
-        };
-        static_for_seq(std::make_integer_sequence<int, NHALF>{}, pivot2);
-        MXE_STAMPH(3);
-        {
-            const int plo = __builtin_amdgcn_ds_swizzle(__double2loint(b), (1 << 10) | 0x1f);     // lane ^ 1
-            const int phi = __builtin_amdgcn_ds_swizzle(__double2hiint(b), (1 << 10) | 0x1f);
-            const double bp = __hiloint2double(phi, plo);
-            if (ok && live && h == 0) zz[q * NP + i] = fma(ps, b, pc * bp);
-        }
-#endif
+        if (ok && live && h == 0) zz[q * NP + i] = z;
         MXE_STAMPH(4);
 #ifdef MXE_PROFILE_HOME
         prof_acc[6] += 1;                        // solves (slot 6 is a count in this build)
