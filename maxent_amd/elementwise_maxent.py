@@ -128,6 +128,13 @@ class ElementwiseMaxEnt(object):
     # ---- batched phases --------------------------------------------------
     def _run_batch(self, worker, jobs, per_job_D=None):
         """``jobs``: list of (element, re).  All scans in one launch."""
+        batch = self._prepare_batch(worker, jobs, per_job_D)
+        self._solve_batches([batch])
+        return self._finish_batch(batch)
+
+    def _prepare_batch(self, worker, jobs, per_job_D=None):
+        """the specs of the elements of ``jobs`` that are to be solved (the others go to the result's zero
+        elements); leaves ``worker`` loaded with the last element, as the reference does"""
         self.prepare_maxent_result(overwrite=False)
         res = self.maxent_result
         loop = worker.maxent_loop
@@ -172,20 +179,69 @@ class ElementwiseMaxEnt(object):
             spec['A_map'] = loop.A_of_H
             specs.append(spec)
             live.append((element, cidx))
+        return dict(worker=worker, specs=specs, live=live)
+
+    def _solve_batches(self, batches):
+        """one launch for all batches whose workers share the decomposition of the kernel, the minimiser settings
+        and the alpha count (plain ElementwiseMaxEnt: diagonal and off-diagonal elements together, as bench.py
+        times them); otherwise one launch per batch"""
+        batches = [b for b in batches if b['specs']]
+        groups = []
+        for b in batches:
+            for g in groups:
+                if self._same_launch(g[0], b):
+                    g.append(b)
+                    break
+            else:
+                groups.append([b])
+        res = self.maxent_result
+        for g in groups:
+            loop = g[0]['worker'].maxent_loop
+            specs = [s for b in g for s in b['specs']]
+            t0 = datetime.now()
+            for b in g:
+                for (element, cidx) in b['live']:
+                    res.start_timing(element, cidx, time=t0)
+            sols, info = solve_elements(loop.K, specs, loop.minimizer,
+                                        device_id=loop.device_id, device_ids=self.device_ids,
+                                        want_logdet=loop.probability is not None,
+                                        chi2_factor=loop.cost_function.chi2_factor)
+            t1 = datetime.now()
+            self.last_launches.append(info)
+            off = 0
+            for b in g:
+                n = len(b['specs'])
+                b.update(sols=sols[off:off + n], info=info, t0=t0, t1=t1,
+                         per_alpha=(t1 - t0) / max(1, len(specs) * len(specs[0]['alpha'])))
+                off += n
+
+    def _same_launch(self, a, b):
+        la, lb = a['worker'].maxent_loop, b['worker'].maxent_loop
+        if la is lb:
+            return True
+        Ka, Kb = la.K, lb.K
+        try:
+            same = (Ka._U is not None and Ka._U is Kb._U and Ka._S is Kb._S and Ka._V is Kb._V and
+                    Ka.rotation is None and Kb.rotation is None and
+                    len(a['specs'][0]['alpha']) == len(b['specs'][0]['alpha']) and
+                    (la.probability is None) == (lb.probability is None) and
+                    la.device_id == lb.device_id and
+                    la.cost_function.chi2_factor == lb.cost_function.chi2_factor and
+                    bytes(la.minimizer.to_opts()) == bytes(lb.minimizer.to_opts()))
+        except Exception:
+            return False
+        return bool(same)
+
+    def _finish_batch(self, batch):
+        """records and analyzers of a solved batch"""
+        res = self.maxent_result
+        worker, specs, live = batch['worker'], batch['specs'], batch['live']
         if not specs:
             return res
+        loop = worker.maxent_loop
         if res._default_analyzer_name is None and loop.analyzers:
             res._default_analyzer_name = loop.analyzers[0].name
-        t0 = datetime.now()
-        for (element, cidx) in live:
-            res.start_timing(element, cidx, time=t0)
-        sols, info = solve_elements(loop.K, specs, loop.minimizer,
-                                    device_id=loop.device_id, device_ids=self.device_ids,
-                                    want_logdet=loop.probability is not None,
-                                    chi2_factor=loop.cost_function.chi2_factor)
-        self.last_launches.append(info)
-        t1 = datetime.now()
-        per_alpha = (t1 - t0) / max(1, len(specs) * len(specs[0]['alpha']))
+        sols, info, t1, per_alpha = batch['sols'], batch['info'], batch['t1'], batch['per_alpha']
         talk = bool(worker.logtaker.verbose & (VerbosityFlags.ElementInfo | VerbosityFlags.AlphaLoop))
         for spec, sol, (element, cidx) in zip(specs, sols, live):
             if talk:
@@ -255,10 +311,7 @@ class ElementwiseMaxEnt(object):
         self.maxent_diagonal.logtaker.message(
             VerbosityFlags.ElementInfo, 'Calculating diagonal elements.')
         res = self._run_batch(self.maxent_diagonal, self._diag_jobs())
-        if self.use_complex:
-            for i in range(self.shape[0]):
-                if (i, i, 1) not in res._zero_elements:
-                    res._zero_elements.append((i, i, 1))
+        self._mark_imaginary_diagonal(res)
         return res
 
     def run_offdiagonal(self):
@@ -268,9 +321,27 @@ class ElementwiseMaxEnt(object):
         return self._run_batch(self.maxent_offdiagonal, self._offdiag_jobs())
 
     def run(self):
-        self.run_diagonal()
-        self.run_offdiagonal()
-        return self.maxent_result
+        cls = type(self)
+        if (cls.run_diagonal is not ElementwiseMaxEnt.run_diagonal or
+                cls.run_offdiagonal is not ElementwiseMaxEnt.run_offdiagonal):
+            self.run_diagonal()              # (a subclass with phases of its own: PoormanMaxEnt needs the
+            self.run_offdiagonal()           #  diagonal results before the off-diagonal elements start)
+            return self.maxent_result
+        # both phases in ONE launch where the two workers share the kernel's decomposition
+        self.maxent_diagonal.logtaker.message(VerbosityFlags.ElementInfo, 'Calculating diagonal elements.')
+        diag = self._prepare_batch(self.maxent_diagonal, self._diag_jobs())
+        self.maxent_offdiagonal.logtaker.message(VerbosityFlags.ElementInfo, 'Calculating off-diagonal elements.')
+        off = self._prepare_batch(self.maxent_offdiagonal, self._offdiag_jobs())
+        self._solve_batches([diag, off])
+        res = self._finish_batch(diag)
+        self._mark_imaginary_diagonal(res)
+        return self._finish_batch(off)
+
+    def _mark_imaginary_diagonal(self, res):
+        if self.use_complex:
+            for i in range(self.shape[0]):
+                if (i, i, 1) not in res._zero_elements:
+                    res._zero_elements.append((i, i, 1))
 
     # ---- input ----------------------------------------------------------------
     def set_G(self, G_mat, set_G_element, determine_shape):
