@@ -42,15 +42,15 @@ N_EVAL_NOMINAL = {'normal': 160, 'plusminus': 84}   # the refere
 PMC_DEFAULT = dict(
     source='profiles/r02_k_pmc_summary.csv',
     # mean per dispatch of mxe::chain_kernel_mc<32, 2> over ~200 dispatches
-    valu_active_quadcycles=2.66584e8,      # SQ_ACTIVE_INST_VALU (counts quad-cycles: MI355X_MICROARCH.md, cycle constants)
-    mfma_busy_cycles=4.25153e8,            # SQ_VALU_MFMA_BUSY_CYCLES (cycles)
-    coexec_cycles=3.18031e7,               # SQ_VALU_MFMA_COEXEC_CYCLES: both at once, counted once below
-    any_active_quadcycles=3.94147e8,       # SQ_ACTIVE_INST_ANY
-    wave_quadcycles=9.70495e8,            # SQ_WAVE_CYCLES
-    wait_inst_quadcycles=3.15671e8, wait_any_quadcycles=2.60677e8,
-    gui_active_cycles_all_xcd=1.80296e7,   # GRBM_GUI_ACTIVE (sum over the 8 XCDs)
-    fetch_kb=12637.1, write_kb=132701.0,  # FETCH_SIZE (x 2 on gfx950, MI355X_MICROARCH.md section HBM), WRITE_SIZE
-    l2_hit=7.59391e7, l2_miss=1.21157e6)
+    valu_active_quadcycles=2.66445e+08,      # SQ_ACTIVE_INST_VALU (counts quad-cycles: MI355X_MICROARCH.md, cycle constants)
+    mfma_busy_cycles=4.24972e+08,            # SQ_VALU_MFMA_BUSY_CYCLES (cycles)
+    coexec_cycles=3.1718e+07,               # SQ_VALU_MFMA_COEXEC_CYCLES: both at once, counted once below
+    any_active_quadcycles=3.94005e+08,       # SQ_ACTIVE_INST_ANY
+    wave_quadcycles=9.73155e+08,            # SQ_WAVE_CYCLES
+    wait_inst_quadcycles=3.16274e+08, wait_any_quadcycles=2.62875e+08,
+    gui_active_cycles_all_xcd=1.80783e+07,   # GRBM_GUI_ACTIVE (sum over the 8 XCDs)
+    fetch_kb=12786.5, write_kb=132573,  # FETCH_SIZE (x 2 on gfx950, MI355X_MICROARCH.md section HBM), WRITE_SIZE
+    l2_hit=7.58981e+07, l2_miss=1.2074e+06)
 N_SIMD = 256 * 4
 CLOCK_PEAK_GHZ = 2.4                      # MI355X_MICROARCH.md: max clock
 
@@ -195,7 +195,7 @@ def audit_block(ctx):
 
 
 def end_to_end_block(batch, n_orb, n_alpha):
-    """what a caller of the reference's API sees: ElementwiseMaxEnt on the same input -- H2D, two launches,
+    """what a caller of the reference's API sees: ElementwiseMaxEnt on the same input -- H2D, one launch,
     D2H of what the result object needs, records, analyzers -- next to the device-resident figure"""
     import maxent_amd as mx
 
@@ -226,7 +226,7 @@ def end_to_end_block(batch, n_orb, n_alpha):
     return dict(api='ElementwiseMaxEnt(use_hermiticity=False).run()', problems=P,
                 fresh_object_ms=1e3 * min(cold), same_object_ms=1e3 * min(warm),
                 alpha_solves_per_s_same_object=P / min(warm), alpha_solves_per_s_fresh_object=P / min(cold),
-                includes='kernel fill + SVD + staging (fresh object only), H2D of G / D / alpha, two launches, D2H of '
+                includes='kernel fill + SVD + staging (fresh object only), H2D of G / D / alpha, one launch (diagonal and off-diagonal elements together), D2H of '
                          'chi2 / S / Q / v, records, LineFit / Chi2Curvature / Entropy analyzers, D2H of the A_out rows',
                 first_access_of_all_H_ms=1e3 * t_H, all_H_MB=nbytes / 1e6)
 

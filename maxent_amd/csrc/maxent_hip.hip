@@ -33,6 +33,20 @@ struct DataSet {
     std::vector<double> err;    // n_rows
 };
 
+// Wait for the ctx stream by polling: a blocking hipStreamSynchronize was seen to return tens of
+// milliseconds after the work had finished in a quarter of the processes on the MI355X boxes (the
+// device time of 20 launches 33 ms, the host-side wait 67 ms); the launches last 1-20 ms, so the host
+// thread spins on hipStreamQuery for up to two seconds and only then blocks.
+static hipError_t stream_wait(hipStream_t s)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return hipStreamSynchronize(s);
+    }
+}
+
 template <typename T> struct DevBuf {
     T* p = nullptr; size_t n = 0;
     hipError_t ensure(size_t count) {
@@ -239,7 +253,7 @@ int upload_bases(mxe_ctx* ctx)
     HIPCHK(ctx, ctx->dVtf.ensure(hVtf.size()));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dVf.p, hVf.data(), hVf.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dVtf.p, hVtf.data(), hVtf.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));
     ctx->ds_dirty = false;
     return MXE_OK;
 }
@@ -421,16 +435,18 @@ try {
         const double* Ge = G + G_offset[e];
         Gt.assign(DS.n_rows, 0.0);
         for (int i = 0; i < DS.n_rows; ++i) Gt[i] = Ge[i] / DS.err[i];
-        // ghat = Uhat^T Gt ;  c_perp = |Gt - Uhat ghat|^2
-        for (int k = 0; k < ns; ++k) {
-            double s = 0.0;
-            for (int i = 0; i < DS.n_rows; ++i) s += DS.Uhat[(size_t)i * ns + k] * Gt[i];
-            hghat[(size_t)e * NP + k] = s;
+        // ghat = Uhat^T Gt ;  c_perp = |Gt - Uhat ghat|^2   (both along the rows of Uhat: unit stride)
+        double* gh = hghat.data() + (size_t)e * NP;
+        for (int i = 0; i < DS.n_rows; ++i) {
+            const double* ui = DS.Uhat.data() + (size_t)i * ns;
+            const double gi = Gt[i];
+            for (int k = 0; k < ns; ++k) gh[k] += ui[k] * gi;
         }
         double cp = 0.0;
         for (int i = 0; i < DS.n_rows; ++i) {
+            const double* ui = DS.Uhat.data() + (size_t)i * ns;
             double r = Gt[i];
-            for (int k = 0; k < ns; ++k) r -= DS.Uhat[(size_t)i * ns + k] * hghat[(size_t)e * NP + k];
+            for (int k = 0; k < ns; ++k) r -= ui[k] * gh[k];
             cp += r * r;
         }
         hcperp[e] = cp;
@@ -454,7 +470,7 @@ try {
     HIPCHK(ctx, hipMemcpyAsync(ctx->dsumD.p, hsumD.data(), (size_t)n_elem * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->delem_ds.p, ctx->elem_ds.data(), (size_t)n_elem * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->delem_kind.p, ctx->elem_kind.data(), (size_t)n_elem * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));
     if (ctx->ds_dirty) { int rc = upload_bases(ctx); if (rc != MXE_OK) return rc; }
     ctx->chains_ready = false;
     return MXE_OK;
@@ -523,7 +539,7 @@ int build_init_table(mxe_ctx* ctx, int n_chain, const int32_t* elem_of_chain, co
     HIPCHK(ctx, hipMemcpyAsync(hw.data(), ep.w, hw.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(hh.data(), ep.h, hh.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(hW.data(), ep.W, hW.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));
     const int STR = mxe::MC_INIT_STRIDE;
     std::vector<double> tab((size_t)P * STR, 0.0);
     for (int q = 0; q < P; ++q) {
@@ -555,7 +571,7 @@ int build_init_table(mxe_ctx* ctx, int n_chain, const int32_t* elem_of_chain, co
     HIPCHK(ctx, ctx->dsub_init.ensure(sub_init.size()));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dinit_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_init.p, sub_init.data(), sub_init.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));
     ctx->has_init = true;
     return MXE_OK;
 }
@@ -815,7 +831,7 @@ try {
         HIPCHK(ctx, hipMemcpyAsync(ctx->dwg_chains.p, ctx->wg_chains.data(), ctx->wg_chains.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dalpha.p, alpha_dev.data(), P * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dv0.p, hv0.data(), hv0.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));
     ctx->n_chain = n_chain; ctx->n_alpha = n_alpha;
     ctx->has_init = false;
     { const int rc_init = build_init_table(ctx, n_chain, elem_of_chain, hv0); if (rc_init != MXE_OK) return rc_init; }
@@ -945,20 +961,6 @@ try {
 }
 MXE_CATCH_ALL
 
-// Wait for the ctx stream by polling: a blocking hipStreamSynchronize was seen to return tens of
-// milliseconds after the work had finished in a quarter of the processes on the MI355X boxes (the
-// device time of 20 launches 33 ms, the host-side wait 67 ms); the launches last 1-20 ms, so the host
-// thread spins on hipStreamQuery for up to two seconds and only then blocks.
-static hipError_t stream_wait(hipStream_t s)
-{
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        const hipError_t e = hipStreamQuery(s);
-        if (e != hipErrorNotReady) return e;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return hipStreamSynchronize(s);
-    }
-}
-
 int mxe_sync(mxe_ctx* ctx)
 {
     if (!ctx) return MXE_ERR_ARG;
@@ -1083,7 +1085,7 @@ int mxe_chains_fetch_nact(mxe_ctx* ctx, int32_t* out_nact)
     if (!ctx || !out_nact) return MXE_ERR_ARG;
     if (!ctx->launched) return MXE_ERR_STATE;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));
     const size_t P = (size_t)ctx->n_chain * ctx->n_alpha;
     HIPCHK(ctx, hipMemcpy(out_nact, ctx->dout_nact.p, P * 4, hipMemcpyDeviceToHost));
     return MXE_OK;
@@ -1183,7 +1185,7 @@ int mxe_last_launch_info(mxe_ctx* ctx, int* waves_per_chain, int* n_workgroups, 
 extern "C" int mxe_prof_fetch(mxe_ctx* ctx, long long* out /*[n_sub + 8192][8]*/)
 {
     if (!ctx || !out) return MXE_ERR_ARG;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));
     HIPCHK(ctx, hipMemcpy(out, ctx->dprof.p, ((size_t)ctx->n_sub + 8 * 1024) * 64, hipMemcpyDeviceToHost));
     return MXE_OK;
 }
@@ -1317,7 +1319,7 @@ try {
 #undef MXE_LAUNCH_LOGDET
     HIPCHK(ctx, e);
     HIPCHK(ctx, hipMemcpyAsync(out_logdet, ctx->dlogdet.p, P * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));
     return MXE_OK;
 }
 MXE_CATCH_ALL
@@ -1437,7 +1439,7 @@ try {
     if (out_g) { hg.resize((size_t)P * NP); HIPCHK(ctx, hipMemcpyAsync(hg.data(), ep.g, hg.size() * 8, hipMemcpyDeviceToHost, ctx->stream)); }
     if (wantW) { hW.resize((size_t)P * NP * NP); HIPCHK(ctx, hipMemcpyAsync(hW.data(), ep.W, hW.size() * 8, hipMemcpyDeviceToHost, ctx->stream)); }
     if (wantW2) { hW2.resize((size_t)P * NP * NP); HIPCHK(ctx, hipMemcpyAsync(hW2.data(), ep.W2, hW2.size() * 8, hipMemcpyDeviceToHost, ctx->stream)); }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));
     // whitened basis -> caller basis:  x = Q x',  X = Q X' Q^T
     std::vector<double> tmp((size_t)ns * ns);
     for (int p = 0; p < P; ++p) {
@@ -1524,7 +1526,7 @@ try {
     if (rc != MXE_OK) return rc;
     if (out_corr) HIPCHK(ctx, hipMemcpyAsync(out_corr, ep.corr, P * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (out_gmax) HIPCHK(ctx, hipMemcpyAsync(out_gmax, ep.gmax, P * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));
     return MXE_OK;
 }
 MXE_CATCH_ALL
@@ -1879,7 +1881,7 @@ try {
                        ctx->dB.p, ctx->dout_H.p, ctx->dA.p, nw);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(out_A, ctx->dA.p, P * nw * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));
     return MXE_OK;
 }
 MXE_CATCH_ALL
