@@ -866,7 +866,7 @@ static void fill_kparams(mxe_ctx* ctx, KParams& kp)
     kp.theta = o.decouple_tol; kp.out_nact = ctx->dout_nact.p;
     kp.prof = nullptr;
     kp.gstate = nullptr;
-    kp.mc_maxiter = std::min(o.maxiter, MC_MAXITER);
+    kp.mc_maxiter = std::min(o.maxiter, std::max(MC_MAXITER, o.miniter + 8));     // (a caller's miniter above the limit moves it)
 }
 
 int mxe_chains_launch(mxe_ctx* ctx)
@@ -1017,7 +1017,7 @@ try {
     kp.chain_v0 = ctx->dfin_v0.p; kp.v0 = ctx->dfin_start.p;
     kp.chain_lead = nullptr; kp.init_tab = nullptr; kp.chain_init = nullptr;
     kp.n_chain = n;
-    kp.maxiter = std::max(1, o.maxiter - MC_MAXITER);
+    kp.maxiter = std::max(1, o.maxiter - kp.mc_maxiter);
     const int NW = 4;
     const size_t lds = lds_bytes(NP, ctx->nwp, NW, false);
     if (lds > 160 * 1024) return MXE_ERR_LIMIT;               // (the lock-step layout holds less than this one)

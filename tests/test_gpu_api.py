@@ -187,6 +187,18 @@ def test_elementwise_drivers():
     pm_h = _ew(mx.PoormanMaxEnt, g, True)
     r_pm_herm = pm_h.run()
     r_pm_herm.data        # must be callable
+    # plain element-wise: both phases in ONE launch (the workers share the kernel's decomposition); Poorman's
+    # off-diagonal default models need the diagonal results first: two; the separate phases still work and agree
+    ew1 = _ew(mx.ElementwiseMaxEnt, g, False)
+    ew1.run()
+    assert len(ew1.last_launches) == 1
+    assert len(pm_h.last_launches) == 2
+    ew2 = _ew(mx.ElementwiseMaxEnt, g, False)
+    ew2.run_diagonal()
+    r_two = ew2.run_offdiagonal()
+    assert len(ew2.last_launches) == 2
+    np.testing.assert_allclose(r_two.A, r_ew.A, rtol=1e-9, atol=1e-12)
+    np.testing.assert_array_equal(r_two.A_out, r_ew.A_out)
     # hermiticity copies exactly
     assert np.all(r_herm.A_out[0, 1] == r_herm.A_out[1, 0])
     assert np.all(r_pm_herm.A_out[0, 1] == r_pm_herm.A_out[1, 0])
