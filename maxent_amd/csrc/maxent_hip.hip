@@ -693,13 +693,30 @@ try {
             // (the warm step from the leading alpha is safe over a factor of 1.5 in alpha -- measured: at most 11
             //  evaluations; over a factor of 2 single scans took 100-300 --: deeper into the range, the piece
             //  before runs on instead)
-            if (guarded && std::log(pre_alpha / ac[a0]) > 0.45) { ctx->sub_len.back() += a1 - a0; continue; }
-            ctx->sub_elem.push_back(elem_of_chain[c]);
-            ctx->sub_prob0.push_back(c * n_alpha + a0);
-            ctx->sub_len.push_back(a1 - a0);
-            ctx->sub_v0.push_back(c);
-            ctx->sub_pre.push_back(guarded ? a0 - pre_index : 0);
-            if (guarded) ctx->has_pre = true;
+            // (lock-step kernel: the piece WALKS from the leading alpha down the mesh to its first alpha with a loose
+            //  tolerance -- every step as safe as the scan itself --, so every piece of the tail stands alone and the tail
+            //  of a scan is as many short chains side by side as it has pieces.  A jump over more than a factor 1.5 in
+            //  alpha -- single scans took 100-300 evaluations over a factor 2 -- was what joined pieces until r02_k)
+            // (a led piece is cut into single alphas: each walks down from the leading alpha on its own, and the tail of
+            //  the scan -- the longest chain of every launch that does not fill the GPU -- is as deep as ONE walk)
+            // (a piece that starts above the range and runs into it stays whole: cutting it where it enters cost the
+            //  batch that fills the GPU 6 % -- cfg4 on one GPU 0.947 -> 1.01 ms)
+            const int g0 = guarded ? a0 : a1;
+            if (g0 > a0) {
+                ctx->sub_elem.push_back(elem_of_chain[c]);
+                ctx->sub_prob0.push_back(c * n_alpha + a0);
+                ctx->sub_len.push_back(g0 - a0);
+                ctx->sub_v0.push_back(c);
+                ctx->sub_pre.push_back(0);
+            }
+            for (int b0 = g0; b0 < a1; ++b0) {
+                ctx->sub_elem.push_back(elem_of_chain[c]);
+                ctx->sub_prob0.push_back(c * n_alpha + b0);
+                ctx->sub_len.push_back(1);
+                ctx->sub_v0.push_back(c);
+                ctx->sub_pre.push_back(b0 - pre_index);
+                ctx->has_pre = true;
+            }
         }
     }
     ctx->n_sub = (int)ctx->sub_elem.size();
@@ -761,7 +778,8 @@ try {
                 double amin = 1e300;
                 for (int i = 0; i < ctx->sub_len[sc]; ++i) amin = std::min(amin, alpha_dev[ctx->sub_prob0[sc] + i]);
                 cost[sc] = ctx->sub_len[sc] * (ctx->elem_kind[e] == MXE_ENTROPY_NORMAL ? 4.0 : 3.0) +
-                           (ctx->elem_kind[e] == MXE_ENTROPY_NORMAL ? 16.0 : 6.0) - 1e-3 * std::log10(amin);
+                           (ctx->elem_kind[e] == MXE_ENTROPY_NORMAL ? 16.0 : 6.0) - 1e-3 * std::log10(amin) +
+                           2.0 * ctx->sub_pre[sc];                    // (the walk of a led piece)
             }
             ctx->queue.resize(ctx->n_sub);
             for (int sc = 0; sc < ctx->n_sub; ++sc) ctx->queue[sc] = sc;

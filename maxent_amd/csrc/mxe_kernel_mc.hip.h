@@ -61,6 +61,9 @@ constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
 #ifndef MXE_X_DEPTH2
 #define MXE_X_DEPTH2 2        // V ring of the fused pass at two workgroups per CU (4: 1.33 ms and 300 MB of spill stores per launch; 2: 1.29 ms, none)
 #endif
+#ifndef MXE_X_WALK_TOL
+#define MXE_X_WALK_TOL 3e-2     // tolerance of the alphas a led piece walks through (1e-3: two rounds each, 3e-2: one; 1e-1: the scan with the hardest tail of the BASELINE batch runs away, 2.0 ms)
+#endif
 #ifndef MXE_X_RD1
 #define MXE_X_RD1 4        // (8: the shards of an 8-GPU job 0.593 / 0.653 -> 0.617 / 0.688 ms)
 #endif
@@ -130,19 +133,22 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         double alpha, mu, chi2, S, Hn2, wmax, Q, Qprev, cperp, steplim, muh;    // muh: damping the last damped step of this piece needed
         double sc2;        // the power of two the sw in LDS (and the Gram tiles computed from it) carry
         int elem, prob0, clen, ia, niter, nevals, nact, active, scratch, okprev, bt, capp;
+        int lead;          // LEAD builds: alphas of the scan the piece walks through before its own first one (see start_piece)
     };
     // the alphas of a slot's piece (a dependent global load in the accept step costs its full latency)
     constexpr int ACAP = UREG ? 32 : 128;
     __shared__ double s_alpha[MCC][ACAP];
     __shared__ double s_sd[MCC][12];
     __shared__ double s_scw[MCC][2];             // row pass: 1 / sc2 of the sw it reads, sc2 of the sw it writes
-    __shared__ int s_si[MCC][12];
+    __shared__ int s_si[MCC][LEAD ? 13 : 12];
     auto load_slot = [&](Slot& t) {
         const double* d = s_sd[wave]; const int* n = s_si[wave];
         t.alpha = d[0]; t.mu = d[1]; t.chi2 = d[2]; t.S = d[3]; t.Hn2 = d[4]; t.wmax = d[5];
         t.Q = d[6]; t.Qprev = d[7]; t.cperp = d[8]; t.steplim = d[9]; t.muh = d[10]; t.sc2 = d[11];
         t.elem = n[0]; t.prob0 = n[1]; t.clen = n[2]; t.ia = n[3]; t.niter = n[4]; t.nevals = n[5];
         t.nact = n[6]; t.active = n[7]; t.scratch = n[8]; t.okprev = n[9]; t.bt = n[10]; t.capp = n[11];
+        t.lead = 0;
+        if constexpr (LEAD) t.lead = n[12];
     };
     auto store_slot = [&](const Slot& t) {
         if (lane == 0) {
@@ -151,6 +157,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             d[6] = t.Q; d[7] = t.Qprev; d[8] = t.cperp; d[9] = t.steplim; d[10] = t.muh; d[11] = t.sc2;
             n[0] = t.elem; n[1] = t.prob0; n[2] = t.clen; n[3] = t.ia; n[4] = t.niter; n[5] = t.nevals;
             n[6] = t.nact; n[7] = t.active; n[8] = t.scratch; n[9] = t.okprev; n[10] = t.bt; n[11] = t.capp;
+            if constexpr (LEAD) n[12] = t.lead;
             s_act[wave] = t.active; s_scr[wave] = t.scratch;
         }
         wave_sync();
@@ -160,12 +167,14 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         t.cperp = p.cperp[t.elem];
         t.steplim = p.step_max * p.sumD[t.elem];
         t.prob0 = p.chain_prob0[c]; t.clen = p.chain_len[c];
-        // a piece may be led by an earlier (larger) alpha of its scan, where the cold start from the default model is
-        // cheap and safe: chain_lead = how many entries before the piece's first alpha it sits (0: none).  It is
-        // solved as alpha number -1 and leaves no record of its own
+        // a piece may be led by earlier (larger) alphas of its scan: chain_lead = how many entries before the piece's
+        // first alpha the walk starts (0: none) -- at the last alpha above the range where a cold start from the default
+        // model is expensive and unsafe.  The piece solves that alpha cold, walks down the mesh to its own first alpha
+        // with a loose tolerance (alphas number -lead .. -1: starting points only, no records), and goes on as usual
         const int lead = LEAD ? p.chain_lead[c] : 0;
-        t.ia = lead ? -1 : 0; t.niter = 0; t.nevals = 0; t.nact = 0; t.okprev = 0; t.bt = 0; t.capp = 0;
-        for (int i = lane; i < min(t.clen, ACAP); i += 64) s_alpha[wave][i] = p.alpha[(size_t)t.prob0 + i];
+        t.lead = lead;
+        t.ia = -lead; t.niter = 0; t.nevals = 0; t.nact = 0; t.okprev = 0; t.bt = 0; t.capp = 0;
+        for (int i = lane; i < min(t.clen + lead, ACAP); i += 64) s_alpha[wave][i] = p.alpha[(size_t)(t.prob0 - lead) + i];
         t.alpha = p.alpha[(size_t)(t.prob0 - lead)];
         t.mu = 0.0; t.muh = 0.0; t.Qprev = __builtin_nan("");
         t.chi2 = 0.0; t.S = 0.0; t.Hn2 = 1.0; t.wmax = 1.0; t.Q = 0.0; t.sc2 = 1.0;
@@ -195,8 +204,8 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         }
     };
 
-    auto alpha_at = [&](const Slot& t, int i) -> double {
-        return (t.clen <= ACAP) ? s_alpha[wave][i] : p.alpha[(size_t)t.prob0 + i];
+    auto alpha_at = [&](const Slot& t, int i) -> double {       // alpha number i of the piece (i < 0: the walk before it)
+        return (t.clen + t.lead <= ACAP) ? s_alpha[wave][i + t.lead] : p.alpha[(size_t)t.prob0 + i];
     };
 
     // ---- first pieces ----
@@ -220,7 +229,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         if (c >= 0) start_piece(t, c);
         else {
             // empty slot: evaluates v = 0 of a neighbour's element every round (finite, never used)
-            t = Slot{1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0};
+            t = Slot{1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0};
             gh[wave * NP + lane] = 0.0; vv[wave * NP + lane] = 0.0;
             if (lane == 0) { s_elem[wave] = -1; s_kind[wave] = 0; }
         }
@@ -811,7 +820,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     }
                     const double relH2_min = fac2 * sdH;            // min(relH, relH_next)^2 * Hn2
                     // (a leading alpha is only a starting point for the piece's first alpha: 1e-3 is enough)
-                    const double tol_here = (LEAD && t.ia < 0) ? fmax(p.tol_h, 1e-3) : p.tol_h;
+                    const double tol_here = (LEAD && t.ia < 0) ? fmax(p.tol_h, MXE_X_WALK_TOL) : p.tol_h;
                     const double tol2Hn = tol_here * tol_here * t.Hn2;
                     vv[q * NP + k] -= dlc[q * NP + k];
                     if (t.niter == 0) t.capp = (t.okprev == 5) ? 2 : (t.okprev == 1 && t.mu == 0.0) ? 1 : 0;
@@ -832,15 +841,16 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     //  write its own over it -- no branch; where it fails, the first alpha starts from the state it
                     //  ended in and reports what becomes of it)
                     const size_t prob = (size_t)t.prob0 + max(t.ia, 0);
-                    if (p.out_H) {
+                    const bool own = !LEAD || t.ia >= 0;          // (an alpha of the walk leaves no record)
+                    if (p.out_H && own) {
                         // H of the point just evaluated = the accepted one.  An alpha that FAILED (damping out of
                         // range, nothing finite to evaluate) ends on a rejected trial point: its H does not belong
                         // to the v, chi2, S, Q of the record (the last accepted state) and is written as NaN
                         double* Ho = p.out_H + prob * nw;
                         for (int i = lane; i < nw; i += 64) Ho[i] = failed ? __builtin_nan("") : Hi[i * MCC + q];
                     }
-                    if (p.out_v) p.out_v[prob * NP + lane] = vv[q * NP + lane];
-                    if (lane == 0) {
+                    if (p.out_v && own) p.out_v[prob * NP + lane] = vv[q * NP + lane];
+                    if (lane == 0 && own) {
                         p.out_chi2[prob] = t.chi2; p.out_S[prob] = t.S; p.out_Q[prob] = t.Q;
                         p.out_niter[prob] = t.niter; p.out_conv[prob] = conv;
                         p.out_nevals[prob] = t.nevals; p.out_nact[prob] = t.nact;
