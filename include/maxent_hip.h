@@ -102,8 +102,10 @@ typedef struct mxe_opts {
                                 1 = never.  In either case a piece of a normal-entropy scan
                                 that would start among the scan's smallest alphas (the last 6 %
                                 of its logarithmic range, where a cold start from the default
-                                model can take hundreds of iterations) is started from the last
-                                alpha above that range instead, or joined to the piece before */
+                                model can take hundreds of iterations) solves the last alpha above
+                                that range cold instead and walks down the mesh to its own alpha with a
+                                loose tolerance (lock-step layout: every alpha of that range is a piece
+                                of its own; one-chain layout: joined to the piece before) */
     int32_t stop_estimate;   /* 1 (default): after a full (undamped) Newton step the next
                                 correction is estimated as (expm1(max|du|) + decouple_tol) * ||dH||/||H||
                                 (the relative change of the weights w bounds the relative
