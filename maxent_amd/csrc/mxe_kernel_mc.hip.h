@@ -61,8 +61,16 @@ constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
 #ifndef MXE_X_DEPTH2
 #define MXE_X_DEPTH2 2        // V ring of the fused pass at two workgroups per CU (4: 1.33 ms and 300 MB of spill stores per launch; 2: 1.29 ms, none)
 #endif
+// A led piece solves its leading alpha cold to 1e-3 and then walks down the mesh: every alpha on the way gets Newton
+// rounds until the estimated next correction is below MXE_X_WALK_TOL, at most MXE_X_WALK_ITERS of them -- in practice
+// ONE (a path follower with one corrector step).  Measured on the shards of the BASELINE batch (slowest rank of 8 /
+// rank 0): 6e-2 ... 4e-1 all 0.526 / 0.483 ms; with the leading alpha itself only at the walk's tolerance 3e-2 was as
+// fast and 6e-2 ran away on the scan with the hardest tail (2.4 ms): the walk needs a start ON the path.
 #ifndef MXE_X_WALK_TOL
-#define MXE_X_WALK_TOL 3e-2     // tolerance of the alphas a led piece walks through (1e-3: two rounds each, 3e-2: one; 1e-1: the scan with the hardest tail of the BASELINE batch runs away, 2.0 ms)
+#define MXE_X_WALK_TOL 1e-1
+#endif
+#ifndef MXE_X_WALK_ITERS
+#define MXE_X_WALK_ITERS 4
 #endif
 #ifndef MXE_X_RD1
 #define MXE_X_RD1 4        // (8: the shards of an 8-GPU job 0.593 / 0.653 -> 0.617 / 0.688 ms)
@@ -820,7 +828,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     }
                     const double relH2_min = fac2 * sdH;            // min(relH, relH_next)^2 * Hn2
                     // (a leading alpha is only a starting point for the piece's first alpha: 1e-3 is enough)
-                    const double tol_here = (LEAD && t.ia < 0) ? fmax(p.tol_h, MXE_X_WALK_TOL) : p.tol_h;
+                    const double tol_here = (LEAD && t.ia < 0) ? fmax(p.tol_h, (t.ia == -t.lead) ? 1e-3 : MXE_X_WALK_TOL) : p.tol_h;
                     const double tol2Hn = tol_here * tol_here * t.Hn2;
                     vv[q * NP + k] -= dlc[q * NP + k];
                     if (t.niter == 0) t.capp = (t.okprev == 5) ? 2 : (t.okprev == 1 && t.mu == 0.0) ? 1 : 0;
@@ -832,7 +840,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     t.bt = 0;
                     if (newton_step && p.tol_h > 0.0 && relH2_min < tol2Hn && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                     else if (p.tol_relq > 0.0 && fabs(fabs(t.Qprev - t.Q) / t.Q) < p.tol_relq && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
-                    else if (t.niter >= p.mc_maxiter) finish_alpha = true;
+                    else if (t.niter >= ((LEAD && t.ia < 0 && t.ia > -t.lead) ? MXE_X_WALK_ITERS : p.mc_maxiter)) finish_alpha = true;   // (an alpha of a walk is a starting point: a few rounds, then on)
                 }
                 MXE_STAMPA(2);
                 if (fresh && t.scratch == 2) t.scratch = 0;     // accepted or to be halved: the state in LDS is that trial point
