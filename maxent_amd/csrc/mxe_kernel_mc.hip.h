@@ -72,6 +72,9 @@ constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
 #ifndef MXE_X_WALK_ITERS
 #define MXE_X_WALK_ITERS 4
 #endif
+#ifndef MXE_X_DEPTH1
+#define MXE_X_DEPTH1 4        // V ring of the fused pass at one workgroup per CU (8: the shards of an 8-GPU job 0.464 / 0.508 ms, 4: 0.455 / 0.497, 2: 0.463 / 0.508)
+#endif
 #ifndef MXE_X_RD1
 #define MXE_X_RD1 4        // (8: the shards of an 8-GPU job 0.593 / 0.653 -> 0.617 / 0.688 ms)
 #endif
@@ -645,7 +648,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             // the padding behind H / sw in LDS and is not used.
             constexpr int ST = NWV;
             constexpr int TRIP = 8;
-            constexpr int DEPTH = (WGPC == 1) ? 8 : MXE_X_DEPTH2;
+            constexpr int DEPTH = (WGPC == 1) ? MXE_X_DEPTH1 : MXE_X_DEPTH2;
             static_assert(TRIP % DEPTH == 0 && DEPTH >= 2, "ring indices are static across trips");
             int g = wave;
             {
