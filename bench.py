@@ -42,15 +42,15 @@ N_EVAL_NOMINAL = {'normal': 160, 'plusminus': 84}   # the refere
 PMC_DEFAULT = dict(
     source='profiles/r02_k_pmc_summary.csv',
     # mean per dispatch of mxe::chain_kernel_mc<32, 2> over ~200 dispatches
-    valu_active_quadcycles=2.66445e+08,      # SQ_ACTIVE_INST_VALU (counts quad-cycles: MI355X_MICROARCH.md, cycle constants)
-    mfma_busy_cycles=4.24972e+08,            # SQ_VALU_MFMA_BUSY_CYCLES (cycles)
-    coexec_cycles=3.1718e+07,               # SQ_VALU_MFMA_COEXEC_CYCLES: both at once, counted once below
-    any_active_quadcycles=3.94005e+08,       # SQ_ACTIVE_INST_ANY
-    wave_quadcycles=9.73155e+08,            # SQ_WAVE_CYCLES
-    wait_inst_quadcycles=3.16274e+08, wait_any_quadcycles=2.62875e+08,
-    gui_active_cycles_all_xcd=1.80783e+07,   # GRBM_GUI_ACTIVE (sum over the 8 XCDs)
-    fetch_kb=12786.5, write_kb=132573,  # FETCH_SIZE (x 2 on gfx950, MI355X_MICROARCH.md section HBM), WRITE_SIZE
-    l2_hit=7.58981e+07, l2_miss=1.2074e+06)
+    valu_active_quadcycles=2.66444e+08,      # SQ_ACTIVE_INST_VALU (counts quad-cycles: MI355X_MICROARCH.md, cycle constants)
+    mfma_busy_cycles=4.2497e+08,            # SQ_VALU_MFMA_BUSY_CYCLES (cycles)
+    coexec_cycles=3.17594e+07,               # SQ_VALU_MFMA_COEXEC_CYCLES: both at once, counted once below
+    any_active_quadcycles=3.94004e+08,       # SQ_ACTIVE_INST_ANY
+    wave_quadcycles=9.7309e+08,            # SQ_WAVE_CYCLES
+    wait_inst_quadcycles=3.16332e+08, wait_any_quadcycles=2.62754e+08,
+    gui_active_cycles_all_xcd=1.80695e+07,   # GRBM_GUI_ACTIVE (sum over the 8 XCDs)
+    fetch_kb=12693.7, write_kb=132895,  # FETCH_SIZE (x 2 on gfx950, MI355X_MICROARCH.md section HBM), WRITE_SIZE
+    l2_hit=7.584e+07, l2_miss=1.21139e+06)
 N_SIMD = 256 * 4
 CLOCK_PEAK_GHZ = 2.4                      # MI355X_MICROARCH.md: max clock
 
