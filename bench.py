@@ -418,8 +418,11 @@ def main():
         return
 
     ctx.launch()
-    out = ctx.fetch()
     info = ctx.last_launch_info()
+    # (mxe_chains_finish -- the alphas a lock-step launch gives up on, solved again in the one-chain layout -- is not part
+    #  of the timed step: on this workload it has nothing to do, which is what this records)
+    n_left_to_finish = ctx.finish()
+    out = ctx.fetch()
     n_conv = int(out['converged'].sum())
     value = P_job * args.steps / elapsed
 
@@ -506,7 +509,7 @@ def main():
                                                             % (what, float(np.sum(counts)) * 8 / 1e6) if use_comm else ''),
                     problems_per_step=P_job, problems_on_rank0=P_rank,
                     waves_per_chain=info['waves_per_chain'], workgroups=info['n_workgroups'],
-                    lds_bytes=info['lds_bytes'], converged_on_rank0=n_conv,
+                    lds_bytes=info['lds_bytes'], converged_on_rank0=n_conv, alphas_left_to_mxe_chains_finish=n_left_to_finish,
                     svd_seconds_host=batch['t_svd'], host_split=host_split,
                     gather_checked=gather_checked,
                     multi_gpu_note='N > 1 has not been run by the builders (one-GPU boxes); the gather path is '
