@@ -87,7 +87,7 @@ struct mxe_ctx {
     std::string last_kernel;
     // device
     DevBuf<float> dVf, dVtf;          // binary32 copies of dV / dVt (mxe_opts.precision = F32)
-    DevBuf<double> dV, dVt, dc, dcinv, dghat, dcperp, dD, dsumD, dalpha, dv0;
+    DevBuf<double> dV, dVx, dVt, dc, dcinv, dghat, dcperp, dD, dsumD, dalpha, dv0;
     DevBuf<int> delem_ds, delem_kind, dchain_elem, dsub_prob0, dsub_len, dsub_v0, dwg_chains;
     // H, chi2, S, Q live back to back in ONE allocation (dout_pack) so that a
     // multi-GPU driver can move all per-alpha results with a single collective
@@ -241,6 +241,20 @@ int upload_bases(mxe_ctx* ctx)
         for (int k = 0; k < ns; ++k) { hc[(size_t)d * NP + k] = D.c[k]; hci[(size_t)d * NP + k] = 1.0 / D.c[k]; }
     }
     HIPCHK(ctx, ctx->dV.ensure(hV.size()));
+    if (NP == 64) {
+        // the lock-step fused pass reads V with 16-byte loads (the address unit takes a wave-instruction in 16 cycles
+        // whatever its width: 8 B per lane stream at 32 B per cycle and CU, 16 B at 64 -- tools/l2_stream_rate.hip):
+        // a lane's two doubles are the same lane position of two neighbouring 16-column tiles
+        std::vector<double> hVx(hV.size(), 0.0);
+        for (size_t r = 0; r < hV.size() / NP; ++r)
+            for (int tp = 0; tp < 2; ++tp)
+                for (int m = 0; m < 16; ++m)
+                    for (int sdx = 0; sdx < 2; ++sdx)
+                        hVx[r * NP + 32 * tp + 2 * m + sdx] = hV[r * NP + 16 * (2 * tp + sdx) + m];
+        HIPCHK(ctx, ctx->dVx.ensure(hVx.size()));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->dVx.p, hVx.data(), hVx.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, stream_wait(ctx->stream));
+    }
     HIPCHK(ctx, ctx->dVt.ensure(hVt.size()));
     HIPCHK(ctx, ctx->dc.ensure(hc.size()));
     HIPCHK(ctx, ctx->dcinv.ensure(hci.size()));
@@ -259,10 +273,10 @@ int upload_bases(mxe_ctx* ctx)
 }
 
 // dynamic LDS of chain_kernel_mc<NA, WGPC> in bytes (the carve at the top of the kernel)
-size_t mc_lds_bytes(int NA, int nwp, int wgpc)
+size_t mc_lds_bytes(int NA, int nwp, int wgpc, int nwv = 4)
 {
     const int NT = NA / 16, NPAIR = NT * (NT + 1) / 2;
-    const size_t doubles = 8 * 4 * 64 + 2 * 64 + 64 * 4 + (wgpc == 2 ? 1 : 4) * 4 * 64 + 4 * 32 +   // vectors, c, 1/c, step, h, sums
+    const size_t doubles = 8 * 4 * 64 + 2 * 64 + 64 * 4 + (wgpc == 2 ? 1 : nwv) * 4 * 64 + nwv * 32 +   // vectors, c, 1/c, step, h, sums
                            (wgpc == 2 ? (size_t)MXE_X_UL * 256 + (size_t)nwp * 4 : (size_t)2 * nwp * 4) +
                            (size_t)4 * NPAIR * 256;                                                  // u, H, Gram tiles
     const size_t floats = (size_t)nwp * 4;                                              // sw
@@ -866,7 +880,7 @@ static void fill_kparams(mxe_ctx* ctx, KParams& kp)
     kp.n_omega = ctx->n_omega; kp.n_omega_pad = ctx->nwp; kp.n_s = ctx->n_s; kp.NP = ctx->NP;
     kp.n_alpha = ctx->n_alpha; kp.n_chain = ctx->n_chain;
     kp.Vf = ctx->dVf.p; kp.Vtf = ctx->dVtf.p;
-    kp.V = ctx->dV.p; kp.Vt = ctx->dVt.p; kp.c = ctx->dc.p; kp.cinv = ctx->dcinv.p;
+    kp.V = ctx->dV.p; kp.Vx = ctx->dVx.p; kp.Vt = ctx->dVt.p; kp.c = ctx->dc.p; kp.cinv = ctx->dcinv.p;
     kp.elem_ds = ctx->delem_ds.p; kp.elem_kind = ctx->delem_kind.p;
     kp.ghat = ctx->dghat.p; kp.cperp = ctx->dcperp.p; kp.D = ctx->dD.p; kp.sumD = ctx->dsumD.p;
     kp.chain_elem = ctx->dchain_elem.p; kp.alpha = ctx->dalpha.p; kp.v0 = ctx->dv0.p;
@@ -903,8 +917,13 @@ try {
     hipError_t e;
     if (ctx->mc_na > 0) {
         // four chains per workgroup, lock-step (mxe_kernel_mc.hip.h)
-        const int NA = ctx->mc_na, WGPC = ctx->mc_wgpc, NWV = 4;
-        const size_t lds = mc_lds_bytes(NA, ctx->nwp, WGPC);
+        // Eight waves per workgroup (four helpers for the streaming passes) where the launch runs one workgroup per
+        // CU, i.e. does not fill the GPU and is as long as its deepest chain of rounds; mxe_opts.waves_per_chain = 4 / 8
+        // overrides (the passes of that build want n_omega_pad in units of 256)
+        const int NA = ctx->mc_na, WGPC = ctx->mc_wgpc;
+        const int NWV = (WGPC == 1 && ctx->nwp % 256 == 0 && o.waves_per_chain != 4 &&
+                         mc_lds_bytes(NA, ctx->nwp, 1, 8) <= 160 * 1024 - 6144) ? 8 : 4;
+        const size_t lds = mc_lds_bytes(NA, ctx->nwp, WGPC, NWV);
         if (lds > 160 * 1024 - 6144) return MXE_ERR_LIMIT;
         mxe::MCExtra ex; ex.wg_chains = ctx->dwg_chains.p; ex.n_wg = ctx->n_wg;
         ex.queue = ctx->dqueue.p; ex.n_queue = ctx->n_queue; ex.counter = ctx->dcounter.p;
@@ -918,16 +937,18 @@ try {
         HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->dcounter.p, counter0, 1, ctx->stream));
         ctx->last_nw = NWV; ctx->last_lds = (int)lds;
         const bool lead = kp.chain_lead != nullptr;
-        ctx->last_kernel = "mxe::chain_kernel_mc<" + std::to_string(NA) + ", " + std::to_string(WGPC) + (lead ? ", lead>" : ">");
+        ctx->last_kernel = "mxe::chain_kernel_mc<" + std::to_string(NA) + ", " + std::to_string(WGPC) + (lead ? ", lead" : "") +
+                           (NWV == 8 ? ", 8 waves>" : ">");
         HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-#define MXE_LAUNCH_MC(NA_, WG_, LD_) do { constexpr int NWV_ = 4; \
-        e = hipFuncSetAttribute((const void*)mxe::chain_kernel_mc<NA_, WG_, LD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+#define MXE_LAUNCH_MC(NA_, WG_, LD_, NWV_) do { \
+        e = hipFuncSetAttribute((const void*)mxe::chain_kernel_mc<NA_, WG_, LD_, NWV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e == hipSuccess && getenv("MXE_DEBUG_OCC")) { int nb__ = 0; \
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb__, (const void*)mxe::chain_kernel_mc<NA_, WG_, LD_>, 64 * NWV_, lds); \
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb__, (const void*)mxe::chain_kernel_mc<NA_, WG_, LD_, NWV_>, 64 * NWV_, lds); \
             fprintf(stderr, "[mxe] lock-step kernel NA=%d NWV=%d lds=%zu: %d workgroup(s) per CU resident\n", NA_, NWV_, (size_t)lds, nb__); } \
-        if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<NA_, WG_, LD_>), dim3(ctx->n_wg), dim3(64 * NWV_), lds, ctx->stream, kp, ex); e = hipGetLastError(); } } while (0)
-        if (NA == 32 && WGPC == 2) { if (lead) MXE_LAUNCH_MC(32, 2, true); else MXE_LAUNCH_MC(32, 2, false); }
-        else { if (lead) MXE_LAUNCH_MC(32, 1, true); else MXE_LAUNCH_MC(32, 1, false); }
+        if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<NA_, WG_, LD_, NWV_>), dim3(ctx->n_wg), dim3(64 * NWV_), lds, ctx->stream, kp, ex); e = hipGetLastError(); } } while (0)
+        if (NA == 32 && WGPC == 2) { if (lead) MXE_LAUNCH_MC(32, 2, true, 4); else MXE_LAUNCH_MC(32, 2, false, 4); }
+        else if (NWV == 8) { if (lead) MXE_LAUNCH_MC(32, 1, true, 8); else MXE_LAUNCH_MC(32, 1, false, 8); }
+        else { if (lead) MXE_LAUNCH_MC(32, 1, true, 4); else MXE_LAUNCH_MC(32, 1, false, 4); }
 #undef MXE_LAUNCH_MC
         HIPCHK(ctx, e);
     } else {

@@ -46,6 +46,8 @@ struct KParams {
     // basis arrays, indexed by data-set id
     const double* V;     // [n_ds][n_omega_pad][NP]  zero padded rows and columns
     const double* Vt;    // [n_ds][NP][n_omega_pad]  zero padded
+    const double* Vx;    // V with the columns of every row interleaved for 16-byte loads in the lock-step fused pass (NP = 64):
+                         //   position 32 t' + 2 m + s holds column 16 (2 t' + s) + m
     const double* c;     // [n_ds][NP]               descending, padded with 1
     const double* cinv;  // [n_ds][NP]
     // elements

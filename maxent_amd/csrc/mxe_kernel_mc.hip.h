@@ -83,14 +83,19 @@ constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
 #endif
 // LEAD  pieces may be led by an earlier alpha of their scan (KParams::chain_lead); a build of its own, because the
 //       two extra instructions of start_piece cost the schedule without such pieces 1.6 % (register allocation)
-template <int NA, int WGPC, bool LEAD = false>
-__global__ __launch_bounds__(256, WGPC)
+// NWV   wavefronts per workgroup: 4 (wave q is the home of slot q and nothing else) or, for launches that do not fill
+//       the GPU (WGPC = 1: single scans, small matrices, one rank's shard of a multi-GPU job), 8 -- waves 4 .. 7 are
+//       helpers that take half of the rows of the two streaming passes.  Such a launch is as long as its deepest chain
+//       of rounds, and at one wave per SIMD the passes wait for L2 and for the wave's own issue rate (a v_fma_f64 every
+//       9 cycles from one wave, every 4.75 from two: tools/mfma_f64_rate.hip); a second wave per SIMD halves them.
+template <int NA, int WGPC, bool LEAD = false, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, WGPC)
 void chain_kernel_mc(const KParams p, const MCExtra x)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int NWV = 4;                        // one wavefront per chain slot
     constexpr int T = 64 * NWV;
     static_assert(WGPC == 1 || WGPC == 2, "one or two workgroups per CU");
+    static_assert(NWV == 4 || (NWV == 8 && WGPC == 1), "helper waves only in the one-workgroup-per-CU build");
     constexpr bool UREG = (WGPC == 2);            // u in registers, h summed with atomics
     constexpr int NP = 64;
     constexpr int NT = NA / 16;                   // 16-column tiles of the Gram block
@@ -253,7 +258,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     for (int q = 0; q < MCC; ++q) if (s_elem[q] >= 0 && any_elem < 0) any_elem = s_elem[q];
     if (any_elem < 0) return;                    // nothing for this workgroup
     const int ds = __builtin_amdgcn_readfirstlane(p.elem_ds[__builtin_amdgcn_readfirstlane(any_elem)]);     // wave-uniform: V, Vt become scalar base pointers
-    const double* __restrict__ V  = p.V  + (size_t)ds * nwp * NP;
+    const double* __restrict__ V  = p.Vx + (size_t)ds * nwp * NP;       // (columns interleaved for 16-byte loads, see KParams)
     const double* __restrict__ Vt = p.Vt + (size_t)ds * NP * nwp;
     if (wave == 0) { cc[lane] = p.c[ds * NP + lane]; ci[lane] = p.cinv[ds * NP + lane]; }
     __syncthreads();
@@ -509,7 +514,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             double pS = 0.0, pdH = 0.0, pHn = 0.0, pwm = 0.0, pdu = 0.0;
             const int nblk = nwp >> 5;                           // blocks of 32 omega rows = two 16-row tiles
             const int nchunk = (ns + 3) >> 2;                    // chunks of four singular directions
-            constexpr int TB = 8;                                // tiles per batch (accumulators)
+            constexpr int TB = (NWV == 8) ? 4 : 8;               // tiles per batch (accumulators)
             constexpr int RD = (WGPC == 1) ? MXE_X_RD1 : 4;           // ring depth in chunks (one workgroup per CU: registers to spare)
             constexpr int NCHK = NP / 4;
             // The two tiles of a block interleave: tile parity = omega parity, so that a lane's operands of
@@ -648,7 +653,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             // the padding behind H / sw in LDS and is not used.
             constexpr int ST = NWV;
             constexpr int TRIP = 8;
-            constexpr int DEPTH = (WGPC == 1) ? MXE_X_DEPTH1 : MXE_X_DEPTH2;
+            constexpr int DEPTH = (WGPC == 1 && NWV == 4) ? MXE_X_DEPTH1 : MXE_X_DEPTH2;   // (256 registers: WGPC = 2 and the eight-wave build)
             static_assert(TRIP % DEPTH == 0 && DEPTH >= 2, "ring indices are static across trips");
             int g = wave;
             {
@@ -661,12 +666,14 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 // no 64-bit vector address arithmetic
                 typedef unsigned u2v __attribute__((ext_vector_type(2)));
                 const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, 0x7fffffff, 0x00020000);
-                const int loff = (kq * NP + cn) * 8;                  // bytes
+                // 16 bytes per lane: columns 16 (2 t') + cn and 16 (2 t' + 1) + cn of the row sit side by side in Vx
+                const int loff = (kq * NP + 2 * cn) * 8;              // bytes
                 auto loadV = [&](double (&f)[4], int soff_bytes) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const u2v v2 = __builtin_amdgcn_raw_buffer_load_b64(vrsrc, loff + 128 * t, soff_bytes, 0);
-                        f[t] = __hiloint2double((int)v2.y, (int)v2.x);
+                    for (int tp = 0; tp < 2; ++tp) {
+                        const u4v v4 = __builtin_amdgcn_raw_buffer_load_b128(vrsrc, loff + 256 * tp, soff_bytes, 0);
+                        f[2 * tp] = __hiloint2double((int)v4.y, (int)v4.x);
+                        f[2 * tp + 1] = __hiloint2double((int)v4.w, (int)v4.z);
                     }
                 };
                 constexpr int VSTEPB = 4 * ST * NP * 8;              // bytes per group step (V)

@@ -522,6 +522,86 @@ def elementwise_shared_cov_case():
     np.savez_compressed(os.path.join(HERE, 'elementwise_shared_cov.npz'), **out)
 
 
+def _ref_newton_corr(tm, alpha_scaled, v):
+    """the REFERENCE's own binary64 Newton correction at v: delta = solve(Q.dd(v), Q.d(v)) with its default
+    MaxEntCostFunction (maxent_cost_function.py:120-165), measured like the device audit as
+    ||dH/dv delta||_2 / ||H||_2"""
+    Q = tm.cost_function
+    Q.set_alpha(alpha_scaled)
+    v = np.array(v, copy=True)
+    delta = np.linalg.solve(np.array(Q.dd(v)), np.array(Q.d(v)))
+    b = Q(v)
+    H = np.array(b.H_of_v.f())
+    return float(np.linalg.norm(np.array(b.H_of_v.d()) @ delta) / np.linalg.norm(H))
+
+
+def tight_case():
+    """the reference itself under ``MaxDerivativeConvergenceMethod(1e-7)``
+    (convergence_methods.py:81-89) next to its default stopping rules, for BASELINE cfg2 (normal entropy)
+    and one plus-minus scan -- H of both runs, the extended-precision fixed point, and the reference's OWN
+    binary64 Newton correction at the three points.  It shows what a 1e-6 parity gate can be anchored on:
+    the tight run is still 1e-6 ... 1e-5 from the fixed point at the smallest alphas while its Newton
+    correction there is far above that of H_truth."""
+    out = {}
+    for name, n_tau, n_w, n_alpha, cf, off, rows in (
+            ('cfg2', 200, 500, 100, 'normal', False, list(range(0, 100, 9)) + [99]),
+            ('pm', 100, 200, 20, 'plusminus', True, list(range(20)))):
+        beta = 40.0
+        rng = np.random.RandomState(1234)
+        tau = np.linspace(0, beta, n_tau)
+        omega = HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=n_w)
+        K = TauKernel(tau=tau, omega=omega, beta=beta)
+        if off:
+            A = 0.3 * (np.exp(-(omega - 1.0) ** 2 / (2 * 0.5 ** 2)) -
+                       np.exp(-(omega + 1.5) ** 2 / (2 * 0.8 ** 2)))
+        else:
+            A = 0.6 * np.exp(-(omega - 1.0) ** 2 / (2 * 0.5 ** 2)) + \
+                0.4 * np.exp(-(omega + 1.5) ** 2 / (2 * 0.8 ** 2))
+            A /= np.trapezoid(A, omega)
+        G = K.K_delta @ np.array(A) + 1e-4 * rng.randn(n_tau)
+        runs = {}
+        for tag, minimizer in (('ref', None),
+                               ('tight', LevenbergMinimizer(convergence=MaxDerivativeConvergenceMethod(1e-7),
+                                                            maxiter=20000))):
+            kw = {} if minimizer is None else dict(minimizer=minimizer)
+            tm = TauMaxEnt(cost_function=cf, **kw)
+            tm.set_verbosity(VerbosityFlags.Quiet)
+            tm.omega = omega
+            tm.set_G_tau_data(tau, G)
+            tm.set_error(1e-4)
+            tm.alpha_mesh = LogAlphaMesh(alpha_min=1e-2, alpha_max=1e4, n_points=n_alpha)
+            vs, its, conv = record_v(tm)
+            res = tm.run()
+            runs[tag] = (tm, res, vs, its, conv)
+        tm, res, vs, its, conv = runs['ref']
+        tmt, rest, vst, itst, convt = runs['tight']
+        ent = 'plusminus' if cf == 'plusminus' else 'normal'
+        p = R.Problem(np.array(tm.K.K), tm.K.U, tm.K.S, tm.K.V, G, 1e-4 * np.ones(n_tau), np.array(tm.D.D),
+                      entropy=ent)
+        alphas = np.array(res.alpha)
+        Ht = np.empty((len(rows), n_w))
+        corr = np.empty((3, len(rows)))
+        for n, ia in enumerate(rows):
+            vt, Ht[n] = hp_truth.polish(p.K, p.G, p.err, p.D, p.V, p.S, alphas[ia], vs[ia], ent, iters=5)
+            corr[0, n] = _ref_newton_corr(tm, alphas[ia], vs[ia])
+            corr[1, n] = _ref_newton_corr(tm, alphas[ia], vst[ia])
+            corr[2, n] = _ref_newton_corr(tm, alphas[ia], vt)
+
+        def rel(a):
+            return np.linalg.norm(a - Ht, axis=1) / np.linalg.norm(Ht, axis=1)
+        e_ref, e_tight = rel(np.array(res.H)[rows]), rel(np.array(rest.H)[rows])
+        print('%-28s ref-vs-truth max %.2e  tight-ref-vs-truth max %.2e  iterations %d / %d' %
+              ('tight_' + name, e_ref.max(), e_tight.max(), sum(its), sum(itst)))
+        print('   reference Newton correction  at H_ref %.1e..%.1e  at H_tight %.1e..%.1e  at H_truth %.1e..%.1e' %
+              (corr[0].min(), corr[0].max(), corr[1].min(), corr[1].max(), corr[2].min(), corr[2].max()))
+        out.update({name + '_rows': np.array(rows), name + '_alpha': alphas,
+                    name + '_H_ref': np.array(res.H)[rows], name + '_H_tight_ref': np.array(rest.H)[rows],
+                    name + '_H_truth': Ht, name + '_n_iter_ref': np.array(its),
+                    name + '_n_iter_tight_ref': np.array(itst), name + '_converged_tight_ref': np.array(convt),
+                    name + '_ref_newton_corr': corr})
+    np.savez_compressed(os.path.join(HERE, 'tight_ref.npz'), **out)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     if only:
@@ -547,5 +627,6 @@ if __name__ == '__main__':
     elementwise_cov_case()
     elementwise_shared_cov_case()
     logtaker_case()
+    tight_case()
     shutil.rmtree(TMP, ignore_errors=True)
     print('fixtures written to', HERE)
