@@ -341,6 +341,67 @@ __device__ __forceinline__ bool gj2_solve64(double (&A)[N / 2], double b, int i,
     return ok;
 }
 
+// The same elimination in binary32: half the cross-lane traffic (one dword per value instead of two) and full-rate
+// multiply-adds.  For the lock-step kernel, whose Newton matrix is inexact at the 1e-6 level anyway (Gram tiles from split
+// binary16 products, 21 bits; decoupling threshold 1e-5): the backward error of this solve, ~N eps_32 |A| = 2e-6 |A|, is of
+// the same size.  The caller scales rows and columns by powers of two so that the diagonal is O(1) (the entries span
+// twenty decades otherwise and det P would leave the binary32 range).
+template <int J> __device__ __forceinline__ float half_bcast_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), J << 5));
+}
+__device__ __forceinline__ float wave_bcast_f(float x, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src));
+}
+template <int N>
+__device__ __forceinline__ bool gj2_solve64_f32(float (&A)[N / 2], float b, int i, float& z, bool& small_pivot)
+{
+    constexpr int NHALF = N / 2;
+#ifndef MXE_X_PIV_TAU
+#define MXE_X_PIV_TAU 1e-3f
+#endif
+    constexpr float PIV_TAU = MXE_X_PIV_TAU;    // pivots below this (the diagonal was scaled to [1, 4)): 24 bits are too few
+    bool ok = true;
+    small_pivot = false;
+    float ps = 1.0f, pc = 0.0f;                 // z_i = ps b_i + pc b_(i ^ 1)
+    auto pivot2 = [&](auto KTag) {
+        constexpr int kj = decltype(KTag)::value, j = 2 * kj;
+        float c0, c1;
+        {
+            const unsigned x = __builtin_bit_cast(unsigned, A[kj]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+            c0 = __builtin_bit_cast(float, (unsigned)sw[0]);      // column j (the lower half's values in both halves)
+            c1 = __builtin_bit_cast(float, (unsigned)sw[1]);      // column j + 1
+        }
+        const float pa = wave_bcast_f(c0, j), pb = wave_bcast_f(c1, j), pd = wave_bcast_f(c1, j + 1);
+        const float det = __builtin_fmaf(pa, pd, -pb * pb);
+        if (!(pa > 0.0f) || !(det > 0.0f)) ok = false;
+        if (pa < PIV_TAU || det < PIV_TAU * pa) small_pivot = true;      // (pivots: pa and det / pa)
+        float inv = __builtin_amdgcn_rcpf(det);
+        inv = __builtin_fmaf(__builtin_fmaf(-det, inv, 1.0f), inv, inv);
+        const float qa = pa * inv, qb = pb * inv, qd = pd * inv;       // P^-1 = [[qd, -qb], [-qb, qa]]
+        const bool prow = (i >> 1) == kj;
+        if (prow) { ps = (i & 1) ? qa : qd; pc = -qb; }
+        const float f0 = prow ? 0.0f : __builtin_fmaf(c0, qd, -c1 * qb);
+        const float f1 = prow ? 0.0f : __builtin_fmaf(c1, qa, -c0 * qb);
+        {
+            const float b0 = wave_bcast_f(b, j), b1 = wave_bcast_f(b, j + 1);
+            b = __builtin_fmaf(-f1, b1, __builtin_fmaf(-f0, b0, b));
+        }
+#pragma unroll
+        for (int k0 = kj + 1; k0 < NHALF; k0 += 8) {
+            float r0[8], r1[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (k0 + r < NHALF) { r0[r] = half_bcast_f<j>(A[k0 + r]); r1[r] = half_bcast_f<j + 1>(A[k0 + r]); }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (k0 + r < NHALF) A[k0 + r] = __builtin_fmaf(-f1, r1[r], __builtin_fmaf(-f0, r0[r], A[k0 + r]));
+        }
+    };
+    static_for_seq(std::make_integer_sequence<int, NHALF>{}, pivot2);
+    const float bp = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, b), (1 << 10) | 0x1f));     // lane ^ 1
+    z = __builtin_fmaf(ps, b, pc * bp);
+    return ok;
+}
+
 // block-wide reduction of NV sums and one max; results valid in every thread.
 template <int NW, int NV>
 __device__ __forceinline__ void block_reduce(double (&x)[NV], double& mx, double* red /*[NW*(NV+1)]*/) {

@@ -75,6 +75,9 @@ constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
 #ifndef MXE_X_DEPTH1
 #define MXE_X_DEPTH1 4        // V ring of the fused pass at one workgroup per CU (8: the shards of an 8-GPU job 0.464 / 0.508 ms, 4: 0.455 / 0.497, 2: 0.463 / 0.508)
 #endif
+#ifndef MXE_X_ILL_ITERS
+#define MXE_X_ILL_ITERS 8      // iterations an alpha gets after its solve first met a small pivot, before it is handed to the one-chain kernel
+#endif
 #ifndef MXE_X_RD1
 #define MXE_X_RD1 4        // (8: the shards of an 8-GPU job 0.593 / 0.653 -> 0.617 / 0.688 ms)
 #endif
@@ -130,7 +133,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     constexpr int HPW = UREG ? 1 : NWV;          // copies of the partial h: one per wave, or one summed with atomics
     double* hpart = vecI + NP * MCC;             // [HPW][MCC chains][NP]
     double* red  = hpart + HPW * MCC * NP;       // [NWV waves][32]
-    double* ui   = red + NWV * 32;               // [nwp][MCC]   (WGPC = 1 only)
+    double* ssc  = red + NWV * 32;               // [MCC][NP]   binary32 solve: power-of-two scale of row / column k, ~ 1 / sqrt(c_k^2 wmax + alpha)
+    double* csc  = ssc + MCC * NP;               // [MCC][NP]   ... times c_k
+    double* ui   = csc + MCC * NP;               // [nwp][MCC]   (WGPC = 1 only)
     // (the look-ahead of the fused pass reads up to MC_LOOKAHEAD_LDS entries past the end of Hi and of swF:
     //  they land in swF and Wt, are never used, and need no padding)
     // WGPC = 2: u of a lane's eight (row, slot) elements: the first 8 - UL in registers, the last UL in LDS
@@ -148,32 +153,38 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     struct Slot {
         double alpha, mu, chi2, S, Hn2, wmax, Q, Qprev, cperp, steplim, muh;    // muh: damping the last damped step of this piece needed
         double sc2;        // the power of two the sw in LDS (and the Gram tiles computed from it) carry
+        double pred;       // what the stopping estimate of this alpha's previous Newton step predicted for the square of the
+                           //   next correction (times |H|^2); 0: nothing predicted
         int elem, prob0, clen, ia, niter, nevals, nact, active, scratch, okprev, bt, capp;
         int lead;          // LEAD builds: alphas of the scan the piece walks through before its own first one (see start_piece)
+        int wide;          // 1 + the iteration of this alpha at which the binary32 elimination first met a small pivot (0: never)
     };
     // the alphas of a slot's piece (a dependent global load in the accept step costs its full latency)
     constexpr int ACAP = UREG ? 32 : 128;
     __shared__ double s_alpha[MCC][ACAP];
-    __shared__ double s_sd[MCC][12];
+    __shared__ double s_sd[MCC][13];
+    __shared__ float s_zp[MCC][2][16];          // binary32 solve: z of the scaled system by column parity
     __shared__ double s_scw[MCC][2];             // row pass: 1 / sc2 of the sw it reads, sc2 of the sw it writes
-    __shared__ int s_si[MCC][LEAD ? 13 : 12];
+    __shared__ int s_si[MCC][14];
     auto load_slot = [&](Slot& t) {
         const double* d = s_sd[wave]; const int* n = s_si[wave];
         t.alpha = d[0]; t.mu = d[1]; t.chi2 = d[2]; t.S = d[3]; t.Hn2 = d[4]; t.wmax = d[5];
-        t.Q = d[6]; t.Qprev = d[7]; t.cperp = d[8]; t.steplim = d[9]; t.muh = d[10]; t.sc2 = d[11];
+        t.Q = d[6]; t.Qprev = d[7]; t.cperp = d[8]; t.steplim = d[9]; t.muh = d[10]; t.sc2 = d[11]; t.pred = d[12];
         t.elem = n[0]; t.prob0 = n[1]; t.clen = n[2]; t.ia = n[3]; t.niter = n[4]; t.nevals = n[5];
         t.nact = n[6]; t.active = n[7]; t.scratch = n[8]; t.okprev = n[9]; t.bt = n[10]; t.capp = n[11];
         t.lead = 0;
         if constexpr (LEAD) t.lead = n[12];
+        t.wide = n[13];
     };
     auto store_slot = [&](const Slot& t) {
         if (lane == 0) {
             double* d = s_sd[wave]; int* n = s_si[wave];
             d[0] = t.alpha; d[1] = t.mu; d[2] = t.chi2; d[3] = t.S; d[4] = t.Hn2; d[5] = t.wmax;
-            d[6] = t.Q; d[7] = t.Qprev; d[8] = t.cperp; d[9] = t.steplim; d[10] = t.muh; d[11] = t.sc2;
+            d[6] = t.Q; d[7] = t.Qprev; d[8] = t.cperp; d[9] = t.steplim; d[10] = t.muh; d[11] = t.sc2; d[12] = t.pred;
             n[0] = t.elem; n[1] = t.prob0; n[2] = t.clen; n[3] = t.ia; n[4] = t.niter; n[5] = t.nevals;
             n[6] = t.nact; n[7] = t.active; n[8] = t.scratch; n[9] = t.okprev; n[10] = t.bt; n[11] = t.capp;
             if constexpr (LEAD) n[12] = t.lead;
+            n[13] = t.wide;
             s_act[wave] = t.active; s_scr[wave] = t.scratch;
         }
         wave_sync();
@@ -189,11 +200,11 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         // with a loose tolerance (alphas number -lead .. -1: starting points only, no records), and goes on as usual
         const int lead = LEAD ? p.chain_lead[c] : 0;
         t.lead = lead;
-        t.ia = -lead; t.niter = 0; t.nevals = 0; t.nact = 0; t.okprev = 0; t.bt = 0; t.capp = 0;
+        t.ia = -lead; t.niter = 0; t.nevals = 0; t.nact = 0; t.okprev = 0; t.bt = 0; t.capp = 0; t.wide = 0;
         for (int i = lane; i < min(t.clen + lead, ACAP); i += 64) s_alpha[wave][i] = p.alpha[(size_t)(t.prob0 - lead) + i];
         t.alpha = p.alpha[(size_t)(t.prob0 - lead)];
         t.mu = 0.0; t.muh = 0.0; t.Qprev = __builtin_nan("");
-        t.chi2 = 0.0; t.S = 0.0; t.Hn2 = 1.0; t.wmax = 1.0; t.Q = 0.0; t.sc2 = 1.0;
+        t.chi2 = 0.0; t.S = 0.0; t.Hn2 = 1.0; t.wmax = 1.0; t.Q = 0.0; t.sc2 = 1.0; t.pred = 0.0;
         t.active = 1; t.scratch = 1;
         gh[wave * NP + lane] = p.ghat[(size_t)t.elem * NP + lane];
         vv[wave * NP + lane] = p.v0[(size_t)p.chain_v0[c] * NP + lane];
@@ -245,7 +256,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         if (c >= 0) start_piece(t, c);
         else {
             // empty slot: evaluates v = 0 of a neighbour's element every round (finite, never used)
-            t = Slot{1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0};
+            t = Slot{1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0};
             gh[wave * NP + lane] = 0.0; vv[wave * NP + lane] = 0.0;
             if (lane == 0) { s_elem[wave] = -1; s_kind[wave] = 0; }
         }
@@ -304,7 +315,15 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     // matrix ends block diagonal: z of a row pair is P^-1 (b_j, b_j+1), no back substitution.
     // The solve only preconditions the (inexact) Newton step; rows >= n_act are identity rows.
     // ------------------------------------------------------------------
-    auto gj_home = [&](auto NTag, double a, int n_act, double isc2) -> bool {
+    // Precision: the elimination runs in binary32 (gj2_solve64_f32: one dword per cross-lane move, full-rate multiply-
+    // adds) on the system scaled to a diagonal of O(1) -- the Newton matrix is inexact at the 1e-6 level anyway (Gram
+    // tiles from binary16 products, decoupling threshold) and the backward error of that solve, ~N eps |A|, is of the
+    // same size: cfg4 0.915 -> 0.868 ms with the same iteration counts and audit.  Where it meets a small pivot (an
+    // ill-conditioned block: few data points, tiny alpha) 24 bits slow the iteration down; such alphas are handed to the
+    // one-chain kernel (binary64 throughout) early, like those the binary16 Gram products stall (mxe_chains_finish).
+    // Measured and dropped: a binary64 body beside the binary32 one for those slots -- inlined it cost the kernel 3 %
+    // through its register allocation even when it never ran (0.870 -> 0.899 ms), as a function of its own 5 % (0.919).
+    auto gj_home = [&](auto NTag, double a, int n_act, double isc2, double& nrm_out, bool& small_pivot) -> bool {
         constexpr int N = decltype(NTag)::value;
         static_assert(N <= 32 && N % 2 == 0, "two half-waves of 32 rows");
         constexpr int NHALF = N / 2;
@@ -318,9 +337,12 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         const double* rq = rhs + q * NP;
         bool ok = true;
         const bool live = i < n_act;
-        const double ci_ = live ? cc[i] : 0.0;
+        // rows and columns times s_k = 2^-e_k ~ 1 / sqrt(c_k^2 wmax + alpha) (W_kk <= wmax: V has orthonormal columns)
+        const double* cq = csc + q * NP;
+        const double si = ssc[q * NP + min(i, NP - 1)];
+        const double ci_ = live ? cq[i] : 0.0;
         const double cis = ci_ * isc2;               // the tiles carry the factor sc2 of their operands
-        double A[NHALF];
+        float A[NHALF], A0[NHALF];                   // A0: c W c alone (scaled), for the norm of the step
         {
             // W is kept as the upper-triangular 16x16 tiles in the accumulator layout of the MFMA: entry
             // (r, c), r <= c, sits in tile pair (r >> 4, c >> 4) at register r & 3, lane 16 ((r & 15) >> 2) +
@@ -339,21 +361,38 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 const int up_s = kmt * 256 + kri;
                 const int lo_s = (kmt * NT - kmt * (kmt - 1) / 2 - kmt) * 256 + (kri & 3) * 64 + (kri >> 2) * 16;
                 wr[kk] = Wq[(k0 + h >= ic) ? up_l + up_s : lo_l + lo_s];
-                ck[kk] = cc[k0 + h];
+                ck[kk] = cq[k0 + h];
             }
 #pragma unroll
             for (int kk = 0; kk < NHALF; ++kk) {
                 const int k = 2 * kk + h;
                 double xv = (k < n_act) ? cis * wr[kk] * ck[kk] : 0.0;      // 0 in the rows and columns >= n_act
-                if (k == i) xv = live ? xv + a : 1.0;
-                A[kk] = xv;
+                A0[kk] = (float)xv;
+                if (k == i) xv = live ? fma(a * si, si, xv) : 1.0;
+                A[kk] = (float)xv;
             }
         }
-        double b = live ? rq[i] : 0.0;
-        // two pivots per step: gj2_solve64 (mxe_kernel.hip.h)
+        // two pivots per step: gj2_solve64 / gj2_solve64_f32 (mxe_kernel.hip.h)
         MXE_STAMPH(1);
         double z;
-        ok = gj2_solve64<N>(A, b, i, z);
+        small_pivot = false;
+        {
+            float zf;
+            ok = gj2_solve64_f32<N>(A, live ? (float)(rq[i] * si) : 0.0f, i, zf, small_pivot);
+            z = (double)zf * si;
+            // delta^T W delta = z^T (c W c) z for Bryan's bound, as the quadratic form itself: z (rhs - a z) -- the
+            // binary64 shortcut -- cancels to nothing where a dominates the matrix and z carries 24 bits.  Lane (h, i)
+            // sums its columns (parity h) of row i, the halves are added, row i weighs in with z_i
+            if (h == 0) s_zp[q][i & 1][i >> 1] = live ? zf : 0.0f;
+            wave_sync();
+            float y = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < NHALF; ++kk) y = __builtin_fmaf(A0[kk], s_zp[q][h][kk], y);
+            const unsigned yu = __builtin_bit_cast(unsigned, y);
+            const auto ys = __builtin_amdgcn_permlane32_swap(yu, yu, false, false);
+            const float yt = __builtin_bit_cast(float, (unsigned)ys[0]) + __builtin_bit_cast(float, (unsigned)ys[1]);
+            nrm_out = wave_sum((h == 0 && live) ? (double)(zf * yt) : 0.0);
+        }
         MXE_STAMPH(3);
         if (ok && live && h == 0) zz[q * NP + i] = z;
         MXE_STAMPH(4);
@@ -415,6 +454,10 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 int na = (p.theta > 0.0) ? __popcll(m) : ns;
                 na = max(1, min(na, NA));
                 t.nact = na;
+                {
+                    const double sk = ldexp(1.0, -(ilogb(fma(cc[k] * cc[k], wmx, t.alpha)) >> 1));
+                    ssc[q * NP + k] = sk; csc[q * NP + k] = cc[k] * sk;
+                }
                 wave_sync();
                 MXE_STAMPH(0);
                 // damping loop: raise mu until the factorisation succeeds and Bryan's bound holds
@@ -423,18 +466,21 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     double ia = __builtin_amdgcn_rcp(a);             // (the decoupled directions: z = rhs / a)
                     ia = fma(fma(-a, ia, 1.0), ia, ia);
                     ia = fma(fma(-a, ia, 1.0), ia, ia);
-                    bool ok;
-                    if (na <= 16) ok = gj_home(std::integral_constant<int, 16>{}, a, na, isc2);
-                    else if (na <= 20) ok = gj_home(std::integral_constant<int, 20>{}, a, na, isc2);
-                    else if (na <= 24) ok = gj_home(std::integral_constant<int, 24>{}, a, na, isc2);
-                    else if (na <= 28) ok = gj_home(std::integral_constant<int, 28>{}, a, na, isc2);
-                    else if (NA <= 32 || na <= 32) ok = gj_home(std::integral_constant<int, 32>{}, a, na, isc2);
-                    else ok = gj_home(std::integral_constant<int, (NA > 32 ? NA : 32)>{}, a, na, isc2);
+                    bool ok, small = false;
+                    double nrm_gj = -1.0;
+                    if (na <= 16) ok = gj_home(std::integral_constant<int, 16>{}, a, na, isc2, nrm_gj, small);
+                    else if (na <= 20) ok = gj_home(std::integral_constant<int, 20>{}, a, na, isc2, nrm_gj, small);
+                    else if (na <= 24) ok = gj_home(std::integral_constant<int, 24>{}, a, na, isc2, nrm_gj, small);
+                    else if (na <= 28) ok = gj_home(std::integral_constant<int, 28>{}, a, na, isc2, nrm_gj, small);
+                    else ok = gj_home(std::integral_constant<int, 32>{}, a, na, isc2, nrm_gj, small);
+                    // (a small pivot: the block is ill conditioned for 24 bits.  The step is still a descent direction --
+                    //  an inexact Newton step -- but the iteration may crawl: the alpha is given up early, see step 4)
+                    if (t.wide == 0 && __builtin_amdgcn_readfirstlane(__any(small ? 1 : 0))) t.wide = t.niter + 1;       // (pivots are wave-uniform)
                     if (ok) {
                         double z = 0.0, nrm = 0.0;
                         if (k < na) { z = zz[q * NP + k]; nrm = z * (rhs[q * NP + k] - a * z); }
                         else if (k < ns) z = rhs[q * NP + k] * ia;
-                        nrm = wave_sum(nrm);
+                        nrm = nrm_gj;
                         if (nrm <= t.steplim) {
                             okflag = 1; dk = (k < ns) ? cc[k] * z : 0.0;
 #ifndef MXE_X_NO_PREDICTOR
@@ -704,8 +750,18 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                                 if (j & 1) {
                                     const float x0 = xe[c][t];
                                     const auto hh = __builtin_amdgcn_cvt_pkrtz(x0, xv);
+                                    const unsigned hu = __builtin_bit_cast(unsigned, hh);
+#ifndef MXE_X_MIX      // (v_fma_mix_f32 for the remainder -- two instructions less per pair -- measured SLOWER: 0.927 against 0.915 ms, profiles/r03_a_experiments.txt)
                                     const auto ll = __builtin_amdgcn_cvt_pkrtz(x0 - (float)hh[0], xv - (float)hh[1]);
-                                    xh[c][t][j >> 1] = __builtin_bit_cast(unsigned, hh);
+#else
+                                    // remainder x - hi in ONE instruction per element: v_fma_mix_f32 reads the binary16
+                                    // half of hu as an operand (hi * -1 + x, exact), no v_cvt_f32_f16 + v_sub_f32 pair
+                                    float l0, l1;
+                                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hu), "v"(x0));
+                                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hu), "v"(xv));
+                                    const auto ll = __builtin_amdgcn_cvt_pkrtz(l0, l1);
+#endif
+                                    xh[c][t][j >> 1] = hu;
                                     xl[c][t][j >> 1] = __builtin_bit_cast(unsigned, ll);
                                 } else {
                                     xe[c][t] = xv;
@@ -831,12 +887,23 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     // expm1 by its series up to x^4 for x <= 1 (relative error < 1e-2, an estimate), no
                     // estimate beyond
                     double fac2 = 1.0;
-                    if (p.stop_estimate && t.mu == 0.0 && t.okprev == 1 && sdu <= 1.0) {
+                    const bool estimated = p.stop_estimate && t.mu == 0.0 && t.okprev == 1 && sdu <= 1.0;
+                    if (estimated) {
                         const double em1 = sdu * fma(sdu, fma(sdu, fma(sdu, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0);
                         const double fac = em1 + p.theta + MC_GRAM_ERR;
                         fac2 = fmin(1.0, fac * fac);
                     }
-                    const double relH2_min = fac2 * sdH;            // min(relH, relH_next)^2 * Hn2
+                    // The estimate assumes a Newton matrix that is exact up to theta.  The matrix this kernel solves with
+                    // is not (Gram tiles from binary16 products, binary32 elimination): harmless where the system is well
+                    // conditioned, but an ill-conditioned one contracts slower than predicted.  The estimate therefore
+                    // checks itself: what it predicted at the previous step of this alpha for the correction just taken
+                    // (t.pred) against that correction (sdH); an optimistic prediction inflates the present one by the
+                    // same factor
+                    double relH2_min = fac2 * sdH;                  // min(relH, relH_next)^2 * Hn2
+                    const double pred_here = estimated ? relH2_min : 0.0;
+#ifndef MXE_X_NO_PRED_CHECK
+                    if (estimated && t.pred > 0.0 && sdH > t.pred) relH2_min = fmin(sdH, relH2_min * (sdH / t.pred));     // (rare: one division)
+#endif
                     // (a leading alpha is only a starting point for the piece's first alpha: 1e-3 is enough)
                     const double tol_here = (LEAD && t.ia < 0) ? fmax(p.tol_h, (t.ia == -t.lead) ? 1e-3 : MXE_X_WALK_TOL) : p.tol_h;
                     const double tol2Hn = tol_here * tol_here * t.Hn2;
@@ -845,12 +912,14 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     else eacc[q * NP + k] -= dlc[q * NP + k];     // what the later iterations add to the first iterate
                     t.chi2 = chi2t; t.S = St; t.Hn2 = sHn; t.wmax = swm;
                     t.Qprev = t.Q; t.Q = Qt; t.muh = t.mu; t.mu = 0.0;
+                    t.pred = pred_here;
                     ++t.niter;
                     const bool newton_step = t.okprev != 4 && !fresh;       // a halved step says nothing about convergence
                     t.bt = 0;
                     if (newton_step && p.tol_h > 0.0 && relH2_min < tol2Hn && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                     else if (p.tol_relq > 0.0 && fabs(fabs(t.Qprev - t.Q) / t.Q) < p.tol_relq && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                     else if (t.niter >= ((LEAD && t.ia < 0 && t.ia > -t.lead) ? MXE_X_WALK_ITERS : p.mc_maxiter)) finish_alpha = true;   // (an alpha of a walk is a starting point: a few rounds, then on)
+                    else if (t.wide > 0 && t.niter - t.wide >= MXE_X_ILL_ITERS) finish_alpha = true;    // (ill conditioned for the binary32 solve: handed over)
                 }
                 MXE_STAMPA(2);
                 if (fresh && t.scratch == 2) t.scratch = 0;     // accepted or to be halved: the state in LDS is that trial point
@@ -892,7 +961,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         ecor[q * NP + k] = e; eacc[q * NP + k] = 0.0;
                     }
                     ++t.ia;
-                    t.niter = 0; t.nevals = 0; t.mu = 0.0; t.bt = 0; t.capp = 0;
+                    t.niter = 0; t.nevals = 0; t.mu = 0.0; t.bt = 0; t.capp = 0; t.pred = 0.0; t.wide = 0;
                     t.Qprev = __builtin_nan("");
                     if (t.ia >= t.clen) {
                         t.active = 0;
