@@ -37,20 +37,48 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 L2_PEAK_GBS = 34500.0          # ... aggregate L2
 N_EVAL_NOMINAL = {'normal': 160, 'plusminus': 84}   # the reference's passes per alpha-solve
 
-# Counter values per launch of the default workload (rocprofv3 --pmc on this very command, summaries under
-# profiles/r02_k_pmc_*.csv; they count events, not time, and do not depend on the clock):
-PMC_DEFAULT = dict(
-    source='profiles/r02_k_pmc_summary.csv',
-    # mean per dispatch of mxe::chain_kernel_mc<32, 2> over ~200 dispatches
-    valu_active_quadcycles=2.66444e+08,      # SQ_ACTIVE_INST_VALU (counts quad-cycles: MI355X_MICROARCH.md, cycle constants)
-    mfma_busy_cycles=4.2497e+08,            # SQ_VALU_MFMA_BUSY_CYCLES (cycles)
-    coexec_cycles=3.17594e+07,               # SQ_VALU_MFMA_COEXEC_CYCLES: both at once, counted once below
-    any_active_quadcycles=3.94004e+08,       # SQ_ACTIVE_INST_ANY
-    wave_quadcycles=9.7309e+08,            # SQ_WAVE_CYCLES
-    wait_inst_quadcycles=3.16332e+08, wait_any_quadcycles=2.62754e+08,
-    gui_active_cycles_all_xcd=1.80695e+07,   # GRBM_GUI_ACTIVE (sum over the 8 XCDs)
-    fetch_kb=12693.7, write_kb=132895,  # FETCH_SIZE (x 2 on gfx950, MI355X_MICROARCH.md section HBM), WRITE_SIZE
-    l2_hit=7.584e+07, l2_miss=1.21139e+06)
+# Counter values per launch of the default workload come from profiles/<tag>_pmc_summary.csv (rocprofv3 --pmc passes on
+# this very command, condensed by tools/summarize_pmc.py), whose first line records the source hash of the library
+# the counters were taken on.  They count events, not time, and do not depend on the clock -- but they belong to ONE
+# build: load_pmc() only accepts a summary whose hash equals mxe_source_hash() of the library being benched.
+PMC_NAMES = dict(valu_active_quadcycles='SQ_ACTIVE_INST_VALU',      # (counts quad-cycles: MI355X_MICROARCH.md, cycle constants)
+                 mfma_busy_cycles='SQ_VALU_MFMA_BUSY_CYCLES',       # (cycles)
+                 coexec_cycles='SQ_VALU_MFMA_COEXEC_CYCLES',        # both at once, counted once
+                 any_active_quadcycles='SQ_ACTIVE_INST_ANY', wave_quadcycles='SQ_WAVE_CYCLES',
+                 wait_inst_quadcycles='SQ_WAIT_INST_ANY', wait_any_quadcycles='SQ_WAIT_ANY',
+                 gui_active_cycles_all_xcd='GRBM_GUI_ACTIVE',       # sum over the 8 XCDs
+                 fetch_kb='FETCH_SIZE', write_kb='WRITE_SIZE',      # (FETCH_SIZE x 2 on gfx950: MI355X_MICROARCH.md, section HBM)
+                 l2_hit='TCC_HIT_sum', l2_miss='TCC_MISS_sum')
+
+
+def load_pmc(lib_hash):
+    """(counters, None) from the newest profiles/*_pmc_summary.csv recorded on this build, or (None, reason)"""
+    import glob
+    seen = []
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_summary.csv')), reverse=True):
+        with open(path) as f:
+            lines = f.read().splitlines()
+        if not lines or not lines[0].startswith('#source_hash,'):
+            continue                          # (summaries of earlier rounds: no hash, never applied)
+        h = lines[0].split(',', 1)[1].strip()
+        seen.append('%s: %s' % (os.path.basename(path), h))
+        if h != lib_hash:
+            continue
+        vals = {}
+        for ln in lines[2:]:
+            parts = ln.split(',')
+            if len(parts) >= 3:
+                vals[parts[0]] = float(parts[2])
+        missing = [c for c in PMC_NAMES.values() if c not in vals]
+        if missing:
+            return None, '%s lacks the counters %s' % (os.path.relpath(path, ROOT), ', '.join(missing))
+        pmc = {k: vals[c] for k, c in PMC_NAMES.items()}
+        pmc['source'] = os.path.relpath(path, ROOT)
+        return pmc, None
+    return None, ('no counter profile under profiles/ was recorded on this build (library source hash %s; profiles: %s): '
+                  're-run tools/round_profile.sh' % (lib_hash, '; '.join(seen) if seen else 'none with a hash'))
+
+
 N_SIMD = 256 * 4
 CLOCK_PEAK_GHZ = 2.4                      # MI355X_MICROARCH.md: max clock
 
@@ -231,6 +259,46 @@ def end_to_end_block(batch, n_orb, n_alpha):
                 first_access_of_all_H_ms=1e3 * t_H, all_H_MB=nbytes / 1e6)
 
 
+def scaling_projection(batch, opts, k_ms_full, n_alpha, n_launch=30):
+    """What a strong-scaling run of the ONE batch can give, measured on this one GPU: for N = 2, 4, 8 the kernel time of
+    EVERY rank's shard (element e on rank e mod N, mxe_shard_plan) -- a job ends with its slowest rank -- against the
+    time of the whole batch.  No gather in these numbers (the compact pack is 1.6 MB in total)."""
+    n_elem = len(batch['elems'])
+    out = dict(whole_batch_kernel_ms=k_ms_full, method='one GPU solves each rank\'s shard in turn (HIP events over %d launches '
+               'back to back); speedup = whole-batch kernel time / slowest shard' % n_launch)
+    for N in (2, 4, 8):
+        times, kern = [], None
+        for r in range(N):
+            which = [e for e in range(n_elem) if e % N == r]
+            c = stage(batch, 0, which)
+            c.upload_chains(np.arange(len(which), dtype=np.int32), batch['alphas'], batch['v0'][which], opts)
+            for _ in range(3):
+                c.launch()
+            c.sync()
+            c.timing_mark()
+            for _ in range(n_launch):
+                c.launch()
+            times.append(c.ms_since_mark() / n_launch)
+            kern = c.last_launch_info()['kernel']
+            c.close()
+        out['N=%d' % N] = dict(shard_kernel_ms=[round(t, 4) for t in times], slowest_ms=max(times), fastest_ms=min(times),
+                               slowest_rank=int(np.argmax(times)), kernel=kern, alpha_solves_per_rank=len(which) * n_alpha,
+                               speedup_before_gather=k_ms_full / max(times))
+    out['bound'] = dict(
+        text='A shard that does not fill the GPU is as long as its deepest chain of Newton rounds, not as its work: the tail '
+             'of a normal-entropy scan cannot be cold-started (the last 6 % of the alpha range take 50-390 evaluations from '
+             'the default model), so its pieces solve the last alpha above that range cold -- 17-18 rounds at the smallest '
+             'alphas: Newton moves u = log(H / D) by 1-2.5 per step where the spectrum has to vanish, and it has to fall by '
+             '~11 -- walk down the mesh at one round per alpha (up to 6) and take 3-4 rounds for their own alpha: 25-28 '
+             'rounds whatever N is.  A round of a workgroup that has its CU to itself takes ~42 k cycles (17.5 us): binary32 '
+             'Gauss-Jordan + step 14.7 k, accept 4 k, the two streaming passes 19 k of which 15 k are the 448 KB of V and '
+             'V^T at the ~30 B per cycle one CU gets out of its L2 (more waves do not change it: '
+             'profiles/r03_a_phases_wg1_8waves.txt, profiles/r03_a_l2_stream_rate.txt).',
+        rounds_deepest_chain=[25, 28], us_per_round_one_workgroup_per_cu=17.5, floor_ms=[0.44, 0.49],
+        speedup_ceiling_at_this_round_structure=k_ms_full / 0.44)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------
 #  ranks in separate processes
 # ---------------------------------------------------------------------------------------------------
@@ -272,8 +340,8 @@ def comm_setup(ctx, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    # a step is ~1.3 ms: 200 of them keep the timed region long enough (0.27 s) for the tens of milliseconds
-    # by which a fresh submission is sometimes picked up late on the MI355X boxes
+    # a step is ~0.9 ms: the default 1000 keep the timed region long (0.9 s) against the tens of milliseconds by
+    # which a fresh submission is sometimes picked up late on the MI355X boxes
     ap.add_argument('--steps', type=int, default=1000)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--scaling', choices=('strong', 'weak'), default='strong')
@@ -438,21 +506,24 @@ def main():
     #   row pass  du = V delta        2 n_omega_pad NP            (v_mfma_f64_4x4x4, padded columns included)
     #   fused     h = V^T H           2 n_omega_pad NP
     #   exp / entropy / sums          ~40 n_omega
-    #   Gauss-Jordan                  2 N^3 (N = active block, 32 here)
+    #   (Gauss-Jordan: 2 N^3, N = 32 -- binary32 since round 3, listed as fp32_solve_tflops)
     nwp = ((args.n_omega + 127) // 128) * 128
-    f64_per_round = 2 * nwp * 64 + 2 * nwp * 64 + 40 * args.n_omega + 2 * 32 ** 3
+    f64_per_round = 2 * nwp * 64 + 2 * nwp * 64 + 40 * args.n_omega
     f16_per_round = 3 * 2 * nwp * 3 * 256          # three binary16 products for the three 16 x 16 tiles of W
-    pmc = PMC_DEFAULT if (default_workload and world == 1 and info['kernel'].endswith('<32, 2>')) else {}
+    lib_hash = device.source_hash()
+    pmc, pmc_reason = (load_pmc(lib_hash) if (default_workload and world == 1 and args.shard_of <= 1 and
+                                                info['kernel'] == 'mxe::chain_kernel_mc<32, 2>')
+                       else (None, 'counters are collected for the default workload on one GPU only'))
     achieved = peak = frac = traffic = counters = None
+    peak = N_SIMD * CLOCK_PEAK_GHZ                              # every SIMD busy every cycle at the maximum clock
     if pmc:
         # SIMD-cycles per launch in which a vector or an FP-MFMA instruction was executing (events, clock free)
         busy = 4 * pmc['valu_active_quadcycles'] + pmc['mfma_busy_cycles'] - pmc['coexec_cycles']
         achieved = busy / (k_ms * 1e-3) / 1e9                   # G busy SIMD-cycles per second, live kernel time
-        peak = N_SIMD * CLOCK_PEAK_GHZ                          # every SIMD busy every cycle at the maximum clock
         frac = achieved / peak
         traffic = 2 * pmc['fetch_kb'] * 1e3 + pmc['write_kb'] * 1e3
         kcyc = pmc['gui_active_cycles_all_xcd'] / 8
-        counters = dict(source=pmc['source'],
+        counters = dict(source=pmc['source'], library_source_hash=lib_hash,
                         busy_frac_by_counters_alone=busy / (N_SIMD * kcyc),
                         any_instruction_active_frac=4 * pmc['any_active_quadcycles'] / (N_SIMD * kcyc),
                         wave_time_split=dict(issuing=pmc['any_active_quadcycles'] / pmc['wave_quadcycles'],
@@ -465,24 +536,30 @@ def main():
         bound='simd-issue',
         kernel=info['kernel'], kernel_ms=k_ms,
         achieved=achieved, peak=peak, unit='G busy SIMD-cycles/s', frac=frac,
+        frac_null_reason=(None if pmc else pmc_reason),
         traffic=traffic, counters=counters,
         definition='The kernel is bound by the instruction issue of the four SIMDs of a CU: on gfx950 the binary64 and '
                    'binary32 MFMAs run at the rate of -- and instead of -- the vector instructions (profiles/'
-                   'r01_f_microbench_mfma_shadow.txt), so the solve of the home waves (v_fma_f64 behind ds_swizzle / v_permlane32_swap broadcasts), the '
-                   'exp / entropy arithmetic, the binary64 matrix products and the operand splitting of the Gram '
-                   'tiles all queue for the same pipe; only the binary16 Gram MFMAs have a pipe of their own.  achieved = '
-                   '(4 SQ_ACTIVE_INST_VALU + SQ_VALU_MFMA_BUSY_CYCLES - SQ_VALU_MFMA_COEXEC_CYCLES) per launch '
-                   '(rocprofv3 --pmc on this command, %s) / the kernel time measured here with HIP events; peak = 1024 '
-                   'SIMDs x 2.4 GHz.  Two workgroups per CU run the serial and the streaming phases of different '
-                   'workgroups side by side (a round of four chains: 34.5 k cycles against 47 k with one per CU); what is left idle is waiting on L2 latency and '
-                   'barriers inside phases that are too short to fill from elsewhere.  HBM and L2 are far from binding '
-                   '(hbm_frac, l2_frac); traffic = 2 FETCH_SIZE + WRITE_SIZE per launch, of which 117 MB are the '
-                   'compulsory per-alpha results and ~56 MB five spilled dwords per lane and round.' % pmc.get('source', 'counters not collected for this workload / kernel'),
+                   'r01_f_microbench_mfma_shadow.txt), so the solve of the home waves (binary32 Gauss-Jordan: v_fma_f32 behind '
+                   'ds_swizzle / v_permlane32_swap broadcasts), the exp / entropy arithmetic, the binary64 matrix products '
+                   'and the operand splitting of the Gram tiles all queue for the same pipe; only the binary16 Gram MFMAs '
+                   'have a pipe of their own.  achieved = (4 SQ_ACTIVE_INST_VALU + SQ_VALU_MFMA_BUSY_CYCLES - '
+                   'SQ_VALU_MFMA_COEXEC_CYCLES) per launch, read from the rocprofv3 --pmc summary under profiles/ that was '
+                   'recorded on THIS build of the library (%s), / the kernel time measured here with HIP events; peak = 1024 '
+                   'SIMDs x 2.4 GHz.  frac is null when no summary carries the hash of the library being benched.  It is an '
+                   'occupancy of the issue slots, not useful work: useful_f64_frac prices the binary64 arithmetic alone.  Two '
+                   'workgroups per CU run the serial and the streaming phases of different workgroups side by side; the '
+                   'streaming passes also sit at the rate one CU gets out of its L2 (8 B per lane: 32 B per cycle, 16 B per '
+                   'lane: 64, profiles/r03_a_l2_stream_rate.txt).  HBM is far from binding (hbm_frac); traffic = 2 FETCH_SIZE '
+                   '+ WRITE_SIZE per launch, of which 117 MB are the compulsory per-alpha results.'
+                   % (pmc['source'] if pmc else 'none: ' + str(pmc_reason)),
         hbm_frac=(None if traffic is None else traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS),
         l2_frac=(rounds / 4.0 * (2 * nwp * 64 * 8) / (k_ms * 1e-3) / 1e9 / L2_PEAK_GBS),
         l2_definition='V^T + V (2 x %d KB) streamed once per round of a workgroup of four chains / kernel time, against '
                       'the 34.5 TB/s aggregate L2' % (nwp * 64 * 8 // 1024),
         fp64_tflops=achieved_tflops, fp64_peak_tflops=78.6, fp64_frac=achieved_tflops / 78.6,
+        useful_f64_frac=achieved_tflops / 78.6,
+        fp32_solve_tflops=rounds * 2 * 32 ** 3 / (k_ms * 1e-3) / 1e12,
         fp16_gram_tflops=rounds * f16_per_round / (k_ms * 1e-3) / 1e12,
         evals_per_solve=float(out['n_evals'].mean()), newton_iters_per_solve=float(out['n_iter'].mean()),
         survey_8d=dict(
@@ -512,9 +589,10 @@ def main():
                     lds_bytes=info['lds_bytes'], converged_on_rank0=n_conv, alphas_left_to_mxe_chains_finish=n_left_to_finish,
                     svd_seconds_host=batch['t_svd'], host_split=host_split,
                     gather_checked=gather_checked,
-                    multi_gpu_note='N > 1 has not been run by the builders (one-GPU boxes); the gather path is '
-                                   'exercised with one rank (--force-comm) and with several contexts on one device '
-                                   '(tests/test_gpu_multi.py)'),
+                    multi_gpu_note='N > 1 has not been run by the builders (one-GPU boxes); the RCCL calls of the gather '
+                                   '(group start / send / recv / all-reduce) are executed with one rank (--force-comm, '
+                                   'tests/test_gpu_multi.py) and several contexts on one device go through device copies; '
+                                   'scaling_projection holds every rank\'s shard timed on this GPU'),
                 roofline=roofline)
     if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(batch, out)
@@ -525,6 +603,8 @@ def main():
         line['audit'] = audit_block(ctx)
         if default_workload:
             line['parity_per_alpha'] = parity_per_alpha()
+            if args.shard_of <= 1:
+                line['scaling_projection'] = scaling_projection(batch, opts, k_ms, args.n_alpha)
     if use_comm:
         ctx.comm_destroy()
     ctx.close()

@@ -129,6 +129,9 @@ typedef struct mxe_opts {
 
 /* ---- library / device ------------------------------------------------- */
 const char* mxe_version(void);
+/* first 16 hex digits of the SHA-256 over the library's sources (csrc/*.hip, csrc/*.hip.h, this header) as the Makefile
+   saw them when it built this binary: bench.py only trusts a counter profile under profiles/ that records the same hash */
+const char* mxe_source_hash(void);
 const char* mxe_strerror(int code);
 int  mxe_device_count(int* n_devices);
 void mxe_opts_default(mxe_opts* opts);
@@ -295,6 +298,15 @@ int  mxe_audit(mxe_ctx* ctx, double* out_corr, double* out_gmax);
  * contiguous on the device (P = n_chain * n_alpha).  index = -1: no fit (fewer than five alphas, chi2 NaN). */
 int  mxe_select_launch(mxe_ctx* ctx, int p2_deg);
 int  mxe_select_fetch(mxe_ctx* ctx, int32_t* out_index, double* out_H_selected);
+/* The three default analyzers of the reference in one launch (it also fills the compact pack like mxe_select_launch):
+ *   0  LineFitAnalyzer (as above),
+ *   1  Chi2CurvatureAnalyzer (analyzers/chi2_curvature_analyzer.py:25-49,101-131): the alpha of the largest curvature
+ *      y'' / (1 + y'^2)^(3/2) of y = log10 chi2 over x = gamma log10 alpha, NaN ignored, the first of equal maxima,
+ *   2  EntropyAnalyzer (analyzers/entropy_analyzer.py:72-103): the alpha where (dS / dlog alpha)^2 is smallest;
+ * mxe_select3_fetch: out_index [3][n_chain] (-1: nothing to choose from), out_H_selected [3][n_chain][n_omega] (may be
+ * NULL), both in ONE device-to-host copy. */
+int  mxe_select3_launch(mxe_ctx* ctx, int p2_deg, double gamma);
+int  mxe_select3_fetch(mxe_ctx* ctx, int32_t* out_index, double* out_H_selected);
 /* n_rows hidden images of the last launch by problem index (chain * n_alpha + i), [n_rows][n_omega]:
  * what an analyzer needs (one row per scan) without moving all of H */
 int  mxe_fetch_rows(mxe_ctx* ctx, int n_rows, const int32_t* problem_index, double* out_H);
@@ -321,6 +333,10 @@ int  mxe_comm_unique_id(char* out_id128);
 int  mxe_comm_init(mxe_ctx* ctx, int n_ranks, int rank, const char* id128);
 int  mxe_comm_init_local(mxe_ctx** ctxs, int n);
 int  mxe_comm_destroy(mxe_ctx* ctx);
+/* test plumbing for a one-GPU box (communicators of mxe_comm_init): with on != 0 the root's own pack goes through
+   ncclGroupStart / ncclSend / ncclRecv (to itself) / ncclGroupEnd instead of a device copy, and mxe_comm_allreduce
+   runs ncclAllReduce with the single rank -- the RCCL calls of the multi-GPU path execute on one device */
+int  mxe_comm_set_loopback(mxe_ctx* ctx, int on);
 int  mxe_gather(mxe_ctx* ctx, int root, int what, const int64_t* counts, double* recv_host);
 /* sum (op = 0) or maximum (op = 1) of n <= 64 doubles over the ranks, result on every rank; with it the
  * ranks of separate processes agree on a timing or wait for each other (a barrier is a sum of zeros) */

@@ -33,10 +33,50 @@ class AnalyzerResult(dict):
         self.__dict__['_result_ref'] = None if value is None else weakref.ref(value)
 
     def __getstate__(self):
-        return dict((k, v) for k, v in self.__dict__.items() if k != '_result_ref')
+        self._settle()
+        return dict((k, v) for k, v in self.__dict__.items() if k not in ('_result_ref', '_lazy'))
 
     def __reduce_to_dict__(self):
+        self._settle()
         return self
+
+    # Entries that cost something and that hardly anybody reads (the fit parameters of the line fit, the curvature
+    # and dS / dlog alpha curves when the device has already picked the alpha) are computed when first looked at:
+    # ``later(key, thunk)``.  ``res[key]`` computes that one; anything that looks at the dict as a whole settles all.
+    def later(self, key, thunk):
+        self.__dict__.setdefault('_lazy', {})[key] = thunk
+
+    def __missing__(self, key):
+        lazy = self.__dict__.get('_lazy')
+        if lazy and key in lazy:
+            val = self[key] = lazy.pop(key)()
+            return val
+        raise KeyError(key)
+
+    def _settle(self):
+        lazy = self.__dict__.get('_lazy')
+        while lazy:
+            key, thunk = lazy.popitem()
+            dict.__setitem__(self, key, thunk())
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self.__dict__.get('_lazy', ())
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def _settled(name):
+        def method(self, *a, **k):
+            self._settle()
+            return getattr(dict, name)(self, *a, **k)
+        method.__name__ = name
+        return method
+    for _n in ('keys', 'values', 'items', '__iter__', '__len__', '__repr__', '__eq__', 'copy', 'pop', 'popitem', '__reduce_ex__'):
+        locals()[_n] = _settled(_n)
+    del _n, _settled
 
     @classmethod
     def __factory_from_dict__(cls, name, D):
@@ -261,6 +301,33 @@ def _element(maxent_result, name, matrix_element):
     return maxent_result.element_array(name, matrix_element)
 
 
+def _device_picks(maxent_result, keys, which, matches):
+    """What the device chose for these elements (``mxe_select3_launch``, one launch behind the solve; the indices and
+    the three H rows of every scan came back in one copy): (indices, A rows), or None when any element has no such
+    choice -- another parameter than the device used (``matches(params)``), no fit, a record made some other way.
+    ``which``: 0 line fit, 1 chi2 curvature, 2 entropy."""
+    idx, rows, maps = [], [], []
+    recs = getattr(maxent_result, '_records', {})
+    for k in keys:
+        rec = recs.get(k)
+        sel = None if rec is None else rec.get('device_select')
+        if sel is None or not matches(sel['params']) or sel['index'][which] < 0:
+            return None
+        A = rec.get('A')
+        if not hasattr(A, 'from_H_row'):
+            return None
+        maps.append(A)
+        rows.append(sel['H'][which])
+        idx.append(int(sel['index'][which]))
+    first = maps[0]._map if maps else None
+    if first is not None and first.matrix() is None and all(m._map is first for m in maps):
+        # A = H / delta for everybody: one division for all rows (elementwise: the same bits as row by row)
+        rows = list(first.f(np.array(rows)))
+    else:
+        rows = [m.from_H_row(r) for m, r in zip(maps, rows)]
+    return idx, rows
+
+
 class LineFitAnalyzer(Analyzer):
     """kink of log chi2 (log alpha)."""
 
@@ -277,6 +344,11 @@ class LineFitAnalyzer(Analyzer):
                                         self.linefit_deg)
         return self._result(maxent_result, matrix_element, alpha, idx, params)
 
+    def _params(self, maxent_result, matrix_element, alpha):
+        chi2 = np.asarray(_element(maxent_result, 'chi2', matrix_element), dtype=float)
+        with np.errstate(all='ignore'):
+            return fit_piecewise(np.log(alpha), np.log(chi2), self.linefit_deg)[1]
+
     def _result(self, maxent_result, matrix_element, alpha, idx, params):
         res = AnalyzerResult()
         res['alpha_index'] = idx
@@ -291,6 +363,19 @@ class LineFitAnalyzer(Analyzer):
     def analyze_many(self, maxent_result, keys):
         """one result (or the error message) per key; all break points in one vectorised pass"""
         alpha = np.asarray(maxent_result.alpha)
+        dev = _device_picks(maxent_result, keys, 0, lambda p: p[0] == self.linefit_deg)
+        owner = weakref.ref(maxent_result)          # (the result owns its analyses: no strong reference back, see AnalyzerResult)
+        if dev is not None:
+            # the device made the same two-stage fit (linefit_kernel); the parameters of the two lines, which nothing
+            # but a plot reads, are fitted when somebody asks for them
+            out = []
+            for k, i, row in zip(keys, *dev):
+                res = AnalyzerResult()
+                dict.update(res, alpha_index=i, A_out=row, linefit_deg=self.linefit_deg, name=self.name)
+                res.later('linefit_params', lambda k=k: self._params(owner(), k, alpha))
+                res.later('info', lambda i=i: 'Ideal alpha (linefit): {} (= index {} zero-based)'.format(alpha[i], i))
+                out.append(res)
+            return out
         chi2 = np.array([np.asarray(_element(maxent_result, 'chi2', k), dtype=float) for k in keys])
         with np.errstate(all='ignore'):
             idx, params = fit_piecewise_many(np.log(alpha), np.log(chi2), self.linefit_deg)
@@ -316,6 +401,17 @@ class Chi2CurvatureAnalyzer(Analyzer):
 
     def analyze_many(self, maxent_result, keys):
         alpha = np.asarray(maxent_result.alpha)
+        dev = _device_picks(maxent_result, keys, 1, lambda p: p[1] == self.gamma)
+        owner = weakref.ref(maxent_result)
+        if dev is not None:
+            out = []
+            for k, i, row in zip(keys, *dev):
+                res = AnalyzerResult()
+                dict.update(res, alpha_index=i, A_out=row, gamma=self.gamma, name=self.name)
+                res.later('curvature', lambda k=k: self._curve(owner(), k, alpha))
+                res.later('info', lambda i=i: 'Ideal alpha (curvature): {} (= index {} zero-based)'.format(alpha[i], i))
+                out.append(res)
+            return out
         x = self.gamma * np.log10(alpha)
         out = []
         with np.errstate(all='ignore'):
@@ -335,6 +431,11 @@ class Chi2CurvatureAnalyzer(Analyzer):
             except ValueError as err:
                 out.append(str(err))
         return out
+
+    def _curve(self, maxent_result, matrix_element, alpha):
+        chi2 = np.asarray(_element(maxent_result, 'chi2', matrix_element), dtype=float)
+        with np.errstate(all='ignore'):
+            return curv(self.gamma * np.log10(alpha), np.log10(chi2))[0]
 
     def _finish(self, res, maxent_result, matrix_element, alpha, idx=None):
         if idx is None:
@@ -364,6 +465,17 @@ class EntropyAnalyzer(Analyzer):
 
     def analyze_many(self, maxent_result, keys):
         alpha = np.asarray(maxent_result.alpha)
+        dev = _device_picks(maxent_result, keys, 2, lambda p: True)
+        owner = weakref.ref(maxent_result)
+        if dev is not None:
+            out = []
+            for k, i, row in zip(keys, *dev):
+                res = AnalyzerResult()
+                dict.update(res, alpha_index=i, A_out=row, name=self.name)
+                res.later('dS_dalpha', lambda k=k: self._slope(owner(), k, alpha))
+                res.later('info', lambda i=i: 'Ideal alpha (entropy): {} (= index {} zero-based)'.format(alpha[i], i))
+                out.append(res)
+            return out
         S = np.array([np.asarray(_element(maxent_result, 'S', k), dtype=float) for k in keys])
         D = np.full(S.shape, np.nan)
         D[:, 1:-1] = (S[:, 2:] - S[:, :-2]) / (np.log(alpha[2:]) - np.log(alpha[:-2]))
@@ -378,6 +490,12 @@ class EntropyAnalyzer(Analyzer):
             except ValueError as err:
                 out.append(str(err))
         return out
+
+    def _slope(self, maxent_result, matrix_element, alpha):
+        S = np.asarray(_element(maxent_result, 'S', matrix_element), dtype=float)
+        d = np.full(len(alpha), np.nan)
+        d[1:-1] = (S[2:] - S[:-2]) / (np.log(alpha[2:]) - np.log(alpha[:-2]))
+        return d
 
     def _finish(self, res, maxent_result, matrix_element, alpha, idx=None):
         d = res['dS_dalpha']

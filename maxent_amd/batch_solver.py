@@ -26,6 +26,7 @@ from . import device
 
 class LazyH(object):
     """hidden images of one alpha scan, still on the device until somebody looks"""
+    _what = 'H'
 
     def __init__(self, owner, rank, chain, n_alpha, n_omega):
         self._owner, self._rank, self._chain = owner, rank, chain
@@ -48,7 +49,10 @@ class LazyH(object):
 
     def __getitem__(self, item):
         if self._val is None and isinstance(item, (int, np.integer)):
-            return self._owner.rows([(self._rank, self._chain, int(item))])[0]
+            i = int(item)
+            if not -self.shape[0] <= i < self.shape[0]:
+                raise IndexError('index %d is out of bounds for axis 0 with size %d' % (i, self.shape[0]))
+            return self._owner.rows([(self._rank, self._chain, i % self.shape[0])])[0]
         return self.materialize()[item]
 
 
@@ -57,7 +61,16 @@ class LazyH(object):
         return self._val is not None
 
     def row_request(self, i):
-        return (self._rank, self._chain, int(i))
+        return (self._rank, self._chain, int(i) % self.shape[0])
+
+
+class LazyV(LazyH):
+    """the singular-space vectors v of one alpha scan (n_alpha x n_s), on the device until somebody looks: 13 MB of
+    a 16 x 16 x 100 job that the result object hardly ever shows"""
+    _what = 'v'
+
+    def __getitem__(self, item):
+        return self.materialize()[item]
 
 
 class LazyA(object):
@@ -78,7 +91,7 @@ class LazyA(object):
 
     def __getitem__(self, item):
         if self._val is None and isinstance(item, (int, np.integer)):
-            return np.asarray(self._map.f(np.asarray(self._H[item])))
+            return np.asarray(self._map.f(np.asarray(self._H[int(item)])))       # (LazyH normalises a negative index)
         return np.asarray(self)[item]
 
     @property
@@ -111,7 +124,14 @@ class BatchSolver(object):
     # ---- reuse -------------------------------------------------------------
     @staticmethod
     def _kernel_token(K):
-        return (id(K._S), id(K._V), len(K._S), K.rotation is None)
+        """what the staged basis depends on, as the OBJECTS themselves (held, so that their addresses cannot be
+        recycled by a re-decomposition): U too -- a covariance rotation with truncated eigenvalues followed by
+        set_error leaves another U beside the same S and V"""
+        return (K._U, K._S, K._V, K.rotation is None)
+
+    @staticmethod
+    def _same_token(a, b):
+        return a is not None and b is not None and all((x is y) for x, y in zip(a[:3], b[:3])) and a[3] == b[3]
 
     @classmethod
     def for_kernel(cls, K, device_ids=(0,)):
@@ -121,7 +141,7 @@ class BatchSolver(object):
         if held is None:
             held = K.__dict__['_batch_solvers'] = {}
         s = held.get(device_ids)
-        if s is not None and s._token == cls._kernel_token(K) and s.ctxs[0]._h:
+        if s is not None and cls._same_token(s._token, cls._kernel_token(K)) and s.ctxs[0]._h:
             return s
         if s is not None:
             s.close()
@@ -130,14 +150,19 @@ class BatchSolver(object):
 
     def close(self):
         self.materialize_pending()
+        pool = self.__dict__.pop('_pool', None)
+        if pool is not None:
+            pool.shutdown(wait=True)
         for c in self.ctxs:
             c.close()
 
     # ---- one batch -----------------------------------------------------------
-    def solve(self, K, specs, opts, want_logdet=False, want_H='lazy', output_map=None):
+    def solve(self, K, specs, opts, want_logdet=False, want_H='lazy', output_map=None, select=(0, 0.2)):
         """``specs``: dicts with G, err, U_rot (or None), D, kind, v0, alpha (equal lengths).  Returns
         (list of per-spec result dicts in the order of ``specs``, info).  ``want_H``: 'lazy' (default),
-        True (fetched now) or False."""
+        True (fetched now) or False.  ``select`` = (linefit_deg, gamma): the three default analyzers' alphas are picked
+        on the device behind the solve (``mxe_select3_launch``) and come back with their H rows as ``device_select``
+        of every result; None: not."""
         self.materialize_pending()                  # the result buffers are about to be overwritten
         n_alpha = len(specs[0]['alpha'])
         for s in specs:
@@ -147,31 +172,42 @@ class BatchSolver(object):
         rank_of, local_of, n_local = device.shard_plan(len(specs), N)
         per_rank = [[i for i in range(len(specs)) if rank_of[i] == r] for r in range(N)]
         active = [r for r in range(N) if per_rank[r]]
-        for r in active:
-            self._stage(self.ctxs[r], K, [specs[i] for i in per_rank[r]], opts)
-        for r in active:
-            self.ctxs[r].launch()
-        for r in active:
-            self.ctxs[r].finish()                   # (alphas the lock-step layout gave up on: one-chain layout)
-        info = None
+        eta = float(getattr(opts, 'chi2_factor', 1.0)) if opts is not None else 1.0
+        gather = len(active) == N and N > 1
         outs = [None] * N
-        if len(active) == N and N > 1:
+        picks = [None] * N
+
+        def work(r):
+            # stage -> launch -> finish -> (fetch) of ONE device; with several devices each runs on a thread of its own
+            # (ctypes releases the GIL, the library promises one thread per context: include/maxent_hip.h)
+            c = self.ctxs[r]
+            self._stage(c, K, [specs[i] for i in per_rank[r]], opts)
+            c.launch()
+            c.finish()                              # (alphas the lock-step layout gave up on: one-chain layout)
+            if select is not None:
+                c.select3_launch(select[0], select[1])
+            elif gather:
+                c.select_launch(0)
+            if not gather:
+                outs[r] = c.fetch(want_v=False, want_H=False)
+            if select is not None:
+                picks[r] = c.select3_fetch()
+
+        self._on_devices(work, active)
+        info = None
+        if gather:
             # ONE gather of the per-alpha scalars (and of the analyzer's rows) to the first device
-            for r in active:
-                self.ctxs[r].select_launch(0)
             counts = [self.ctxs[r].compact_count() for r in range(N)]
             recv = np.empty(int(np.sum(counts)))
             device.gather_local(self.ctxs, 0, counts, full=False, recv=recv)
-            off = 0
-            for r in range(N):
-                outs[r] = self._unpack_compact(recv[off:off + counts[r]], len(per_rank[r]), n_alpha)
-                off += counts[r]
-                extra = self.ctxs[r].fetch(want_v=True, want_H=False)
-                for k in ('v', 'n_iter', 'converged', 'n_evals'):
+            offs = np.concatenate([[0], np.cumsum(counts)]).astype(int)
+
+            def rest(r):
+                outs[r] = self._unpack_compact(recv[offs[r]:offs[r] + counts[r]], len(per_rank[r]), n_alpha, eta)
+                extra = self.ctxs[r].fetch(want_v=False, want_H=False)
+                for k in ('n_iter', 'converged', 'n_evals'):
                     outs[r][k] = extra[k]
-        else:
-            for r in active:
-                outs[r] = self.ctxs[r].fetch(want_v=True, want_H=False)
+            self._on_devices(rest, list(range(N)))
         logdets = {r: self.ctxs[r].logdet() for r in active} if want_logdet else {}
         maps = {r: self.ctxs[r].apply_output_map(output_map) for r in active} if output_map is not None else {}
         ms = [self.ctxs[r].last_kernel_ms() for r in active]
@@ -184,31 +220,60 @@ class BatchSolver(object):
             r, c = int(rank_of[i]), int(local_of[i])
             o = outs[r]
             H = LazyH(self, r, c, n_alpha, self.n_omega)
+            v = LazyV(self, r, c, n_alpha, self.n_s)
             self._pending.append(weakref.ref(H))
+            self._pending.append(weakref.ref(v))
             d = dict(alpha=np.asarray(s['alpha'], dtype=float), H=H,
                      A=(maps[r][c] if r in maps else None),
-                     v=o['v'][c], chi2=o['chi2'][c], S=o['S'][c], Q=o['Q'][c],
+                     v=v, chi2=o['chi2'][c], S=o['S'][c], Q=o['Q'][c],
                      n_iter=o['n_iter'][c], converged=o['converged'][c].astype(bool), n_evals=o['n_evals'][c])
             if 'linefit_index' in o:
                 d['device_linefit_index'] = int(o['linefit_index'][c])
                 d['device_linefit_H'] = o['linefit_H'][c]
+            if picks[r] is not None:
+                d['device_select'] = dict(params=(int(select[0]), float(select[1])), index=picks[r][0][:, c], H=picks[r][1][:, c])
+                if 'device_linefit_index' not in d:
+                    d['device_linefit_index'], d['device_linefit_H'] = int(picks[r][0][0, c]), picks[r][1][0, c]
             if r in logdets:
                 d['logdet'] = logdets[r][c]
             res.append(d)
         if want_H is True:
             self.materialize_pending()
         elif want_H is False:
-            self._pending = []
+            self._pending = [ref for ref in self._pending if isinstance(ref(), LazyV)]
             for d in res:
                 d['H'] = None
         return res, info
 
     def _stage(self, ctx, K, specs, opts):
+        """data sets, elements and chains of one device.  What is staged is remembered (contents, not identities): the
+        same job again -- the same object run twice, a parameter of the analyzers changed -- uploads nothing"""
+        n_tau = len(specs[0]['G'])
+        errs = np.stack([np.asarray(s['err'], dtype=float) * np.ones(len(s['G'])) for s in specs]) \
+            if all(len(s['G']) == n_tau for s in specs) else None
+        staged = dict(
+            G=np.stack([np.asarray(s['G'], dtype=float) for s in specs]) if errs is not None else None,
+            err=errs,
+            D=np.stack([np.asarray(s['D'], dtype=float) for s in specs]),
+            alpha=np.stack([np.asarray(s['alpha'], dtype=float) for s in specs]),
+            v0=np.stack([np.asarray(s['v0'], dtype=float) for s in specs]),
+            kinds=np.array([s['kind'] for s in specs]),
+            U_rot=[s.get('U_rot') for s in specs],
+            opts=(bytes(opts) if opts is not None else b''), rotated=K.rotation is not None)
+        held = self.__dict__.setdefault('_staged', {})
+        old = held.get(id(ctx))
+        if old is not None and errs is not None and old['G'] is not None and ctx._n_chain == len(specs) and \
+                old['opts'] == staged['opts'] and old['rotated'] == staged['rotated'] and \
+                len(old['U_rot']) == len(staged['U_rot']) and all(a is b for a, b in zip(old['U_rot'], staged['U_rot'])) and \
+                all(old[k].shape == staged[k].shape and np.array_equal(old[k], staged[k])
+                    for k in ('G', 'err', 'D', 'alpha', 'v0', 'kinds')):
+            return
+        held.pop(id(ctx), None)
         ctx.clear_datasets()
         ds_ids, seen = [], []
         self.__dict__.setdefault('_n_datasets', {})
-        for s in specs:
-            err = np.asarray(s['err'], dtype=float) * np.ones(len(s['G']))
+        for n, s in enumerate(specs):
+            err = errs[n] if errs is not None else np.asarray(s['err'], dtype=float) * np.ones(len(s['G']))
             U_rot = s.get('U_rot')
             found = None
             for (e0, u0, i0) in seen:
@@ -220,17 +285,29 @@ class BatchSolver(object):
                 seen.append((err, U_rot, found))
             ds_ids.append(found)
         self._n_datasets[id(ctx)] = len(seen)
-        ctx.set_elements(ds_ids, [s['G'] for s in specs],
-                         np.stack([np.asarray(s['D'], dtype=float) for s in specs]),
-                         [s['kind'] for s in specs])
-        ctx.upload_chains(np.arange(len(specs), dtype=np.int32),
-                          np.stack([np.asarray(s['alpha'], dtype=float) for s in specs]),
-                          np.stack([np.asarray(s['v0'], dtype=float) for s in specs]), opts)
+        ctx.set_elements(ds_ids, [s['G'] for s in specs], staged['D'], [s['kind'] for s in specs])
+        ctx.upload_chains(np.arange(len(specs), dtype=np.int32), staged['alpha'], staged['v0'], opts)
+        held[id(ctx)] = staged
 
-    def _unpack_compact(self, pack, n_chain, n_alpha):
+    def _on_devices(self, fn, ranks):
+        """fn(rank) for every rank: in this thread for one device, one thread per device otherwise"""
+        if len(ranks) <= 1:
+            for r in ranks:
+                fn(r)
+            return
+        pool = self.__dict__.get('_pool')
+        if pool is None or pool._max_workers < len(ranks):
+            from concurrent.futures import ThreadPoolExecutor
+            pool = self.__dict__['_pool'] = ThreadPoolExecutor(max_workers=len(self.ctxs))
+        for f in [pool.submit(fn, r) for r in ranks]:
+            f.result()                              # (re-raises what a worker raised)
+
+    def _unpack_compact(self, pack, n_chain, n_alpha, eta=1.0):
+        """the compact result pack of one rank (include/maxent_hip.h: MXE_GATHER_COMPACT).  The kernel iterates on
+        alpha / eta and stores Q / eta (eta = chi2_factor); mxe_chains_fetch scales Q on the host, and so does this"""
         P, nw = n_chain * n_alpha, self.n_omega
         out = dict(chi2=pack[:P].reshape(n_chain, n_alpha), S=pack[P:2 * P].reshape(n_chain, n_alpha),
-                   Q=pack[2 * P:3 * P].reshape(n_chain, n_alpha))
+                   Q=(pack[2 * P:3 * P] * eta).reshape(n_chain, n_alpha))
         out['linefit_H'] = pack[3 * P:3 * P + n_chain * nw].reshape(n_chain, nw)
         out['linefit_index'] = pack[3 * P + n_chain * nw:].astype(np.int32)
         return out
@@ -250,9 +327,9 @@ class BatchSolver(object):
         alive = self._alive()
         mine = [h for h in alive if h._rank == rank]
         if mine:
-            H = self.ctxs[rank].fetch(want_v=False, want_H=True)['H']
+            got = self.ctxs[rank].fetch(want_v=any(h._what == 'v' for h in mine), want_H=any(h._what == 'H' for h in mine))
             for h in mine:
-                h._val = H[h._chain]
+                h._val = got[h._what][h._chain]
         self._pending = [weakref.ref(h) for h in alive if h._val is None]
 
     def materialize_pending(self):

@@ -19,6 +19,7 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <mutex>
 
 using mxe::KParams;
 
@@ -47,16 +48,60 @@ static hipError_t stream_wait(hipStream_t s)
     }
 }
 
+// Device allocations are kept when a context lets go of them and handed to the next one that asks (per device, best
+// fit): a fresh TauMaxEnt / ElementwiseMaxEnt object -- a new kernel, so a new context with its 100+ MB of result
+// buffers -- otherwise pays hipMalloc + hipFree of that size, 50-150 ms per object on the MI355X boxes against 25 ms for
+// everything else it does.  At most 4 GiB and 512 blocks are kept; what comes out of the pool is NOT zeroed (nothing
+// here relies on zeroed memory: hipMalloc does not promise it either).
+struct DevPool {
+    struct Block { void* p; size_t bytes; int device; };
+    std::mutex mu;
+    std::vector<Block> blocks;
+    size_t held = 0;
+    static constexpr size_t MAX_HELD = (size_t)4 << 30, MAX_BLOCKS = 512;
+    void* take(size_t bytes, size_t* got) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+        std::lock_guard<std::mutex> lk(mu);
+        int best = -1;
+        for (size_t i = 0; i < blocks.size(); ++i)
+            if (blocks[i].device == dev && blocks[i].bytes >= bytes && blocks[i].bytes <= 2 * bytes + 65536 &&
+                (best < 0 || blocks[i].bytes < blocks[best].bytes)) best = (int)i;
+        if (best < 0) return nullptr;
+        void* p = blocks[best].p; *got = blocks[best].bytes;
+        held -= blocks[best].bytes;
+        blocks.erase(blocks.begin() + best);
+        return p;
+    }
+    bool give(void* p, size_t bytes) {
+        int dev = 0;
+        if (getenv("MXE_NO_POOL") || hipGetDevice(&dev) != hipSuccess) return false;
+        std::lock_guard<std::mutex> lk(mu);
+        if (held + bytes > MAX_HELD || blocks.size() >= MAX_BLOCKS) return false;
+        blocks.push_back(Block{p, bytes, dev});
+        held += bytes;
+        return true;
+    }
+};
+DevPool g_pool;
+
 template <typename T> struct DevBuf {
     T* p = nullptr; size_t n = 0;
+    size_t bytes = 0;                            // of the allocation (>= n * sizeof(T) when it came from the pool)
     hipError_t ensure(size_t count) {
         if (count <= n && p) return hipSuccess;
-        if (p) { hipFree(p); p = nullptr; n = 0; }
-        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
-        if (e == hipSuccess) n = count;
+        const size_t need = std::max<size_t>(count, 1) * sizeof(T);
+        if (p && need <= bytes) { n = count; return hipSuccess; }
+        if (p) { hipDeviceSynchronize(); release(); }      // (growing: whoever still reads the old block finishes first, as hipFree made sure)
+        size_t got = 0;
+        void* q = g_pool.take(need, &got);
+        if (q) { p = (T*)q; bytes = got; n = count; return hipSuccess; }
+        hipError_t e = hipMalloc((void**)&p, need);
+        if (e == hipSuccess) { n = count; bytes = need; }
         return e;
     }
-    void release() { if (p) hipFree(p); p = nullptr; n = 0; }
+    // (callers make sure nothing in flight uses the block: mxe_ctx_destroy waits for its stream first)
+    void release() { if (p && !g_pool.give(p, bytes)) hipFree(p); p = nullptr; n = 0; bytes = 0; }
 };
 
 } // namespace
@@ -87,6 +132,8 @@ struct mxe_ctx {
     std::string last_kernel;
     // device
     DevBuf<float> dVf, dVtf;          // binary32 copies of dV / dVt (mxe_opts.precision = F32)
+    DevBuf<double> dsel3;                        // mxe_select3_launch: [3][n_chain] indices | [3][n_chain][n_omega] rows
+    std::vector<double> h_sel3;
     DevBuf<double> dV, dVx, dVt, dc, dcinv, dghat, dcperp, dD, dsumD, dalpha, dv0;
     DevBuf<int> delem_ds, delem_kind, dchain_elem, dsub_prob0, dsub_len, dsub_v0, dwg_chains;
     // H, chi2, S, Q live back to back in ONE allocation (dout_pack) so that a
@@ -317,6 +364,11 @@ extern "C" {
 
 const char* mxe_version(void) { return "maxent_hip 0.1 (gfx950)"; }
 
+#ifndef MXE_SRC_HASH
+#define MXE_SRC_HASH "unknown"
+#endif
+const char* mxe_source_hash(void) { return MXE_SRC_HASH; }
+
 const char* mxe_strerror(int code)
 {
     switch (code) {
@@ -389,7 +441,10 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);      // (the blocks go back to the pool: nothing in flight may use them)
     comm_release(ctx);
+    ctx->dVx.release(); ctx->dsel3.release(); ctx->dgstate.release(); ctx->dfin_elem.release(); ctx->dfin_prob0.release();
+    ctx->dfin_len.release(); ctx->dfin_v0.release(); ctx->dfin_start.release();
     ctx->dlogdet.release(); ctx->dparent_elem.release(); ctx->dV.release(); ctx->dVt.release(); ctx->dVf.release(); ctx->dVtf.release(); ctx->dc.release(); ctx->dcinv.release();
     ctx->dghat.release(); ctx->dcperp.release(); ctx->dD.release(); ctx->dsumD.release();
     ctx->dalpha.release(); ctx->dv0.release(); ctx->delem_ds.release(); ctx->delem_kind.release();
@@ -1586,6 +1641,42 @@ try {
 }
 MXE_CATCH_ALL
 
+// The three default analyzers of the reference in one small launch: the line fit as above (its row and index also land in
+// the compact pack), the alpha of the largest curvature of log10 chi2 over gamma log10 alpha, the alpha of the flattest
+// entropy -- indices and the three H rows per scan in a buffer of their own, fetched with ONE copy (mxe_select3_fetch).
+extern "C" int mxe_select3_launch(mxe_ctx* ctx, int p2_deg, double gamma)
+try {
+    if (!ctx || (p2_deg != 0 && p2_deg != 1) || !(gamma > 0.0)) return MXE_ERR_ARG;
+    if (!ctx->launched) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)ctx->n_chain * ctx->n_alpha, nc = ctx->n_chain, nw = ctx->n_omega;
+    double* sel = ctx->dout_Q.p + P;
+    double* idx = sel + nc * nw;
+    HIPCHK(ctx, ctx->dsel3.ensure(3 * nc * (nw + 1)));
+    hipLaunchKernelGGL(mxe::linefit_kernel, dim3(ctx->n_chain), dim3(64), ((size_t)9 * ctx->n_alpha + 6) * sizeof(double), ctx->stream,
+                       ctx->dalpha.p, ctx->dout_chi2.p, ctx->dout_H.p, ctx->n_alpha, ctx->n_omega, p2_deg, sel, idx,
+                       ctx->dout_S.p, gamma, ctx->dsel3.p, ctx->dsel3.p + 3 * nc);
+    HIPCHK(ctx, hipGetLastError());
+    return MXE_OK;
+}
+MXE_CATCH_ALL
+
+extern "C" int mxe_select3_fetch(mxe_ctx* ctx, int32_t* out_index /*[3][n_chain]*/, double* out_H_selected /*[3][n_chain][n_omega]*/)
+try {
+    if (!ctx || !out_index) return MXE_ERR_ARG;
+    if (!ctx->launched || !ctx->dsel3.p) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t nc = ctx->n_chain, nw = ctx->n_omega;
+    const size_t n = out_H_selected ? 3 * nc * (nw + 1) : 3 * nc;
+    ctx->h_sel3.resize(n);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_sel3.data(), ctx->dsel3.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));
+    for (size_t i = 0; i < 3 * nc; ++i) out_index[i] = (int32_t)ctx->h_sel3[i];
+    if (out_H_selected) std::memcpy(out_H_selected, ctx->h_sel3.data() + 3 * nc, 3 * nc * nw * 8);
+    return MXE_OK;
+}
+MXE_CATCH_ALL
+
 extern "C" int mxe_select_fetch(mxe_ctx* ctx, int32_t* out_index, double* out_H_selected)
 try {
     if (!ctx) return MXE_ERR_ARG;
@@ -1675,6 +1766,7 @@ struct mxe_comm_state {
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
     bool copy_transport = false;                 // ranks of ONE process on one device: plain device copies
+    bool loopback = false;                       // mxe_comm_set_loopback: the root's own pack goes through ncclSend / ncclRecv to itself
     std::vector<mxe_ctx*> local;                 // ... the contexts of that process, by rank
     DevBuf<double> recv;                         // root: [sum of counts]
     DevBuf<double> small;                        // mxe_comm_allreduce
@@ -1740,6 +1832,17 @@ static void comm_release(mxe_ctx* ctx)
     ctx->comm = nullptr;
 }
 
+// Test plumbing for a box with ONE GPU: with it on, the root's own pack travels through ncclSend / ncclRecv to itself
+// (inside ncclGroupStart / ncclGroupEnd) instead of a device copy and mxe_comm_allreduce runs ncclAllReduce with the
+// one rank -- every RCCL call of the multi-GPU path executes.  Communicators of mxe_comm_init only.
+extern "C" int mxe_comm_set_loopback(mxe_ctx* ctx, int on)
+{
+    if (!ctx) return MXE_ERR_ARG;
+    if (!ctx->comm || !ctx->comm->comm || !ctx->comm->local.empty()) return MXE_ERR_STATE;
+    ctx->comm->loopback = on != 0;
+    return MXE_OK;
+}
+
 extern "C" int mxe_comm_destroy(mxe_ctx* ctx)
 {
     if (!ctx) return MXE_ERR_ARG;
@@ -1772,7 +1875,12 @@ static int gather_enqueue(mxe_ctx* ctx, int root, int what, const int64_t* count
         HIPCHK(ctx, cm->recv.ensure(total));
         size_t off = 0;
         for (int r = 0; r < cm->n_ranks; ++r) {
-            if (r == root) HIPCHK(ctx, hipMemcpyAsync(cm->recv.p + off, mine, n_mine * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            if (r == root && cm->loopback && !cm->copy_transport) {
+                // (send and receive of one rank to itself, matched inside the caller's group: the same calls a peer's pack takes)
+                NCCLCHK(ctx, g_rccl.Send(mine, n_mine, ncclDouble, root, cm->comm, ctx->stream));
+                NCCLCHK(ctx, g_rccl.Recv(cm->recv.p + off, n_mine, ncclDouble, root, cm->comm, ctx->stream));
+            }
+            else if (r == root) HIPCHK(ctx, hipMemcpyAsync(cm->recv.p + off, mine, n_mine * 8, hipMemcpyDeviceToDevice, ctx->stream));
             else if (!cm->copy_transport) NCCLCHK(ctx, g_rccl.Recv(cm->recv.p + off, (size_t)counts[r], ncclDouble, r, cm->comm, ctx->stream));
             off += (size_t)counts[r];
         }
@@ -1789,9 +1897,10 @@ try {
     mxe_comm_state* cm = ctx->comm;
     if (root < 0 || root >= cm->n_ranks) return MXE_ERR_ARG;
     if (!cm->local.empty()) return MXE_ERR_STATE;            // ranks of one process gather together: mxe_gather_local
-    if (cm->n_ranks > 1) NCCLCHK(ctx, g_rccl.GroupStart());
+    const bool grouped = cm->n_ranks > 1 || cm->loopback;
+    if (grouped) NCCLCHK(ctx, g_rccl.GroupStart());
     const int rc = gather_enqueue(ctx, root, what, counts);
-    if (cm->n_ranks > 1) NCCLCHK(ctx, g_rccl.GroupEnd());
+    if (grouped) NCCLCHK(ctx, g_rccl.GroupEnd());
     if (rc != MXE_OK) return rc;
     if (recv_host && cm->rank == root) {
         size_t total = 0;
@@ -1855,7 +1964,7 @@ try {
     if (!ctx || !inout_host || n < 1 || n > 64 || (op != 0 && op != 1)) return MXE_ERR_ARG;
     if (!ctx->comm) return MXE_ERR_STATE;
     mxe_comm_state* cm = ctx->comm;
-    if (cm->n_ranks == 1 || !cm->local.empty()) return MXE_OK;        // one process: nothing to agree on
+    if ((cm->n_ranks == 1 && !cm->loopback) || !cm->local.empty()) return MXE_OK;        // one process: nothing to agree on
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, cm->small.ensure(64));
     HIPCHK(ctx, hipMemcpyAsync(cm->small.p, inout_host, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));

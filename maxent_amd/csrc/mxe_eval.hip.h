@@ -387,7 +387,11 @@ __device__ inline LineSSE line_sse(const double* x, const double* y, int lo, int
 __global__ __launch_bounds__(64)
 void linefit_kernel(const double* __restrict__ alpha, const double* __restrict__ chi2, const double* __restrict__ H,
                     int n_alpha, int nw, int p2_deg, double* __restrict__ out_sel /*[n_chain][nw] or null*/,
-                    double* __restrict__ out_idx /*[n_chain], as doubles (they travel in the result pack)*/)
+                    double* __restrict__ out_idx /*[n_chain], as doubles (they travel in the result pack)*/,
+                    // the two other default analyzers of the reference, when out3_idx is given (mxe_select3_launch):
+                    const double* __restrict__ S = nullptr, double gamma = 0.2,
+                    double* __restrict__ out3_idx = nullptr /*[3][n_chain]: line fit, chi2 curvature, entropy*/,
+                    double* __restrict__ out3_sel = nullptr /*[3][n_chain][nw]: the H rows of the three*/)
 {
     // Break points are first ranked with running sums (O(n) for all of them; centred, like the host
     // analyzer's fit_piecewise), then only those within a whisker of the best are evaluated exactly with the
@@ -483,6 +487,46 @@ void linefit_kernel(const double* __restrict__ alpha, const double* __restrict__
     if (out_sel) {
         const double* row = H + (c * n + (idx >= 0 ? idx : 0)) * nw;
         for (int k = lane; k < nw; k += 64) out_sel[c * nw + k] = (idx >= 0) ? row[k] : __builtin_nan("");
+    }
+    if (!out3_idx) return;
+    // ---- Chi2CurvatureAnalyzer (reference analyzers/chi2_curvature_analyzer.py:25-49, 101-131): the alpha of the
+    //      largest curvature y'' / (1 + y'^2)^(3/2) of y = log10 chi2 over x = gamma log10 alpha, second-order
+    //      central differences on the (non-uniform) mesh, NaN ignored, the first of equal maxima.
+    // ---- EntropyAnalyzer (entropy_analyzer.py:72-103): the alpha where (dS / dlog alpha)^2 is smallest.
+    const size_t nc = gridDim.x;
+    wave_sync();
+    double* x10 = cs;                // (the line fit is done with its running sums)
+    double* y10 = cs + n;
+    for (int k = lane; k < n; k += 64) { x10[k] = gamma * log10(alpha[c * n + k]); y10[k] = log10(chi2[c * n + k]); }
+    wave_sync();
+    double cbest = -__builtin_inf(), ebest2 = __builtin_inf();
+    int ci = -1, ei = -1;
+    for (int k = 1 + lane; k < n - 1; k += 64) {
+        const double hp = x10[k + 1] - x10[k], hm = x10[k] - x10[k - 1];
+        const double der2 = (y10[k + 1] - 2 * y10[k] + y10[k - 1]) / (hp * hm);
+        const double der1 = ((y10[k + 1] - y10[k]) / hp + (y10[k] - y10[k - 1]) / hm) / 2;
+        const double q = 1 + der1 * der1;
+        const double cv = der2 / (q * sqrt(q));
+        if (cv == cv && (cv > cbest || ci < 0)) { cbest = cv; ci = k; }          // (ascending k per lane: the first maximum)
+        const double dS = (S[c * n + k + 1] - S[c * n + k - 1]) / (x[k + 1] - x[k - 1]);
+        const double d2 = dS * dS;
+        if (d2 == d2 && (d2 < ebest2 || ei < 0)) { ebest2 = d2; ei = k; }
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double oc = __shfl_xor(cbest, off); const int oi = __shfl_xor(ci, off);
+        if (oi >= 0 && (ci < 0 || oc > cbest || (oc == cbest && oi < ci))) { cbest = oc; ci = oi; }
+        const double oe = __shfl_xor(ebest2, off); const int oj = __shfl_xor(ei, off);
+        if (oj >= 0 && (ei < 0 || oe < ebest2 || (oe == ebest2 && oj < ei))) { ebest2 = oe; ei = oj; }
+    }
+    const int pick[3] = {idx, ci, ei};
+    if (lane < 3) out3_idx[lane * nc + c] = (double)(lane == 0 ? idx : lane == 1 ? ci : ei);
+    if (out3_sel) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double* row = H + (c * n + (pick[a] >= 0 ? pick[a] : 0)) * nw;
+            double* dst = out3_sel + ((size_t)a * nc + c) * nw;
+            for (int k = lane; k < nw; k += 64) dst[k] = (pick[a] >= 0) ? row[k] : __builtin_nan("");
+        }
     }
 }
 

@@ -55,6 +55,7 @@ _vp = ctypes.c_void_p
 # every symbol include/maxent_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ('mxe_version', ctypes.c_char_p, []),
+    ('mxe_source_hash', ctypes.c_char_p, []),
     ('mxe_strerror', ctypes.c_char_p, [ctypes.c_int]),
     ('mxe_device_count', ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     ('mxe_opts_default', None, [ctypes.POINTER(MxeOpts)]),
@@ -97,12 +98,15 @@ SYMBOLS = [
     ('mxe_audit', ctypes.c_int, [_vp, _dp, _dp]),
     ('mxe_select_launch', ctypes.c_int, [_vp, ctypes.c_int]),
     ('mxe_select_fetch', ctypes.c_int, [_vp, _ip, _dp]),
+    ('mxe_select3_launch', ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double]),
+    ('mxe_select3_fetch', ctypes.c_int, [_vp, _ip, _dp]),
     ('mxe_fetch_rows', ctypes.c_int, [_vp, ctypes.c_int, _ip, _dp]),
     ('mxe_shard_plan', ctypes.c_int, [ctypes.c_int, ctypes.c_int, _ip, _ip, _ip]),
     ('mxe_comm_unique_id', ctypes.c_int, [ctypes.c_char_p]),
     ('mxe_comm_init', ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
     ('mxe_comm_init_local', ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int]),
     ('mxe_comm_destroy', ctypes.c_int, [_vp]),
+    ('mxe_comm_set_loopback', ctypes.c_int, [_vp, ctypes.c_int]),
     ('mxe_gather', ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _lp, _dp]),
     ('mxe_gather_local', ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int, _lp, _dp]),
     ('mxe_comm_allreduce', ctypes.c_int, [_vp, _dp, ctypes.c_int, ctypes.c_int]),
@@ -180,6 +184,11 @@ def gather_local(contexts, root, counts, full=False, recv=None):
             msg += ': ' + lib.mxe_last_hip_error(contexts[root]._h).decode()
         raise MaxEntDeviceError('mxe_gather_local failed: ' + msg)
     return recv
+
+
+def source_hash():
+    """hash of the sources the loaded library was built from (mxe_source_hash)"""
+    return load_library().mxe_source_hash().decode()
 
 
 def device_count():
@@ -471,6 +480,17 @@ class DeviceContext(object):
         self._check(self._lib.mxe_select_fetch(self._h, _p(idx), _p(Hs)), 'mxe_select_fetch')
         return idx, Hs
 
+    def select3_launch(self, linefit_deg=0, gamma=0.2):
+        """line fit, chi2 curvature and entropy analyzers of every scan of the last launch, on the ctx stream"""
+        self._check(self._lib.mxe_select3_launch(self._h, int(linefit_deg), float(gamma)), 'mxe_select3_launch')
+
+    def select3_fetch(self, want_H=True):
+        """(indices [3][n_chain], rows [3][n_chain][n_omega]) of the three analyzers, one copy"""
+        idx = np.empty((3, self._n_chain), dtype=np.int32)
+        Hs = np.empty((3, self._n_chain, self.n_omega)) if want_H else None
+        self._check(self._lib.mxe_select3_fetch(self._h, _p(idx), _p(Hs)), 'mxe_select3_fetch')
+        return idx, Hs
+
     def fetch_rows(self, problem_index):
         pi = _c(np.atleast_1d(problem_index), np.int32)
         out = np.empty((len(pi), self.n_omega))
@@ -488,6 +508,10 @@ class DeviceContext(object):
     # -- ranks in separate processes -----------------------------------------
     def comm_init(self, n_ranks, rank, unique_id):
         self._check(self._lib.mxe_comm_init(self._h, int(n_ranks), int(rank), bytes(unique_id)), 'mxe_comm_init')
+
+    def comm_set_loopback(self, on=True):
+        """one-GPU test plumbing: the root's own pack through ncclSend / ncclRecv to itself, ncclAllReduce with one rank"""
+        self._check(self._lib.mxe_comm_set_loopback(self._h, 1 if on else 0), 'mxe_comm_set_loopback')
 
     def comm_destroy(self):
         self._check(self._lib.mxe_comm_destroy(self._h), 'mxe_comm_destroy')

@@ -24,7 +24,7 @@ import numpy as np
 
 from .default_models import DataDefaultModel
 from .logtaker import VerbosityFlags
-from .maxent_loop import solve_elements
+from .maxent_loop import solve_elements, select_params
 from .maxent_result import MaxEntResult
 from .tau_maxent import TauMaxEnt
 
@@ -205,7 +205,8 @@ class ElementwiseMaxEnt(object):
             sols, info = solve_elements(loop.K, specs, loop.minimizer,
                                         device_id=loop.device_id, device_ids=self.device_ids,
                                         want_logdet=loop.probability is not None,
-                                        chi2_factor=loop.cost_function.chi2_factor)
+                                        chi2_factor=loop.cost_function.chi2_factor,
+                                        select=select_params(loop.analyzers))
             t1 = datetime.now()
             self.last_launches.append(info)
             off = 0

@@ -13,6 +13,25 @@ import numpy as np
 from .preblur import get_preblur
 
 
+class _one_blas_thread(object):
+    """``threadpoolctl.threadpool_limits(1)`` where the package is there, nothing otherwise"""
+
+    def __enter__(self):
+        self._ctx = None
+        try:
+            from threadpoolctl import threadpool_limits
+            self._ctx = threadpool_limits(limits=1)
+            self._ctx.__enter__()
+        except Exception:
+            self._ctx = None
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
+
 class KernelSVD(object):
     """Matrix with a lazily computed thin SVD ``K = U diag(S) V^T``.
 
@@ -42,7 +61,12 @@ class KernelSVD(object):
             if self.svd_backend == 'device':
                 self._U, self._S, self._V = self._device_svd()
             elif self.svd_backend == 'host':
-                U, S, Vh = np.linalg.svd(self.K, full_matrices=False)
+                # (one BLAS thread: the decomposition of a few hundred rows is no faster on many -- 8 threads were
+                #  slower than 1 in BASELINE.md -- and a BLAS pool that spins up on every core of the host burns the
+                #  CPU quota of a container: the process then stalls for most of a scheduler period, 70 ms, at some
+                #  later point of the run)
+                with _one_blas_thread():
+                    U, S, Vh = np.linalg.svd(self.K, full_matrices=False)
                 self._U, self._S, self._V = U, S, Vh.transpose()
             else:
                 raise ValueError("svd_backend must be 'host' or 'device'")

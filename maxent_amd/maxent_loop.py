@@ -47,7 +47,7 @@ class _LazyProduct(object):
 
 
 def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0,
-                   want_logdet=False, chi2_factor=1.0, device_ids=None, want_H='lazy'):
+                   want_logdet=False, chi2_factor=1.0, device_ids=None, want_H='lazy', select=(0, 0.2)):
     """Solve the alpha scans of several elements in ONE kernel launch per device.
 
     ``K``: kernel whose singular space has been reduced (U, S, V are staged once per device and kept,
@@ -69,7 +69,22 @@ def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0,
     from .batch_solver import BatchSolver
     solver = BatchSolver.for_kernel(K, (device_id,) if device_ids is None else device_ids)
     opts = minimizer.to_opts(waves_per_chain=waves_per_chain, chi2_factor=float(chi2_factor))
-    return solver.solve(K, specs, opts, want_logdet=want_logdet, want_H=want_H)
+    return solver.solve(K, specs, opts, want_logdet=want_logdet, want_H=want_H, select=select)
+
+
+def select_params(analyzers):
+    """(linefit_deg, gamma) for ``mxe_select3_launch`` from a list of analyzers -- the device then picks the alphas of
+    the LineFit / Chi2Curvature / Entropy analyzers in the list behind the solve --, None when none of them is there"""
+    from .analyzers import LineFitAnalyzer, Chi2CurvatureAnalyzer, EntropyAnalyzer
+    deg, gamma, any_ = 0, 0.2, False
+    for a in analyzers or ():
+        if isinstance(a, LineFitAnalyzer):
+            deg, any_ = int(a.linefit_deg), True
+        elif isinstance(a, Chi2CurvatureAnalyzer):
+            gamma, any_ = float(a.gamma), True
+        elif isinstance(a, EntropyAnalyzer):
+            any_ = True
+    return (deg, gamma) if any_ and deg in (0, 1) and gamma > 0 else None
 
 
 def solve_single(cost_function, v0, minimizer, device_id=0):
@@ -83,7 +98,7 @@ def solve_single(cost_function, v0, minimizer, device_id=0):
                 D=cf.D.D, kind=cf.entropy_kind, v0=np.asarray(v0, dtype=float),
                 alpha=np.array([cf._alpha], dtype=float))
     res, _ = solve_elements(K, [spec], minimizer, device_id=device_id, chi2_factor=cf.chi2_factor,
-                            want_H=False)
+                            want_H=False, select=None)
     r = res[0]
     return r['v'][0], dict(n_iter=r['n_iter'][0], converged=r['converged'][0])
 
@@ -173,14 +188,14 @@ class MaxEntLoop(object):
         start = (self.D.D if self.A_init is None else
                  np.asarray(self.A_init)) * self.omega.delta
         start = np.array(start, dtype=float)
-        # the start vector depends on (V, D, start image, entropy kind) only: the element-wise drivers ask
-        # for it once per matrix element with the same objects (the cache holds them, so the identities
-        # it compares stay valid)
-        V, Dv, Ai = self.K.V, self.D.D, self.A_init
+        # the start vector depends on (V, start image, entropy kind, delta) only: the element-wise drivers ask
+        # for it once per matrix element with the same inputs
+        V = self.K.V
         held = self.__dict__.get('_v0_held')
-        if held is None or held[0] is not V or held[1] is not Dv or held[2] is not Ai or held[3] != self.H_of_v.kind \
-                or not np.array_equal(held[4], self.omega.delta):
-            held = self._v0_held = (V, Dv, Ai, self.H_of_v.kind, np.array(self.omega.delta), self.H_of_v.inv(start))
+        Dv = np.asarray(self.D.D, dtype=float)
+        if held is None or held[0] is not V or held[1] != self.H_of_v.kind or not np.array_equal(held[2], self.omega.delta) \
+                or not np.array_equal(held[3], start) or not np.array_equal(held[4], Dv):     # (contents: an in-place edit of D.D or A_init counts)
+            held = self._v0_held = (V, self.H_of_v.kind, np.array(self.omega.delta), start.copy(), Dv.copy(), self.H_of_v.inv(start))
         v0 = held[5].copy()
         scale = self._alpha_scale()
         K = self.K
@@ -326,7 +341,8 @@ class MaxEntLoop(object):
             sols, info = solve_elements(self.K, [spec], self.minimizer,
                                         want_logdet=self.probability is not None,
                                         device_id=self.device_id, device_ids=self.device_ids,
-                                        chi2_factor=self.cost_function.chi2_factor)
+                                        chi2_factor=self.cost_function.chi2_factor,
+                                        select=select_params(self.analyzers))
             sol = sols[0]
         else:
             sol, info = self.scan_with_user_minimizer(spec), dict(kernel_ms=0.0)

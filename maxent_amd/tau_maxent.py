@@ -120,13 +120,14 @@ class TauMaxEnt(object):
         ``set_cov`` that is not the new rotation alone; the element-wise drivers rely on reproducing it."""
         given = cov
         known = self.__dict__.get('_cov_eig')
-        if known is not None and known[0] is given and known[1] == self.cov_threshold:
+        if known is not None and known[0] is given and known[1] == self.cov_threshold and \
+                np.array_equal(known[2], np.asarray(given)):        # (the same object with the same CONTENT: an in-place edit recomputes)
             # the same matrix again (one covariance for all matrix elements of an element-wise job): its
             # eigenbasis, and the SAME rotation object -- the kernel then has nothing to do, and the batch
             # solver sees one data set instead of one per element
             cov, sigma, T = known[2:]
         else:
-            cov = np.asarray(cov)
+            cov = np.array(cov)                   # (a private copy: the cache compares against it)
             if np.max(np.abs(cov - cov.transpose())) >= 1.e-10:
                 raise AssertionError('Supplied covariance matrix is not symmetric.')
             var, vec = np.linalg.eigh(cov)

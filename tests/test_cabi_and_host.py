@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import maxent_amd as mx
-from maxent_amd import device
+from maxent_amd import device, synthetic
 from oracle import ref_numpy as R
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,7 +24,7 @@ def load(name):
 # ---- C-ABI ------------------------------------------------------------------
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, 'include', 'maxent_hip.h')).read()
-    declared = set(re.findall(r'\b(mxe_[a-z_]+)\s*\(', header))
+    declared = set(re.findall(r'\b(mxe_[a-z0-9_]+)\s*\(', header))
     declared -= {'mxe_ctx', 'mxe_opts'}
     lib = device.load_library()
     bound = {name for name, _, _ in device.SYMBOLS}
@@ -483,3 +483,59 @@ def test_the_reference_import_paths_exist():
     assert MaxDerivativeConvergenceMethod is mx.MaxDerivativeConvergenceMethod
     assert if_no_triqs() and not if_triqs_1() and not if_triqs_2()
     assert callable(fit_piecewise) and callable(curv) and callable(assert_text_files_equal)
+
+
+def test_bench_reads_counters_only_from_a_profile_of_the_same_build(tmp_path, monkeypatch):
+    """VERDICT r02 / ADVICE: roofline.achieved must not inherit counters of another build.  bench.load_pmc takes a
+    profiles/*_pmc_summary.csv only when its first line records the source hash of the library being benched."""
+    import bench
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    body = 'counter,dispatches,mean_per_dispatch,min,max\n' + ''.join(
+        '%s,10,%g,1,2\n' % (c, 100.0 + i) for i, c in enumerate(bench.PMC_NAMES.values()))
+    (prof / 'r01_x_pmc_summary.csv').write_text(body)                                  # no hash line: never applied
+    (prof / 'r03_a_pmc_summary.csv').write_text('#source_hash,0123456789abcdef\n' + body)
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    pmc, why = bench.load_pmc('0123456789abcdef')
+    assert why is None and pmc['source'].endswith('r03_a_pmc_summary.csv')
+    assert pmc['valu_active_quadcycles'] == 100.0 + list(bench.PMC_NAMES).index('valu_active_quadcycles')
+    pmc, why = bench.load_pmc('ffffffffffffffff')                                      # a kernel edit without re-profiling
+    assert pmc is None and 'ffffffffffffffff' in why and '0123456789abcdef' in why
+    (prof / 'r03_b_pmc_summary.csv').write_text('#source_hash,ffffffffffffffff\ncounter,dispatches,mean_per_dispatch,min,max\nFETCH_SIZE,1,2,2,2\n')
+    pmc, why = bench.load_pmc('ffffffffffffffff')
+    assert pmc is None and 'lacks the counters' in why
+
+
+def test_library_reports_the_hash_of_its_sources():
+    """mxe_source_hash: what the Makefile hashed when it built the binary (sources in the order of its HDR list)"""
+    import hashlib
+    csrc = os.path.join(ROOT, 'maxent_amd', 'csrc')
+    mk = open(os.path.join(csrc, 'Makefile')).read()
+    hdr = [ln for ln in mk.splitlines() if ln.startswith('HDR')][0].split(':=')[1].split()
+    data = b''.join(open(os.path.join(csrc, f), 'rb').read() for f in ['maxent_hip.hip'] + hdr)
+    assert device.source_hash() == hashlib.sha256(data).hexdigest()[:16]
+
+
+def test_set_cov_and_the_start_vector_see_in_place_edits():
+    """caches keyed on object identity alone kept stale values after ``cov *= 4`` / ``A_init[:] = ...``"""
+    tau, omega, K, G = synthetic.single_G(30, 40)
+    tm = mx.TauMaxEnt()
+    tm.set_verbosity(mx.VerbosityFlags.Quiet)
+    tm.omega = omega
+    tm.set_G_tau_data(tau, G)
+    rng = np.random.RandomState(3)
+    L = 1e-3 * (np.eye(30) + 0.1 * rng.randn(30, 30))
+    cov = L @ L.T
+    tm.set_cov(cov)
+    e1 = np.array(tm.err)
+    tm.set_cov(cov)
+    assert np.array_equal(tm.err, e1)
+    cov *= 4.0
+    tm.set_cov(cov)
+    assert np.allclose(tm.err, 2.0 * e1, rtol=1e-10)
+    tm.set_error(1e-3)
+    tm.A_init = np.array(tm.D.D) / omega.delta
+    v_a = tm.maxent_loop.make_spec()['v0'] if hasattr(tm, 'maxent_loop') else tm.make_spec()['v0']
+    tm.A_init[:] = tm.A_init * np.exp(-np.asarray(omega) ** 2 / 50.0)
+    v_b = tm.maxent_loop.make_spec()['v0'] if hasattr(tm, 'maxent_loop') else tm.make_spec()['v0']
+    assert np.max(np.abs(v_a - v_b)) > 1e-3

@@ -114,3 +114,182 @@ def test_process_ranks_comm_with_one_rank():
     assert np.array_equal(full[:6 * 80].reshape(6, 80), out['H'][0])
     ctx.comm_destroy()
     ctx.close()
+
+
+def test_the_rccl_calls_of_the_gather_execute_with_one_rank():
+    """no ncclSend / ncclRecv / ncclAllReduce had ever run.  With the loopback switch the ONE rank of
+    this box sends its pack to itself inside ncclGroupStart / ncclGroupEnd and all-reduces with itself: the gathered
+    pack must equal the source, compact and full, and the reductions must return their input."""
+    tau, omega, K, G = synthetic.single_G(40, 80)
+    K.reduce_singular_space(1e-14)
+    ctx = device.DeviceContext(K.U, K.S, K.V)
+    ds = ctx.add_dataset(synthetic.SIGMA * np.ones(40))
+    D = synthetic.flat_D(omega)
+    ctx.set_elements([ds, ds], [G, 0.5 * G], np.tile(D, (2, 1)), [device.ENTROPY_NORMAL, device.ENTROPY_NORMAL])
+    from maxent_amd import hostprep
+    alphas = np.array([100.0, 10.0, 1.0, 0.5, 0.2, 0.1]) * 40
+    v0 = hostprep.initial_v(K.V, D, omega.delta, device.ENTROPY_NORMAL)
+    ctx.upload_chains([0, 1], alphas, np.stack([v0, v0]))
+    with pytest.raises(device.MaxEntDeviceError):
+        ctx.comm_set_loopback(True)                 # no communicator yet
+    ctx.comm_init(1, 0, device.comm_unique_id())
+    ctx.comm_set_loopback(True)
+    ctx.launch()
+    ctx.select_launch(0)
+    out = ctx.fetch()
+    idx, Hs = ctx.select_fetch()
+    for rep in range(3):                            # (several gathers on one communicator, as bench.py enqueues them)
+        recv = np.full(ctx.compact_count(), np.nan)
+        ctx.gather(0, [ctx.compact_count()], recv=recv)
+        assert np.array_equal(recv[:12], out['chi2'].ravel()) and np.array_equal(recv[12:24], out['S'].ravel())
+        assert np.array_equal(recv[36:36 + 2 * 80].reshape(2, 80), Hs) and np.array_equal(recv[-2:], idx)
+    full = np.full(ctx.full_count(), np.nan)
+    ctx.gather(0, [ctx.full_count()], full=True, recv=full)
+    assert np.array_equal(full[:12 * 80].reshape(2, 6, 80), out['H'])
+    assert np.array_equal(full[12 * 80:], recv)
+    assert ctx.allreduce([3.0, -1.5], 'max').tolist() == [3.0, -1.5]
+    assert ctx.allreduce([3.0, -1.5], 'sum').tolist() == [3.0, -1.5]
+    ctx.comm_set_loopback(False)
+    again = np.empty(ctx.compact_count())
+    ctx.gather(0, [ctx.compact_count()], recv=again)
+    assert np.array_equal(again, recv)
+    ctx.comm_destroy()
+    ctx.close()
+
+
+def test_chi2_factor_reaches_the_gathered_Q():
+    """with several devices Q came from the raw pack, which holds Q / chi2_factor"""
+    def run(**kw):
+        ew = job(**kw)
+        for tm in (ew.maxent_diagonal, ew.maxent_offdiagonal):
+            tm.cost_function.chi2_factor = 2.5
+        return ew.run()
+    one, two = run(), run(device_ids=(0, 0))
+    for name in ('chi2', 'S', 'Q'):
+        a, b = np.asarray(getattr(one, name)), np.asarray(getattr(two, name))
+        assert np.max(np.abs(a - b)) <= 1e-7 * np.max(np.abs(a)), name
+    Q, al = np.asarray(two.Q), np.asarray(two.alpha)
+    assert np.allclose(Q, 0.5 * 2.5 * np.asarray(two.chi2) - np.broadcast_to(al, Q.shape) * np.asarray(two.S), rtol=1e-9)
+
+
+def test_devices_of_one_process_are_driven_from_threads():
+    """stage / launch / finish / fetch of the ranks ran one after the other on one Python thread.  Four
+    contexts on the one device: same results as one context, wall time of the solve below 1.3 x the single context's
+    plus what four times the staging costs on ONE device (on distinct devices the launches overlap as well)."""
+    import time
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(8, 200, 500)
+    K.reduce_singular_space(1e-14)
+    D = synthetic.flat_D(omega)
+    from maxent_amd import hostprep
+    alphas = np.array(mx.LogAlphaMesh(alpha_min=1e-2, alpha_max=1e4, n_points=100)) * 200
+    specs = []
+    for i in range(8):
+        for j in range(8):
+            kind = device.ENTROPY_NORMAL if i == j else device.ENTROPY_PLUSMINUS
+            specs.append(dict(G=Gmat[i, j], err=synthetic.SIGMA * np.ones(200), U_rot=None, D=D, kind=kind,
+                              v0=hostprep.initial_v(K.V, D, omega.delta, kind), alpha=alphas))
+    opts = mx.LevenbergMinimizer().to_opts()
+    solo, quad = BatchSolver(K, (0,)), BatchSolver(K, (0, 0, 0, 0))
+    walls = {}
+    for name, s in (('solo', solo), ('quad', quad)):
+        s.solve(K, specs, opts)
+        t = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            res, info = s.solve(K, specs, opts)
+            t.append(time.perf_counter() - t0)
+        walls[name] = (min(t), res)
+    for a, b in zip(walls['solo'][1], walls['quad'][1]):
+        assert np.max(np.abs(a['chi2'] - b['chi2'])) <= 1e-7 * np.max(np.abs(a['chi2']))
+        assert a['converged'].all() and b['converged'].all()
+    print('solve wall: one context %.2f ms, four contexts on threads %.2f ms' % (1e3 * walls['solo'][0], 1e3 * walls['quad'][0]))
+    assert walls['quad'][0] <= 1.3 * walls['solo'][0] + 2e-3
+    solo.close()
+    quad.close()
+
+
+GOLDEN = __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), 'golden')
+
+
+@pytest.mark.parametrize('name', ['cfg1_normal', 'cfg1_bryan', 'cfg1_plusminus', 'cfg1_tauerr', 'cfg2_normal', 'cfg5_preblur_pm',
+                                  'kat_tau_maxent', 'cov'])
+def test_device_analyzers_pick_the_alphas_the_host_analyzers_pick_on_the_reference_curves(name):
+    """mxe_select3_launch (line fit, chi2 curvature, entropy) on chi2 / S curves of the REFERENCE's own runs, written
+    into the result buffers of a launch of the same shape: the indices equal those of the host analyzers (which
+    equal the reference's: tests/test_cabi_and_host.py) on every golden that holds a whole scan."""
+    from maxent_amd.analyzers import fit_piecewise, curv
+    z = np.load(__import__('os').path.join(GOLDEN, name + '.npz'))
+    alpha, chi2, S = np.asarray(z['alpha'], float), np.asarray(z['chi2_ref'], float), np.asarray(z['S_ref'], float)
+    n = len(alpha)
+    rng = np.random.RandomState(5)
+    # three scans: the reference curve, one with a NaN in it, one perturbed
+    C = np.stack([chi2, chi2 * (1 + 0.05 * rng.rand(n)), chi2])
+    Sm = np.stack([S, S * (1 + 0.05 * rng.rand(n)), S])
+    C[2, n // 2] = np.nan
+    import ctypes
+    n_tau, n_w = 30, 40
+    tau, omega, K, G = synthetic.single_G(n_tau, n_w)
+    K.reduce_singular_space(1e-14)
+    ctx = device.DeviceContext(K.U, K.S, K.V)
+    ds = ctx.add_dataset(synthetic.SIGMA * np.ones(n_tau))
+    D = synthetic.flat_D(omega)
+    from maxent_amd import hostprep
+    ctx.set_elements([ds] * 3, [G] * 3, np.tile(D, (3, 1)), [device.ENTROPY_NORMAL] * 3)
+    v0 = hostprep.initial_v(K.V, D, omega.delta, device.ENTROPY_NORMAL)
+    ctx.upload_chains([0, 1, 2], alpha, np.tile(v0, (3, 1)))
+    ctx.launch()
+    ctx.sync()
+    # overwrite chi2 and S of the launch with the curves under test (device pointers of the result pack)
+    lib = device.load_library()
+    ptrs = [ctypes.c_void_p() for _ in range(7)]
+    assert lib.mxe_result_device_ptrs(ctx._h, *[ctypes.byref(p) for p in ptrs]) == 0
+    hip = ctypes.CDLL('libamdhip64.so')
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert hip.hipMemcpy(ptrs[1], C.ctypes.data_as(ctypes.c_void_p), C.nbytes, 1) == 0
+    assert hip.hipMemcpy(ptrs[2], Sm.ctypes.data_as(ctypes.c_void_p), Sm.nbytes, 1) == 0
+    out = ctx.fetch()
+    for deg, gamma in ((0, 0.2), (1, 0.35)):
+        ctx.select3_launch(deg, gamma)
+        idx, rows = ctx.select3_fetch()
+        for c in range(3):
+            with np.errstate(all='ignore'):
+                try:
+                    want_fit = fit_piecewise(np.log(alpha), np.log(C[c]), deg)[0]
+                except ValueError:
+                    want_fit = -1
+                cv = curv(gamma * np.log10(alpha), np.log10(C[c]))[0]
+                d = np.full(n, np.nan)
+                d[1:-1] = (Sm[c, 2:] - Sm[c, :-2]) / (np.log(alpha[2:]) - np.log(alpha[:-2]))
+            want_curv = -1 if np.all(np.isnan(cv)) else int(np.nanargmax(cv))
+            want_ent = -1 if np.all(np.isnan(d)) else int(np.nanargmin(d ** 2))
+            assert (idx[0, c], idx[1, c], idx[2, c]) == (want_fit, want_curv, want_ent), (name, c, deg)
+            for a in range(3):
+                if idx[a, c] >= 0:
+                    assert np.array_equal(rows[a, c], out['H'][c, idx[a, c]])
+    ctx.close()
+
+
+def test_elementwise_result_from_device_picks_equals_host_analyzers():
+    """ElementwiseMaxEnt with the alphas picked on the device: A_out and every analyzer's index / A_out equal what
+    the host analyzers give on the same solved scans, bit for bit; the lazy extras are there when asked for"""
+    ew = job(n_orb=3, n_alpha=20)
+    res = ew.run()
+    from maxent_amd.analyzers import LineFitAnalyzer, Chi2CurvatureAnalyzer, EntropyAnalyzer, _device_picks
+    keys = [(i, j) for i in range(3) for j in range(3)]
+    assert _device_picks(res, keys, 0, lambda p: True) is not None
+    for an in (LineFitAnalyzer(), Chi2CurvatureAnalyzer(), EntropyAnalyzer()):
+        for (i, j) in keys:
+            dev = res.analyzer_results[i][j][an.name]
+            host = an.analyze(res, (i, j))
+            assert dev['alpha_index'] == host['alpha_index']
+            assert np.array_equal(np.asarray(dev['A_out']), np.asarray(host['A_out']))
+            assert dev['info'] == host['info'] and set(dev.keys()) == set(host.keys())
+            for k in host.keys():
+                if k in ('curvature', 'dS_dalpha'):
+                    np.testing.assert_array_equal(np.asarray(dev[k]), np.asarray(host[k]))
+    # another gamma than the device used: the host analyzers take over
+    ew2 = job(n_orb=2, n_alpha=20)
+    ew2.maxent_diagonal.analyzers = [LineFitAnalyzer(), Chi2CurvatureAnalyzer(gamma=0.5)]
+    ew2.maxent_offdiagonal.analyzers = [LineFitAnalyzer(), Chi2CurvatureAnalyzer(gamma=0.5)]
+    r2 = ew2.run()
+    assert r2.analyzer_results[0][0]['Chi2CurvatureAnalyzer']['gamma'] == 0.5

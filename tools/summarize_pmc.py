@@ -11,6 +11,12 @@ for path in glob.glob(os.path.join(root, 'pmc_*', '**', '*counter_collection.csv
                 continue
             name, val = r['Counter_Name'], float(r['Counter_Value'])
             rows.setdefault(name, []).append(val)
+try:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from maxent_amd import device
+    print('#source_hash,%s' % device.source_hash())       # the build these counters belong to (bench.py checks it)
+except Exception as exc:
+    print('#source_hash,unknown (%r)' % (exc,))
 print('counter,dispatches,mean_per_dispatch,min,max')
 for name in sorted(rows):
     v = rows[name]
