@@ -300,6 +300,12 @@ class PreblurKernel(Kernel):
     def b(self):
         return self._b
 
+    @b.setter
+    def b(self, value):
+        # (reference test/python/cov.py:158-159 assigns ``K.b`` and calls ``parameter_change()``; in the reference the
+        #  assignment creates an attribute nobody reads and the refill blurs with the old width -- here it is the width)
+        self._b = value
+
     @property
     def B(self):
         return self._B

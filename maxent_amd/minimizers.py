@@ -17,6 +17,8 @@ Differences to the reference, by design (DESIGN.md "Minimiser"):
   reference.
 """
 
+import numpy as np
+
 from . import device
 
 
@@ -34,6 +36,11 @@ class ConvergenceMethod(object):
     def apply(self, opts):
         raise NotImplementedError
 
+    def __call__(self, function, v, **kwargs):
+        """(value, converged) for the host iteration of :meth:`LevenbergMinimizer.minimize` on a general function
+        (reference convergence_methods.py:24-34); ``Q0``, ``Q1``: the function value before and after the last step"""
+        raise NotImplementedError
+
 
 class _Pair(ConvergenceMethod):
     def __init__(self, one, two):
@@ -43,6 +50,12 @@ class _Pair(ConvergenceMethod):
     def apply(self, opts):
         self.one.apply(opts)
         self.two.apply(opts)
+
+    def __call__(self, function, v, **kwargs):
+        a, ok_a = self.one(function, v, **kwargs)
+        b, ok_b = self.two(function, v, **kwargs)
+        value = np.nan if (np.isnan(a) or np.isnan(b)) else min(a, b)
+        return value, (ok_a or ok_b)
 
 
 class AndConvergenceMethod(_Pair):
@@ -65,6 +78,10 @@ class MaxDerivativeConvergenceMethod(ConvergenceMethod):
     def apply(self, opts):
         opts.tol_d = float(self.convergence_criterion)
 
+    def __call__(self, function, v, **kwargs):
+        value = float(np.max(np.abs(function.d(v))))
+        return value, value < self.convergence_criterion
+
 
 class FunctionChangeConvergenceMethod(ConvergenceMethod):
     """|Q0 - Q1| < criterion (reference convergence_methods.py:99-109).  The device solver tests the RELATIVE
@@ -77,6 +94,10 @@ class FunctionChangeConvergenceMethod(ConvergenceMethod):
         raise NotImplementedError('the device solver stops on the relative change of Q: use '
                                   'RelativeFunctionChangeConvergenceMethod (or NewtonStepConvergenceMethod)')
 
+    def __call__(self, function, v, **kwargs):
+        value = abs(kwargs['Q0'] - kwargs['Q1'])
+        return value, value < self.convergence_criterion
+
 
 class RelativeFunctionChangeConvergenceMethod(ConvergenceMethod):
     """|Q0 - Q1| / |Q1| < criterion between two accepted iterates."""
@@ -86,6 +107,11 @@ class RelativeFunctionChangeConvergenceMethod(ConvergenceMethod):
 
     def apply(self, opts):
         opts.tol_relq = float(self.convergence_criterion)
+
+    def __call__(self, function, v, **kwargs):
+        with np.errstate(all='ignore'):
+            value = abs(abs(kwargs['Q0'] - kwargs['Q1']) / kwargs['Q1'])
+        return value, value < self.convergence_criterion
 
 
 class NewtonStepConvergenceMethod(ConvergenceMethod):
@@ -114,6 +140,9 @@ class NullConvergenceMethod(ConvergenceMethod):
     def apply(self, opts):
         opts.tol_h = 1e300
 
+    def __call__(self, function, v, **kwargs):
+        return 0, True
+
 
 class Minimizer(object):
     def minimize(self, function, v0):
@@ -130,10 +159,13 @@ class LevenbergMinimizer(Minimizer):
 
     ``J_squared`` and ``marquardt`` (levenberg_minimizer.py:177-185) choose the
     damping matrix of the reference's search (J^T J instead of J; diag J instead
-    of 1).  They change the iterates, not the point where dQ/dv = 0; the device
-    iteration damps in the entropy metric and raises mu only when Bryan's bound
-    or the descent test asks for it, so both flags are accepted and recorded
-    and the result is the same minimum.
+    of 1).  They change the iterates, not the point where dQ/dv = 0.  For a
+    general ``DoublyDerivableFunction`` -- anything but the MaxEnt cost function
+    -- ``minimize`` runs that search on the host and both flags do what they do
+    in the reference; for the MaxEnt cost function the device iteration damps in
+    the entropy metric and raises mu only when Bryan's bound or the descent test
+    asks for it: there both flags are accepted and recorded and the result is
+    the same minimum.
 
     ``verbose_callback`` (levenberg_minimizer.py:165-170) is called once per
     alpha, after the launch, with the record of the last iterate -- the
@@ -185,15 +217,90 @@ class LevenbergMinimizer(Minimizer):
         return o
 
     def minimize(self, function, v0):
-        """One alpha on the device: ``function`` is a bound cost function with
-        ``set_alpha`` called (reference minimizer.py:23-28)."""
+        """``function`` a MaxEnt cost function with ``set_alpha`` called: one alpha on the device (reference
+        minimizer.py:23-28).  Any other ``DoublyDerivableFunction`` -- ``function(v)`` pins an argument, ``f / d / dd``
+        (reference functions.py:96-146) --: the reference's damped Newton search on the host,
+        :meth:`_minimize_general`."""
         if not hasattr(function, 'entropy_kind') or getattr(function, '_alpha', None) is None:
-            raise TypeError('LevenbergMinimizer runs on the device and minimises MaxEnt cost functions '
-                            '(MaxEntCostFunction / BryanCostFunction with set_alpha called); a general '
-                            'DoublyDerivableFunction has no device form')
+            return self._minimize_general(function, v0)
         from .maxent_loop import solve_single
         v, info = solve_single(function, v0, self)
         self.n_iter_last = int(info['n_iter'])
         self.n_iter += self.n_iter_last
         self.converged = bool(info['converged'])
+        return v
+
+    def _general_convergence(self):
+        """the stopping rule of the host search: the caller's, or -- the device's default rule has no meaning for a
+        general function -- the reference's default (levenberg_minimizer.py:103-106)"""
+        if isinstance(self.convergence, NewtonStepConvergenceMethod):
+            return OrConvergenceMethod(MaxDerivativeConvergenceMethod(1.e-4),
+                                       RelativeFunctionChangeConvergenceMethod(1.e-16))
+        return self.convergence
+
+    def _minimize_general(self, function, v0):
+        """Levenberg-Marquardt search for a root of ``function.d`` (reference levenberg_minimizer.py:123-248), for
+        functions that are not the MaxEnt cost function -- the alpha scan never comes here, it runs in the chain kernel.
+
+        Every iteration solves ``(J + mu D) dv = g`` for the step, with ``g = d(v)``, ``J = dd(v)`` (``J_squared``: the
+        normal equations ``J^T J``, ``J^T g``; levenberg_minimizer.py:177-180) and ``D`` the identity or, with
+        ``marquardt``, the diagonal of ``J`` (:182-185), and searches the damping ``mu``:
+
+        1. ``mu`` grows by factors ``nu`` until the step does not increase the function (a NaN counts as an increase);
+        2. the neighbour ``nu mu`` is tried: the search then walks in the direction that lowers the function --
+           up while the neighbour is better, else down --, as long as it keeps falling and ``mu`` stays inside
+           ``(nu eps, max_mu)``; the last step before it rose again is taken.
+
+        ``mu`` carries over to the next iteration."""
+        if self.nu <= 1.0:
+            raise Exception('If nu <= 1, there will be an infinite loop.')
+        convergence = self._general_convergence()
+        nu, tiny = float(self.nu), float(self.nu) * np.finfo(float).eps
+        v = np.array(v0, dtype=float)
+        mu = float(self.mu0)
+        self.converged = False
+        here = function(v)
+        Q_now, Q_before = here.f(), np.nan
+        done = 0
+        for it in range(int(self.maxiter)):
+            done = it + 1
+            g, J = np.asarray(here.d(), dtype=float), np.atleast_2d(np.asarray(here.dd(), dtype=float))
+            status, self.converged = convergence(here, v, Q0=Q_before, Q1=Q_now)
+            if self.verbose_callback is not None:
+                self.verbose_callback('{:6d} Q: {:12.6e}, max_f: {:12.6e}, conv: {:12.6e}'.format(
+                    it + 1, Q_now, np.max(np.abs(g)), status))
+            if self.converged and it >= self.miniter:
+                break
+            if self.J_squared:
+                g, J = np.dot(J.T, g), np.dot(J.T, J)
+            D = np.diag(np.diag(J)) if self.marquardt else np.eye(len(J))
+
+            def trial(m):
+                with np.errstate(all='ignore'):
+                    try:
+                        step = np.linalg.solve(J + m * D, g)
+                        return step, function(v - step).f()
+                    except np.linalg.LinAlgError:
+                        return np.zeros_like(g), np.nan
+
+            Q_before = Q_now
+            step, Q = trial(mu)
+            while (Q > Q_before or np.isnan(Q)) and mu < self.max_mu:        # 1. a step that does not go uphill
+                mu *= nu
+                step, Q = trial(mu)
+            step_up, Q_up = trial(nu * mu)                                    # 2. which way does mu want to go?
+            if Q_up < Q:
+                factor, mu, best_step, best_Q, next_step, next_Q = nu, nu * mu, step, Q, step_up, Q_up
+            else:
+                factor, best_step, best_Q, next_step, next_Q = 1.0 / nu, step, np.inf, step, Q
+                mu *= nu                                                      # (the walk below starts by undoing this)
+            while next_Q < best_Q and tiny < mu < self.max_mu:
+                best_step, best_Q = next_step, next_Q
+                mu *= factor
+                next_step, next_Q = trial(mu)
+            v = v - best_step
+            here = function(v)
+            Q_now = here.f()
+        self.n_iter_last = done
+        self.n_iter += done
         return v

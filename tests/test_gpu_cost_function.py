@@ -295,3 +295,39 @@ def test_result_filled_alpha_by_alpha_has_the_reference_shapes():
     assert mr.A.shape == (2, 2, 1, 100) and mr.v.shape == (2, 2, 1, ns) and mr.omega.shape == (100,)
     assert mr.run_times.shape == (2, 2, 1) and mr.run_time_total.shape == (2, 2)
     assert mr.chi2[0, 1, 0] == mr.chi2[0, 0, 0] and mr.chi2[1, 0, 0] == mr.chi2[1, 1, 0]
+
+
+def test_pinned_cost_function_evaluates_once(case):
+    """reference test/python/maxent_cost_function_lazy.py:66-113 restated: the reference traces its Python calls and asserts
+    that a cost function pinned to v -- ``me1 = me(v)`` -- evaluates every component function ONCE however many of
+    ``d / dH / ddH / dd / f / chi2.f / H_of_v.f / A_of_H.f`` are asked for, while the same method called twice on the
+    unpinned object evaluates twice.  Here the evaluations are launches of the device evaluation kernel
+    (``DeviceContext.eval_batch``), counted."""
+    z, omega, K, D = case
+    v = z['v']
+    Q = make_Q(z, K, D)
+    calls = []
+    orig = device.DeviceContext.eval_batch
+
+    def counting(self, *a, **k):
+        calls.append(k.get('want', a[5] if len(a) > 5 else None))
+        return orig(self, *a, **k)
+    device.DeviceContext.eval_batch = counting
+    try:
+        Q.dH(v)
+        n_first = len(calls)
+        Q.dH(v)
+        assert n_first >= 1 and len(calls) == 2 * n_first        # unpinned: every call evaluates (first block of the reference test)
+        calls.clear()
+        me1 = Q(v)
+        n_pin = len(calls)
+        assert n_pin == 1                                        # pinning evaluates H (eagerly, like the reference)
+        for rep in range(2):
+            me1.d(); me1.dH(); me1.ddH(); me1.dd(); me1.f()
+            me1.chi2.f(); me1.H_of_v.f(); me1.A_of_H.f(); me1.S.f(); me1.S.d(); me1.H_of_v.d()
+            if rep == 0:
+                n_block = len(calls)
+        assert len(calls) == n_block                             # the second round of the block: nothing evaluated again
+        assert n_block <= 2                                      # one launch serves f, d, dH, ddH, dd and the components
+    finally:
+        device.DeviceContext.eval_batch = orig

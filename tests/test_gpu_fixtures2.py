@@ -139,3 +139,36 @@ def test_cfg5_full_size_fp32_against_fp64_and_the_reference_port():
     # the spectral function of the blurred element is B H
     B = runs['f64'][0].maxent_offdiagonal.A_of_H.matrix()
     np.testing.assert_allclose(r64.A[1, 5, 50], B @ r64.H[1, 5, 50], rtol=1e-12, atol=1e-14)
+
+
+def test_bryan_cost_function_run_with_an_error_per_tau():
+    """reference test/python/bryan_cost_function.py:32-58 restated: TauMaxEnt(cost_function='bryan') on the semicircular
+    G(tau) of the reference's test data with an error bar proportional to G (set through ``set_err``, the loop's
+    forwarded setter), five alphas from 0.01 to 2000.  The reference only runs it; here the scan is also compared with
+    the oracle port of the reference's Bryan iteration on the same input (its stopping slack) and every problem with
+    the device audit."""
+    from oracle import ref_numpy as R
+    z = np.load(os.path.join(GOLD, 'kat_tau_maxent.npz'))
+    table = z['G_clean_file']
+    tau, G = table[:, 0].copy(), table[:, 1].copy()
+    rng = np.random.RandomState(298347923 % (2 ** 31))
+    err = -1.e-3 * G
+    G = G + err * rng.randn(len(err))
+    tm = mx.TauMaxEnt(cost_function='bryan')
+    tm.set_verbosity(mx.VerbosityFlags.Quiet)
+    tm.set_G_tau_data(tau, G)
+    tm.set_err(err)
+    tm.alpha_mesh = mx.LogAlphaMesh(alpha_min=0.01, alpha_max=2000, n_points=5)
+    res = tm.run()
+    assert res.A.shape == (5, len(tm.omega)) and np.all(np.isfinite(res.A))
+    K = tm.K
+    p = R.Problem(np.array(K.K), K.U, K.S, K.V, G, err, np.array(tm.D.D), form='bryan')
+    ref = R.alpha_loop(p, tm.omega.delta, np.array(tm.alpha_mesh))
+    np.testing.assert_allclose(res.alpha, ref['alpha'], rtol=1e-13)
+    assert rel_l2(np.asarray(res.H), ref['H']).max() < 5e-5
+    np.testing.assert_allclose(res.chi2, ref['chi2'], rtol=1e-4)
+    # (the analyzers of a single scan run on the host: the same index as the oracle's curve gives)
+    from maxent_amd.analyzers import fit_piecewise
+    with np.errstate(all='ignore'):
+        assert res.analyzer_results['LineFitAnalyzer']['alpha_index'] == \
+            fit_piecewise(np.log(ref['alpha']), np.log(np.asarray(res.chi2)))[0]
