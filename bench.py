@@ -206,10 +206,21 @@ def parity_per_alpha():
 
     def rel(a, b):
         return [float(x) for x in np.linalg.norm(a - b, axis=1) / np.linalg.norm(b, axis=1)]
-    return dict(config='cfg2: n_tau=200 n_omega=500, 100 alpha, normal entropy; fixture rows (alpha index)',
-                alpha_index=[int(r) for r in rows], alpha_scaled=[float(a) for a in z['alpha'][rows]],
-                gpu_vs_ref=rel(H, z['H_ref']), ref_vs_truth=rel(z['H_ref'], z['H_truth']),
-                gpu_vs_truth=rel(H, z['H_truth']), gate_gpu_vs_truth=1e-6)
+    out = dict(config='cfg2: n_tau=200 n_omega=500, 100 alpha, normal entropy; fixture rows (alpha index)',
+               alpha_index=[int(r) for r in rows], alpha_scaled=[float(a) for a in z['alpha'][rows]],
+               gpu_vs_ref=rel(H, z['H_ref']), ref_vs_truth=rel(z['H_ref'], z['H_truth']),
+               gpu_vs_truth=rel(H, z['H_truth']), gate_gpu_vs_truth=1e-6)
+    tight = os.path.join(ROOT, 'tests', 'golden', 'tight_ref.npz')
+    if os.path.exists(tight):
+        # the reference itself under MaxDerivativeConvergenceMethod(1e-7) (tests/golden/make_golden.py: tight_case) and
+        # the reference's own binary64 Newton correction at its default result, its tight result and the truth
+        t = np.load(tight)
+        out.update(tight_ref_vs_truth=rel(t['cfg2_H_tight_ref'], t['cfg2_H_truth']), gpu_vs_tight_ref=rel(H, t['cfg2_H_tight_ref']),
+                   tight_ref_iterations=int(t['cfg2_n_iter_tight_ref'].sum()), tight_ref_converged=int(t['cfg2_converged_tight_ref'].sum()),
+                   reference_newton_correction=dict(at_H_ref=[float(x) for x in t['cfg2_ref_newton_corr'][0]],
+                                                    at_H_tight_ref=[float(x) for x in t['cfg2_ref_newton_corr'][1]],
+                                                    at_H_truth=[float(x) for x in t['cfg2_ref_newton_corr'][2]]))
+    return out
 
 
 def audit_block(ctx):

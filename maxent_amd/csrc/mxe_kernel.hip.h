@@ -95,6 +95,7 @@ struct KParams {
     // (21 bits), which stalls the iteration where the Newton matrix is very ill conditioned; mxe_chains_finish hands
     // those alphas to the one-chain kernel (binary64 Gram matrix)
     int mc_maxiter;
+    int mc_abandon;      // lock-step kernel: an alpha it gives up on ends its piece (the rest is left to mxe_chains_finish)
 };
 
 #if defined(MXE_PROFILE) && defined(MXE_PROFILE_EVAL)

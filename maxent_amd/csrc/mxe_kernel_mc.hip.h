@@ -961,6 +961,16 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         ecor[q * NP + k] = e; eacc[q * NP + k] = 0.0;
                     }
                     ++t.ia;
+                    if (!conv && p.mc_abandon) {
+                        // An alpha this layout gave up on: the rest of the piece would start from a point that is not a
+                        // solution and go the same way.  Its alphas are marked open -- mxe_chains_finish solves every run of
+                        // open alphas as one warm-started chain from the converged alpha before it -- and the slot moves on
+                        for (int i = max(t.ia, 0) + lane; i < t.clen; i += 64) {
+                            const size_t pr = (size_t)t.prob0 + i;
+                            p.out_conv[pr] = 0; p.out_niter[pr] = 0; p.out_nevals[pr] = 0; p.out_nact[pr] = 0;
+                        }
+                        t.ia = t.clen;
+                    }
                     t.niter = 0; t.nevals = 0; t.mu = 0.0; t.bt = 0; t.capp = 0; t.pred = 0.0; t.wide = 0;
                     t.Qprev = __builtin_nan("");
                     if (t.ia >= t.clen) {
