@@ -301,6 +301,42 @@ def _element(maxent_result, name, matrix_element):
     return maxent_result.element_array(name, matrix_element)
 
 
+class Picks(object):
+    """the alphas one analyzer takes for the elements ``keys`` of a batch, as the device chose them: indices and A rows.
+    ``build(n)`` makes the :class:`AnalyzerResult` of element n; :class:`maxent_result.MaxEntResult` keeps the batch
+    and builds single results when somebody looks at them (``result.A_out`` reads the rows directly)."""
+
+    def __init__(self, analyzer, maxent_result, keys, idx, rows, fixed, extras, info):
+        self.analyzer, self.keys, self.idx, self.rows = analyzer, keys, idx, rows
+        self.owner = weakref.ref(maxent_result)      # (the result owns its analyses: no strong reference back)
+        self.alpha = np.asarray(maxent_result.alpha)
+        self.fixed, self.extras, self.info = fixed, extras, info
+
+    def build(self, n):
+        res = AnalyzerResult()
+        i, k = self.idx[n], self.keys[n]
+        dict.update(res, alpha_index=i, A_out=self.rows[n], name=self.analyzer.name, **self.fixed)
+        for name, fn in self.extras.items():
+            res.later(name, lambda fn=fn, k=k: fn(self.owner(), k, self.alpha))
+        res.later('info', lambda: self.info.format(self.alpha[i], i))
+        res.maxent_result = self.owner()
+        return res
+
+
+class Deferred(object):
+    """element n of a :class:`Picks` batch, not yet an AnalyzerResult"""
+    __slots__ = ('picks', 'n')
+
+    def __init__(self, picks, n):
+        self.picks, self.n = picks, n
+
+    def build(self):
+        return self.picks.build(self.n)
+
+    def A_out(self):
+        return self.picks.rows[self.n]
+
+
 def _device_picks(maxent_result, keys, which, matches):
     """What the device chose for these elements (``mxe_select3_launch``, one launch behind the solve; the indices and
     the three H rows of every scan came back in one copy): (indices, A rows), or None when any element has no such
@@ -344,6 +380,15 @@ class LineFitAnalyzer(Analyzer):
                                         self.linefit_deg)
         return self._result(maxent_result, matrix_element, alpha, idx, params)
 
+    def pick_many(self, maxent_result, keys):
+        """the device's line fit for these elements (the same two-stage fit: linefit_kernel), or None; the parameters
+        of the two lines, which nothing but a plot reads, are fitted when somebody asks for them"""
+        dev = _device_picks(maxent_result, keys, 0, lambda p: p[0] == self.linefit_deg)
+        if dev is None:
+            return None
+        return Picks(self, maxent_result, keys, dev[0], dev[1], dict(linefit_deg=self.linefit_deg),
+                     dict(linefit_params=self._params), 'Ideal alpha (linefit): {} (= index {} zero-based)')
+
     def _params(self, maxent_result, matrix_element, alpha):
         chi2 = np.asarray(_element(maxent_result, 'chi2', matrix_element), dtype=float)
         with np.errstate(all='ignore'):
@@ -363,19 +408,9 @@ class LineFitAnalyzer(Analyzer):
     def analyze_many(self, maxent_result, keys):
         """one result (or the error message) per key; all break points in one vectorised pass"""
         alpha = np.asarray(maxent_result.alpha)
-        dev = _device_picks(maxent_result, keys, 0, lambda p: p[0] == self.linefit_deg)
-        owner = weakref.ref(maxent_result)          # (the result owns its analyses: no strong reference back, see AnalyzerResult)
-        if dev is not None:
-            # the device made the same two-stage fit (linefit_kernel); the parameters of the two lines, which nothing
-            # but a plot reads, are fitted when somebody asks for them
-            out = []
-            for k, i, row in zip(keys, *dev):
-                res = AnalyzerResult()
-                dict.update(res, alpha_index=i, A_out=row, linefit_deg=self.linefit_deg, name=self.name)
-                res.later('linefit_params', lambda k=k: self._params(owner(), k, alpha))
-                res.later('info', lambda i=i: 'Ideal alpha (linefit): {} (= index {} zero-based)'.format(alpha[i], i))
-                out.append(res)
-            return out
+        picks = self.pick_many(maxent_result, keys)
+        if picks is not None:
+            return [picks.build(n) for n in range(len(keys))]
         chi2 = np.array([np.asarray(_element(maxent_result, 'chi2', k), dtype=float) for k in keys])
         with np.errstate(all='ignore'):
             idx, params = fit_piecewise_many(np.log(alpha), np.log(chi2), self.linefit_deg)
@@ -401,17 +436,9 @@ class Chi2CurvatureAnalyzer(Analyzer):
 
     def analyze_many(self, maxent_result, keys):
         alpha = np.asarray(maxent_result.alpha)
-        dev = _device_picks(maxent_result, keys, 1, lambda p: p[1] == self.gamma)
-        owner = weakref.ref(maxent_result)
-        if dev is not None:
-            out = []
-            for k, i, row in zip(keys, *dev):
-                res = AnalyzerResult()
-                dict.update(res, alpha_index=i, A_out=row, gamma=self.gamma, name=self.name)
-                res.later('curvature', lambda k=k: self._curve(owner(), k, alpha))
-                res.later('info', lambda i=i: 'Ideal alpha (curvature): {} (= index {} zero-based)'.format(alpha[i], i))
-                out.append(res)
-            return out
+        picks = self.pick_many(maxent_result, keys)
+        if picks is not None:
+            return [picks.build(n) for n in range(len(keys))]
         x = self.gamma * np.log10(alpha)
         out = []
         with np.errstate(all='ignore'):
@@ -431,6 +458,13 @@ class Chi2CurvatureAnalyzer(Analyzer):
             except ValueError as err:
                 out.append(str(err))
         return out
+
+    def pick_many(self, maxent_result, keys):
+        dev = _device_picks(maxent_result, keys, 1, lambda p: p[1] == self.gamma)
+        if dev is None:
+            return None
+        return Picks(self, maxent_result, keys, dev[0], dev[1], dict(gamma=self.gamma), dict(curvature=self._curve),
+                     'Ideal alpha (curvature): {} (= index {} zero-based)')
 
     def _curve(self, maxent_result, matrix_element, alpha):
         chi2 = np.asarray(_element(maxent_result, 'chi2', matrix_element), dtype=float)
@@ -465,17 +499,9 @@ class EntropyAnalyzer(Analyzer):
 
     def analyze_many(self, maxent_result, keys):
         alpha = np.asarray(maxent_result.alpha)
-        dev = _device_picks(maxent_result, keys, 2, lambda p: True)
-        owner = weakref.ref(maxent_result)
-        if dev is not None:
-            out = []
-            for k, i, row in zip(keys, *dev):
-                res = AnalyzerResult()
-                dict.update(res, alpha_index=i, A_out=row, name=self.name)
-                res.later('dS_dalpha', lambda k=k: self._slope(owner(), k, alpha))
-                res.later('info', lambda i=i: 'Ideal alpha (entropy): {} (= index {} zero-based)'.format(alpha[i], i))
-                out.append(res)
-            return out
+        picks = self.pick_many(maxent_result, keys)
+        if picks is not None:
+            return [picks.build(n) for n in range(len(keys))]
         S = np.array([np.asarray(_element(maxent_result, 'S', k), dtype=float) for k in keys])
         D = np.full(S.shape, np.nan)
         D[:, 1:-1] = (S[:, 2:] - S[:, :-2]) / (np.log(alpha[2:]) - np.log(alpha[:-2]))
@@ -490,6 +516,13 @@ class EntropyAnalyzer(Analyzer):
             except ValueError as err:
                 out.append(str(err))
         return out
+
+    def pick_many(self, maxent_result, keys):
+        dev = _device_picks(maxent_result, keys, 2, lambda p: True)
+        if dev is None:
+            return None
+        return Picks(self, maxent_result, keys, dev[0], dev[1], {}, dict(dS_dalpha=self._slope),
+                     'Ideal alpha (entropy): {} (= index {} zero-based)')
 
     def _slope(self, maxent_result, matrix_element, alpha):
         S = np.asarray(_element(maxent_result, 'S', matrix_element), dtype=float)

@@ -27,6 +27,7 @@ from itertools import product
 import numpy as np
 
 from .alpha_meshes import DataAlphaMesh
+from .analyzers import Deferred
 from .omega_meshes import DataOmegaMesh
 
 _ALL_FIELDS = ['alpha', 'v', 'chi2', 'S', 'A', 'Q', 'omega', 'probability',
@@ -237,6 +238,48 @@ class MaxEntResultData(object):
         return tuple(self._matrix_structure)
 
 
+class ElementAnalysis(OrderedDict):
+    """{analyzer name: AnalyzerResult} of one element.  An entry may still be a :class:`analyzers.Deferred` -- the
+    device picked the alpha, nobody has looked at the result object yet --: it is built when it is first read;
+    ``raw(name)`` reads without building (``MaxEntResult.A_out`` takes the A row straight from the batch)."""
+
+    def raw(self, name, default=None):
+        return OrderedDict.get(self, name, default)
+
+    def __getitem__(self, name):
+        val = OrderedDict.__getitem__(self, name)
+        if isinstance(val, Deferred):
+            val = val.build()
+            OrderedDict.__setitem__(self, name, val)
+        return val
+
+    def get(self, name, default=None):
+        return self[name] if OrderedDict.__contains__(self, name) else default
+
+    def settle(self):
+        for name in list(OrderedDict.keys(self)):
+            self[name]
+        return self
+
+    def values(self):
+        return OrderedDict.values(self.settle())
+
+    def items(self):
+        return OrderedDict.items(self.settle())
+
+    def copy(self):
+        return OrderedDict(OrderedDict.items(self.settle()))
+
+    def __eq__(self, other):
+        return OrderedDict.__eq__(self.settle(), other)
+
+    def __reduce__(self):
+        return (OrderedDict, (list(OrderedDict.items(self.settle())),))
+
+    def __repr__(self):
+        return OrderedDict.__repr__(self.settle())
+
+
 class MaxEntResult(MaxEntResultData):
     """live result that the solver fills element by element."""
 
@@ -361,6 +404,45 @@ class MaxEntResult(MaxEntResultData):
         deferred.append(ph)
         return ph
 
+    def get_A_out(self, analyzer=None):
+        if self.matrix_structure is None or not self.element_wise:
+            return self.get_default_analyzer(analyzer)['A_out']
+        if analyzer is None:
+            analyzer = self.default_analyzer_name
+        if analyzer is None:
+            analyzer = 'LineFitAnalyzer'
+
+        def chosen(elem):
+            """A_out of the analyzer for this element, None where it has none (the rows of a batch the device picked
+            are read as they are: no result object is built for this)"""
+            out = self._analysis.get(tuple(elem))
+            if out is None:
+                return None
+            val = out.raw(analyzer) if hasattr(out, 'raw') else out.get(analyzer)
+            if isinstance(val, Deferred):
+                return val.A_out()
+            return None if (val is None or isinstance(val, str)) else val['A_out']
+        n_omega = len(self.omega)
+        ems = self.effective_matrix_structure
+        A_out = np.full(tuple(ems) + (n_omega,), np.nan)
+        for elem in self.zero_elements:
+            A_out[elem] = 0.0
+        for elem in product(*map(range, ems)):
+            sign, row = 1.0, chosen(elem)
+            if row is None and self.use_hermiticity and tuple(elem) not in self._analysis:
+                t = list(elem)
+                t[0], t[1] = t[1], t[0]
+                if self.complex_elements and t[-1] == 1:
+                    sign = -1.0
+                row = chosen(t)
+            if row is not None:
+                A_out[elem] = sign * row
+        if self.complex_elements:
+            return A_out[..., 0, :] + 1.0j * A_out[..., 1, :]
+        return A_out
+
+    A_out = property(get_A_out)
+
     def analyze_batch(self, analyzers, keys):
         """:meth:`analyze` for many elements (``keys``: tuples as :meth:`_key` makes them); the rows of A
         the analyzers pick are fetched from the device in ONE go at the end"""
@@ -368,13 +450,21 @@ class MaxEntResult(MaxEntResultData):
         try:
             many = {}
             for analyzer in analyzers:
+                if len(keys) > 1 and hasattr(analyzer, 'pick_many'):
+                    picks = analyzer.pick_many(self, keys)        # the device chose: result objects when somebody looks
+                    if picks is not None:
+                        many[analyzer.name] = [Deferred(picks, n) for n in range(len(keys))]
+                        continue
                 if hasattr(analyzer, 'analyze_many') and len(keys) > 1:
                     many[analyzer.name] = analyzer.analyze_many(self, keys)
             for n, key in enumerate(keys):
-                out = OrderedDict()
+                out = ElementAnalysis()
                 for analyzer in analyzers:
                     try:
                         res = many[analyzer.name][n] if analyzer.name in many else analyzer.analyze(self, key)
+                        if isinstance(res, Deferred):
+                            OrderedDict.__setitem__(out, analyzer.name, res)
+                            continue
                         if isinstance(res, str):
                             out[analyzer.name] = res
                         else:
@@ -397,7 +487,7 @@ class MaxEntResult(MaxEntResultData):
             for ph, row in zip(pending, rows):
                 ph.value = ph.lazy.from_H_row(row) if hasattr(ph.lazy, 'from_H_row') else row
             for key in keys:
-                for res in self._analysis.get(key, {}).values():
+                for res in OrderedDict.values(self._analysis.get(key, {})):
                     if isinstance(res, dict):
                         for k, v in list(res.items()):
                             if isinstance(v, MaxEntResult._RowPlaceholder):
