@@ -29,6 +29,11 @@
  *      self.probability(Q_min)       maxent_loop.py:258-264 | mxe_logdet (the determinant of
  *        NormalLogProbability        probabilities.py:60-85 |   the posterior curvature)
  *   PreblurA_of_H.f  A = B H         functions.py:999-1001 | mxe_apply_output_map
+ *   result.analyze(analyzers): LineFitAnalyzer,            | mxe_select3_launch / mxe_select3_fetch
+ *     Chi2CurvatureAnalyzer, EntropyAnalyzer               |   (alpha_index and the H row of each,
+ *     maxent_result.py:793-822, analyzers/*.py             |    for every scan of the launch)
+ *   CostFunction.__call__ / .f / .d / .dd at a given v     | mxe_eval_batch, mxe_entropy, mxe_audit
+ *     cost_function.py:73-85, maxent_cost_function.py:68-165
  *   TauKernel / PreblurKernel fill + KernelSVD.svd         | mxe_kernel_svd (optional: the host
  *     kernels.py:53-122,244-271,384-393                    |   numpy path stays the default)
  *
