@@ -336,6 +336,10 @@ def comm_setup(ctx, rank, world):
     os.dup2(2, 1)
     try:
         ctx.comm_init(world, rank, uid)
+        if world == 1:
+            # --force-comm on a one-GPU box: the rank's own pack goes through ncclSend / ncclRecv to itself and the
+            # reductions through ncclAllReduce, so that the RCCL calls of the multi-GPU step execute (and are timed)
+            ctx.comm_set_loopback(True)
         ctx.allreduce([0.0])                   # everybody is in
     finally:
         sys.stdout.flush()
