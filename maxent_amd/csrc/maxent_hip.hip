@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <tuple>
 
 using mxe::KParams;
 
@@ -123,6 +124,8 @@ struct mxe_ctx {
     std::vector<int> chain_elem;      // per parent chain
     std::vector<int> sub_elem, sub_prob0, sub_len, sub_v0, wg_chains;   // per launched (sub-)chain
     int n_sub = 0, n_wg = 0, mc_na = 0, mc_wgpc = 1, wgpc_auto = 2, n_queue = 0, n_solo = 0;
+    bool mc_gst = false;              // lock-step layout with u, H, sw in device memory (frequency meshes beyond the LDS)
+    DevBuf<double> dgstate_mc;
     std::vector<int> queue;
     std::vector<int> sub_pre;                                           // leading alpha of a piece: entries before its first alpha (0: none)
     bool has_pre = false;
@@ -320,9 +323,10 @@ int upload_bases(mxe_ctx* ctx)
 }
 
 // dynamic LDS of chain_kernel_mc<NA, WGPC> in bytes (the carve at the top of the kernel)
-size_t mc_lds_bytes(int NA, int nwp, int wgpc, int nwv = 4)
+size_t mc_lds_bytes(int NA, int nwp, int wgpc, int nwv = 4, bool gst = false)
 {
     const int NT = NA / 16, NPAIR = NT * (NT + 1) / 2;
+    if (gst) nwp = 0;                        // (u, H, sw in device memory: MCExtra::gstate)
     const size_t doubles = 8 * 4 * 64 + 2 * 64 + 64 * 4 + (wgpc == 2 ? 1 : nwv) * 4 * 64 + nwv * 32 + 2 * 4 * 64 +   // vectors, c, 1/c, step, h, sums, solve scales
                            (wgpc == 2 ? (size_t)MXE_X_UL * 256 + (size_t)nwp * 4 : (size_t)2 * nwp * 4) +
                            (size_t)4 * NPAIR * 256;                                                  // u, H, Gram tiles
@@ -426,6 +430,7 @@ try {
     ctx->n_tau = n_tau; ctx->n_omega = n_omega; ctx->n_s = n_s;
     ctx->NP = (n_s <= 64) ? 64 : 128;
     ctx->nwp = ((n_omega + 127) / 128) * 128;   // the lock-step kernel's fused pass runs whole trips of 128 rows
+    if (ctx->nwp > 1536) ctx->nwp = ((n_omega + 255) / 256) * 256;     // (long meshes run its eight-wave build: trips of 256)
     if (U) ctx->U.assign(U, U + (size_t)n_tau * n_s);
     ctx->S.assign(S, S + n_s);
     ctx->V.assign(V, V + (size_t)n_omega * n_s);
@@ -443,7 +448,7 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);      // (the blocks go back to the pool: nothing in flight may use them)
     comm_release(ctx);
-    ctx->dVx.release(); ctx->dsel3.release(); ctx->dgstate.release(); ctx->dfin_elem.release(); ctx->dfin_prob0.release();
+    ctx->dVx.release(); ctx->dsel3.release(); ctx->dgstate.release(); ctx->dgstate_mc.release(); ctx->dfin_elem.release(); ctx->dfin_prob0.release();
     ctx->dfin_len.release(); ctx->dfin_v0.release(); ctx->dfin_start.release();
     ctx->dlogdet.release(); ctx->dparent_elem.release(); ctx->dV.release(); ctx->dVt.release(); ctx->dVf.release(); ctx->dVtf.release(); ctx->dc.release(); ctx->dcinv.release();
     ctx->dghat.release(); ctx->dcperp.release(); ctx->dD.release(); ctx->dsumD.release();
@@ -819,7 +824,12 @@ try {
         if (layout == 4) {
             ctx->mc_wgpc = (o.wg_per_cu != 1 && (o.wg_per_cu == 2 || ctx->wgpc_auto == 2) && ctx->mc_na == 32 && ctx->nwp <= 512 &&
                             mc_lds_bytes(32, ctx->nwp, 2) <= 80 * 1024 - 2048) ? 2 : 1;
-            if (mc_lds_bytes(ctx->mc_na, ctx->nwp, ctx->mc_wgpc) > 160 * 1024 - 6144) { layout = 1; ctx->mc_na = 0; }
+            ctx->mc_gst = false;
+            if (mc_lds_bytes(ctx->mc_na, ctx->nwp, ctx->mc_wgpc) > 160 * 1024 - 6144) {
+                // a frequency mesh whose state (u, H, sw of four slots: 80 B per omega) does not fit the LDS beside the
+                // rest: the state goes to device memory (chain_kernel_mc<.., GSTATE>, one workgroup per CU)
+                ctx->mc_wgpc = 1; ctx->mc_gst = true;
+            }
         }
     }
     if (layout != 4 && ctx->has_pre) {
@@ -912,7 +922,7 @@ try {
     HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_prob0.p, ctx->sub_prob0.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_len.p, ctx->sub_len.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_v0.p, ctx->sub_v0.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (ctx->has_pre)
+    if (ctx->has_pre || ctx->mc_gst)     // (the device-memory-state build is the LEAD build: it reads the array)
         HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_pre.p, ctx->sub_pre.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
     if (!ctx->wg_chains.empty())
         HIPCHK(ctx, hipMemcpyAsync(ctx->dwg_chains.p, ctx->wg_chains.data(), ctx->wg_chains.size() * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -940,7 +950,7 @@ static void fill_kparams(mxe_ctx* ctx, KParams& kp)
     kp.ghat = ctx->dghat.p; kp.cperp = ctx->dcperp.p; kp.D = ctx->dD.p; kp.sumD = ctx->dsumD.p;
     kp.chain_elem = ctx->dchain_elem.p; kp.alpha = ctx->dalpha.p; kp.v0 = ctx->dv0.p;
     kp.chain_prob0 = ctx->dsub_prob0.p; kp.chain_len = ctx->dsub_len.p; kp.chain_v0 = ctx->dsub_v0.p;
-    kp.chain_lead = (ctx->has_pre && ctx->mc_na > 0) ? ctx->dsub_pre.p : nullptr;
+    kp.chain_lead = ((ctx->has_pre || ctx->mc_gst) && ctx->mc_na > 0) ? ctx->dsub_pre.p : nullptr;
     kp.init_tab = (ctx->has_init && ctx->mc_na > 0) ? ctx->dinit_tab.p : nullptr;
     kp.chain_init = ctx->dsub_init.p;
     kp.n_chain = ctx->n_sub;
@@ -977,11 +987,18 @@ try {
         // CU, i.e. does not fill the GPU and is as long as its deepest chain of rounds; mxe_opts.waves_per_chain = 4 / 8
         // overrides (the passes of that build want n_omega_pad in units of 256)
         const int NA = ctx->mc_na, WGPC = ctx->mc_wgpc;
+        const bool GST = ctx->mc_gst;
         const int NWV = (WGPC == 1 && ctx->nwp % 256 == 0 && o.waves_per_chain != 4 &&
-                         mc_lds_bytes(NA, ctx->nwp, 1, 8) <= 160 * 1024 - 6144) ? 8 : 4;
-        const size_t lds = mc_lds_bytes(NA, ctx->nwp, WGPC, NWV);
+                         mc_lds_bytes(NA, ctx->nwp, 1, 8, GST) <= 160 * 1024 - 6144) ? 8 : 4;
+        const size_t lds = mc_lds_bytes(NA, ctx->nwp, WGPC, NWV, GST);
         if (lds > 160 * 1024 - 6144) return MXE_ERR_LIMIT;
         mxe::MCExtra ex; ex.wg_chains = ctx->dwg_chains.p; ex.n_wg = ctx->n_wg;
+        ex.gstate = nullptr; ex.gstate_stride = 0;
+        if (GST) {
+            ex.gstate_stride = mxe::mc_gstate_doubles(ctx->nwp);
+            HIPCHK(ctx, ctx->dgstate_mc.ensure((size_t)ctx->n_wg * ex.gstate_stride + 4096));
+            ex.gstate = ctx->dgstate_mc.p;
+        }
         ex.queue = ctx->dqueue.p; ex.n_queue = ctx->n_queue; ex.counter = ctx->dcounter.p;
         ex.stagger = 0;              // (a late start of the second half of the grid never paid: 0 ... 14 units measured; 5 cost 0.4 %)
         ex.n_solo = 0;
@@ -994,15 +1011,16 @@ try {
         ctx->last_nw = NWV; ctx->last_lds = (int)lds;
         const bool lead = kp.chain_lead != nullptr;
         ctx->last_kernel = "mxe::chain_kernel_mc<" + std::to_string(NA) + ", " + std::to_string(WGPC) + (lead ? ", lead" : "") +
-                           (NWV == 8 ? ", 8 waves>" : ">");
+                           (NWV == 8 ? ", 8 waves" : "") + (GST ? ", device-memory state>" : ">");
         HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-#define MXE_LAUNCH_MC(NA_, WG_, LD_, NWV_) do { \
-        e = hipFuncSetAttribute((const void*)mxe::chain_kernel_mc<NA_, WG_, LD_, NWV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+#define MXE_LAUNCH_MC(NA_, WG_, LD_, ...) do { constexpr int NWV_ = std::get<0>(std::make_tuple(__VA_ARGS__)); \
+        e = hipFuncSetAttribute((const void*)mxe::chain_kernel_mc<NA_, WG_, LD_, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e == hipSuccess && getenv("MXE_DEBUG_OCC")) { int nb__ = 0; \
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb__, (const void*)mxe::chain_kernel_mc<NA_, WG_, LD_, NWV_>, 64 * NWV_, lds); \
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb__, (const void*)mxe::chain_kernel_mc<NA_, WG_, LD_, __VA_ARGS__>, 64 * NWV_, lds); \
             fprintf(stderr, "[mxe] lock-step kernel NA=%d NWV=%d lds=%zu: %d workgroup(s) per CU resident\n", NA_, NWV_, (size_t)lds, nb__); } \
-        if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<NA_, WG_, LD_, NWV_>), dim3(ctx->n_wg), dim3(64 * NWV_), lds, ctx->stream, kp, ex); e = hipGetLastError(); } } while (0)
-        if (NA == 32 && WGPC == 2) { if (lead) MXE_LAUNCH_MC(32, 2, true, 4); else MXE_LAUNCH_MC(32, 2, false, 4); }
+        if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<NA_, WG_, LD_, __VA_ARGS__>), dim3(ctx->n_wg), dim3(64 * NWV_), lds, ctx->stream, kp, ex); e = hipGetLastError(); } } while (0)
+        if (GST) { if (NWV == 8) MXE_LAUNCH_MC(32, 1, true, 8, true); else MXE_LAUNCH_MC(32, 1, true, 4, true); }
+        else if (NA == 32 && WGPC == 2) { if (lead) MXE_LAUNCH_MC(32, 2, true, 4); else MXE_LAUNCH_MC(32, 2, false, 4); }
         else if (NWV == 8) { if (lead) MXE_LAUNCH_MC(32, 1, true, 8); else MXE_LAUNCH_MC(32, 1, false, 8); }
         else { if (lead) MXE_LAUNCH_MC(32, 1, true, 4); else MXE_LAUNCH_MC(32, 1, false, 4); }
 #undef MXE_LAUNCH_MC
@@ -1130,9 +1148,18 @@ try {
     kp.chain_lead = nullptr; kp.init_tab = nullptr; kp.chain_init = nullptr;
     kp.n_chain = nr;
     const int NW = 4;
-    const size_t lds = lds_bytes(NP, ctx->nwp, NW, false);
-    if (lds > 160 * 1024) return MXE_ERR_LIMIT;               // (the lock-step layout holds less than this one)
-    hipError_t e = launch_t<4, 2>(kp, lds, ctx->stream);
+    size_t lds = lds_bytes(NP, ctx->nwp, NW, false);
+    hipError_t e;
+    if (lds > 160 * 1024) {
+        // (a frequency mesh beyond the LDS -- the lock-step launch kept its state in device memory --: so does this one)
+        lds = lds_bytes(NP, ctx->nwp, NW, false, true);
+        if (lds > 160 * 1024) return MXE_ERR_LIMIT;
+        HIPCHK(ctx, ctx->dgstate.ensure((size_t)nr * 5 * ctx->nwp));
+        kp.gstate = ctx->dgstate.p;
+        e = launch_t<4, 2, double, true>(kp, lds, ctx->stream);
+    } else {
+        e = launch_t<4, 2>(kp, lds, ctx->stream);
+    }
     HIPCHK(ctx, e);
     HIPCHK(ctx, stream_wait(ctx->stream));
     // the counters of the records: both passes (whole arrays: one copy each way)

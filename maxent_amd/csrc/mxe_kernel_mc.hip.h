@@ -41,7 +41,13 @@ struct MCExtra {
     int n_solo;                   // WGPC = 2, dynamic layout, gridDim = 2 x CUs: workgroups b and b + gridDim / 2 share a CU
                                   //   (tools/wg_placement.hip); the first n_solo workgroups get their CU to themselves --
                                   //   their partners leave at once -- and the first pieces of the queue (the most expensive)
+    double* gstate;               // GSTATE builds: the omega-space state of the workgroups, gstate_stride doubles each
+    size_t gstate_stride;         //   (mc_gstate_doubles)
 };
+
+// omega-space state of one workgroup of a GSTATE build, in doubles: u [nwp][4] | H [nwp][4] + look-ahead | sw [nwp][4] floats + look-ahead
+constexpr int MC_GSTATE_PAD = 1024;
+inline size_t mc_gstate_doubles(int nwp) { return (size_t)nwp * 4 + ((size_t)nwp * 4 + MC_GSTATE_PAD) + ((size_t)nwp * 4 + MC_GSTATE_PAD) / 2; }
 
 // NA    capacity of the active block: 32 or 48
 // WGPC  workgroups per CU the kernel is built for:
@@ -91,13 +97,19 @@ constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
 //       helpers that take half of the rows of the two streaming passes.  Such a launch is as long as its deepest chain
 //       of rounds, and at one wave per SIMD the passes wait for L2 and for the wave's own issue rate (a v_fma_f64 every
 //       9 cycles from one wave, every 4.75 from two: tools/mfma_f64_rate.hip); a second wave per SIMD halves them.
-template <int NA, int WGPC, bool LEAD = false, int NWV = 4>
+// GSTATE  frequency meshes whose state does not fit the LDS (n_omega_pad > ~1500): u, H and sw of the four slots live in
+//       device memory (MCExtra::gstate, one slice per workgroup; the L2 holds them).  Their access pattern is the one the
+//       LDS arrays have -- [row][slot], 512 contiguous bytes per tile in the row pass, 128 per row group in the fused pass
+//       -- and adds ~190 B per omega row and round to the 1024 B of V and V^T.  Waves of a workgroup share the CU's
+//       L1, the workgroup barriers order the accesses (as in chain_kernel<.., GST>).
+template <int NA, int WGPC, bool LEAD = false, int NWV = 4, bool GSTATE = false>
 __global__ __launch_bounds__(64 * NWV, WGPC)
 void chain_kernel_mc(const KParams p, const MCExtra x)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int T = 64 * NWV;
     static_assert(WGPC == 1 || WGPC == 2, "one or two workgroups per CU");
+    static_assert(!GSTATE || WGPC == 1, "device-memory state: the one-workgroup-per-CU build");
     static_assert(NWV == 4 || (NWV == 8 && WGPC == 1), "helper waves only in the one-workgroup-per-CU build");
     constexpr bool UREG = (WGPC == 2);            // u in registers, h summed with atomics
     constexpr int NP = 64;
@@ -135,15 +147,16 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     double* red  = hpart + HPW * MCC * NP;       // [NWV waves][32]
     double* ssc  = red + NWV * 32;               // [MCC][NP]   binary32 solve: power-of-two scale of row / column k, ~ 1 / sqrt(c_k^2 wmax + alpha)
     double* csc  = ssc + MCC * NP;               // [MCC][NP]   ... times c_k
-    double* ui   = csc + MCC * NP;               // [nwp][MCC]   (WGPC = 1 only)
+    double* gs   = GSTATE ? x.gstate + (size_t)blockIdx.x * x.gstate_stride : nullptr;
+    double* ui   = GSTATE ? gs : csc + MCC * NP;  // [nwp][MCC]   (WGPC = 1 only)
     // (the look-ahead of the fused pass reads up to MC_LOOKAHEAD_LDS entries past the end of Hi and of swF:
     //  they land in swF and Wt, are never used, and need no padding)
     // WGPC = 2: u of a lane's eight (row, slot) elements: the first 8 - UL in registers, the last UL in LDS
     // ([UL][256], one 8-byte slot per thread: what the 80 KB of a half CU leave room for)
     constexpr int UL = UREG ? MXE_X_UL : 0;
     double* Hi   = ui + (UREG ? (size_t)UL * T : (size_t)nwp * MCC);  // [nwp][MCC]
-    float*  swF  = reinterpret_cast<float*>(Hi + (size_t)nwp * MCC);    // [nwp][MCC]
-    double* Wt   = reinterpret_cast<double*>(swF + (size_t)nwp * MCC);  // [MCC][NPAIR][4][64]
+    float*  swF  = reinterpret_cast<float*>(Hi + (size_t)nwp * MCC + (GSTATE ? MC_GSTATE_PAD : 0));    // [nwp][MCC]
+    double* Wt   = GSTATE ? csc + MCC * NP : reinterpret_cast<double*>(swF + (size_t)nwp * MCC);  // [MCC][NPAIR][4][64]
     static_assert(MCC * NPAIR * 256 * 2 >= MC_LOOKAHEAD_LDS, "the look-ahead stays inside the allocation");
     __shared__ int s_elem[MCC], s_kind[MCC], s_act[MCC], s_scr[MCC];
 

@@ -83,7 +83,12 @@ def test_frequency_mesh_beyond_the_lds(n_omega, precision):
     n = len(elems)
     ctx.set_elements([ds] * n, [Gmat[i, j] for i, j in elems], np.tile(D, (n, 1)), kinds)
     out = ctx.solve_chains(np.arange(n), alphas, v0, device.default_opts(precision=device.PRECISION_F64))
-    assert 'device-memory state' in ctx.last_launch_info()['kernel']
+    # (round 3: the lock-step layout itself keeps u, H, sw in device memory; until then the one-chain kernel took these)
+    assert ctx.last_launch_info()['kernel'].startswith('mxe::chain_kernel_mc<32, 1, lead') and \
+        'device-memory state' in ctx.last_launch_info()['kernel']
+    one = ctx.solve_chains(np.arange(n), alphas, v0, device.default_opts(chains_per_wg=1))
+    assert ctx.last_launch_info()['kernel'].startswith('mxe::chain_kernel<') and rel_l2(out['H'], one['H']).max() < 1e-7
+    out = ctx.solve_chains(np.arange(n), alphas, v0, device.default_opts(precision=device.PRECISION_F64))
     assert out['converged'].all() and np.all(np.isfinite(out['H']))
     assert ctx.audit()['corr'].max() < 1e-6
     if precision == device.PRECISION_F64:
