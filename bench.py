@@ -298,15 +298,15 @@ def scaling_projection(batch, opts, k_ms_full, n_alpha, n_launch=30):
     out['bound'] = dict(
         text='A shard that does not fill the GPU is as long as its deepest chain of Newton rounds, not as its work: the tail '
              'of a normal-entropy scan cannot be cold-started (the last 6 % of the alpha range take 50-390 evaluations from '
-             'the default model), so its pieces solve the last alpha above that range cold -- 17-18 rounds at the smallest '
-             'alphas: Newton moves u = log(H / D) by 1-2.5 per step where the spectrum has to vanish, and it has to fall by '
-             '~11 -- walk down the mesh at one round per alpha (up to 6) and take 3-4 rounds for their own alpha: 25-28 '
-             'rounds whatever N is.  A round of a workgroup that has its CU to itself takes ~42 k cycles (17.5 us): binary32 '
-             'Gauss-Jordan + step 14.7 k, accept 4 k, the two streaming passes 19 k of which 15 k are the 448 KB of V and '
-             'V^T at the ~30 B per cycle one CU gets out of its L2 (more waves do not change it: '
-             'profiles/r03_a_phases_wg1_8waves.txt, profiles/r03_a_l2_stream_rate.txt).',
-        rounds_deepest_chain=[25, 28], us_per_round_one_workgroup_per_cu=17.5, floor_ms=[0.44, 0.49],
-        speedup_ceiling_at_this_round_structure=k_ms_full / 0.44)
+             'the default model), so its pieces solve the last alpha above that range cold -- 14-16 rounds to the 2e-2 the walk '
+             'needs at the smallest alphas: Newton moves u = log(H / D) by 1-2.5 per step where the spectrum has to vanish, and '
+             'it has to fall by ~11 --, walk down the mesh at one round per alpha (up to 6) and take 3-4 rounds for their own '
+             'alpha: 23-27 rounds whatever N is.  A round of a workgroup that has its CU to itself takes ~39 k cycles (16.3 us, '
+             'eight waves): binary32 Gauss-Jordan + step 12.9 k on one wave per slot, accept 5 k, the two streaming passes 21 k of '
+             'which the 448 KB of V and V^T at the 32-64 B per cycle one CU gets out of its L2 are 7-15 k (more waves do not '
+             'change that: profiles/r03_a_phases_wg1_*waves.txt, profiles/r03_a_l2_stream_rate.txt).',
+        rounds_deepest_chain=[23, 27], us_per_round_one_workgroup_per_cu=16.3, floor_ms=[0.37, 0.44],
+        speedup_ceiling_at_this_round_structure=k_ms_full / 0.37)
     return out
 
 

@@ -31,7 +31,7 @@
  *   PreblurA_of_H.f  A = B H         functions.py:999-1001 | mxe_apply_output_map
  *   result.analyze(analyzers): LineFitAnalyzer,            | mxe_select3_launch / mxe_select3_fetch
  *     Chi2CurvatureAnalyzer, EntropyAnalyzer               |   (alpha_index and the H row of each,
- *     maxent_result.py:793-822, analyzers/*.py             |    for every scan of the launch)
+ *     maxent_result.py:793-822, analyzers/               |    for every scan of the launch)
  *   CostFunction.__call__ / .f / .d / .dd at a given v     | mxe_eval_batch, mxe_entropy, mxe_audit
  *     cost_function.py:73-85, maxent_cost_function.py:68-165
  *   TauKernel / PreblurKernel fill + KernelSVD.svd         | mxe_kernel_svd (optional: the host
@@ -134,7 +134,7 @@ typedef struct mxe_opts {
 
 /* ---- library / device ------------------------------------------------- */
 const char* mxe_version(void);
-/* first 16 hex digits of the SHA-256 over the library's sources (csrc/*.hip, csrc/*.hip.h, this header) as the Makefile
+/* first 16 hex digits of the SHA-256 over the library's sources (the .hip and .hip.h files of csrc/, this header) as the Makefile
    saw them when it built this binary: bench.py only trusts a counter profile under profiles/ that records the same hash */
 const char* mxe_source_hash(void);
 const char* mxe_strerror(int code);

@@ -75,6 +75,11 @@ constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
 #ifndef MXE_X_WALK_TOL
 #define MXE_X_WALK_TOL 1e-1
 #endif
+#ifndef MXE_X_LEAD_TOL
+#define MXE_X_LEAD_TOL 2e-2     // the leading alpha of a walking piece: a start ON the path.  Measured (r03, slowest rank of cfg4 / 8,
+                                // cfg2, cfg3): 1e-3 0.492 / 0.434 / 0.465 ms, 1e-2 0.473 / 0.418 / 0.445, 3e-2 0.454 / 0.386 / 0.414, 6e-2 runs away
+                                // on the scan with the hardest tail (rank 5 of cfg4 / 8: 1.6 ms, as in r02); 2e-2 keeps a factor 3 to that
+#endif
 #ifndef MXE_X_WALK_ITERS
 #define MXE_X_WALK_ITERS 4
 #endif
@@ -918,7 +923,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     if (estimated && t.pred > 0.0 && sdH > t.pred) relH2_min = fmin(sdH, relH2_min * (sdH / t.pred));     // (rare: one division)
 #endif
                     // (a leading alpha is only a starting point for the piece's first alpha: 1e-3 is enough)
-                    const double tol_here = (LEAD && t.ia < 0) ? fmax(p.tol_h, (t.ia == -t.lead) ? 1e-3 : MXE_X_WALK_TOL) : p.tol_h;
+                    const double tol_here = (LEAD && t.ia < 0) ? fmax(p.tol_h, (t.ia == -t.lead) ? MXE_X_LEAD_TOL : MXE_X_WALK_TOL) : p.tol_h;
                     const double tol2Hn = tol_here * tol_here * t.Hn2;
                     vv[q * NP + k] -= dlc[q * NP + k];
                     if (t.niter == 0) t.capp = (t.okprev == 5) ? 2 : (t.okprev == 1 && t.mu == 0.0) ? 1 : 0;
