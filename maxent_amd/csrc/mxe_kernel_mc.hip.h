@@ -80,6 +80,9 @@ constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
                                 // cfg2, cfg3): 1e-3 0.492 / 0.434 / 0.465 ms, 1e-2 0.473 / 0.418 / 0.445, 3e-2 0.454 / 0.386 / 0.414, 6e-2 runs away
                                 // on the scan with the hardest tail (rank 5 of cfg4 / 8: 1.6 ms, as in r02); 2e-2 keeps a factor 3 to that
 #endif
+#ifndef MXE_X_WALK_STRIDE
+#define MXE_X_WALK_STRIDE 1
+#endif
 #ifndef MXE_X_WALK_ITERS
 #define MXE_X_WALK_ITERS 4
 #endif
@@ -979,6 +982,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         ecor[q * NP + k] = e; eacc[q * NP + k] = 0.0;
                     }
                     ++t.ia;
+#if MXE_X_WALK_STRIDE > 1
+                    if (LEAD && t.ia < -1) t.ia = min(t.ia + (MXE_X_WALK_STRIDE - 1), -1);      // (the walk: every MXE_X_WALK_STRIDE-th alpha of the mesh)
+#endif
                     if (!conv && p.mc_abandon) {
                         // An alpha this layout gave up on: the rest of the piece would start from a point that is not a
                         // solution and go the same way.  Its alphas are marked open -- mxe_chains_finish solves every run of
