@@ -265,8 +265,10 @@ def end_to_end_block(batch, n_orb, n_alpha):
     return dict(api='ElementwiseMaxEnt(use_hermiticity=False).run()', problems=P,
                 fresh_object_ms=1e3 * min(cold), same_object_ms=1e3 * min(warm),
                 alpha_solves_per_s_same_object=P / min(warm), alpha_solves_per_s_fresh_object=P / min(cold),
-                includes='kernel fill + SVD + staging (fresh object only), H2D of G / D / alpha, one launch (diagonal and off-diagonal elements together), D2H of '
-                         'chi2 / S / Q / v, records, LineFit / Chi2Curvature / Entropy analyzers, D2H of the A_out rows',
+                includes='kernel fill + SVD + staging (fresh object only; the same object again uploads nothing when the job is unchanged), one '
+                         'launch (diagonal and off-diagonal elements together) + the selection kernel of the LineFit / Chi2Curvature / '
+                         'Entropy analyzers, D2H of chi2 / S / Q / flags and of the analyzers\' rows and indices (v and H stay on the device until '
+                         'looked at), records, the analysis batch',
                 first_access_of_all_H_ms=1e3 * t_H, all_H_MB=nbytes / 1e6)
 
 
