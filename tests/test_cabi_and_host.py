@@ -539,3 +539,51 @@ def test_set_cov_and_the_start_vector_see_in_place_edits():
     tm.A_init[:] = tm.A_init * np.exp(-np.asarray(omega) ** 2 / 50.0)
     v_b = tm.maxent_loop.make_spec()['v0'] if hasattr(tm, 'maxent_loop') else tm.make_spec()['v0']
     assert np.max(np.abs(v_a - v_b)) > 1e-3
+
+
+def test_analyzer_results_are_built_when_looked_at():
+    """round 3: the analyzers' alphas come from the device and nothing is built that nobody reads -- AnalyzerResult
+    computes its costly entries on first access, ElementAnalysis turns a Deferred pick into a result object when it is
+    read, and both behave like the plain dicts of the reference (analyzers/analyzer.py:25-46) for everything else."""
+    import pickle
+    from maxent_amd.analyzers import AnalyzerResult, Picks, Deferred
+    from maxent_amd.maxent_result import ElementAnalysis
+    calls = []
+    r = AnalyzerResult()
+    r['alpha_index'] = 3
+    r.later('curve', lambda: calls.append('curve') or np.arange(4.0))
+    assert 'curve' in r and calls == []
+    assert r['alpha_index'] == 3 and calls == []
+    assert np.array_equal(r['curve'], np.arange(4.0)) and calls == ['curve']
+    r['curve']
+    assert calls == ['curve']                                   # once
+    r2 = AnalyzerResult()
+    r2.later('x', lambda: 7)
+    assert sorted(r2.keys()) == ['x'] and r2.get('y', 5) == 5 and len(r2) == 1 and dict(r2) == {'x': 7}
+    r3 = AnalyzerResult()
+    r3['name'] = 'A'
+    r3.later('info', lambda: 'text')
+    back = pickle.loads(pickle.dumps(r3))
+    assert dict(back) == {'name': 'A', 'info': 'text'}
+
+    class FakeAnalyzer(object):
+        name = 'LineFitAnalyzer'
+
+    class FakeResult(object):
+        alpha = np.array([8.0, 4.0, 2.0, 1.0])
+    res = FakeResult()
+    built = []
+    picks = Picks(FakeAnalyzer(), res, [(0, 0), (0, 1)], [2, 1], [np.ones(3), 2 * np.ones(3)], dict(linefit_deg=0),
+                  dict(linefit_params=lambda owner, k, alpha: built.append(k) or ('p', k)),
+                  'Ideal alpha (linefit): {} (= index {} zero-based)')
+    out = ElementAnalysis()
+    from collections import OrderedDict
+    OrderedDict.__setitem__(out, 'LineFitAnalyzer', Deferred(picks, 1))
+    out['Other'] = 'chi2 is all NaN'
+    assert isinstance(out.raw('LineFitAnalyzer'), Deferred) and np.array_equal(out.raw('LineFitAnalyzer').A_out(), 2 * np.ones(3))
+    one = out['LineFitAnalyzer']                                # built now
+    assert isinstance(one, AnalyzerResult) and one['alpha_index'] == 1 and one['name'] == 'LineFitAnalyzer'
+    assert one['info'] == 'Ideal alpha (linefit): 4.0 (= index 1 zero-based)' and built == []
+    assert one['linefit_params'] == ('p', (0, 1)) and built == [(0, 1)]
+    assert out['LineFitAnalyzer'] is one and list(out.keys()) == ['LineFitAnalyzer', 'Other']
+    assert pickle.loads(pickle.dumps(out))['Other'] == 'chi2 is all NaN'
