@@ -437,6 +437,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     long long guard = 0;
     const long long guard_max = (long long)(dynamic ? x.n_queue : 1) * p.n_alpha * (p.maxiter + 64) + 64;
 
+    bool first_round = true;
     while (guard++ < guard_max) {
         // (a slot that finishes its piece takes the next one from the queue right away, in step 4)
 
@@ -444,7 +445,187 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         if (wave < MCC) {
             const int q = wave, k = lane;
             Slot t;
-            load_slot(t);
+            // ---- 4 (of the round before). rho, sums, accept / converge / advance, results ----
+            // Accept and the solve that follows it are ONE serial section of the home wave, in one block: the slot state
+            // goes from one to the other in registers (loaded from LDS behind the passes, stored at the end of the solve;
+            // r02 stored it at the end of the accept step and loaded it again two lines later: ~1 k cycles per round)
+            if (!first_round) {
+                MXE_STAMPA(5);
+                double h = 0.0;
+    #pragma unroll
+                for (int wv = 0; wv < HPW; ++wv) h += hpart[(wv * MCC + q) * NP + k];
+                const double r = (k < ns) ? cc[k] * h - gh[q * NP + k] : 0.0;
+                const double r2 = wave_sum(r * r);
+                double sS = 0.0, sdH = 0.0, sHn = 0.0, swm = 0.0, sdu = 0.0;
+    #pragma unroll
+                for (int wv = 0; wv < NWV; ++wv) {
+                    sS += red[wv * 32 + q * 8 + 0]; sdH += red[wv * 32 + q * 8 + 1];
+                    sHn += red[wv * 32 + q * 8 + 2]; swm = fmax(swm, red[wv * 32 + q * 8 + 3]);
+                    sdu = fmax(sdu, red[wv * 32 + q * 8 + 4]);
+                }
+                MXE_STAMPA(0);
+                load_slot(t);
+                MXE_STAMPA(1);
+                if (t.active) {
+                    rho[q * NP + k] = r;
+                    const double chi2t = r2 + t.cperp, St = sS;
+                    const double Qt = 0.5 * chi2t - t.alpha * St;
+                    const bool finite = fabs(Qt) <= 1.7e308;
+                    bool finish_alpha = false, failed = false; int conv = 0;
+                    // (fresh: the piece's start state came from the table and this round evaluated its first Newton step
+                    //  v0 - delta from scratch: a trial point like any other, except that the row pass has no old state to
+                    //  measure the step against -- no convergence test on it)
+                    const bool fresh = t.scratch == 2;
+                    if (t.scratch == 1 || (fresh && !t.okprev)) {
+                        // state restored from v (or first evaluation of the piece); damping kept
+                        ++t.nevals;
+                        if (finite) { t.scratch = 0; t.chi2 = chi2t; t.S = St; t.Hn2 = sHn; t.wmax = swm; t.Q = Qt; }
+                        else { finish_alpha = true; failed = true; }   // cannot even evaluate: give up on this alpha
+                    } else if (!t.okprev) {
+                        finish_alpha = true; failed = true;         // the damping loop ran out of range
+                    } else if (!finite || ((t.mu > 0.0 || (t.okprev >= 2 && t.okprev <= 4)) && Qt > t.Q + 1e-12 * fabs(t.Q)) ||   // (margin: rounding of Q)
+                               // a predicted step may overshoot like any undamped Newton step (measured: a strict test
+                               // rejects 20 % of them and costs more than the predictor gains); only a gross increase
+                               // of Q -- an extrapolation gone wrong on a coarse alpha mesh -- rejects it
+                               (t.okprev == 5 && Qt > 4.0 * fabs(t.Q) + 1.0) ||
+                               // a full Newton step may overshoot (a cold start does, by factors of hundreds in Q, and
+                               // recovers quadratically); one that multiplies Q by a million (alpha meshes with steps of
+                               // a decade) does not come back
+                               (t.okprev == 1 && Qt > 1e6 * (fabs(t.Q) + 1.0))) {
+                        ++t.nevals;
+                        if (finite && t.bt < 3 && !(t.mu == 0.0 && t.muh > 0.0)) {
+                            // a shortened / damped / halved step that made Q worse: halve it (step 1)
+                            ++t.bt;
+                            t.okprev = 3;
+                        } else {
+                            // not finite, or still worse after three halvings: more damping, restore from v.  Where
+                            // an earlier iteration of this piece needed damping, the search starts one notch below
+                            // that level instead of climbing from mu_first again (alphas far below the physical range
+                            // need it at every iteration)
+                            t.mu = (t.mu == 0.0) ? fmax(p.mu_first * t.alpha, t.muh / p.mu_grow) : t.mu * p.mu_grow;
+                            t.scratch = 1; t.bt = 0;
+                            if (!(t.mu <= p.mu_max * t.alpha)) { finish_alpha = true; failed = true; }
+                        }
+                    } else {
+                        // accepted
+                        ++t.nevals;
+                        // convergence in squares (no division, no square root in this serial section):
+                        // relH^2 = sdH / Hn2 against tol_h^2.
+                        // estimate of the NEXT Newton correction after a full step: the weights
+                        // change by at most expm1(max|du|) relatively, and so does the Jacobian;
+                        // the decoupled directions add the relative error theta of the Newton matrix.
+                        // expm1 by its series up to x^4 for x <= 1 (relative error < 1e-2, an estimate), no
+                        // estimate beyond
+                        double fac2 = 1.0;
+                        const bool estimated = p.stop_estimate && t.mu == 0.0 && t.okprev == 1 && sdu <= 1.0;
+                        if (estimated) {
+                            const double em1 = sdu * fma(sdu, fma(sdu, fma(sdu, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0);
+                            const double fac = em1 + p.theta + MC_GRAM_ERR;
+                            fac2 = fmin(1.0, fac * fac);
+                        }
+                        // The estimate assumes a Newton matrix that is exact up to theta.  The matrix this kernel solves with
+                        // is not (Gram tiles from binary16 products, binary32 elimination): harmless where the system is well
+                        // conditioned, but an ill-conditioned one contracts slower than predicted.  The estimate therefore
+                        // checks itself: what it predicted at the previous step of this alpha for the correction just taken
+                        // (t.pred) against that correction (sdH); an optimistic prediction inflates the present one by the
+                        // same factor
+                        double relH2_min = fac2 * sdH;                  // min(relH, relH_next)^2 * Hn2
+                        const double pred_here = estimated ? relH2_min : 0.0;
+    #ifndef MXE_X_NO_PRED_CHECK
+                        if (estimated && t.pred > 0.0 && sdH > t.pred) relH2_min = fmin(sdH, relH2_min * (sdH / t.pred));     // (rare: one division)
+    #endif
+                        // (a leading alpha is only a starting point for the piece's first alpha: 1e-3 is enough)
+                        const double tol_here = (LEAD && t.ia < 0) ? fmax(p.tol_h, (t.ia == -t.lead) ? MXE_X_LEAD_TOL : MXE_X_WALK_TOL) : p.tol_h;
+                        const double tol2Hn = tol_here * tol_here * t.Hn2;
+                        vv[q * NP + k] -= dlc[q * NP + k];
+                        if (t.niter == 0) t.capp = (t.okprev == 5) ? 2 : (t.okprev == 1 && t.mu == 0.0) ? 1 : 0;
+                        else eacc[q * NP + k] -= dlc[q * NP + k];     // what the later iterations add to the first iterate
+                        t.chi2 = chi2t; t.S = St; t.Hn2 = sHn; t.wmax = swm;
+                        t.Qprev = t.Q; t.Q = Qt; t.muh = t.mu; t.mu = 0.0;
+                        t.pred = pred_here;
+                        ++t.niter;
+                        const bool newton_step = t.okprev != 4 && !fresh;       // a halved step says nothing about convergence
+                        t.bt = 0;
+                        if (newton_step && p.tol_h > 0.0 && relH2_min < tol2Hn && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
+                        else if (p.tol_relq > 0.0 && fabs(fabs(t.Qprev - t.Q) / t.Q) < p.tol_relq && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
+                        else if (t.niter >= ((LEAD && t.ia < 0 && t.ia > -t.lead) ? MXE_X_WALK_ITERS : p.mc_maxiter)) finish_alpha = true;   // (an alpha of a walk is a starting point: a few rounds, then on)
+                        else if (t.wide > 0 && t.niter - t.wide >= MXE_X_ILL_ITERS) finish_alpha = true;    // (ill conditioned for the binary32 solve: handed over)
+                    }
+                    MXE_STAMPA(2);
+                    if (fresh && t.scratch == 2) t.scratch = 0;     // accepted or to be halved: the state in LDS is that trial point
+                    if (finish_alpha) {
+                        // (the leading alpha of a piece, number -1, writes its record where the piece's first alpha will
+                        //  write its own over it -- no branch; where it fails, the first alpha starts from the state it
+                        //  ended in and reports what becomes of it)
+                        const size_t prob = (size_t)t.prob0 + max(t.ia, 0);
+                        const bool own = !LEAD || t.ia >= 0;          // (an alpha of the walk leaves no record)
+                        if (p.out_H && own) {
+                            // H of the point just evaluated = the accepted one.  An alpha that FAILED (damping out of
+                            // range, nothing finite to evaluate) ends on a rejected trial point: its H does not belong
+                            // to the v, chi2, S, Q of the record (the last accepted state) and is written as NaN
+                            double* Ho = p.out_H + prob * nw;
+                            for (int i = lane; i < nw; i += 64) Ho[i] = failed ? __builtin_nan("") : Hi[i * MCC + q];
+                        }
+                        if (p.out_v && own) p.out_v[prob * NP + lane] = vv[q * NP + lane];
+                        if (lane == 0 && own) {
+                            p.out_chi2[prob] = t.chi2; p.out_S[prob] = t.S; p.out_Q[prob] = t.Q;
+                            p.out_niter[prob] = t.niter; p.out_conv[prob] = conv;
+                            p.out_nevals[prob] = t.nevals; p.out_nact[prob] = t.nact;
+                        }
+                        MXE_STAMPA(3);
+                        {
+                            // defect of this alpha's first Newton iterate -> predictor of the next alpha, scaled
+                            // with the square of the ratio of the steps in log alpha
+                            double e = 0.0;
+                            if (conv && t.capp > 0 && t.ia > 0 && t.ia + 1 < t.clen) {
+                                const double a0 = alpha_at(t, t.ia - 1), a1 = t.alpha, a2 = alpha_at(t, t.ia + 1);
+                                const double q0 = a1 / a0, q1 = a2 / a1;       // a logarithmic mesh: equal ratios, no log
+                                const double rr = (fabs(q1 - q0) < 1e-9 * q0) ? 1.0 : log(q1) / log(q0);
+                                // the extrapolation is an expansion in the step h of log alpha: fine meshes only
+                                // (|h| <= MC_PRED_HMAX, i.e. alpha ratios between 0.74 and 1.35)
+                                const bool fine = q0 > 0.74 && q0 < 1.35 && q1 > 0.74 && q1 < 1.35;
+                                if (fine)
+                                e = ((t.capp == 2 ? ecor[q * NP + k] : 0.0) + eacc[q * NP + k]) * rr * rr;
+                                if (!(fabs(e) < 1e300)) e = 0.0;
+                            }
+                            ecor[q * NP + k] = e; eacc[q * NP + k] = 0.0;
+                        }
+                        ++t.ia;
+    #if MXE_X_WALK_STRIDE > 1
+                        if (LEAD && t.ia < -1) t.ia = min(t.ia + (MXE_X_WALK_STRIDE - 1), -1);      // (the walk: every MXE_X_WALK_STRIDE-th alpha of the mesh)
+    #endif
+                        if (!conv && p.mc_abandon) {
+                            // An alpha this layout gave up on: the rest of the piece would start from a point that is not a
+                            // solution and go the same way.  Its alphas are marked open -- mxe_chains_finish solves every run of
+                            // open alphas as one warm-started chain from the converged alpha before it -- and the slot moves on
+                            for (int i = max(t.ia, 0) + lane; i < t.clen; i += 64) {
+                                const size_t pr = (size_t)t.prob0 + i;
+                                p.out_conv[pr] = 0; p.out_niter[pr] = 0; p.out_nevals[pr] = 0; p.out_nact[pr] = 0;
+                            }
+                            t.ia = t.clen;
+                        }
+                        t.niter = 0; t.nevals = 0; t.mu = 0.0; t.bt = 0; t.capp = 0; t.pred = 0.0; t.wide = 0;
+                        t.Qprev = __builtin_nan("");
+                        if (t.ia >= t.clen) {
+                            t.active = 0;
+                            if (dynamic) {           // next piece from the queue (most expensive first)
+                                int idx = 0;
+                                if (lane == 0) idx = atomicAdd(x.counter, 1);
+                                idx = __builtin_amdgcn_readfirstlane(idx);
+                                if (idx < x.n_queue) start_piece(t, x.queue[idx]);
+                            }
+                        } else {
+                            t.alpha = alpha_at(t, t.ia);
+                            t.Q = 0.5 * t.chi2 - t.alpha * t.S;
+                        }
+                    }
+                    MXE_STAMPA(4);
+                    MXE_STAMPA(6);            // (no store: the state stays in registers for the solve below)
+                }
+                MXE_STAMPW(5);
+            } else {
+                load_slot(t);
+            }
             int okflag = 0;
             double dk = 0.0;
             double dtot = 0.0;                       // total step from v of the trial point (dk: operand of the row pass)
@@ -837,189 +1018,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         }
         MXE_STAMPW(4);
 
-        // ---- 4. home wave: rho, sums, accept / converge / advance, results ----
-        if (wave < MCC) {
-            const int q = wave, k = lane;
-            MXE_STAMPA(5);
-            double h = 0.0;
-#pragma unroll
-            for (int wv = 0; wv < HPW; ++wv) h += hpart[(wv * MCC + q) * NP + k];
-            const double r = (k < ns) ? cc[k] * h - gh[q * NP + k] : 0.0;
-            const double r2 = wave_sum(r * r);
-            double sS = 0.0, sdH = 0.0, sHn = 0.0, swm = 0.0, sdu = 0.0;
-#pragma unroll
-            for (int wv = 0; wv < NWV; ++wv) {
-                sS += red[wv * 32 + q * 8 + 0]; sdH += red[wv * 32 + q * 8 + 1];
-                sHn += red[wv * 32 + q * 8 + 2]; swm = fmax(swm, red[wv * 32 + q * 8 + 3]);
-                sdu = fmax(sdu, red[wv * 32 + q * 8 + 4]);
-            }
-            MXE_STAMPA(0);
-            Slot t;
-            load_slot(t);
-            MXE_STAMPA(1);
-            if (t.active) {
-                rho[q * NP + k] = r;
-                const double chi2t = r2 + t.cperp, St = sS;
-                const double Qt = 0.5 * chi2t - t.alpha * St;
-                const bool finite = fabs(Qt) <= 1.7e308;
-                bool finish_alpha = false, failed = false; int conv = 0;
-                // (fresh: the piece's start state came from the table and this round evaluated its first Newton step
-                //  v0 - delta from scratch: a trial point like any other, except that the row pass has no old state to
-                //  measure the step against -- no convergence test on it)
-                const bool fresh = t.scratch == 2;
-                if (t.scratch == 1 || (fresh && !t.okprev)) {
-                    // state restored from v (or first evaluation of the piece); damping kept
-                    ++t.nevals;
-                    if (finite) { t.scratch = 0; t.chi2 = chi2t; t.S = St; t.Hn2 = sHn; t.wmax = swm; t.Q = Qt; }
-                    else { finish_alpha = true; failed = true; }   // cannot even evaluate: give up on this alpha
-                } else if (!t.okprev) {
-                    finish_alpha = true; failed = true;         // the damping loop ran out of range
-                } else if (!finite || ((t.mu > 0.0 || (t.okprev >= 2 && t.okprev <= 4)) && Qt > t.Q + 1e-12 * fabs(t.Q)) ||   // (margin: rounding of Q)
-                           // a predicted step may overshoot like any undamped Newton step (measured: a strict test
-                           // rejects 20 % of them and costs more than the predictor gains); only a gross increase
-                           // of Q -- an extrapolation gone wrong on a coarse alpha mesh -- rejects it
-                           (t.okprev == 5 && Qt > 4.0 * fabs(t.Q) + 1.0) ||
-                           // a full Newton step may overshoot (a cold start does, by factors of hundreds in Q, and
-                           // recovers quadratically); one that multiplies Q by a million (alpha meshes with steps of
-                           // a decade) does not come back
-                           (t.okprev == 1 && Qt > 1e6 * (fabs(t.Q) + 1.0))) {
-                    ++t.nevals;
-                    if (finite && t.bt < 3 && !(t.mu == 0.0 && t.muh > 0.0)) {
-                        // a shortened / damped / halved step that made Q worse: halve it (step 1)
-                        ++t.bt;
-                        t.okprev = 3;
-                    } else {
-                        // not finite, or still worse after three halvings: more damping, restore from v.  Where
-                        // an earlier iteration of this piece needed damping, the search starts one notch below
-                        // that level instead of climbing from mu_first again (alphas far below the physical range
-                        // need it at every iteration)
-                        t.mu = (t.mu == 0.0) ? fmax(p.mu_first * t.alpha, t.muh / p.mu_grow) : t.mu * p.mu_grow;
-                        t.scratch = 1; t.bt = 0;
-                        if (!(t.mu <= p.mu_max * t.alpha)) { finish_alpha = true; failed = true; }
-                    }
-                } else {
-                    // accepted
-                    ++t.nevals;
-                    // convergence in squares (no division, no square root in this serial section):
-                    // relH^2 = sdH / Hn2 against tol_h^2.
-                    // estimate of the NEXT Newton correction after a full step: the weights
-                    // change by at most expm1(max|du|) relatively, and so does the Jacobian;
-                    // the decoupled directions add the relative error theta of the Newton matrix.
-                    // expm1 by its series up to x^4 for x <= 1 (relative error < 1e-2, an estimate), no
-                    // estimate beyond
-                    double fac2 = 1.0;
-                    const bool estimated = p.stop_estimate && t.mu == 0.0 && t.okprev == 1 && sdu <= 1.0;
-                    if (estimated) {
-                        const double em1 = sdu * fma(sdu, fma(sdu, fma(sdu, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0);
-                        const double fac = em1 + p.theta + MC_GRAM_ERR;
-                        fac2 = fmin(1.0, fac * fac);
-                    }
-                    // The estimate assumes a Newton matrix that is exact up to theta.  The matrix this kernel solves with
-                    // is not (Gram tiles from binary16 products, binary32 elimination): harmless where the system is well
-                    // conditioned, but an ill-conditioned one contracts slower than predicted.  The estimate therefore
-                    // checks itself: what it predicted at the previous step of this alpha for the correction just taken
-                    // (t.pred) against that correction (sdH); an optimistic prediction inflates the present one by the
-                    // same factor
-                    double relH2_min = fac2 * sdH;                  // min(relH, relH_next)^2 * Hn2
-                    const double pred_here = estimated ? relH2_min : 0.0;
-#ifndef MXE_X_NO_PRED_CHECK
-                    if (estimated && t.pred > 0.0 && sdH > t.pred) relH2_min = fmin(sdH, relH2_min * (sdH / t.pred));     // (rare: one division)
-#endif
-                    // (a leading alpha is only a starting point for the piece's first alpha: 1e-3 is enough)
-                    const double tol_here = (LEAD && t.ia < 0) ? fmax(p.tol_h, (t.ia == -t.lead) ? MXE_X_LEAD_TOL : MXE_X_WALK_TOL) : p.tol_h;
-                    const double tol2Hn = tol_here * tol_here * t.Hn2;
-                    vv[q * NP + k] -= dlc[q * NP + k];
-                    if (t.niter == 0) t.capp = (t.okprev == 5) ? 2 : (t.okprev == 1 && t.mu == 0.0) ? 1 : 0;
-                    else eacc[q * NP + k] -= dlc[q * NP + k];     // what the later iterations add to the first iterate
-                    t.chi2 = chi2t; t.S = St; t.Hn2 = sHn; t.wmax = swm;
-                    t.Qprev = t.Q; t.Q = Qt; t.muh = t.mu; t.mu = 0.0;
-                    t.pred = pred_here;
-                    ++t.niter;
-                    const bool newton_step = t.okprev != 4 && !fresh;       // a halved step says nothing about convergence
-                    t.bt = 0;
-                    if (newton_step && p.tol_h > 0.0 && relH2_min < tol2Hn && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
-                    else if (p.tol_relq > 0.0 && fabs(fabs(t.Qprev - t.Q) / t.Q) < p.tol_relq && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
-                    else if (t.niter >= ((LEAD && t.ia < 0 && t.ia > -t.lead) ? MXE_X_WALK_ITERS : p.mc_maxiter)) finish_alpha = true;   // (an alpha of a walk is a starting point: a few rounds, then on)
-                    else if (t.wide > 0 && t.niter - t.wide >= MXE_X_ILL_ITERS) finish_alpha = true;    // (ill conditioned for the binary32 solve: handed over)
-                }
-                MXE_STAMPA(2);
-                if (fresh && t.scratch == 2) t.scratch = 0;     // accepted or to be halved: the state in LDS is that trial point
-                if (finish_alpha) {
-                    // (the leading alpha of a piece, number -1, writes its record where the piece's first alpha will
-                    //  write its own over it -- no branch; where it fails, the first alpha starts from the state it
-                    //  ended in and reports what becomes of it)
-                    const size_t prob = (size_t)t.prob0 + max(t.ia, 0);
-                    const bool own = !LEAD || t.ia >= 0;          // (an alpha of the walk leaves no record)
-                    if (p.out_H && own) {
-                        // H of the point just evaluated = the accepted one.  An alpha that FAILED (damping out of
-                        // range, nothing finite to evaluate) ends on a rejected trial point: its H does not belong
-                        // to the v, chi2, S, Q of the record (the last accepted state) and is written as NaN
-                        double* Ho = p.out_H + prob * nw;
-                        for (int i = lane; i < nw; i += 64) Ho[i] = failed ? __builtin_nan("") : Hi[i * MCC + q];
-                    }
-                    if (p.out_v && own) p.out_v[prob * NP + lane] = vv[q * NP + lane];
-                    if (lane == 0 && own) {
-                        p.out_chi2[prob] = t.chi2; p.out_S[prob] = t.S; p.out_Q[prob] = t.Q;
-                        p.out_niter[prob] = t.niter; p.out_conv[prob] = conv;
-                        p.out_nevals[prob] = t.nevals; p.out_nact[prob] = t.nact;
-                    }
-                    MXE_STAMPA(3);
-                    {
-                        // defect of this alpha's first Newton iterate -> predictor of the next alpha, scaled
-                        // with the square of the ratio of the steps in log alpha
-                        double e = 0.0;
-                        if (conv && t.capp > 0 && t.ia > 0 && t.ia + 1 < t.clen) {
-                            const double a0 = alpha_at(t, t.ia - 1), a1 = t.alpha, a2 = alpha_at(t, t.ia + 1);
-                            const double q0 = a1 / a0, q1 = a2 / a1;       // a logarithmic mesh: equal ratios, no log
-                            const double rr = (fabs(q1 - q0) < 1e-9 * q0) ? 1.0 : log(q1) / log(q0);
-                            // the extrapolation is an expansion in the step h of log alpha: fine meshes only
-                            // (|h| <= MC_PRED_HMAX, i.e. alpha ratios between 0.74 and 1.35)
-                            const bool fine = q0 > 0.74 && q0 < 1.35 && q1 > 0.74 && q1 < 1.35;
-                            if (fine)
-                            e = ((t.capp == 2 ? ecor[q * NP + k] : 0.0) + eacc[q * NP + k]) * rr * rr;
-                            if (!(fabs(e) < 1e300)) e = 0.0;
-                        }
-                        ecor[q * NP + k] = e; eacc[q * NP + k] = 0.0;
-                    }
-                    ++t.ia;
-#if MXE_X_WALK_STRIDE > 1
-                    if (LEAD && t.ia < -1) t.ia = min(t.ia + (MXE_X_WALK_STRIDE - 1), -1);      // (the walk: every MXE_X_WALK_STRIDE-th alpha of the mesh)
-#endif
-                    if (!conv && p.mc_abandon) {
-                        // An alpha this layout gave up on: the rest of the piece would start from a point that is not a
-                        // solution and go the same way.  Its alphas are marked open -- mxe_chains_finish solves every run of
-                        // open alphas as one warm-started chain from the converged alpha before it -- and the slot moves on
-                        for (int i = max(t.ia, 0) + lane; i < t.clen; i += 64) {
-                            const size_t pr = (size_t)t.prob0 + i;
-                            p.out_conv[pr] = 0; p.out_niter[pr] = 0; p.out_nevals[pr] = 0; p.out_nact[pr] = 0;
-                        }
-                        t.ia = t.clen;
-                    }
-                    t.niter = 0; t.nevals = 0; t.mu = 0.0; t.bt = 0; t.capp = 0; t.pred = 0.0; t.wide = 0;
-                    t.Qprev = __builtin_nan("");
-                    if (t.ia >= t.clen) {
-                        t.active = 0;
-                        if (dynamic) {           // next piece from the queue (most expensive first)
-                            int idx = 0;
-                            if (lane == 0) idx = atomicAdd(x.counter, 1);
-                            idx = __builtin_amdgcn_readfirstlane(idx);
-                            if (idx < x.n_queue) start_piece(t, x.queue[idx]);
-                        }
-                    } else {
-                        t.alpha = alpha_at(t, t.ia);
-                        t.Q = 0.5 * t.chi2 - t.alpha * t.S;
-                    }
-                }
-                MXE_STAMPA(4);
-                store_slot(t);
-                MXE_STAMPA(6);
-            }
-        }
-        // No barrier here: steps 4 and 1 are ONE serial section of the home wave.  Everything step 1 reads
-        // (its own slot, v, rho, the slot's Gram tiles) was written by this wave or lies behind the barrier
-        // of step 3, and nothing it writes is read by another wave's step 4.  A wave with a short accept
-        // starts its solve while a neighbour still writes results.
-        MXE_STAMPW(5);
+        first_round = false;
 #ifdef MXE_PROFILE
         ++prof_rounds;
 #endif
