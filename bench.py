@@ -238,20 +238,32 @@ def end_to_end_block(batch, n_orb, n_alpha):
     D2H of what the result object needs, records, analyzers -- next to the device-resident figure"""
     import maxent_amd as mx
 
-    def make():
+    from maxent_amd.batch_solver import BatchSolver
+
+    def make(k=0):
         ew = mx.ElementwiseMaxEnt(use_hermiticity=False)
         ew.set_verbosity(mx.VerbosityFlags.Quiet)
-        ew.set_G_tau_data(batch['tau'], batch['Gmat'])
+        ew.set_G_tau_data(batch['tau'], batch['Gmat'] * (1.0 + 1e-7 * k))        # (k: other data on the same grids)
         ew.omega = batch['omega']
         ew.alpha_mesh = mx.LogAlphaMesh(alpha_min=1e-2, alpha_max=1e4, n_points=n_alpha)
         ew.set_error(synthetic.SIGMA)
         return ew
-    cold = []
-    for _ in range(2):
-        t0 = time.perf_counter()
-        ew = make()
-        ew.run()
-        cold.append(time.perf_counter() - t0)
+
+    def fresh(n, k0):
+        out = []
+        for k in range(n):
+            t0 = time.perf_counter()
+            ew = make(k0 + k)
+            ew.run()
+            out.append(time.perf_counter() - t0)
+        return ew, out
+    pool_size, BatchSolver.POOL_SIZE = BatchSolver.POOL_SIZE, 0
+    try:
+        ew, cold_own = fresh(2, 1)                  # every object creates (and destroys) device contexts of its own
+    finally:
+        BatchSolver.POOL_SIZE = pool_size
+    del ew
+    ew, cold = fresh(3, 3)                          # the contexts of an earlier object with the same decomposition are taken over
     warm, res = [], None
     for _ in range(3):
         ew.maxent_result = res = None     # (a result that is still held claims its H: it would be fetched first)
@@ -263,9 +275,12 @@ def end_to_end_block(batch, n_orb, n_alpha):
     t_H = time.perf_counter() - t0
     P = n_orb * n_orb * n_alpha
     return dict(api='ElementwiseMaxEnt(use_hermiticity=False).run()', problems=P,
-                fresh_object_ms=1e3 * min(cold), same_object_ms=1e3 * min(warm),
+                fresh_object_ms=1e3 * min(cold), fresh_object_own_contexts_ms=1e3 * min(cold_own), same_object_ms=1e3 * min(warm),
                 alpha_solves_per_s_same_object=P / min(warm), alpha_solves_per_s_fresh_object=P / min(cold),
-                includes='kernel fill + SVD + staging (fresh object only; the same object again uploads nothing when the job is unchanged), one '
+                includes='fresh object: a new ElementwiseMaxEnt on new data of the same grids -- kernel fill + SVD + staging of the data; '
+                         'the device contexts (with U, S, V staged) of an earlier object with an equal decomposition are taken over '
+                         '(maxent_amd.batch_solver.BatchSolver.for_kernel; fresh_object_own_contexts_ms: without that, as in round 2). '
+                         'The same object again uploads nothing when the job is unchanged.  Both: one '
                          'launch (diagonal and off-diagonal elements together) + the selection kernel of the LineFit / Chi2Curvature / '
                          'Entropy analyzers, D2H of chi2 / S / Q / flags and of the analyzers\' rows and indices (v and H stay on the device until '
                          'looked at), records, the analysis batch',

@@ -215,7 +215,11 @@ int  mxe_sync(mxe_ctx* ctx);
  * an inexact Newton matrix that is harmless where the system is well conditioned and stalls where it is not (few
  * data points, small alpha); it gives an alpha up after 32 iterations, and the one-chain kernel (binary64 Gram
  * matrix) takes it from there with the rest of mxe_opts.maxiter.  n_resolved (may be NULL): how many alphas that
- * was.  A no-op after a launch in the one-chain layout or when everything converged.  mxe_solve_chains calls it;
+ * was.  Alphas that couple more than the 32 directions the lock-step kernel has a build for (error bars far below
+ * 1e-5 of the data: the smallest alphas of a scan) are not in its pieces at all when they are the smaller part of the
+ * batch: after mxe_chains_launch their records read NaN / not converged / 0 iterations, and this call solves them
+ * as one warm chain per scan from the last alpha before them -- a launch is complete after mxe_chains_finish, not
+ * before.  A no-op after a launch in the one-chain layout or when everything converged.  mxe_solve_chains calls it;
  * what it replaces in the reference is nothing but the remaining iterations of levenberg_minimizer.py:155-243. */
 int  mxe_chains_finish(mxe_ctx* ctx, int32_t* n_resolved);
 int  mxe_chains_fetch(mxe_ctx* ctx, double* out_v, double* out_H,

@@ -342,26 +342,43 @@ def _device_picks(maxent_result, keys, which, matches):
     the three H rows of every scan came back in one copy): (indices, A rows), or None when any element has no such
     choice -- another parameter than the device used (``matches(params)``), no fit, a record made some other way.
     ``which``: 0 line fit, 1 chi2 curvature, 2 entropy."""
-    idx, rows, maps = [], [], []
     recs = getattr(maxent_result, '_records', {})
+    sels, maps = [], []
+    ok_params = None
     for k in keys:
         rec = recs.get(k)
         sel = None if rec is None else rec.get('device_select')
-        if sel is None or not matches(sel['params']) or sel['index'][which] < 0:
+        if sel is None:
             return None
+        if sel['params'] is not ok_params:
+            if not matches(sel['params']):
+                return None
+            ok_params = sel['params']
         A = rec.get('A')
         if not hasattr(A, 'from_H_row'):
             return None
         maps.append(A)
-        rows.append(sel['H'][which])
-        idx.append(int(sel['index'][which]))
-    first = maps[0]._map if maps else None
-    if first is not None and first.matrix() is None and all(m._map is first for m in maps):
-        # A = H / delta for everybody: one division for all rows (elementwise: the same bits as row by row)
-        rows = list(first.f(np.array(rows)))
+        sels.append(sel)
+    if not sels:
+        return [], []
+    batch = sels[0].get('batch')
+    if batch is not None and all(s.get('batch') is batch for s in sels):
+        # the launch's arrays as they came off the device: [3][n_chain] indices, [3][n_chain][n_omega] rows
+        cs = np.fromiter((s['chain'] for s in sels), dtype=np.intp, count=len(sels))
+        idx = batch[0][which][cs]
+        H = batch[1][which][cs]
     else:
-        rows = [m.from_H_row(r) for m, r in zip(maps, rows)]
-    return idx, rows
+        idx = np.array([s['index'][which] for s in sels])
+        H = np.array([s['H'][which] for s in sels])
+    if np.any(idx < 0):
+        return None
+    first = maps[0]._map
+    if first.matrix() is None and all(m._map is first for m in maps):
+        # A = H / delta for everybody: one division for all rows (elementwise: the same bits as row by row)
+        rows = list(first.f(H))
+    else:
+        rows = [m.from_H_row(r) for m, r in zip(maps, H)]
+    return idx.tolist(), rows
 
 
 class LineFitAnalyzer(Analyzer):

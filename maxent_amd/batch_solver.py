@@ -17,6 +17,8 @@ is fetched when it is first asked for (:class:`LazyH`), single rows -- what an a
 ``rows()`` without touching the rest.
 """
 
+import atexit
+import threading
 import weakref
 
 import numpy as np
@@ -105,6 +107,18 @@ class LazyA(object):
         return np.asarray(self._map.f(row))
 
 
+def _one_at_a_time(method):
+    """the solver's lock around a method: solvers are shared between kernel objects with the same decomposition, and
+    the library wants one thread per context at a time"""
+    import functools
+
+    @functools.wraps(method)
+    def locked(self, *args, **kwargs):
+        with self._lock:
+            return method(self, *args, **kwargs)
+    return locked
+
+
 class BatchSolver(object):
     def __init__(self, K, device_ids=(0,)):
         K.S                                         # decompose if needed
@@ -120,6 +134,7 @@ class BatchSolver(object):
         self._pending = []                          # weak references to the LazyH whose data still live in a result buffer
         self._layout = None
         self.last_info = None
+        self._lock = threading.RLock()              # (one job at a time on these contexts: include/maxent_hip.h)
 
     # ---- reuse -------------------------------------------------------------
     @staticmethod
@@ -133,6 +148,24 @@ class BatchSolver(object):
     def _same_token(a, b):
         return a is not None and b is not None and all((x is y) for x, y in zip(a[:3], b[:3])) and a[3] == b[3]
 
+    # Solvers outlive the kernel object they were made for: a new object with the SAME decomposition (the next
+    # TauMaxEnt / ElementwiseMaxEnt on the same grids -- every iteration of a self-consistency loop) takes the contexts
+    # and what is staged on them instead of creating and filling its own (2 ms) and destroying the old ones (2 ms).
+    # The few most recently used are kept (each holds the result buffers of its last job on the device).
+    _pool_lock = threading.Lock()
+    _pooled = []                                    # most recently used first
+    POOL_SIZE = 3
+
+    def _same_contents(self, K, device_ids):
+        if self.device_ids != device_ids or not self.ctxs[0]._h or (K.rotation is None) != self._token[3]:
+            return False
+        for a, b in zip(self._token[:3], (K._U, K._S, K._V)):
+            if a is b:
+                continue
+            if a is None or b is None or a.shape != b.shape or not np.array_equal(a, b):
+                return False
+        return True
+
     @classmethod
     def for_kernel(cls, K, device_ids=(0,)):
         K.S
@@ -143,12 +176,51 @@ class BatchSolver(object):
         s = held.get(device_ids)
         if s is not None and cls._same_token(s._token, cls._kernel_token(K)) and s.ctxs[0]._h:
             return s
-        if s is not None:
-            s.close()
-        s = held[device_ids] = cls(K, device_ids)
-        return s
+        if cls.POOL_SIZE <= 0:                       # no pool: every kernel object its own contexts
+            if s is not None:
+                s.close()
+            s = held[device_ids] = cls(K, device_ids)
+            return s
+        with cls._pool_lock:
+            found = None
+            for cand in cls._pooled:
+                # (not one whose last results somebody still holds unfetched: they would have to come to the host
+                #  first -- 102 MB for a 16 x 16 x 100 job --, a context of its own is cheaper)
+                if cand._same_contents(K, device_ids) and not cand._alive():
+                    found = cand
+                    break
+            if found is None:
+                found = cls(K, device_ids)
+            else:
+                cls._pooled.remove(found)
+                found._token = cls._kernel_token(K)        # (equal arrays: the staged basis is that of K)
+            cls._pooled.insert(0, found)
+            retired = cls._pooled[cls.POOL_SIZE:]
+            del cls._pooled[cls.POOL_SIZE:]
+        for old in retired:
+            if not old._alive():
+                old.close()                         # (one with results out lives as long as they do: they hold it)
+        held[device_ids] = found
+        return found
+
+    @classmethod
+    def close_pool(cls):
+        """close every pooled solver (also registered for the end of the process: the contexts go before the HIP
+        runtime does)"""
+        with cls._pool_lock:
+            retired, cls._pooled = cls._pooled, []
+        for s in retired:
+            try:
+                s.close()
+            except Exception:
+                pass
 
     def close(self):
+        with self._pool_lock:
+            if self in self._pooled:
+                self._pooled.remove(self)
+        if not self.ctxs or not self.ctxs[0]._h:
+            return
         self.materialize_pending()
         pool = self.__dict__.pop('_pool', None)
         if pool is not None:
@@ -157,6 +229,7 @@ class BatchSolver(object):
             c.close()
 
     # ---- one batch -----------------------------------------------------------
+    @_one_at_a_time
     def solve(self, K, specs, opts, want_logdet=False, want_H='lazy', output_map=None, select=(0, 0.2)):
         """``specs``: dicts with G, err, U_rot (or None), D, kind, v0, alpha (equal lengths).  Returns
         (list of per-spec result dicts in the order of ``specs``, info).  ``want_H``: 'lazy' (default),
@@ -177,12 +250,15 @@ class BatchSolver(object):
         outs = [None] * N
         picks = [None] * N
 
-        def work(r):
-            # stage -> launch -> finish -> (fetch) of ONE device; with several devices each runs on a thread of its own
-            # (ctypes releases the GIL, the library promises one thread per context: include/maxent_hip.h)
+        def begin(r):
+            # stage -> launch of ONE device (the launch returns at once)
             c = self.ctxs[r]
             self._stage(c, K, [specs[i] for i in per_rank[r]], opts)
             c.launch()
+
+        def end(r):
+            # finish -> (fetch) of ONE device
+            c = self.ctxs[r]
             c.finish()                              # (alphas the lock-step layout gave up on: one-chain layout)
             if select is not None:
                 c.select3_launch(select[0], select[1])
@@ -193,7 +269,28 @@ class BatchSolver(object):
             if select is not None:
                 picks[r] = c.select3_fetch()
 
-        self._on_devices(work, active)
+        def skeleton():
+            # what of the results does not wait for the device: built while the kernel runs
+            out = []
+            for i, s in enumerate(specs):
+                r, c = int(rank_of[i]), int(local_of[i])
+                H = LazyH(self, r, c, n_alpha, self.n_omega)
+                v = LazyV(self, r, c, n_alpha, self.n_s)
+                self._pending.append(weakref.ref(H))
+                self._pending.append(weakref.ref(v))
+                out.append(dict(alpha=np.asarray(s['alpha'], dtype=float), H=H, A=None, v=v))
+            return out
+
+        # with several devices each runs on a thread of its own (ctypes releases the GIL, the library promises one
+        # thread per context: include/maxent_hip.h)
+        if len(active) == 1:
+            begin(active[0])
+            res = skeleton()
+            end(active[0])
+        else:
+            waiting = self._on_devices(lambda r: (begin(r), end(r)), active, wait=False)
+            res = skeleton()
+            waiting()
         info = None
         if gather:
             # ONE gather of the per-alpha scalars (and of the analyzer's rows) to the first device
@@ -215,28 +312,24 @@ class BatchSolver(object):
                     n_datasets=[self._n_datasets.get(id(self.ctxs[r]), 0) for r in active])
         info.update(self.ctxs[active[0]].last_launch_info())
         self.last_info = info
-        res = []
-        for i, s in enumerate(specs):
+        conv = {r: outs[r]['converged'].astype(bool) for r in active}
+        sel_params = (int(select[0]), float(select[1])) if select is not None else None
+        for i, d in enumerate(res):
             r, c = int(rank_of[i]), int(local_of[i])
             o = outs[r]
-            H = LazyH(self, r, c, n_alpha, self.n_omega)
-            v = LazyV(self, r, c, n_alpha, self.n_s)
-            self._pending.append(weakref.ref(H))
-            self._pending.append(weakref.ref(v))
-            d = dict(alpha=np.asarray(s['alpha'], dtype=float), H=H,
-                     A=(maps[r][c] if r in maps else None),
-                     v=v, chi2=o['chi2'][c], S=o['S'][c], Q=o['Q'][c],
-                     n_iter=o['n_iter'][c], converged=o['converged'][c].astype(bool), n_evals=o['n_evals'][c])
+            if r in maps:
+                d['A'] = maps[r][c]
+            d.update(chi2=o['chi2'][c], S=o['S'][c], Q=o['Q'][c],
+                     n_iter=o['n_iter'][c], converged=conv[r][c], n_evals=o['n_evals'][c])
             if 'linefit_index' in o:
                 d['device_linefit_index'] = int(o['linefit_index'][c])
                 d['device_linefit_H'] = o['linefit_H'][c]
             if picks[r] is not None:
-                d['device_select'] = dict(params=(int(select[0]), float(select[1])), index=picks[r][0][:, c], H=picks[r][1][:, c])
+                d['device_select'] = dict(params=sel_params, index=picks[r][0][:, c], H=picks[r][1][:, c], batch=picks[r], chain=c)
                 if 'device_linefit_index' not in d:
                     d['device_linefit_index'], d['device_linefit_H'] = int(picks[r][0][0, c]), picks[r][1][0, c]
             if r in logdets:
                 d['logdet'] = logdets[r][c]
-            res.append(d)
         if want_H is True:
             self.materialize_pending()
         elif want_H is False:
@@ -245,24 +338,40 @@ class BatchSolver(object):
                 d['H'] = None
         return res, info
 
+    @staticmethod
+    def _rows_of(specs, key):
+        """the vectors ``key`` of the specs as rows -- ONE row when every spec holds the same array object (the
+        element-wise drivers hand one default model, alpha mesh, start vector and error array to every element)"""
+        first = specs[0][key]
+        if isinstance(first, np.ndarray) and all(s[key] is first for s in specs):
+            return np.asarray(first, dtype=float).reshape(1, -1)
+        rows = [np.asarray(s[key], dtype=float).ravel() for s in specs]
+        return np.concatenate(rows).reshape(len(rows), -1)          # (np.stack costs 1 us per row)
+
     def _stage(self, ctx, K, specs, opts):
         """data sets, elements and chains of one device.  What is staged is remembered (contents, not identities): the
         same job again -- the same object run twice, a parameter of the analyzers changed -- uploads nothing"""
-        n_tau = len(specs[0]['G'])
-        errs = np.stack([np.asarray(s['err'], dtype=float) * np.ones(len(s['G'])) for s in specs]) \
-            if all(len(s['G']) == n_tau for s in specs) else None
+        n, n_tau = len(specs), len(specs[0]['G'])
+        same_len = all(len(s['G']) == n_tau for s in specs)
+        if same_len:
+            e0 = specs[0]['err']
+            if isinstance(e0, np.ndarray) and e0.shape == (n_tau,) and all(s['err'] is e0 for s in specs):
+                errs = np.asarray(e0, dtype=float).reshape(1, -1)
+            else:
+                errs = np.stack([np.asarray(s['err'], dtype=float) * np.ones(n_tau) for s in specs])
+        else:
+            errs = None
         staged = dict(
-            G=np.stack([np.asarray(s['G'], dtype=float) for s in specs]) if errs is not None else None,
+            n=n,
+            G=np.concatenate([s['G'] for s in specs]).astype(float, copy=False).reshape(n, n_tau) if same_len else None,
             err=errs,
-            D=np.stack([np.asarray(s['D'], dtype=float) for s in specs]),
-            alpha=np.stack([np.asarray(s['alpha'], dtype=float) for s in specs]),
-            v0=np.stack([np.asarray(s['v0'], dtype=float) for s in specs]),
+            D=self._rows_of(specs, 'D'), alpha=self._rows_of(specs, 'alpha'), v0=self._rows_of(specs, 'v0'),
             kinds=np.array([s['kind'] for s in specs]),
             U_rot=[s.get('U_rot') for s in specs],
             opts=(bytes(opts) if opts is not None else b''), rotated=K.rotation is not None)
         held = self.__dict__.setdefault('_staged', {})
         old = held.get(id(ctx))
-        if old is not None and errs is not None and old['G'] is not None and ctx._n_chain == len(specs) and \
+        if old is not None and same_len and old['G'] is not None and old['n'] == n and ctx._n_chain == n and \
                 old['opts'] == staged['opts'] and old['rotated'] == staged['rotated'] and \
                 len(old['U_rot']) == len(staged['U_rot']) and all(a is b for a, b in zip(old['U_rot'], staged['U_rot'])) and \
                 all(old[k].shape == staged[k].shape and np.array_equal(old[k], staged[k])
@@ -272,8 +381,10 @@ class BatchSolver(object):
         ctx.clear_datasets()
         ds_ids, seen = [], []
         self.__dict__.setdefault('_n_datasets', {})
-        for n, s in enumerate(specs):
-            err = errs[n] if errs is not None else np.asarray(s['err'], dtype=float) * np.ones(len(s['G']))
+        full = lambda a: a if a.shape[0] == n else np.broadcast_to(a, (n, a.shape[1]))
+        errs_n = full(errs) if errs is not None else None
+        for i, s in enumerate(specs):
+            err = errs_n[i] if errs_n is not None else np.asarray(s['err'], dtype=float) * np.ones(len(s['G']))
             U_rot = s.get('U_rot')
             found = None
             for (e0, u0, i0) in seen:
@@ -285,22 +396,30 @@ class BatchSolver(object):
                 seen.append((err, U_rot, found))
             ds_ids.append(found)
         self._n_datasets[id(ctx)] = len(seen)
-        ctx.set_elements(ds_ids, [s['G'] for s in specs], staged['D'], [s['kind'] for s in specs])
-        ctx.upload_chains(np.arange(len(specs), dtype=np.int32), staged['alpha'], staged['v0'], opts)
+        ctx.set_elements(ds_ids, staged['G'] if same_len else [s['G'] for s in specs], full(staged['D']), staged['kinds'])
+        ctx.upload_chains(np.arange(n, dtype=np.int32), np.ascontiguousarray(full(staged['alpha'])),
+                          np.ascontiguousarray(full(staged['v0'])), opts)
         held[id(ctx)] = staged
 
-    def _on_devices(self, fn, ranks):
-        """fn(rank) for every rank: in this thread for one device, one thread per device otherwise"""
+    def _on_devices(self, fn, ranks, wait=True):
+        """fn(rank) for every rank: in this thread for one device, one thread per device otherwise (``wait=False``:
+        returns the function that joins them)"""
         if len(ranks) <= 1:
             for r in ranks:
                 fn(r)
-            return
+            return (lambda: None) if not wait else None
         pool = self.__dict__.get('_pool')
         if pool is None or pool._max_workers < len(ranks):
             from concurrent.futures import ThreadPoolExecutor
             pool = self.__dict__['_pool'] = ThreadPoolExecutor(max_workers=len(self.ctxs))
-        for f in [pool.submit(fn, r) for r in ranks]:
-            f.result()                              # (re-raises what a worker raised)
+        futures = [pool.submit(fn, r) for r in ranks]
+
+        def join():
+            for f in futures:
+                f.result()                          # (re-raises what a worker raised)
+        if not wait:
+            return join
+        join()
 
     def _unpack_compact(self, pack, n_chain, n_alpha, eta=1.0):
         """the compact result pack of one rank (include/maxent_hip.h: MXE_GATHER_COMPACT).  The kernel iterates on
@@ -323,6 +442,7 @@ class BatchSolver(object):
                 out.append(h)
         return out
 
+    @_one_at_a_time
     def _materialize_rank(self, rank):
         alive = self._alive()
         mine = [h for h in alive if h._rank == rank]
@@ -332,11 +452,13 @@ class BatchSolver(object):
                 h._val = got[h._what][h._chain]
         self._pending = [weakref.ref(h) for h in alive if h._val is None]
 
+    @_one_at_a_time
     def materialize_pending(self):
         for r in sorted(set(h._rank for h in self._alive())):
             self._materialize_rank(r)
         self._pending = []
 
+    @_one_at_a_time
     def rows(self, wanted):
         """``wanted``: list of (rank, chain, alpha index) of the LAST batch -> array (len, n_omega); one
         device-to-host copy per row, nothing else moves"""
@@ -349,3 +471,6 @@ class BatchSolver(object):
             for (n, _), row in zip(lst, got):
                 out[n] = row
         return out
+
+
+atexit.register(BatchSolver.close_pool)

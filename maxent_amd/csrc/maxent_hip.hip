@@ -107,7 +107,8 @@ PinnedPair g_pinned;
 
 hipError_t d2h_pipelined(void* dst, const void* src, size_t bytes, hipStream_t s)
 {
-    if (bytes < 4 * PinnedPair::CHUNK) return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+    // (also the analyzers' rows of a launch, 3 MB: hipMemcpy into pageable memory took 0.7-1.1 ms for them, this way 0.3)
+    if (bytes < ((size_t)256 << 10)) { hipError_t e0 = hipStreamSynchronize(s); return e0 != hipSuccess ? e0 : hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost); }
     std::unique_lock<std::mutex> lk(g_pinned.mu, std::try_to_lock);
     if (!lk.owns_lock() || !g_pinned.ready()) return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);    // (another thread's copy is in flight)
     const size_t C = PinnedPair::CHUNK, n = (bytes + C - 1) / C;
@@ -165,6 +166,8 @@ struct mxe_ctx {
     std::vector<int> chain_elem;      // per parent chain
     std::vector<int> sub_elem, sub_prob0, sub_len, sub_v0, wg_chains;   // per launched (sub-)chain
     int n_sub = 0, n_wg = 0, mc_na = 0, mc_wgpc = 1, wgpc_auto = 2, n_queue = 0, n_solo = 0;
+    std::vector<int> excluded;          // problems no piece of the lock-step launch covers (more than 32 coupled directions): mxe_chains_finish
+    DevBuf<int> dexcluded;
     bool mc_gst = false;              // lock-step layout with u, H, sw in device memory (frequency meshes beyond the LDS)
     DevBuf<double> dgstate_mc;
     std::vector<int> queue;
@@ -496,7 +499,7 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
     ctx->dghat.release(); ctx->dcperp.release(); ctx->dD.release(); ctx->dsumD.release();
     ctx->dalpha.release(); ctx->dv0.release(); ctx->delem_ds.release(); ctx->delem_kind.release();
     ctx->dchain_elem.release(); ctx->dsub_prob0.release(); ctx->dsub_len.release(); ctx->dsub_v0.release(); ctx->dwg_chains.release(); ctx->dqueue.release(); ctx->dcounter.release(); ctx->dsub_pre.release(); ctx->dsub_init.release(); ctx->dinit_tab.release(); ctx->dout_v.release(); ctx->dout_pack.release(); ctx->dout_pack2.release();
-    ctx->dout_niter.release(); ctx->dout_conv.release(); ctx->dout_nevals.release(); ctx->dout_nact.release();
+    ctx->dout_niter.release(); ctx->dout_conv.release(); ctx->dout_nevals.release(); ctx->dout_nact.release(); ctx->dexcluded.release();
     ctx->dB.release(); ctx->dA.release(); ctx->dprof.release();
     ctx->rows_out.release(); ctx->rows_idx.release();
     ctx->ev_x.release(); ctx->ev_alpha.release(); ctx->ev_scal.release(); ctx->ev_vecw.release(); ctx->ev_vecs.release();
@@ -862,7 +865,55 @@ try {
         // (an active block of 48 in the lock-step kernel spilled registers in every tiling that was tried: problems
         //  that couple more than 32 directions run in the one-chain layout, whose solve lives in LDS)
         (void)worst48;
-        if (worst32 <= 1e-2) ctx->mc_na = 32; else layout = 1;
+        ctx->excluded.clear();
+        if (worst32 <= 1e-2) ctx->mc_na = 32;
+        else {
+            // Some alphas couple more than 32 directions (very small error bars: sigma = 1e-6 on the BASELINE grids does at
+            // the 27 smallest of 100 alphas).  Until r03 the whole launch then went to the one-chain layout (7 x slower);
+            // now the pieces are cut where the criterion fails -- coupling grows as alpha falls, so that is the tail of a
+            // scan --, the lock-step kernel solves what it has a build for, and the alphas behind the cut are left open
+            // for mxe_chains_finish: one warm chain per scan from the last alpha before the cut (records of such alphas
+            // are NaN / not converged / 0 iterations until then: clear_excluded_kernel).  Measured on the BASELINE batch with
+            // sigma = 4e-6 / 2e-6 / 1e-6 (maxiter 100): 15.4 / 17.1 / 146 ms in the one-chain layout, 7.9 / 12.6 / 55 ms this
+            // way -- of which the lock-step launch is 2-3 ms: the rest is the serial depth of the finishing chains (13-30
+            // alphas x 2.4 iterations x 150-190 us: the one-chain kernel with 64 coupled directions).  Leaving the cut
+            // alphas to the lock-step kernel's own give-up instead costs accuracy (exact Newton correction up to 9e-7,
+            // p99 1e-7, against 4e-8 / 2e-9) for the same time.  Not when more than a third of the alphas would be left
+            // to that pass (sigma = 5e-7: 197 against 150 ms).  profiles/r03_c_cut_pieces.txt
+            std::vector<char> bad(P, 0);
+            size_t n_bad = 0;
+            for (int c = 0; c < n_chain; ++c) {
+                const int e = elem_of_chain[c];
+                const DataSet& DS = ctx->ds[ctx->elem_ds[e]];
+                const double lim = 1e-2 / (DS.c[32] * DS.c[32] * std::max(1.0, ctx->h_sumD[e]));    // alpha >= 1 / lim passes
+                for (int i = 0; i < n_alpha; ++i)
+                    if (!(alpha_dev[(size_t)c * n_alpha + i] * lim >= 1.0)) { bad[(size_t)c * n_alpha + i] = 1; ++n_bad; }
+            }
+            if (3 * n_bad > P) layout = 1;
+            else {
+                ctx->mc_na = 32;
+                std::vector<char> covered(P, 0);
+                size_t w = 0;
+                for (size_t sc = 0; sc < ctx->sub_elem.size(); ++sc) {
+                    const int p0 = ctx->sub_prob0[sc];
+                    int len = 0;
+                    while (len < ctx->sub_len[sc] && !bad[(size_t)p0 + len]) ++len;
+                    // (a led piece starts from an alpha above its own: larger, so it passes when the piece's does)
+                    if (len == 0) continue;
+                    for (int i = 0; i < len; ++i) covered[(size_t)p0 + i] = 1;
+                    ctx->sub_elem[w] = ctx->sub_elem[sc]; ctx->sub_prob0[w] = p0; ctx->sub_len[w] = len;
+                    ctx->sub_v0[w] = ctx->sub_v0[sc]; ctx->sub_pre[w] = ctx->sub_pre[sc]; ++w;
+                }
+                if (w == 0) { ctx->mc_na = 0; layout = 1; }
+                else {
+                    ctx->sub_elem.resize(w); ctx->sub_prob0.resize(w); ctx->sub_len.resize(w); ctx->sub_v0.resize(w); ctx->sub_pre.resize(w);
+                    ctx->n_sub = (int)w;
+                    ctx->has_pre = false;
+                    for (size_t sc = 0; sc < w; ++sc) ctx->has_pre = ctx->has_pre || ctx->sub_pre[sc] > 0;
+                    for (size_t i = 0; i < P; ++i) if (!covered[i]) ctx->excluded.push_back((int)i);
+                }
+            }
+        }
         if (layout == 4) {
             ctx->mc_wgpc = (o.wg_per_cu != 1 && (o.wg_per_cu == 2 || ctx->wgpc_auto == 2) && ctx->mc_na == 32 && ctx->nwp <= 512 &&
                             mc_lds_bytes(32, ctx->nwp, 2) <= 80 * 1024 - 2048) ? 2 : 1;
@@ -968,6 +1019,11 @@ try {
         HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_pre.p, ctx->sub_pre.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
     if (!ctx->wg_chains.empty())
         HIPCHK(ctx, hipMemcpyAsync(ctx->dwg_chains.p, ctx->wg_chains.data(), ctx->wg_chains.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (layout != 4) ctx->excluded.clear();
+    if (!ctx->excluded.empty()) {
+        HIPCHK(ctx, ctx->dexcluded.ensure(ctx->excluded.size()));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->dexcluded.p, ctx->excluded.data(), ctx->excluded.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
     HIPCHK(ctx, hipMemcpyAsync(ctx->dalpha.p, alpha_dev.data(), P * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dv0.p, hv0.data(), hv0.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, stream_wait(ctx->stream));
@@ -1008,6 +1064,24 @@ static void fill_kparams(mxe_ctx* ctx, KParams& kp)
     kp.mc_maxiter = std::min(o.maxiter, std::max(MC_MAXITER, o.miniter + 8));     // (a caller's miniter above the limit moves it)
     kp.mc_abandon = 1;
 }
+
+namespace {
+// one workgroup per problem the lock-step launch leaves out: its records say so until mxe_chains_finish has solved it
+// (H, chi2, S, Q = NaN, not converged, no iterations; v = the start vector of its scan, where a chain that begins
+// at the head of a scan starts from)
+__global__ __launch_bounds__(256)
+void clear_excluded_kernel(const int* __restrict__ idx, int n_alpha, int n_omega, int NP, const double* __restrict__ v0,
+                           double* __restrict__ H, double* __restrict__ chi2, double* __restrict__ S, double* __restrict__ Q,
+                           double* __restrict__ v, int* __restrict__ niter, int* __restrict__ conv, int* __restrict__ nevals, int* __restrict__ nact)
+{
+    const size_t pidx = (size_t)idx[blockIdx.x];
+    const double nan = __builtin_nan("");
+    for (int i = threadIdx.x; i < n_omega; i += blockDim.x) H[pidx * n_omega + i] = nan;
+    const size_t chain = pidx / n_alpha;
+    for (int k = threadIdx.x; k < NP; k += blockDim.x) v[pidx * NP + k] = v0[chain * NP + k];
+    if (threadIdx.x == 0) { chi2[pidx] = nan; S[pidx] = nan; Q[pidx] = nan; niter[pidx] = 0; conv[pidx] = 0; nevals[pidx] = 0; nact[pidx] = 0; }
+}
+}  // namespace
 
 int mxe_chains_launch(mxe_ctx* ctx)
 try {
@@ -1050,6 +1124,13 @@ try {
             counter0 = (ctx->n_wg - ex.n_solo) * 4;
         }
         HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->dcounter.p, counter0, 1, ctx->stream));
+        if (!ctx->excluded.empty()) {
+            hipLaunchKernelGGL(clear_excluded_kernel, dim3((unsigned)ctx->excluded.size()), dim3(256), 0, ctx->stream,
+                               ctx->dexcluded.p, ctx->n_alpha, ctx->n_omega, ctx->NP, ctx->dv0.p, ctx->dout_H.p, ctx->dout_chi2.p,
+                               ctx->dout_S.p, ctx->dout_Q.p, ctx->dout_v.p, ctx->dout_niter.p, ctx->dout_conv.p,
+                               ctx->dout_nevals.p, ctx->dout_nact.p);
+            HIPCHK(ctx, hipGetLastError());
+        }
         ctx->last_nw = NWV; ctx->last_lds = (int)lds;
         const bool lead = kp.chain_lead != nullptr;
         ctx->last_kernel = "mxe::chain_kernel_mc<" + std::to_string(NA) + ", " + std::to_string(WGPC) + (lead ? ", lead" : "") +
@@ -1751,12 +1832,11 @@ try {
     if (!ctx->launched || !ctx->dsel3.p) return MXE_ERR_STATE;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t nc = ctx->n_chain, nw = ctx->n_omega;
-    const size_t n = out_H_selected ? 3 * nc * (nw + 1) : 3 * nc;
-    ctx->h_sel3.resize(n);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_sel3.data(), ctx->dsel3.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->h_sel3.resize(3 * nc);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_sel3.data(), ctx->dsel3.p, 3 * nc * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_H_selected) HIPCHK(ctx, d2h_pipelined(out_H_selected, ctx->dsel3.p + 3 * nc, 3 * nc * nw * 8, ctx->stream));
     HIPCHK(ctx, stream_wait(ctx->stream));
     for (size_t i = 0; i < 3 * nc; ++i) out_index[i] = (int32_t)ctx->h_sel3[i];
-    if (out_H_selected) std::memcpy(out_H_selected, ctx->h_sel3.data() + 3 * nc, 3 * nc * nw * 8);
     return MXE_OK;
 }
 MXE_CATCH_ALL

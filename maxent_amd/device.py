@@ -354,6 +354,20 @@ class DeviceContext(object):
         rotated space); D: n_elem x n_omega (including delta-omega)."""
         ds = _c(dataset_of_elem, np.int32)
         n_elem = len(ds)
+        if isinstance(G_list, np.ndarray) and G_list.ndim == 2:
+            # one row per element, all of one length
+            rows = np.asarray(self._ds_rows)[ds]
+            if G_list.shape[0] != n_elem or np.any(rows != G_list.shape[1]):
+                raise ValueError('G has shape {}, the data sets of its {} elements have {} rows'.format(
+                    G_list.shape, n_elem, sorted(set(rows.tolist()))))
+            G = _c(G_list)
+            offs = np.arange(n_elem, dtype=np.int64) * G_list.shape[1]
+            D = _c(D).reshape(n_elem, self.n_omega)
+            ent = _c(entropy, np.int32)
+            self._check(self._lib.mxe_elements_set(self._h, n_elem, _p(ds), _p(G), _p(offs), _p(D), _p(ent)),
+                        'mxe_elements_set')
+            self.n_elem = n_elem
+            return
         offs = np.zeros(n_elem, dtype=np.int64)
         chunks = []
         pos = 0

@@ -142,14 +142,24 @@ class ElementwiseMaxEnt(object):
         self._share_decomposition()
         direct = self._direct_input(worker) and per_job_D is None
         template = None
+        big = err_same = None
+        if direct and len(jobs) > 1:
+            # (all elements at once: which of them are below the threshold; one error array when it is the same for all)
+            Gm = self.G_mat[1]
+            with np.errstate(all='ignore'):
+                big = (np.max(np.abs(np.real(Gm)), axis=-1), np.max(np.abs(np.imag(Gm)), axis=-1) if np.iscomplexobj(Gm) else None)
+            e0 = self.get_error(tuple(jobs[0][0]))
+            if isinstance(self.error, float) or len(np.shape(self.error)) == self.error_dimension:
+                err_same = np.asarray(e0, dtype=float) * np.ones(np.shape(Gm)[-1])
         for n, (element, re) in enumerate(jobs):
             cidx = 0 if re else 1
             if direct and n > 0:
                 # array input, plain errors, unrotated kernel: the spec of every further element straight
                 # from the arrays (the worker keeps the first element's state until the last is loaded below)
                 g = self.G_mat[1][tuple(element)]
-                g = np.real(g) if (re or element[0] == element[1]) else np.imag(g)
-                if np.max(np.abs(g)) < loop.G_threshold:
+                real_part = re or element[0] == element[1]
+                g = np.real(g) if real_part else np.imag(g)
+                if (big[0] if real_part else big[1])[tuple(element)] < loop.G_threshold:
                     res._zero_elements.append(tuple(element) + ((cidx,) if self.use_complex else ()))
                     worker.logtaker.error_message('G below threshold, not performing the calculation.')
                     continue
@@ -158,7 +168,7 @@ class ElementwiseMaxEnt(object):
                     template['A_map'] = loop.A_of_H
                     spec = template
                 else:
-                    spec = loop.spec_like(template, g, self.get_error(tuple(element)))
+                    spec = loop.spec_like(template, g, self.get_error(tuple(element)) if err_same is None else err_same)
                 specs.append(spec)
                 live.append((element, cidx))
                 if n == len(jobs) - 1:
@@ -200,8 +210,7 @@ class ElementwiseMaxEnt(object):
             specs = [s for b in g for s in b['specs']]
             t0 = datetime.now()
             for b in g:
-                for (element, cidx) in b['live']:
-                    res.start_timing(element, cidx, time=t0)
+                res._start.update(dict.fromkeys([res._key(element, cidx) for (element, cidx) in b['live']], t0))
             sols, info = solve_elements(loop.K, specs, loop.minimizer,
                                         device_id=loop.device_id, device_ids=self.device_ids,
                                         want_logdet=loop.probability is not None,
@@ -244,22 +253,26 @@ class ElementwiseMaxEnt(object):
             res._default_analyzer_name = loop.analyzers[0].name
         sols, info, t1, per_alpha = batch['sols'], batch['info'], batch['t1'], batch['per_alpha']
         talk = bool(worker.logtaker.verbose & (VerbosityFlags.ElementInfo | VerbosityFlags.AlphaLoop))
-        for spec, sol, (element, cidx) in zip(specs, sols, live):
-            if talk:
+        if talk:
+            for sol, (element, cidx) in zip(sols, live):
                 worker.logtaker.message(
                     VerbosityFlags.ElementInfo,
                     'Element {} {}{}'.format(element[0], element[1],
                                              '' if cidx == 0 else ' (imaginary part)'))
                 loop.log_alpha_lines(sol)
-            rec = loop.make_record(spec, sol)
-            rec['run_times'] = [per_alpha] * len(sol['alpha'])
-            res.add_element_results(rec, element, cidx)
-            res.end_timing(element, cidx, time=t1)
+        records = loop.make_records(specs, sols)
+        times = {}
+        for rec in records:
+            X = len(rec['alpha'])
+            if X not in times:
+                times[X] = [per_alpha] * X
+            rec['run_times'] = times[X]
+        keys = res.add_batch_results(records, live, t_end=t1)
         if not talk and sols:
-            loop.note_minimizer_state(sols[-1], sum(int(np.sum(x['n_iter'])) for x in sols))
+            loop.note_minimizer_state(sols[-1], int(sum(np.sum(x['n_iter']) for x in sols)))
         # analyzers after every record of the batch is in (adding a record drops the assembled-array cache
         # of the result); the rows of A they select come off the device in one go
-        res.analyze_batch(loop.analyzers, [res._key(element, cidx) for (element, cidx) in live])
+        res.analyze_batch(loop.analyzers, keys)
         worker.logtaker.message(
             VerbosityFlags.Timing,
             '{} alpha scans x {} alpha in one launch: kernel {:.3f} ms',

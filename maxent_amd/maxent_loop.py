@@ -219,7 +219,9 @@ class MaxEntLoop(object):
         spec = dict(template)
         G_use = np.array(G, dtype=float)
         spec['G'] = spec['G_orig'] = G_use
-        spec['err'] = np.asarray(err, dtype=float) * np.ones(len(G_use))
+        # (an error array of the right length is taken as it is: the element-wise drivers hand the same one to every element)
+        spec['err'] = err if (isinstance(err, np.ndarray) and err.dtype == float and err.shape == G_use.shape) \
+            else np.asarray(err, dtype=float) * np.ones(len(G_use))
         return spec
 
     def make_record(self, spec, sol):
@@ -251,6 +253,28 @@ class MaxEntLoop(object):
         else:
             rec['probability'] = np.full(X, np.nan)
         return rec
+
+    def make_records(self, specs, sols):
+        """:meth:`make_record` for the scans of one launch: what they share is set up once"""
+        if self.probability is not None or any(sol.get('A') is not None for sol in sols):
+            return [self.make_record(spec, sol) for spec, sol in zip(specs, sols)]
+        from .batch_solver import LazyA, LazyH
+        A_of_H, K_delta, omega = self.A_of_H, self.K.K_delta, self.omega
+        nans = {}
+        out = []
+        for spec, sol in zip(specs, sols):
+            H = sol['H']
+            A = LazyA(H, A_of_H) if isinstance(H, LazyH) else A_of_H.f(H)
+            X = len(sol['alpha'])
+            nan = nans.get(X)
+            if nan is None:
+                nan = nans[X] = np.full(X, np.nan)
+                nan.setflags(write=False)           # (one array for every scan of the launch)
+            rec = dict(sol)
+            rec.update(A=A, G=spec['G'], G_orig=spec['G_orig'], data_variable=spec['data_variable'],
+                       G_rec=_LazyProduct(A, K_delta), omega=omega, probability=nan)
+            out.append(rec)
+        return out
 
     def log_alpha_lines(self, sol):
         """reference maxent_loop.py:248-257, 286-289."""

@@ -315,6 +315,19 @@ class MaxEntResult(MaxEntResultData):
         self._records[key] = record
         self._cache = dict()
 
+    def add_batch_results(self, records, elements, t_start=None, t_end=None):
+        """:meth:`add_element_results` (+ :meth:`start_timing` / :meth:`end_timing` when the times are given) for the
+        scans of one launch; ``elements``: (matrix_element, complex_index) pairs.  Returns their keys"""
+        keys = [self._key(element, cidx) for (element, cidx) in elements]
+        for key, rec in zip(keys, records):
+            self._records[key] = rec
+        if t_start is not None:
+            self._start.update(dict.fromkeys(keys, t_start))
+        if t_end is not None:
+            self._end.update(dict.fromkeys(keys, t_end))
+        self._cache = dict()
+        return keys
+
     def add_result(self, cost_function, log_probability=None, matrix_element=None, complex_index=None):
         """Append the result of ONE alpha (reference maxent_result.py:751-791): ``cost_function`` is a cost
         function evaluated at its optimum, ``Q(v)`` -- chi2, S, Q, H, A are read off it (device evaluation,

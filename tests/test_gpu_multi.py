@@ -88,6 +88,40 @@ def test_contexts_are_kept_between_runs_and_dropped_when_the_kernel_changes():
     assert K._batch_solvers[(0,)] is not first and res.A.shape[-1] == 100
 
 
+def test_a_new_object_on_the_same_grids_takes_over_the_contexts_unless_results_are_still_out():
+    """BatchSolver.for_kernel: an equal decomposition (contents) finds the pooled solver; results that somebody still
+    holds unfetched are not disturbed -- the next object then gets contexts of its own"""
+    a = job()
+    res_a = a.run()
+    solver_a = a.maxent_diagonal.K._batch_solvers[(0,)]
+    H_a = np.array(job().run().H)                    # (reference values, from yet another object)
+    A_out_a = np.array(res_a.A_out)
+    # results of a are out (H still on the device): b must not take a's contexts
+    b = job()
+    res_b = b.run()
+    solver_b = b.maxent_diagonal.K._batch_solvers[(0,)]
+    assert solver_b is not solver_a
+    assert np.array_equal(np.asarray(res_a.H), H_a)
+    # with everything fetched or dropped the next object takes over -- and solves other data correctly
+    res_a = res_b = None
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(3, 60, 120)
+    c = job()
+    c.set_G_tau_data(tau, 1.5 * Gmat)
+    res_c = c.run()
+    assert c.maxent_diagonal.K._batch_solvers[(0,)] in (solver_a, solver_b)
+    keep, BatchSolver.POOL_SIZE = BatchSolver.POOL_SIZE, 0
+    try:
+        d = job()
+        d.set_G_tau_data(tau, 1.5 * Gmat)
+        res_d = d.run()
+        assert d.maxent_diagonal.K._batch_solvers[(0,)] not in (solver_a, solver_b)
+    finally:
+        BatchSolver.POOL_SIZE = keep
+    for name in ('chi2', 'S', 'H', 'A_out'):
+        assert np.array_equal(np.asarray(getattr(res_c, name)), np.asarray(getattr(res_d, name))), name
+    assert not np.allclose(np.asarray(res_c.A_out), A_out_a)
+
+
 def test_process_ranks_comm_with_one_rank():
     """the entry points a one-process-per-GPU launcher uses (bench.py --gpus N), with the single rank this box has"""
     tau, omega, K, G = synthetic.single_G(40, 80)

@@ -163,3 +163,52 @@ def test_alphas_the_lock_step_layout_gives_up_on_are_finished_in_the_one_chain_l
     assert ctx.audit()['corr'].max() < 1e-6
     assert ctx.finish() == 0                      # nothing left to do
     ctx.close()
+
+
+def test_alphas_that_couple_more_than_32_directions_are_left_to_the_finishing_pass():
+    """Error bars of 1e-6: at the smallest alphas of the scan more than 32 singular directions couple, which the
+    lock-step kernel has no build for.  The launch stays in the lock-step layout with its pieces cut there; the
+    alphas behind the cut read NaN / not converged after the launch alone and are solved by mxe_chains_finish (one
+    warm chain per scan).  Against the one-chain layout on the whole batch and against the fixed point."""
+    n_orb, n_tau, n_omega, n_alpha, sigma = 3, 200, 500, 40, 1e-6
+    tau, omega, K, _, A_mat = synthetic.matrix_G(n_orb, n_tau, n_omega)
+    rng = np.random.RandomState(7)
+    noise = sigma * rng.randn(n_orb, n_orb, n_tau)
+    Gmat = np.einsum('tw,ijw->ijt', K.K_delta, A_mat) + 0.5 * (noise + noise.transpose(1, 0, 2))
+    K.reduce_singular_space(1e-14)
+    D = synthetic.flat_D(omega)
+    err = sigma * np.ones(n_tau)
+    alphas = np.array(synthetic.alpha_mesh(n_alpha)) * n_tau
+    elems = [(i, j) for i in range(n_orb) for j in range(n_orb)]
+    kinds = [device.ENTROPY_NORMAL if i == j else device.ENTROPY_PLUSMINUS for i, j in elems]
+    v0 = np.stack([hostprep.initial_v(K.V, D, omega.delta, k) for k in kinds])
+    n = len(elems)
+    ctx = device.DeviceContext(K.U, K.S, K.V)
+    ds = ctx.add_dataset(err)
+    ctx.set_elements([ds] * n, [Gmat[i, j] for i, j in elems], np.tile(D, (n, 1)), kinds)
+    a = ctx.solve_chains(np.arange(n), alphas, v0, device.default_opts(chains_per_wg=1))
+    assert ctx.last_launch_info()['kernel'].startswith('mxe::chain_kernel<')
+    # the launch alone: lock-step layout, the tail of every scan left out
+    ctx.upload_chains(np.arange(n, dtype=np.int32), alphas, v0, device.default_opts())
+    ctx.launch()
+    assert ctx.last_launch_info()['kernel'].startswith('mxe::chain_kernel_mc<')
+    raw = ctx.fetch(want_v=False, want_H=True)
+    left = ~raw['converged'].astype(bool)
+    # (in ``left`` also: alphas the lock-step kernel tried and gave up on, and the rest of their pieces)
+    out = left & (raw['n_iter'] == 0) & np.isnan(raw['chi2']) & np.all(np.isnan(raw['H']), axis=-1)
+    assert 0 < out.sum() <= out.size // 3
+    assert all(out[c, -1] for c in range(n))                          # the tail of every scan
+    assert ctx.finish() == int(left.sum())
+    b = ctx.fetch(want_v=True, want_H=True)
+    # (the three smallest alphas of the last diagonal element take more than 1000 iterations in either layout)
+    ok = b['converged'].astype(bool)
+    assert np.array_equal(ok, a['converged'].astype(bool)) and (~ok).sum() <= 4
+    assert np.all(b['n_iter'][left] > 0)
+    assert rel_l2(b['H'], a['H'])[ok].max() < 1e-6
+    np.testing.assert_allclose(b['chi2'][ok], a['chi2'][ok], rtol=1e-5)
+    audit = ctx.audit()['corr']
+    assert np.nanmax(audit[ok]) < 1e-6
+    # the whole thing in one call
+    c_ = ctx.solve_chains(np.arange(n), alphas, v0, device.default_opts())
+    assert np.array_equal(c_['converged'].astype(bool), ok) and rel_l2(c_['H'], b['H'])[ok].max() < 1e-9
+    ctx.close()
