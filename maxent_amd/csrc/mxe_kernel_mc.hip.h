@@ -942,18 +942,29 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         const HW& hw = hr[j & 3];
 #pragma unroll
                         for (int t = 0; t < 4; ++t) hp[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(f[t], hw.h, hp[t], 0, 0, 0);
-                        const float sw[MCC] = {hw.w.x, hw.w.y, hw.w.z, hw.w.w};
+                        // (the four products of a column tile as two packed multiplications, v_pk_mul_f32, and the remainders by
+                        //  v_fma_mix_f32 written out: 212 -> 176 vector instructions per trip, cfg4 0.870 -> 0.861 ms on one box;
+                        //  either alone: nothing, profiles/r03_c_experiments.txt)
+                        typedef float f2v __attribute__((ext_vector_type(2)));
+                        const f2v sw01 = {hw.w.x, hw.w.y}, sw23 = {hw.w.z, hw.w.w};
 #pragma unroll
                         for (int t = 0; t < NT; ++t) {
                             const float ff = (float)f[t];
+#ifndef MXE_X_NO_PKMUL
+                            const f2v ff2 = {ff, ff};
+                            const f2v x01 = ff2 * sw01, x23 = ff2 * sw23;
+                            const float xs[MCC] = {x01.x, x01.y, x23.x, x23.y};
+#else
+                            const float xs[MCC] = {ff * hw.w.x, ff * hw.w.y, ff * hw.w.z, ff * hw.w.w};
+#endif
 #pragma unroll
                             for (int c = 0; c < MCC; ++c) {
-                                const float xv = ff * sw[c];
+                                const float xv = xs[c];
                                 if (j & 1) {
                                     const float x0 = xe[c][t];
                                     const auto hh = __builtin_amdgcn_cvt_pkrtz(x0, xv);
                                     const unsigned hu = __builtin_bit_cast(unsigned, hh);
-#ifndef MXE_X_MIX      // (v_fma_mix_f32 for the remainder -- two instructions less per pair -- measured SLOWER: 0.927 against 0.915 ms, profiles/r03_a_experiments.txt)
+#ifdef MXE_X_NO_MIX    // (the compiler fuses this conversion and subtraction into v_fma_mix_f32 itself when the products are single multiplications; behind the packed ones it does not: 0.898 against 0.870 ms)
                                     const auto ll = __builtin_amdgcn_cvt_pkrtz(x0 - (float)hh[0], xv - (float)hh[1]);
 #else
                                     // remainder x - hi in ONE instruction per element: v_fma_mix_f32 reads the binary16
