@@ -344,7 +344,7 @@ class BatchSolver(object):
         element-wise drivers hand one default model, alpha mesh, start vector and error array to every element)"""
         first = specs[0][key]
         if isinstance(first, np.ndarray) and all(s[key] is first for s in specs):
-            return np.asarray(first, dtype=float).reshape(1, -1)
+            return np.array(first, dtype=float).reshape(1, -1)       # (a copy: what is staged must not follow an edit in place)
         rows = [np.asarray(s[key], dtype=float).ravel() for s in specs]
         return np.concatenate(rows).reshape(len(rows), -1)          # (np.stack costs 1 us per row)
 
@@ -356,7 +356,7 @@ class BatchSolver(object):
         if same_len:
             e0 = specs[0]['err']
             if isinstance(e0, np.ndarray) and e0.shape == (n_tau,) and all(s['err'] is e0 for s in specs):
-                errs = np.asarray(e0, dtype=float).reshape(1, -1)
+                errs = np.array(e0, dtype=float).reshape(1, -1)
             else:
                 errs = np.stack([np.asarray(s['err'], dtype=float) * np.ones(n_tau) for s in specs])
         else:

@@ -587,3 +587,126 @@ def test_analyzer_results_are_built_when_looked_at():
     assert one['linefit_params'] == ('p', (0, 1)) and built == [(0, 1)]
     assert out['LineFitAnalyzer'] is one and list(out.keys()) == ['LineFitAnalyzer', 'Other']
     assert pickle.loads(pickle.dumps(out))['Other'] == 'chi2 is all NaN'
+
+
+def test_staging_is_skipped_by_contents_and_shared_arrays_are_compared_as_one_row():
+    """BatchSolver._stage (no device: a stand-in context that counts the uploads): the same job again uploads nothing, an
+    edit of ONE element's data or of the shared default model uploads again; arrays that every element shares (the
+    element-wise drivers hand out one D, alpha, v0, error array) are held as one row"""
+    from maxent_amd.batch_solver import BatchSolver
+    from maxent_amd import device
+
+    class Ctx(object):
+        _n_chain = 0
+        calls = 0
+
+        def clear_datasets(self):
+            pass
+
+        def add_dataset(self, *a):
+            return 0
+
+        def set_elements(self, ds, G, D, kinds):
+            self.G, self.D = np.array(G), np.array(D)
+
+        def upload_chains(self, el, alpha, v0, opts):
+            self.calls += 1
+            self._n_chain = len(el)
+            self.alpha, self.v0 = np.array(alpha), np.array(v0)
+
+    class K(object):
+        rotation, U = None, None
+    n, rng = 5, np.random.RandomState(0)
+    D, al, v0, err = rng.rand(30), rng.rand(7), np.zeros(4), 1e-3 * np.ones(12)
+    specs = [dict(G=rng.rand(12), err=err, D=D, alpha=al, v0=v0, kind=device.ENTROPY_NORMAL, U_rot=None) for _ in range(n)]
+    rows = BatchSolver._rows_of(specs, 'D')
+    assert rows.shape == (1, 30)                               # shared: one row
+    assert BatchSolver._rows_of([dict(D=D), dict(D=D.copy())], 'D').shape == (2, 30)
+    bs = BatchSolver.__new__(BatchSolver)
+    ctx, opts = Ctx(), device.default_opts()
+    bs._stage(ctx, K, specs, opts)
+    assert ctx.calls == 1 and ctx.G.shape == (n, 12) and ctx.D.shape == (n, 30) and ctx.alpha.shape == (n, 7)
+    assert np.array_equal(ctx.D[3], D) and np.array_equal(ctx.G[2], specs[2]['G'])
+    bs._stage(ctx, K, [dict(s) for s in specs], opts)          # other dicts, same contents
+    assert ctx.calls == 1
+    again = [dict(s) for s in specs]
+    again[3]['G'] = again[3]['G'] + 1e-9
+    bs._stage(ctx, K, again, opts)
+    assert ctx.calls == 2 and np.array_equal(ctx.G[3], again[3]['G'])
+    D[5] *= 2.0                                                # the shared default model edited in place
+    bs._stage(ctx, K, again, opts)
+    assert ctx.calls == 3 and ctx.D[0, 5] == D[5]
+    own = [dict(s, D=D.copy()) for s in again]                 # every element its own copy, equal contents: shapes differ (5 rows / 1) -> staged again
+    bs._stage(ctx, K, own, opts)
+    assert ctx.calls == 4
+    bs._stage(ctx, K, [dict(s) for s in own], opts)
+    assert ctx.calls == 4
+    opts2 = device.default_opts(); opts2.maxiter = opts.maxiter + 1
+    bs._stage(ctx, K, own, opts2)
+    assert ctx.calls == 5
+
+
+def test_records_and_picks_of_a_launch_are_made_in_one_go():
+    """MaxEntLoop.make_records == make_record element by element; MaxEntResult.add_batch_results == add_element_results +
+    timings; analyzers._device_picks reads the launch's arrays directly and equals the per-element path"""
+    from maxent_amd import synthetic
+    from maxent_amd.maxent_loop import MaxEntLoop
+    from maxent_amd.maxent_result import MaxEntResult
+    from maxent_amd.analyzers import _device_picks
+    from maxent_amd.batch_solver import LazyA
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(2, 20, 30)
+    tm = mx.TauMaxEnt()
+    tm.set_verbosity(mx.VerbosityFlags.Quiet)
+    tm.set_G_tau_data(tau, Gmat[0, 0])
+    tm.omega = omega
+    tm.alpha_mesh = mx.LogAlphaMesh(alpha_min=1.0, alpha_max=100.0, n_points=4)
+    tm.set_error(1e-3)
+    loop = tm.maxent_loop
+    rng = np.random.RandomState(1)
+    n, X, nw = 3, 4, len(omega)
+    specs = [dict(G=rng.rand(20), G_orig=rng.rand(20), data_variable=np.asarray(tau), D=np.ones(nw), kind=0) for _ in range(n)]
+    sols = [dict(alpha=np.array([8.0, 4.0, 2.0, 1.0]), H=rng.rand(X, nw), A=None, v=rng.rand(X, 5), chi2=rng.rand(X), S=-rng.rand(X),
+                 Q=rng.rand(X), n_iter=np.ones(X, int), converged=np.ones(X, bool), n_evals=np.ones(X, int)) for _ in range(n)]
+    many = loop.make_records(specs, sols)
+    for spec, sol, rec in zip(specs, sols, many):
+        one = loop.make_record(spec, sol)
+        assert set(one) == set(rec)
+        for k in ('A', 'G', 'G_orig', 'chi2', 'omega', 'G_rec', 'probability'):
+            assert np.array_equal(np.asarray(one[k]), np.asarray(rec[k]), equal_nan=True), k
+    assert many[0]['probability'] is many[1]['probability'] and not many[0]['probability'].flags.writeable
+    res = MaxEntResult(matrix_structure=(2, 2), element_wise=True, complex_elements=False, use_hermiticity=False)
+    import datetime
+    t0, t1 = datetime.datetime(2020, 1, 1), datetime.datetime(2020, 1, 1, 0, 0, 2)
+    elements = [((0, 0), 0), ((0, 1), 0), ((1, 1), 0)]
+    res._start.update(dict.fromkeys([res._key(e, c) for e, c in elements], t0))
+    keys = res.add_batch_results(many, elements, t_end=t1)
+    assert keys == [(0, 0), (0, 1), (1, 1)] and res._records[(0, 1)] is many[1]
+    assert res._end[(1, 1)] - res._start[(1, 1)] == datetime.timedelta(seconds=2)
+    # device picks: from the launch's arrays (batch) and element by element
+    class Map(object):
+        def matrix(self):
+            return None
+
+        def f(self, H):
+            return np.asarray(H) / 0.5
+    m = Map()
+    idx = np.array([[1, 2, 0], [3, 3, 3], [0, 1, 2]], dtype=np.int32)
+    rows = rng.rand(3, n, nw)
+    params = (0, 0.2)
+    for c, key in enumerate(keys):
+        rec = res._records[key]
+        rec['A'] = LazyA(rec['H'], m)
+        rec['device_select'] = dict(params=params, index=idx[:, c], H=rows[:, c], batch=(idx, rows), chain=c)
+    for which in (0, 1, 2):
+        got = _device_picks(res, keys, which, lambda p: p[0] == 0)
+        assert got[0] == idx[which].tolist()
+        assert np.array_equal(np.array(got[1]), rows[which] / 0.5)
+        for rec in res._records.values():
+            rec['device_select'].pop('batch')
+        slow = _device_picks(res, keys, which, lambda p: p[0] == 0)
+        assert slow[0] == got[0] and np.array_equal(np.array(slow[1]), np.array(got[1]))
+        for c, key in enumerate(keys):
+            res._records[key]['device_select']['batch'] = (idx, rows)
+    assert _device_picks(res, keys, 0, lambda p: p[0] == 1) is None            # another parameter than the device used
+    idx[2, 1] = -1
+    assert _device_picks(res, keys, 2, lambda p: True) is None                 # an element without a choice
