@@ -869,29 +869,42 @@ try {
         if (worst32 <= 1e-2) ctx->mc_na = 32;
         else {
             // Some alphas couple more than 32 directions (very small error bars: sigma = 1e-6 on the BASELINE grids does at
-            // the 27 smallest of 100 alphas).  Until r03 the whole launch then went to the one-chain layout (7 x slower);
-            // now the pieces are cut where the criterion fails -- coupling grows as alpha falls, so that is the tail of a
-            // scan --, the lock-step kernel solves what it has a build for, and the alphas behind the cut are left open
-            // for mxe_chains_finish: one warm chain per scan from the last alpha before the cut (records of such alphas
-            // are NaN / not converged / 0 iterations until then: clear_excluded_kernel).  Measured on the BASELINE batch with
-            // sigma = 4e-6 / 2e-6 / 1e-6 (maxiter 100): 15.4 / 17.1 / 146 ms in the one-chain layout, 7.9 / 12.6 / 55 ms this
-            // way -- of which the lock-step launch is 2-3 ms: the rest is the serial depth of the finishing chains (13-30
-            // alphas x 2.4 iterations x 150-190 us: the one-chain kernel with 64 coupled directions).  Leaving the cut
-            // alphas to the lock-step kernel's own give-up instead costs accuracy (exact Newton correction up to 9e-7,
-            // p99 1e-7, against 4e-8 / 2e-9) for the same time.  Not when more than a third of the alphas would be left
-            // to that pass (sigma = 5e-7: 197 against 150 ms).  profiles/r03_c_cut_pieces.txt
+            // the 27 smallest of 100 alphas).  Until r03 the whole launch then went to the one-chain layout (7 x slower).
+            // (a) Plus-minus scans: the build with a 64-row active block -- ten Gram tiles per slot (80 KB of the LDS: one
+            // workgroup per CU, n_omega_pad <= 512) and the one-row-per-lane elimination (gj1_solve_rows_f32).  240
+            // off-diagonal scans x 100 alphas at sigma = 4e-6 ... 5e-7: 2.2 / 3.5 / 3.8 / 4.4 ms, nothing left over, audit
+            // 5e-10 (one-chain layout: 12.8 ms).  (b) Normal-entropy scans: their systems at those alphas are ill conditioned
+            // beyond what the binary16 Gram products of either lock-step build resolve (the iteration crawls to its limit
+            // where the one-chain kernel, binary64 throughout, takes 3-28 steps): their pieces are cut where the criterion
+            // fails -- coupling grows as alpha falls, so that is the tail of a scan -- and the alphas behind the cut are left
+            // open for mxe_chains_finish: one warm chain per scan from the last alpha before the cut (records of such alphas
+            // are NaN / not converged / 0 iterations until then: clear_excluded_kernel).  Without the 64-row build (a larger
+            // frequency mesh) the plus-minus scans are cut as well.  Measured on the BASELINE batch (16 diagonal + 240
+            // off-diagonal scans) with sigma = 4e-6 / 2e-6 / 1e-6 (maxiter 100): 15.4 / 17.1 / 146 ms in the one-chain
+            // layout, 8-12 / 11-16 / 55-63 ms in every variant of this -- the serial depth of the 16 finishing chains (13-30
+            // alphas x 3-28 iterations x 150-190 us in the one-chain kernel with 64 coupled directions) is the floor.
+            // Leaving the cut alphas to the lock-step kernel's own give-up costs accuracy in the 32-row build (exact Newton
+            // correction up to 9e-7, p99 1e-7, against 4e-8 / 2e-9) and time in the 64-row build (pieces of 10 alphas x 32
+            // iterations: launch 8-9 ms).  Not when more than a third of the alphas would be left to the finishing pass
+            // (sigma = 5e-7 without the 64-row build: 197 against 150 ms).  profiles/r03_c_cut_pieces.txt, r03_e_na64.txt
+            const bool have64 = !getenv("MXE_NO_NA64") && ns > 32 && o.wg_per_cu != 2 && mc_lds_bytes(64, ctx->nwp, 1) <= 160 * 1024 - 6144;
+            bool need64 = false;
             std::vector<char> bad(P, 0);
             size_t n_bad = 0;
             for (int c = 0; c < n_chain; ++c) {
                 const int e = elem_of_chain[c];
                 const DataSet& DS = ctx->ds[ctx->elem_ds[e]];
                 const double lim = 1e-2 / (DS.c[32] * DS.c[32] * std::max(1.0, ctx->h_sumD[e]));    // alpha >= 1 / lim passes
+                const bool to64 = have64 && ctx->elem_kind[e] != MXE_ENTROPY_NORMAL;
                 for (int i = 0; i < n_alpha; ++i)
-                    if (!(alpha_dev[(size_t)c * n_alpha + i] * lim >= 1.0)) { bad[(size_t)c * n_alpha + i] = 1; ++n_bad; }
+                    if (!(alpha_dev[(size_t)c * n_alpha + i] * lim >= 1.0)) {
+                        if (to64) need64 = true;
+                        else { bad[(size_t)c * n_alpha + i] = 1; ++n_bad; }
+                    }
             }
             if (3 * n_bad > P) layout = 1;
             else {
-                ctx->mc_na = 32;
+                ctx->mc_na = need64 ? 64 : 32;
                 std::vector<char> covered(P, 0);
                 size_t w = 0;
                 for (size_t sc = 0; sc < ctx->sub_elem.size(); ++sc) {
@@ -1104,7 +1117,7 @@ try {
         // overrides (the passes of that build want n_omega_pad in units of 256)
         const int NA = ctx->mc_na, WGPC = ctx->mc_wgpc;
         const bool GST = ctx->mc_gst;
-        const int NWV = (WGPC == 1 && ctx->nwp % 256 == 0 && o.waves_per_chain != 4 &&
+        const int NWV = (NA == 32 && WGPC == 1 && ctx->nwp % 256 == 0 && o.waves_per_chain != 4 &&
                          mc_lds_bytes(NA, ctx->nwp, 1, 8, GST) <= 160 * 1024 - 6144) ? 8 : 4;
         const size_t lds = mc_lds_bytes(NA, ctx->nwp, WGPC, NWV, GST);
         if (lds > 160 * 1024 - 6144) return MXE_ERR_LIMIT;
@@ -1142,7 +1155,8 @@ try {
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb__, (const void*)mxe::chain_kernel_mc<NA_, WG_, LD_, __VA_ARGS__>, 64 * NWV_, lds); \
             fprintf(stderr, "[mxe] lock-step kernel NA=%d NWV=%d lds=%zu: %d workgroup(s) per CU resident\n", NA_, NWV_, (size_t)lds, nb__); } \
         if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<NA_, WG_, LD_, __VA_ARGS__>), dim3(ctx->n_wg), dim3(64 * NWV_), lds, ctx->stream, kp, ex); e = hipGetLastError(); } } while (0)
-        if (GST) { if (NWV == 8) MXE_LAUNCH_MC(32, 1, true, 8, true); else MXE_LAUNCH_MC(32, 1, true, 4, true); }
+        if (NA == 64) { if (lead) MXE_LAUNCH_MC(64, 1, true, 4); else MXE_LAUNCH_MC(64, 1, false, 4); }
+        else if (GST) { if (NWV == 8) MXE_LAUNCH_MC(32, 1, true, 8, true); else MXE_LAUNCH_MC(32, 1, true, 4, true); }
         else if (NA == 32 && WGPC == 2) { if (lead) MXE_LAUNCH_MC(32, 2, true, 4); else MXE_LAUNCH_MC(32, 2, false, 4); }
         else if (NWV == 8) { if (lead) MXE_LAUNCH_MC(32, 1, true, 8); else MXE_LAUNCH_MC(32, 1, false, 8); }
         else { if (lead) MXE_LAUNCH_MC(32, 1, true, 4); else MXE_LAUNCH_MC(32, 1, false, 4); }

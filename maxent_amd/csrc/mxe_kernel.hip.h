@@ -403,6 +403,51 @@ __device__ __forceinline__ bool gj2_solve64_f32(float (&A)[N / 2], float b, int 
     return ok;
 }
 
+// Gauss-Jordan elimination of an N x N positive definite system with MORE than 32 rows (N <= 64) on one wavefront, in
+// binary32: lane i holds row i -- all N columns, static indices -- and its right-hand side; one pivot per step, the pivot
+// row broadcast column by column with v_readlane (the two-half layout of gj2_solve64 has 32 rows).  Rows and columns
+// are scaled by the caller to a diagonal of O(1), as there.  N (N - 1) / 2 multiply-adds and as many broadcasts per
+// lane: 64 rows cost four times what 32 rows cost in the two-half layout -- and a sixth of the Cholesky factorisation in
+// LDS that systems of this size go through in the one-chain kernel.  Steps j >= n_live are identity rows and skipped.
+template <int N>
+__device__ __forceinline__ bool gj1_solve_rows_f32(float (&A)[N], float b, int i, int n_live, float& z, bool& small_pivot)
+{
+#ifndef MXE_X_PIV_TAU
+#define MXE_X_PIV_TAU 1e-3f
+#endif
+    constexpr float PIV_TAU = MXE_X_PIV_TAU;
+    bool ok = true;
+    small_pivot = false;
+    float d = 1.0f;                              // the lane's own pivot
+    auto step = [&](auto JTag) {
+        constexpr int j = decltype(JTag)::value;
+        if (j < n_live) {                        // (wave-uniform)
+            const float pjj = wave_bcast_f(A[j], j);
+            if (!(pjj > 0.0f)) ok = false;
+            if (pjj < PIV_TAU) small_pivot = true;
+            float inv = __builtin_amdgcn_rcpf(pjj);
+            inv = __builtin_fmaf(__builtin_fmaf(-pjj, inv, 1.0f), inv, inv);
+            const bool own = (i == j);
+            if (own) d = pjj;
+            const float m = own ? 0.0f : A[j] * inv;             // this row's multiplier (the pivot row stays)
+            b = __builtin_fmaf(-m, wave_bcast_f(b, j), b);
+#pragma unroll
+            for (int k0 = j + 1; k0 < N; k0 += 8) {
+                float r[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (k0 + e < N) r[e] = wave_bcast_f(A[k0 + e], j);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (k0 + e < N) A[k0 + e] = __builtin_fmaf(-m, r[e], A[k0 + e]);
+            }
+        }
+    };
+    static_for_seq(std::make_integer_sequence<int, N>{}, step);
+    float inv = __builtin_amdgcn_rcpf(d);
+    inv = __builtin_fmaf(__builtin_fmaf(-d, inv, 1.0f), inv, inv);
+    z = b * inv;
+    return ok;
+}
+
 // block-wide reduction of NV sums and one max; results valid in every thread.
 template <int NW, int NV>
 __device__ __forceinline__ void block_reduce(double (&x)[NV], double& mx, double* red /*[NW*(NV+1)]*/) {

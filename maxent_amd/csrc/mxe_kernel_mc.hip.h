@@ -92,6 +92,12 @@ constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
 #ifndef MXE_X_ILL_ITERS
 #define MXE_X_ILL_ITERS 8      // iterations an alpha gets after its solve first met a small pivot, before it is handed to the one-chain kernel
 #endif
+#ifndef MXE_X_SLOW_STEPS
+#define MXE_X_SLOW_STEPS 0     // full Newton steps in a row that do not halve the correction before an alpha is handed over (0: never).
+                               // Built for VERDICT r02 item 7 and measured with 3: an iteration of this kernel costs 1 / 25 of one of the one-chain
+                               // kernel the alpha is handed to, so crawling to the limit of 32 is the cheaper way -- stress set 2401 -> 6953
+                               // alphas finished there, solve wall in sum 1466 -> 1595 ms; sigma = 2e-6 batch 11.0 -> 13.0 ms (profiles/r03_e_na64.txt)
+#endif
 #ifndef MXE_X_RD1
 #define MXE_X_RD1 4        // (8: the shards of an 8-GPU job 0.593 / 0.653 -> 0.617 / 0.688 ms)
 #endif
@@ -179,14 +185,17 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         int elem, prob0, clen, ia, niter, nevals, nact, active, scratch, okprev, bt, capp;
         int lead;          // LEAD builds: alphas of the scan the piece walks through before its own first one (see start_piece)
         int wide;          // 1 + the iteration of this alpha at which the binary32 elimination first met a small pivot (0: never)
+        double dHp;        // square of the correction of this alpha's previous step if that was a full Newton step (times |H|^2), else 0
+        int slow;          // consecutive full Newton steps of this alpha that did not halve the correction
     };
     // the alphas of a slot's piece (a dependent global load in the accept step costs its full latency)
     constexpr int ACAP = UREG ? 32 : 128;
     __shared__ double s_alpha[MCC][ACAP];
-    __shared__ double s_sd[MCC][13];
+    __shared__ double s_sd[MCC][14];
     __shared__ float s_zp[MCC][2][16];          // binary32 solve: z of the scaled system by column parity
+    __shared__ __attribute__((aligned(16))) float s_zr[MCC][NA > 32 ? 64 : 4];     // ... of the one-row-per-lane solve (NA > 32)
     __shared__ double s_scw[MCC][2];             // row pass: 1 / sc2 of the sw it reads, sc2 of the sw it writes
-    __shared__ int s_si[MCC][14];
+    __shared__ int s_si[MCC][15];
     auto load_slot = [&](Slot& t) {
         const double* d = s_sd[wave]; const int* n = s_si[wave];
         t.alpha = d[0]; t.mu = d[1]; t.chi2 = d[2]; t.S = d[3]; t.Hn2 = d[4]; t.wmax = d[5];
@@ -195,7 +204,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         t.nact = n[6]; t.active = n[7]; t.scratch = n[8]; t.okprev = n[9]; t.bt = n[10]; t.capp = n[11];
         t.lead = 0;
         if constexpr (LEAD) t.lead = n[12];
-        t.wide = n[13];
+        t.wide = n[13]; t.slow = n[14]; t.dHp = d[13];
     };
     auto store_slot = [&](const Slot& t) {
         if (lane == 0) {
@@ -205,7 +214,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             n[0] = t.elem; n[1] = t.prob0; n[2] = t.clen; n[3] = t.ia; n[4] = t.niter; n[5] = t.nevals;
             n[6] = t.nact; n[7] = t.active; n[8] = t.scratch; n[9] = t.okprev; n[10] = t.bt; n[11] = t.capp;
             if constexpr (LEAD) n[12] = t.lead;
-            n[13] = t.wide;
+            n[13] = t.wide; n[14] = t.slow; d[13] = t.dHp;
             s_act[wave] = t.active; s_scr[wave] = t.scratch;
         }
         wave_sync();
@@ -221,7 +230,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         // with a loose tolerance (alphas number -lead .. -1: starting points only, no records), and goes on as usual
         const int lead = LEAD ? p.chain_lead[c] : 0;
         t.lead = lead;
-        t.ia = -lead; t.niter = 0; t.nevals = 0; t.nact = 0; t.okprev = 0; t.bt = 0; t.capp = 0; t.wide = 0;
+        t.ia = -lead; t.niter = 0; t.nevals = 0; t.nact = 0; t.okprev = 0; t.bt = 0; t.capp = 0; t.wide = 0; t.slow = 0; t.dHp = 0.0;
         for (int i = lane; i < min(t.clen + lead, ACAP); i += 64) s_alpha[wave][i] = p.alpha[(size_t)(t.prob0 - lead) + i];
         t.alpha = p.alpha[(size_t)(t.prob0 - lead)];
         t.mu = 0.0; t.muh = 0.0; t.Qprev = __builtin_nan("");
@@ -423,6 +432,68 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         return ok;
     };
 
+    // More than 32 coupled directions (NA = 48 / 64 builds): one row per lane, all N columns in registers, pivot rows by
+    // v_readlane (gj1_solve_rows_f32).  Same scaling, same quadratic form for the norm of the step.
+    auto gj_home_rows = [&](auto NTag, double a, int n_act, double isc2, double& nrm_out, bool& small_pivot) -> bool {
+        constexpr int N = decltype(NTag)::value;
+        static_assert(N <= 64 && N <= NA, "one row per lane");
+        const int q = wave;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int i = ln;
+        const double* Wq = Wt + (size_t)q * NPAIR * 256;
+        const double* rq = rhs + q * NP;
+        const double* cq = csc + q * NP;
+        const bool live = i < n_act;
+        const double si = ssc[q * NP + i];
+        const double cis = (live ? cq[i] : 0.0) * isc2;
+        float A[N], A0[N];
+        {
+            const int ic = min(i, N - 1);
+            const int imt = ic >> 4, iri = ic & 15;
+            const int up_l = (imt * NT - imt * (imt - 1) / 2 - imt) * 256 + (iri & 3) * 64 + (iri >> 2) * 16;    // row ic, column k >= ic
+            const int lo_l = imt * 256 + iri;                                                                  // row k < ic, column ic
+#pragma unroll
+            for (int k0 = 0; k0 < N; k0 += 8) {
+                double wr[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = k0 + e, kmt = k >> 4, kri = k & 15;
+                    const int up_s = kmt * 256 + kri;
+                    const int lo_s = (kmt * NT - kmt * (kmt - 1) / 2 - kmt) * 256 + (kri & 3) * 64 + (kri >> 2) * 16;
+                    wr[e] = Wq[(k >= ic) ? up_l + up_s : lo_l + lo_s];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = k0 + e;
+                    double xv = (k < n_act) ? cis * wr[e] * cq[k] : 0.0;
+                    A0[k] = (float)xv;
+                    if (k == i) xv = live ? fma(a * si, si, xv) : 1.0;
+                    A[k] = (float)xv;
+                }
+            }
+        }
+        MXE_STAMPH(1);
+        float zf;
+        small_pivot = false;
+        const bool ok = gj1_solve_rows_f32<N>(A, live ? (float)(rq[i] * si) : 0.0f, i, n_act, zf, small_pivot);
+        const double z = (double)zf * si;
+        s_zr[q][i & (NA > 32 ? 63 : 3)] = live ? zf : 0.0f;
+        wave_sync();
+        float y = 0.0f;
+#pragma unroll
+        for (int k0 = 0; k0 < N; k0 += 4) {
+            const float4 z4 = *reinterpret_cast<const float4*>(&s_zr[q][(NA > 32) ? k0 : 0]);
+            y = __builtin_fmaf(A0[k0], z4.x, y); y = __builtin_fmaf(A0[k0 + 1], z4.y, y);
+            y = __builtin_fmaf(A0[k0 + 2], z4.z, y); y = __builtin_fmaf(A0[k0 + 3], z4.w, y);
+        }
+        nrm_out = wave_sum(live ? (double)(zf * y) : 0.0);
+        MXE_STAMPH(3);
+        if (ok && live) zz[q * NP + i] = z;
+        MXE_STAMPH(4);
+        return ok;
+    };
+
     // WGPC = 2: u of the eight (row, slot) elements this lane updates in the row pass (n_omega_pad <= 512:
     // one batch of eight tiles per wave covers every row)
     double ureg[8 - UL];
@@ -545,11 +616,21 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         t.pred = pred_here;
                         ++t.niter;
                         const bool newton_step = t.okprev != 4 && !fresh;       // a halved step says nothing about convergence
+                        // Contraction: a full Newton step that does not even halve the correction of the full step before it.
+                        // Three of them in a row, eight iterations into the alpha: the Newton matrix of this layout (binary16
+                        // Gram products, binary32 elimination, at most NA coupled directions) does not fit this system and
+                        // the iteration would crawl to its limit of 32 -- the alpha is handed over now (MXE_X_SLOW_STEPS)
+                        {
+                            const bool full = newton_step && t.okprev == 1 && t.muh == 0.0;
+                            t.slow = (full && t.dHp > 0.0 && sdH > 0.25 * t.dHp) ? t.slow + 1 : 0;
+                            t.dHp = full ? sdH : 0.0;
+                        }
                         t.bt = 0;
                         if (newton_step && p.tol_h > 0.0 && relH2_min < tol2Hn && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                         else if (p.tol_relq > 0.0 && fabs(fabs(t.Qprev - t.Q) / t.Q) < p.tol_relq && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                         else if (t.niter >= ((LEAD && t.ia < 0 && t.ia > -t.lead) ? MXE_X_WALK_ITERS : p.mc_maxiter)) finish_alpha = true;   // (an alpha of a walk is a starting point: a few rounds, then on)
                         else if (t.wide > 0 && t.niter - t.wide >= MXE_X_ILL_ITERS) finish_alpha = true;    // (ill conditioned for the binary32 solve: handed over)
+                        else if (MXE_X_SLOW_STEPS > 0 && t.slow >= MXE_X_SLOW_STEPS && t.niter >= 8 && (!LEAD || t.ia >= 0)) finish_alpha = true;    // (crawling: handed over)
                     }
                     MXE_STAMPA(2);
                     if (fresh && t.scratch == 2) t.scratch = 0;     // accepted or to be halved: the state in LDS is that trial point
@@ -604,7 +685,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                             }
                             t.ia = t.clen;
                         }
-                        t.niter = 0; t.nevals = 0; t.mu = 0.0; t.bt = 0; t.capp = 0; t.pred = 0.0; t.wide = 0;
+                        t.niter = 0; t.nevals = 0; t.mu = 0.0; t.bt = 0; t.capp = 0; t.pred = 0.0; t.wide = 0; t.slow = 0; t.dHp = 0.0;
                         t.Qprev = __builtin_nan("");
                         if (t.ia >= t.clen) {
                             t.active = 0;
@@ -670,6 +751,13 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     ia = fma(fma(-a, ia, 1.0), ia, ia);
                     bool ok, small = false;
                     double nrm_gj = -1.0;
+                    if constexpr (NA > 32) {
+                        // (the build for more than 32 coupled directions: two sizes of the one-row-per-lane solve beside the
+                        //  32-row two-half one)
+                        if (na <= 32) ok = gj_home(std::integral_constant<int, 32>{}, a, na, isc2, nrm_gj, small);
+                        else if (na <= 48) ok = gj_home_rows(std::integral_constant<int, 48>{}, a, na, isc2, nrm_gj, small);
+                        else ok = gj_home_rows(std::integral_constant<int, (NA > 48 ? 64 : 48)>{}, a, na, isc2, nrm_gj, small);
+                    } else
                     if (na <= 16) ok = gj_home(std::integral_constant<int, 16>{}, a, na, isc2, nrm_gj, small);
                     else if (na <= 20) ok = gj_home(std::integral_constant<int, 20>{}, a, na, isc2, nrm_gj, small);
                     else if (na <= 24) ok = gj_home(std::integral_constant<int, 24>{}, a, na, isc2, nrm_gj, small);

@@ -165,11 +165,12 @@ def test_alphas_the_lock_step_layout_gives_up_on_are_finished_in_the_one_chain_l
     ctx.close()
 
 
-def test_alphas_that_couple_more_than_32_directions_are_left_to_the_finishing_pass():
-    """Error bars of 1e-6: at the smallest alphas of the scan more than 32 singular directions couple, which the
-    lock-step kernel has no build for.  The launch stays in the lock-step layout with its pieces cut there; the
-    alphas behind the cut read NaN / not converged after the launch alone and are solved by mxe_chains_finish (one
-    warm chain per scan).  Against the one-chain layout on the whole batch and against the fixed point."""
+def test_more_than_32_coupled_directions_stay_in_the_lock_step_layout():
+    """Error bars of 1e-6: at the smallest alphas of the scan more than 32 singular directions couple.  Plus-minus scans
+    run in the build with a 64-row active block; the pieces of the normal-entropy scans are cut there (their systems are
+    too ill conditioned for the binary16 Gram products): the alphas behind the cut read NaN / not converged after the
+    launch alone and are solved by mxe_chains_finish (one warm chain per scan).  Against the one-chain layout on the
+    whole batch, with the audit."""
     n_orb, n_tau, n_omega, n_alpha, sigma = 3, 200, 500, 40, 1e-6
     tau, omega, K, _, A_mat = synthetic.matrix_G(n_orb, n_tau, n_omega)
     rng = np.random.RandomState(7)
@@ -191,13 +192,15 @@ def test_alphas_that_couple_more_than_32_directions_are_left_to_the_finishing_pa
     # the launch alone: lock-step layout, the tail of every scan left out
     ctx.upload_chains(np.arange(n, dtype=np.int32), alphas, v0, device.default_opts())
     ctx.launch()
-    assert ctx.last_launch_info()['kernel'].startswith('mxe::chain_kernel_mc<')
+    assert ctx.last_launch_info()['kernel'].startswith('mxe::chain_kernel_mc<64, 1')
     raw = ctx.fetch(want_v=False, want_H=True)
     left = ~raw['converged'].astype(bool)
     # (in ``left`` also: alphas the lock-step kernel tried and gave up on, and the rest of their pieces)
     out = left & (raw['n_iter'] == 0) & np.isnan(raw['chi2']) & np.all(np.isnan(raw['H']), axis=-1)
     assert 0 < out.sum() <= out.size // 3
-    assert all(out[c, -1] for c in range(n))                          # the tail of every scan
+    normal = np.array(kinds) == device.ENTROPY_NORMAL
+    assert all(out[c, -1] for c in range(n) if normal[c])             # the tail of every normal-entropy scan
+    assert not out[~normal].any() and not left[~normal].any()         # the plus-minus scans are done
     assert ctx.finish() == int(left.sum())
     b = ctx.fetch(want_v=True, want_H=True)
     # (the three smallest alphas of the last diagonal element take more than 1000 iterations in either layout)
@@ -211,4 +214,36 @@ def test_alphas_that_couple_more_than_32_directions_are_left_to_the_finishing_pa
     # the whole thing in one call
     c_ = ctx.solve_chains(np.arange(n), alphas, v0, device.default_opts())
     assert np.array_equal(c_['converged'].astype(bool), ok) and rel_l2(c_['H'], b['H'])[ok].max() < 1e-9
+    ctx.close()
+
+
+def test_off_diagonal_batch_with_64_coupled_directions_needs_no_finishing_pass():
+    """plus-minus scans only, error bars of 1e-6: the 64-row build solves everything; against the one-chain layout"""
+    n_orb, n_tau, n_omega, n_alpha, sigma = 3, 200, 500, 30, 1e-6
+    tau, omega, K, _, A_mat = synthetic.matrix_G(n_orb, n_tau, n_omega)
+    rng = np.random.RandomState(11)
+    noise = sigma * rng.randn(n_orb, n_orb, n_tau)
+    Gmat = np.einsum('tw,ijw->ijt', K.K_delta, A_mat) + 0.5 * (noise + noise.transpose(1, 0, 2))
+    K.reduce_singular_space(1e-14)
+    D = synthetic.flat_D(omega)
+    err = sigma * np.ones(n_tau)
+    alphas = np.array(synthetic.alpha_mesh(n_alpha)) * n_tau
+    elems = [(i, j) for i in range(n_orb) for j in range(n_orb) if i != j]
+    kinds = [device.ENTROPY_PLUSMINUS] * len(elems)
+    v0 = np.stack([hostprep.initial_v(K.V, D, omega.delta, k) for k in kinds])
+    n = len(elems)
+    ctx = device.DeviceContext(K.U, K.S, K.V)
+    ds = ctx.add_dataset(err)
+    ctx.set_elements([ds] * n, [Gmat[i, j] for i, j in elems], np.tile(D, (n, 1)), kinds)
+    a = ctx.solve_chains(np.arange(n), alphas, v0, device.default_opts(chains_per_wg=1))
+    assert ctx.last_launch_info()['kernel'].startswith('mxe::chain_kernel<')
+    ctx.upload_chains(np.arange(n, dtype=np.int32), alphas, v0, device.default_opts())
+    ctx.launch()
+    assert ctx.last_launch_info()['kernel'].startswith('mxe::chain_kernel_mc<64, 1')
+    b = ctx.fetch(want_v=True, want_H=True)
+    assert b['converged'].all() and a['converged'].all() and ctx.finish() == 0
+    assert b['n_act'].max() > 32 if 'n_act' in b else True
+    assert rel_l2(b['H'], a['H']).max() < 1e-7
+    np.testing.assert_allclose(b['chi2'], a['chi2'], rtol=1e-6)
+    assert np.nanmax(ctx.audit()['corr']) < 1e-8
     ctx.close()
