@@ -47,6 +47,7 @@
 #ifndef MAXENT_HIP_H
 #define MAXENT_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -137,6 +138,13 @@ const char* mxe_version(void);
 /* first 16 hex digits of the SHA-256 over the library's sources (the .hip and .hip.h files of csrc/, this header) as the Makefile
    saw them when it built this binary: bench.py only trusts a counter profile under profiles/ that records the same hash */
 const char* mxe_source_hash(void);
+/* Page-locked host memory for result arrays (the destination of mxe_chains_fetch / mxe_fetch_rows / mxe_select3_fetch may be
+   any host memory; into a block of this call the copy is one DMA at the rate of the link -- all H of the BASELINE batch,
+   102 MB: 3 ms against 11-22 ms into pageable memory).  The library keeps a few freed blocks for the next call.  NULL when
+   the runtime cannot pin that much.  What they replace in the reference: numpy's allocation of MaxEntResult's arrays
+   (maxent_result.py:835-967). */
+void* mxe_host_alloc(size_t bytes);
+void  mxe_host_free(void* block);
 const char* mxe_strerror(int code);
 int  mxe_device_count(int* n_devices);
 void mxe_opts_default(mxe_opts* opts);

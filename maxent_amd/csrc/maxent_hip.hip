@@ -18,6 +18,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <map>
 #include <vector>
 #include <mutex>
 #include <tuple>
@@ -105,8 +106,55 @@ struct PinnedPair {
 };
 PinnedPair g_pinned;
 
+// Pinned host memory for the callers' result arrays (mxe_host_alloc / mxe_host_free): a copy into it runs at the rate of the
+// link (102 MB: 2-3 ms) where one into pageable memory takes 11-22 ms even through the staging pair above -- page faults of
+// the fresh destination and the second pass of the host copy.  Blocks are kept (a few, best fit) because pinning costs
+// about as much as the copy it saves.
+struct HostPool {
+    std::mutex mu;
+    std::map<void*, size_t> live;                // handed out: base -> bytes
+    std::vector<std::pair<void*, size_t>> idle;
+    static constexpr size_t KEEP = 3;
+    void* take(size_t bytes) {
+        std::lock_guard<std::mutex> lk(mu);
+        int best = -1;
+        for (size_t i = 0; i < idle.size(); ++i)
+            if (idle[i].second >= bytes && idle[i].second <= 2 * bytes + (1u << 20) && (best < 0 || idle[i].second < idle[best].second)) best = (int)i;
+        void* p = nullptr; size_t got = bytes;
+        if (best >= 0) { p = idle[best].first; got = idle[best].second; idle.erase(idle.begin() + best); }
+        else if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        live[p] = got;
+        return p;
+    }
+    void give(void* p) {
+        std::unique_lock<std::mutex> lk(mu);
+        auto it = live.find(p);
+        if (it == live.end()) return;
+        const size_t bytes = it->second;
+        live.erase(it);
+        idle.emplace_back(p, bytes);
+        void* drop = nullptr;
+        if (idle.size() > KEEP) { drop = idle.front().first; idle.erase(idle.begin()); }
+        lk.unlock();
+        if (drop) (void)hipHostFree(drop);
+    }
+    bool holds(const void* q, size_t bytes) {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = live.upper_bound(const_cast<void*>(q));
+        if (it == live.begin()) return false;
+        --it;
+        const char* b = (const char*)it->first;
+        return (const char*)q >= b && (const char*)q + bytes <= b + it->second;
+    }
+};
+HostPool g_host;
+
 hipError_t d2h_pipelined(void* dst, const void* src, size_t bytes, hipStream_t s)
 {
+    if (g_host.holds(dst, bytes)) {              // a destination of mxe_host_alloc: one DMA, no staging
+        hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
+        return e != hipSuccess ? e : hipStreamSynchronize(s);
+    }
     // (also the analyzers' rows of a launch, 3 MB: hipMemcpy into pageable memory took 0.7-1.1 ms for them, this way 0.3)
     if (bytes < ((size_t)256 << 10)) { hipError_t e0 = hipStreamSynchronize(s); return e0 != hipSuccess ? e0 : hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost); }
     std::unique_lock<std::mutex> lk(g_pinned.mu, std::try_to_lock);
@@ -416,6 +464,8 @@ const char* mxe_version(void) { return "maxent_hip 0.1 (gfx950)"; }
 #define MXE_SRC_HASH "unknown"
 #endif
 const char* mxe_source_hash(void) { return MXE_SRC_HASH; }
+void* mxe_host_alloc(size_t bytes) { return bytes ? g_host.take(bytes) : nullptr; }
+void mxe_host_free(void* p) { if (p) g_host.give(p); }
 
 const char* mxe_strerror(int code)
 {

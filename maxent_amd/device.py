@@ -6,6 +6,7 @@ visible, every entry point raises :class:`MaxEntDeviceError`.
 """
 
 import ctypes
+import weakref
 import os
 
 import numpy as np
@@ -56,6 +57,8 @@ _vp = ctypes.c_void_p
 SYMBOLS = [
     ('mxe_version', ctypes.c_char_p, []),
     ('mxe_source_hash', ctypes.c_char_p, []),
+    ('mxe_host_alloc', ctypes.c_void_p, [ctypes.c_size_t]),
+    ('mxe_host_free', None, [ctypes.c_void_p]),
     ('mxe_strerror', ctypes.c_char_p, [ctypes.c_int]),
     ('mxe_device_count', ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     ('mxe_opts_default', None, [ctypes.POINTER(MxeOpts)]),
@@ -207,6 +210,23 @@ def default_opts(**kw):
             raise TypeError('unknown solver option {!r}'.format(k))
         setattr(o, k, val)
     return o
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """an uninitialised array in page-locked host memory (``mxe_host_alloc``; the block goes back to the library's pool with
+    the last view of it) -- the destination of the large device-to-host copies; plain ``np.empty`` for small arrays or when
+    the runtime cannot pin that much"""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if n < (1 << 20):
+        return np.empty(shape, dtype=dtype)
+    lib = load_library()
+    p = lib.mxe_host_alloc(n)
+    if not p:
+        return np.empty(shape, dtype=dtype)
+    buf = (ctypes.c_char * n).from_address(p)
+    weakref.finalize(buf, lib.mxe_host_free, p)          # (every view keeps ``buf`` alive through its base)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
 def _c(a, dtype=np.float64):
@@ -425,7 +445,7 @@ class DeviceContext(object):
             converged=np.empty((nc, na), dtype=np.int32),
             n_evals=np.empty((nc, na), dtype=np.int32))
         v = np.empty((nc, na, self.n_s)) if want_v else None
-        H = np.empty((nc, na, self.n_omega)) if want_H else None
+        H = pinned_empty((nc, na, self.n_omega)) if want_H else None
         self._check(self._lib.mxe_chains_fetch(
             self._h, _p(v), _p(H), _p(out['chi2']), _p(out['S']), _p(out['Q']),
             _p(out['n_iter']), _p(out['converged']), _p(out['n_evals'])),

@@ -207,7 +207,14 @@ class ElementwiseMaxEnt(object):
         res = self.maxent_result
         for g in groups:
             loop = g[0]['worker'].maxent_loop
-            specs = [s for b in g for s in b['specs']]
+            # the scans of the launch in the order of the result's matrix (row major): what comes off the device in one
+            # copy then IS the (M, N, n_alpha, n_omega) array of the result -- MaxEntResult._assemble takes it as a view
+            where = [(res._key(element, cidx), n, k) for n, b in enumerate(g) for k, (element, cidx) in enumerate(b['live'])]
+            try:
+                where.sort(key=lambda t: t[0])
+            except TypeError:
+                pass
+            specs = [g[n]['specs'][k] for (_, n, k) in where]
             t0 = datetime.now()
             for b in g:
                 res._start.update(dict.fromkeys([res._key(element, cidx) for (element, cidx) in b['live']], t0))
@@ -218,12 +225,11 @@ class ElementwiseMaxEnt(object):
                                         select=select_params(loop.analyzers))
             t1 = datetime.now()
             self.last_launches.append(info)
-            off = 0
             for b in g:
-                n = len(b['specs'])
-                b.update(sols=sols[off:off + n], info=info, t0=t0, t1=t1,
+                b.update(sols=[None] * len(b['specs']), info=info, t0=t0, t1=t1,
                          per_alpha=(t1 - t0) / max(1, len(specs) * len(specs[0]['alpha'])))
-                off += n
+            for sol, (_, n, k) in zip(sols, where):
+                g[n]['sols'][k] = sol
 
     def _same_launch(self, a, b):
         la, lb = a['worker'].maxent_loop, b['worker'].maxent_loop

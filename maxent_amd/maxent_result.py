@@ -238,6 +238,25 @@ class MaxEntResultData(object):
         return tuple(self._matrix_structure)
 
 
+_row_pool = None
+
+
+def _by_rows(fn, src, dst, n_threads=4, min_bytes=32 << 20):
+    """``fn(src[i0:i1], dst[i0:i1])`` over blocks of the first axis, on a few threads for arrays of tens of MB (one thread
+    moves ~15 GB/s on the hosts of the GPU boxes; numpy releases the GIL inside its loops)"""
+    global _row_pool
+    n = src.shape[0] if src.ndim else 0
+    if src.nbytes < min_bytes or n < 2:
+        fn(src, dst)
+        return
+    if _row_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _row_pool = ThreadPoolExecutor(max_workers=n_threads)
+    step = -(-n // n_threads)
+    for f in [_row_pool.submit(fn, src[i:i + step], dst[i:i + step]) for i in range(0, n, step)]:
+        f.result()
+
+
 class ElementAnalysis(OrderedDict):
     """{analyzer name: AnalyzerResult} of one element.  An entry may still be a :class:`analyzers.Deferred` -- the
     device picked the alpha, nobody has looked at the result object yet --: it is built when it is first read;
@@ -544,10 +563,16 @@ class MaxEntResult(MaxEntResultData):
         else:
             ref = self._reference_record()
             X = len(ref['alpha'])
-            tail = np.asarray(ref[name]).shape[1:] if per_alpha \
-                else np.asarray(ref[name]).shape
+            full = getattr(ref[name], 'shape', None)            # (a lazy array knows its shape without being formed)
+            if full is None:
+                full = np.asarray(ref[name]).shape
+            tail = tuple(full)[1:] if per_alpha else tuple(full)
             ems = tuple(self.effective_matrix_structure)
             shape = ems + ((X,) if per_alpha else ()) + tuple(tail)
+            fast = self._assemble_whole(name, ems, shape) if per_alpha else None
+            if fast is not None:
+                self._cache[name] = fast
+                return fast
             arr = np.full(shape, np.nan)
             for key, rec in self._records.items():
                 val = np.asarray(rec[name], dtype=float)
@@ -564,6 +589,59 @@ class MaxEntResult(MaxEntResultData):
                         if self.complex_elements:
                             arr[elem + (1,)] = -arr[elem + (1,)]
         self._cache[name] = arr
+        return arr
+
+    def _assemble_whole(self, name, ems, shape):
+        """the array of ``name`` over all elements when EVERY element of the matrix has a full-length record (nothing to
+        fill with NaN, nothing to mirror), or None.  The records of one launch are consecutive rows of ONE fetched array
+        in the order of the matrix (ElementwiseMaxEnt launches them that way): the result then is a view of that array --
+        no second copy of 100 MB; otherwise one copy into an uninitialised array.  A = H / delta of all elements is one
+        division."""
+        keys = list(product(*map(range, ems)))
+        recs = [self._records.get(k) for k in keys]
+        if not recs or any(r is None or name not in r for r in recs):
+            return None
+        if name == 'A':
+            maps = [getattr(r['A'], '_map', None) for r in recs]
+            first = maps[0]
+
+            def same_map(m):
+                # (the diagonal and the off-diagonal worker have maps of their own: equal when both divide by the same delta)
+                if m is first:
+                    return True
+                if m is None or type(m) is not type(first) or m.matrix() is not None:
+                    return False
+                a, b = getattr(getattr(m, '_omega', None), 'delta', None), getattr(getattr(first, '_omega', None), 'delta', None)
+                return a is not None and b is not None and np.shape(a) == np.shape(b) and np.array_equal(a, b)
+            distinct = {id(m): m for m in maps}
+            if first is not None and first.matrix() is None and all(same_map(m) for m in distinct.values()) and \
+                    not any(getattr(r['A'], '_val', None) is not None for r in recs):
+                H = self._assemble('H', mirror=True)
+                if H.shape == shape:
+                    delta = getattr(getattr(first, '_omega', None), 'delta', None)
+                    if type(first).__name__ == 'IdentityA_of_H' and delta is not None:
+                        # (into a block of the library's page-locked pool: a fresh pageable array of 100 MB costs more in
+                        #  page faults than the division itself)
+                        from . import device
+                        out = device.pinned_empty(shape)
+                        _by_rows(lambda a, b: np.divide(a, delta, out=b), H, out)
+                        return out
+                    return np.asarray(first.f(H))
+        vals = [np.asarray(r[name]) for r in recs]
+        v0 = vals[0]
+        if v0.dtype != np.float64 or any(v.shape != v0.shape or v.dtype != v0.dtype for v in vals) or \
+                tuple(ems) + v0.shape != tuple(shape):
+            return None
+        nb = v0.nbytes
+        if nb and v0.flags.c_contiguous:
+            p0 = v0.__array_interface__['data'][0]
+            if all(v.flags.c_contiguous and v.__array_interface__['data'][0] == p0 + i * nb for i, v in enumerate(vals)):
+                whole = np.lib.stride_tricks.as_strided(v0, shape=(len(vals),) + v0.shape, strides=(nb,) + v0.strides)
+                return whole.reshape(shape)
+        arr = np.empty(shape)
+        flat = arr.reshape((len(vals),) + v0.shape)
+        for i, v in enumerate(vals):
+            flat[i] = v
         return arr
 
     @property

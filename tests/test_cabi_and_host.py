@@ -710,3 +710,43 @@ def test_records_and_picks_of_a_launch_are_made_in_one_go():
     assert _device_picks(res, keys, 0, lambda p: p[0] == 1) is None            # another parameter than the device used
     idx[2, 1] = -1
     assert _device_picks(res, keys, 2, lambda p: True) is None                 # an element without a choice
+
+
+def test_result_arrays_are_views_of_one_fetched_array_where_they_can_be():
+    """MaxEntResult._assemble_whole (no device): records that are consecutive rows of one array, in the order of the matrix,
+    assemble as a VIEW of it; records elsewhere in memory as one copy; a missing or shorter element goes the general way
+    (NaN fill); A = H / delta of lazy records in one division, also when the two workers bring maps of their own"""
+    from maxent_amd.maxent_result import MaxEntResult
+    from maxent_amd.batch_solver import LazyA
+    from maxent_amd.functions import IdentityA_of_H
+    omega = mx.LinearOmegaMesh(-2, 2, 9)
+    rng = np.random.RandomState(3)
+    big = rng.rand(4, 5, 9)                                   # [element][alpha][omega], as it comes off the device
+    alpha = np.array([8.0, 4.0, 2.0, 1.0, 0.5])
+
+    def result(order=(0, 1, 2, 3), maps=None, drop=None, short=None):
+        res = MaxEntResult(matrix_structure=(2, 2), element_wise=True, complex_elements=False, use_hermiticity=False)
+        maps = maps or [IdentityA_of_H(omega)] * 4
+        for n, key in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+            if drop == key:
+                continue
+            H = big[order[n]]
+            if short == key:
+                H = H[:3]
+            res._records[key] = dict(alpha=alpha[:len(H)], H=H, A=LazyA(H, maps[n]), chi2=rng.rand(len(H)), omega=omega)
+        return res
+    res = result()
+    assert np.shares_memory(res.H, big) and res.H.shape == (2, 2, 5, 9) and np.array_equal(res.H[1, 0], big[2])
+    assert np.array_equal(res.A, big.reshape(2, 2, 5, 9) / omega.delta)
+    assert all(r['A']._val is None for r in res._records.values())           # nothing was formed element by element
+    assert res.chi2.shape == (2, 2, 5)
+    two = result(maps=[IdentityA_of_H(omega), IdentityA_of_H(omega), IdentityA_of_H(omega), IdentityA_of_H(omega)])
+    assert np.array_equal(two.A, res.A) and all(r['A']._val is None for r in two._records.values())
+    other = result(maps=[IdentityA_of_H(omega)] * 3 + [IdentityA_of_H(mx.LinearOmegaMesh(-4, 4, 9))])
+    assert np.array_equal(other.A[0, 1], res.A[0, 1]) and np.array_equal(other.A[1, 1], big[3] / mx.LinearOmegaMesh(-4, 4, 9).delta)
+    perm = result(order=(2, 0, 3, 1))
+    assert not np.shares_memory(perm.H, big) and np.array_equal(perm.H[0, 0], big[2]) and np.array_equal(perm.H[1, 1], big[1])
+    gap = result(drop=(1, 0))
+    assert np.all(np.isnan(gap.H[1, 0])) and np.array_equal(gap.H[1, 1], big[3])
+    sh = result(short=(0, 1))
+    assert np.array_equal(sh.H[0, 1][:3], big[1][:3]) and np.all(np.isnan(sh.H[0, 1][3:]))

@@ -12,9 +12,9 @@ from maxent_amd.batch_solver import BatchSolver, LazyH
 pytestmark = pytest.mark.gpu
 
 
-def job(n_orb=3, n_tau=60, n_omega=120, n_alpha=12, **kw):
+def job(n_orb=3, n_tau=60, n_omega=120, n_alpha=12, use_hermiticity=False, **kw):
     tau, omega, K, Gmat, _ = synthetic.matrix_G(n_orb, n_tau, n_omega)
-    ew = mx.ElementwiseMaxEnt(use_hermiticity=False, **kw)
+    ew = mx.ElementwiseMaxEnt(use_hermiticity=use_hermiticity, **kw)
     ew.set_verbosity(mx.VerbosityFlags.Quiet)
     ew.set_G_tau_data(tau, Gmat)
     ew.omega = omega
@@ -237,7 +237,8 @@ def test_devices_of_one_process_are_driven_from_threads():
         assert np.max(np.abs(a['chi2'] - b['chi2'])) <= 1e-7 * np.max(np.abs(a['chi2']))
         assert a['converged'].all() and b['converged'].all()
     print('solve wall: one context %.2f ms, four contexts on threads %.2f ms' % (1e3 * walls['solo'][0], 1e3 * walls['quad'][0]))
-    assert walls['quad'][0] <= 1.3 * walls['solo'][0] + 2e-3
+    # (a guard against the ranks running one after the other again, with room for a busy box: measured 4.4 against 2.3 ms)
+    assert walls['quad'][0] <= 1.5 * walls['solo'][0] + 4e-3
     solo.close()
     quad.close()
 
@@ -327,3 +328,26 @@ def test_elementwise_result_from_device_picks_equals_host_analyzers():
     ew2.maxent_offdiagonal.analyzers = [LineFitAnalyzer(), Chi2CurvatureAnalyzer(gamma=0.5)]
     r2 = ew2.run()
     assert r2.analyzer_results[0][0]['Chi2CurvatureAnalyzer']['gamma'] == 0.5
+
+
+def test_result_arrays_of_a_full_matrix_are_views_of_what_came_off_the_device():
+    """ElementwiseMaxEnt launches its scans in the order of the result's matrix and MaxEntResult assembles H as a view of
+    the ONE fetched array (A = H / delta in one division); the values are those of the element-by-element assembly, and a
+    result with mirrored elements (use_hermiticity) goes the general way"""
+    from maxent_amd.maxent_result import MaxEntResult
+    res = job().run()
+    H = res.H
+    rec = res._records[(1, 2)]
+    assert np.shares_memory(H, np.asarray(rec['H'])) and np.array_equal(H[1, 2], np.asarray(rec['H']))
+    got = {name: np.array(getattr(res, name)) for name in ('H', 'A', 'chi2', 'S', 'v', 'A_out')}
+    res2 = job().run()
+    orig = MaxEntResult._assemble_whole
+    MaxEntResult._assemble_whole = lambda self, *a: None
+    try:
+        for name in ('H', 'A', 'chi2', 'S', 'v', 'A_out'):
+            assert np.array_equal(got[name], np.asarray(getattr(res2, name))), name
+    finally:
+        MaxEntResult._assemble_whole = orig
+    herm = job(use_hermiticity=True).run()
+    assert herm.H.shape == H.shape and np.array_equal(herm.H[2, 0], herm.H[0, 2])
+    assert np.max(np.abs(herm.H[0, 2] - H[0, 2])) <= 1e-7 * np.max(np.abs(H[0, 2]))
