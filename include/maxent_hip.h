@@ -36,6 +36,8 @@
  *     cost_function.py:73-85, maxent_cost_function.py:68-165
  *   TauKernel / PreblurKernel fill + KernelSVD.svd         | mxe_kernel_svd (optional: the host
  *     kernels.py:53-122,244-271,384-393                    |   numpy path stays the default)
+ *   the arrays of MaxEntResult (numpy allocations)         | mxe_host_alloc / mxe_host_free (optional:
+ *     maxent_result.py:835-967                             |   page-locked destinations, one DMA per fetch)
  *
  * Conventions: plain C, no C++ types; every function returns 0 (MXE_OK) or a
  * negative error code and never throws or aborts; the caller owns every host
