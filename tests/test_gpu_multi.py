@@ -351,3 +351,33 @@ def test_result_arrays_of_a_full_matrix_are_views_of_what_came_off_the_device():
     herm = job(use_hermiticity=True).run()
     assert herm.H.shape == H.shape and np.array_equal(herm.H[2, 0], herm.H[0, 2])
     assert np.max(np.abs(herm.H[0, 2] - H[0, 2])) <= 1e-7 * np.max(np.abs(H[0, 2]))
+
+
+def test_page_locked_result_blocks_come_from_a_pool_and_go_back_with_the_last_view():
+    """device.pinned_empty (mxe_host_alloc): an ordinary writable array; the block returns to the library's pool when the last
+    view of it is gone and the next request of that size takes it again; small requests are plain numpy arrays"""
+    import gc
+    a = device.pinned_empty((300, 1000))
+    a[:] = 3.0
+    addr = a.__array_interface__['data'][0]
+    view = a[5]
+    del a
+    gc.collect()
+    assert view[7] == 3.0                                      # the view keeps the block
+    b = device.pinned_empty((300, 1000))
+    assert b.__array_interface__['data'][0] != addr            # ... so another block was pinned
+    del view, b
+    gc.collect()
+    c = device.pinned_empty((300, 1000))
+    assert c.__array_interface__['data'][0] in (addr,) or c.nbytes == 2400000      # taken from the pool (either of the two)
+    small = device.pinned_empty((10, 10))
+    assert small.shape == (10, 10) and small.flags.owndata
+    # a fetch into such a block and into pageable memory give the same bytes
+    ew = job()
+    res = ew.run()
+    ctx = ew.maxent_diagonal.K._batch_solvers[(0,)].ctxs[0]
+    H1 = ctx.fetch(want_v=False, want_H=True)['H']
+    lib = device.load_library()
+    H2 = np.empty(H1.shape)
+    assert lib.mxe_chains_fetch(ctx._h, None, device._p(H2), None, None, None, None, None, None) == 0
+    assert np.array_equal(H1, H2)
