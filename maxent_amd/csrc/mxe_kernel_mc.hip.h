@@ -92,6 +92,19 @@ constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
 #ifndef MXE_X_ILL_ITERS
 #define MXE_X_ILL_ITERS 8      // iterations an alpha gets after its solve first met a small pivot, before it is handed to the one-chain kernel
 #endif
+// Wave priorities (s_setprio).  Two workgroups share a CU and run out of phase, so a SIMD holds one wave of each: a home wave
+// in its serial section (dependent chains: every instruction waits for the one before) beside a wave of the partner that
+// streams -- and the arbiter, left alone, lets the streaming wave's instructions (a 16-cycle MFMA, a burst of loads) go first
+// as often as not.  The serial section is the critical path of a round: with priority 2 for it cfg4 0.863 -> 0.823 ms; the fused
+// pass at 1 (its matrix instructions and the split that feeds them, over the partner's row pass) 0.823 -> 0.815; the row pass
+// at 1 instead: 0.833 (worse); levels 3 / 2 / 0 the same as 2 / 1 / 0.  No effect where a workgroup has its CU to itself
+// (profiles/r03_h_experiments.txt).
+#ifndef MXE_X_HOME_PRIO
+#define MXE_X_HOME_PRIO 2
+#endif
+#ifndef MXE_X_FUSED_PRIO
+#define MXE_X_FUSED_PRIO 1
+#endif
 #ifndef MXE_X_SLOW_STEPS
 #define MXE_X_SLOW_STEPS 0     // full Newton steps in a row that do not halve the correction before an alpha is handed over (0: never).
                                // Built for VERDICT r02 item 7 and measured with 3: an iteration of this kernel costs 1 / 25 of one of the one-chain
@@ -514,6 +527,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 
         // ---- 1. home wave: right-hand side, active block, factorise, solve, step ----
         if (wave < MCC) {
+#if MXE_X_HOME_PRIO > 0
+            __builtin_amdgcn_s_setprio(MXE_X_HOME_PRIO);     // the serial section: its dependent chains go first on a SIMD that a streaming wave shares
+#endif
             const int q = wave, k = lane;
             Slot t;
             // ---- 4 (of the round before). rho, sums, accept / converge / advance, results ----
@@ -817,12 +833,18 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             vecI[k * MCC + q] = dk;
             t.okprev = okflag;
             store_slot(t);
+#if MXE_X_HOME_PRIO > 0
+            __builtin_amdgcn_s_setprio(0);
+#endif
             MXE_STAMPH(0);
         }
         __syncthreads();
         MXE_STAMPW(2);
         if (!(s_act[0] | s_act[1] | s_act[2] | s_act[3])) break;      // uniform: LDS flags behind a barrier
 
+#ifdef MXE_X_ROW_PRIO
+        __builtin_amdgcn_s_setprio(MXE_X_ROW_PRIO);
+#endif
         // ---- 2. row pass (V^T once): u, w, H of the four trial points, in place ----
         // du = V delta of the four slots as v_mfma_f64_4x4x4 (four independent 4x4x4 blocks per
         // instruction): block b = omega rows 4b .. 4b+3 of a 16-row tile, columns = the four slots,
@@ -939,10 +961,16 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 red[wave * 32 + lane * 8 + 4] = pdu;
             }
         }
+#ifdef MXE_X_ROW_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         MXE_STAMPW(3);
         __syncthreads();                         // Hi, wi, ui and the partial sums complete
         MXE_STAMPW(7);
 
+#if MXE_X_FUSED_PRIO > 0
+        __builtin_amdgcn_s_setprio(MXE_X_FUSED_PRIO);
+#endif
         // ---- 3. fused pass (V once): h = V^T H (binary64) and W = V_a^T diag(w) V_a (split binary16) ----
         {
             // h_q = V^T H_q of the four slots is v_mfma_f64_4x4x4 (four blocks per instruction: block b =
@@ -1089,6 +1117,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         }
                 }
             }
+#if MXE_X_FUSED_PRIO > 0
+            __builtin_amdgcn_s_setprio(0);
+#endif
             MXE_STAMPW(1);
             // h: lane 16 i + 4 b + j holds column 16 t + 4 b + i of slot j; the waves are summed in step 4
             {
