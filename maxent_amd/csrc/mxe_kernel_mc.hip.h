@@ -97,7 +97,11 @@ constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
 // streams -- and the arbiter, left alone, lets the streaming wave's instructions (a 16-cycle MFMA, a burst of loads) go first
 // as often as not.  The serial section is the critical path of a round: with priority 2 for it cfg4 0.863 -> 0.823 ms; the fused
 // pass at 1 (its matrix instructions and the split that feeds them, over the partner's row pass) 0.823 -> 0.815; the row pass
-// at 1 instead: 0.833 (worse); levels 3 / 2 / 0 the same as 2 / 1 / 0.  No effect where a workgroup has its CU to itself
+// at 1 instead: 0.833 (worse); levels 3 / 2 / 0 the same as 2 / 1 / 0.  One workgroup per CU with eight waves (two per SIMD, all in
+// the same phase): the waves still inside the loop of the fused pass go before those that have left it -- cfg2 0.393 -> 0.383,
+// cfg3 0.421 -> 0.405, the shards of 4 / 8 GPUs 0.495 / 0.449 -> 0.481 / 0.438 ms (same box, twice).  A launch of two workgroups
+// per CU that does NOT fill the GPU (one rank's shard of a two-GPU job: the <32, 2, lead> build) is bound by the depth of its
+// chains, where the partner's delayed passes are on the critical path too: 0.554 -> 0.579 ms with them -- not there
 // (profiles/r03_h_experiments.txt).
 #ifndef MXE_X_HOME_PRIO
 #define MXE_X_HOME_PRIO 2
@@ -139,6 +143,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     static_assert(!GSTATE || WGPC == 1, "device-memory state: the one-workgroup-per-CU build");
     static_assert(NWV == 4 || (NWV == 8 && WGPC == 1), "helper waves only in the one-workgroup-per-CU build");
     constexpr bool UREG = (WGPC == 2);            // u in registers, h summed with atomics
+    constexpr bool PRIO = (WGPC == 1) || !LEAD;   // wave priorities (MXE_X_HOME_PRIO): not in the two-workgroups-per-CU build of launches that do not fill the GPU, see there
     constexpr int NP = 64;
     constexpr int NT = NA / 16;                   // 16-column tiles of the Gram block
     constexpr int NPAIR = NT * (NT + 1) / 2;
@@ -528,7 +533,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         // ---- 1. home wave: right-hand side, active block, factorise, solve, step ----
         if (wave < MCC) {
 #if MXE_X_HOME_PRIO > 0
-            __builtin_amdgcn_s_setprio(MXE_X_HOME_PRIO);     // the serial section: its dependent chains go first on a SIMD that a streaming wave shares
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(MXE_X_HOME_PRIO);     // the serial section: its dependent chains go first on a SIMD that a streaming wave shares
 #endif
             const int q = wave, k = lane;
             Slot t;
@@ -834,7 +839,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
             t.okprev = okflag;
             store_slot(t);
 #if MXE_X_HOME_PRIO > 0
-            __builtin_amdgcn_s_setprio(0);
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
 #endif
             MXE_STAMPH(0);
         }
@@ -969,7 +974,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         MXE_STAMPW(7);
 
 #if MXE_X_FUSED_PRIO > 0
-        __builtin_amdgcn_s_setprio(MXE_X_FUSED_PRIO);
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(MXE_X_FUSED_PRIO);
 #endif
         // ---- 3. fused pass (V once): h = V^T H (binary64) and W = V_a^T diag(w) V_a (split binary16) ----
         {
@@ -1118,7 +1123,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 }
             }
 #if MXE_X_FUSED_PRIO > 0
-            __builtin_amdgcn_s_setprio(0);
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
 #endif
             MXE_STAMPW(1);
             // h: lane 16 i + 4 b + j holds column 16 t + 4 b + i of slot j; the waves are summed in step 4
