@@ -329,12 +329,13 @@ def scaling_projection(batch, opts, k_ms_full, n_alpha, n_launch=30):
              'the default model), so its pieces solve the last alpha above that range cold -- 14-16 rounds to the 2e-2 the walk '
              'needs at the smallest alphas: Newton moves u = log(H / D) by 1-2.5 per step where the spectrum has to vanish, and '
              'it has to fall by ~11 --, walk down the mesh at one round per alpha (up to 6) and take 3-4 rounds for their own '
-             'alpha: 23-27 rounds whatever N is.  A round of a workgroup that has its CU to itself takes ~39 k cycles (16.3 us, '
-             'eight waves): binary32 Gauss-Jordan + step 12.9 k on one wave per slot, accept 5 k, the two streaming passes 21 k of '
-             'which the 448 KB of V and V^T at the 32-64 B per cycle one CU gets out of its L2 are 7-15 k (more waves do not '
-             'change that: profiles/r03_a_phases_wg1_*waves.txt, profiles/r03_a_l2_stream_rate.txt).',
-        rounds_deepest_chain=[23, 27], us_per_round_one_workgroup_per_cu=16.3, floor_ms=[0.37, 0.44],
-        speedup_ceiling_at_this_round_structure=k_ms_full / 0.37)
+             'alpha: 23-27 rounds whatever N is.  A round of a workgroup that has its CU to itself takes ~37 k cycles (15.6 us, '
+             'eight waves, stamps of profiles/r03_h_phases_mc_wg1_8waves.txt): binary32 Gauss-Jordan + step 12.5 k on one wave per '
+             'slot, accept 4.6 k, the two streaming passes 20 k of which the 448 KB of V and V^T at the 32-64 B per cycle one CU '
+             'gets out of its L2 are 7-15 k (more waves do not change that: profiles/r03_a_phases_wg1_*waves.txt, '
+             'profiles/r03_a_l2_stream_rate.txt).',
+        rounds_deepest_chain=[23, 27], us_per_round_one_workgroup_per_cu=15.6, floor_ms=[0.36, 0.42],
+        speedup_ceiling_at_this_round_structure=k_ms_full / 0.36)
     return out
 
 
