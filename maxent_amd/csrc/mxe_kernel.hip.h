@@ -1244,7 +1244,13 @@ void chain_kernel(const KParams p)
             mu_hint = mu;
             Q = 0.5 * chi2 - alpha * S;
             ++n_iter;
-            if (p.tol_h > 0.0 && fmin(relH, relH_next) < p.tol_h && n_iter > p.miniter) { conv = 1; break; }
+            // A DAMPED step is short because of its damping, not because the minimum is near: (B + mu) delta_mu = g against
+            // B delta = g gives |delta| <= (1 + mu / alpha) |delta_mu| (B >= alpha in this metric), and the test is made on
+            // that bound.  Without it alphas that need heavy damping at every iteration (error bars a hundred times below
+            // the noise of the data, few data points) were reported converged with exact Newton corrections up to 9e-4
+            // (profiles/r03_i_small_sigma.txt).
+            const double undamped = (mu > 0.0) ? 1.0 + mu / alpha : 1.0;
+            if (p.tol_h > 0.0 && fmin(relH, relH_next) * undamped < p.tol_h && n_iter > p.miniter) { conv = 1; break; }
             if constexpr (!F64) {
                 // binary32 noise floor: an undamped Newton correction that is already small and no
                 // longer shrinks is rounding noise of h = V^T H; the point cannot be improved

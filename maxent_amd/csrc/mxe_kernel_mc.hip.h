@@ -622,6 +622,10 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                         // (t.pred) against that correction (sdH); an optimistic prediction inflates the present one by the
                         // same factor
                         double relH2_min = fac2 * sdH;                  // min(relH, relH_next)^2 * Hn2
+                        if (t.mu > 0.0) {                               // (a damped step: the bound on the undamped one, see chain_kernel; rare: one division)
+                            const double ud = 1.0 + t.mu / t.alpha;
+                            relH2_min *= ud * ud;
+                        }
                         const double pred_here = estimated ? relH2_min : 0.0;
     #ifndef MXE_X_NO_PRED_CHECK
                         if (estimated && t.pred > 0.0 && sdH > t.pred) relH2_min = fmin(sdH, relH2_min * (sdH / t.pred));     // (rare: one division)

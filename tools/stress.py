@@ -17,7 +17,7 @@ def cases(n_cases, seed=7):
         n_alpha = int(rng.choice([3, 8, 20, 50, 100, 150]))
         lo, hi = 10.0 ** rng.uniform(-3, 0), 10.0 ** rng.uniform(2, 5)
         ascending = bool(rng.rand() < 0.2)
-        sigma = 10.0 ** rng.uniform(-5, -2.5)
+        sigma = 10.0 ** rng.uniform(float(os.environ.get('STRESS_LOG_SIGMA_MIN', '-5')), float(os.environ.get('STRESS_LOG_SIGMA_MAX', '-2.5')))     # (defaults: the range of the recorded runs)
         yield dict(case=case, n_orb=n_orb, n_tau=n_tau, n_omega=n_omega, n_alpha=n_alpha, lo=lo, hi=hi,
                    ascending=ascending, sigma=sigma, seed=int(rng.randint(1 << 30)))
 
