@@ -74,3 +74,31 @@ def test_hard_scans_converge_at_least_where_the_reference_does():
         ctx.close()
         done += 1
     assert done == 3
+
+
+def test_a_damped_step_is_not_taken_for_convergence():
+    """Error bars a hundred times below the noise of the data (40 ... 100 data points): many small alphas need heavy damping
+    at every iteration.  A damped step is short because of its damping: the one-chain kernel (the finishing pass) reported such
+    alphas converged with exact Newton corrections of 2e-6 (this case) to 9e-4 until the test was put on the bound of the
+    undamped step.  Whatever is reported converged has to pass the audit."""
+    import maxent_amd as mx
+    n_orb, n_tau, n_omega, n_alpha, sigma, seed = 6, 100, 60, 8, 8.282919140649033e-06, 30528765
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(n_orb, n_tau, n_omega, seed=seed)
+    K.reduce_singular_space(1e-14)
+    D = synthetic.flat_D(omega)
+    err = sigma * np.ones(n_tau)
+    alphas = np.array(mx.LogAlphaMesh(alpha_min=0.015386490709282183, alpha_max=71437.6549945734, n_points=n_alpha))[::-1].copy() * n_tau
+    elems = [(i, j) for i in range(n_orb) for j in range(n_orb)]
+    kinds = [device.ENTROPY_NORMAL if i == j else device.ENTROPY_PLUSMINUS for i, j in elems]
+    v0 = np.stack([hostprep.initial_v(K.V, D, omega.delta, k) for k in kinds])
+    n = len(elems)
+    ctx = device.DeviceContext(K.U, K.S, K.V)
+    ds = ctx.add_dataset(err)
+    ctx.set_elements([ds] * n, [Gmat[i, j] for i, j in elems], np.tile(D, (n, 1)), kinds)
+    out = ctx.solve_chains(np.arange(n), alphas, v0)
+    conv = out['converged'].astype(bool)
+    corr = ctx.audit()['corr']
+    assert conv.sum() >= 0.8 * conv.size
+    assert np.max(corr[conv]) < 1e-6, np.max(corr[conv])
+    assert np.all(np.isfinite(out['H'][conv]))
+    ctx.close()
