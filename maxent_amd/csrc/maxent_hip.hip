@@ -746,6 +746,8 @@ int build_init_table(mxe_ctx* ctx, int n_chain, const int32_t* elem_of_chain, co
 }
 }  // namespace
 
+constexpr double MC_COUPLING_MAX = 1e-3;     // relative coupling of the first direction the 32-row active block leaves out (see below)
+
 int mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
                       const int32_t* elem_of_chain, const double* alpha_scaled,
                       const double* v0, const mxe_opts* opts)
@@ -901,7 +903,11 @@ try {
         // capacity of the active block: the kernel clamps n_act to NA, and the
         // first neglected direction couples with relative strength
         // c_NA^2 wmax / alpha (wmax <= sum w ~ max(1, sum D)); accept NA when that
-        // is below 1e-2 for every chain (inexact Newton, contraction ~1e-2).
+        // is below MC_COUPLING_MAX for every chain (inexact Newton: the contraction is that number, and the stopping
+        // estimate of the kernel does not know about it -- an alpha stops when (e^{|du|} - 1 + theta) relH < tol_h, so its
+        // last correction relH may be as large as tol_h / theta = 1e-4 and what the neglected direction leaves behind is
+        // coupling x relH.  With 1e-2, the value until r03, converged alphas of launches AT that limit were 1.1e-6 ... 1.6e-6
+        // from their fixed points (profiles/r03_i_small_sigma.txt); 1e-3 keeps a factor ten to the 1e-6 of the audit).
         double worst32 = 0.0, worst48 = 0.0;
         for (int sc = 0; sc < ctx->n_sub; ++sc) {
             const int e = ctx->sub_elem[sc];
@@ -916,7 +922,7 @@ try {
         //  that couple more than 32 directions run in the one-chain layout, whose solve lives in LDS)
         (void)worst48;
         ctx->excluded.clear();
-        if (worst32 <= 1e-2) ctx->mc_na = 32;
+        if (worst32 <= MC_COUPLING_MAX) ctx->mc_na = 32;
         else {
             // Some alphas couple more than 32 directions (very small error bars: sigma = 1e-6 on the BASELINE grids does at
             // the 27 smallest of 100 alphas).  Until r03 the whole launch then went to the one-chain layout (7 x slower).
@@ -944,7 +950,7 @@ try {
             for (int c = 0; c < n_chain; ++c) {
                 const int e = elem_of_chain[c];
                 const DataSet& DS = ctx->ds[ctx->elem_ds[e]];
-                const double lim = 1e-2 / (DS.c[32] * DS.c[32] * std::max(1.0, ctx->h_sumD[e]));    // alpha >= 1 / lim passes
+                const double lim = MC_COUPLING_MAX / (DS.c[32] * DS.c[32] * std::max(1.0, ctx->h_sumD[e]));    // alpha >= 1 / lim passes
                 const bool to64 = have64 && ctx->elem_kind[e] != MXE_ENTROPY_NORMAL;
                 for (int i = 0; i < n_alpha; ++i)
                     if (!(alpha_dev[(size_t)c * n_alpha + i] * lim >= 1.0)) {
