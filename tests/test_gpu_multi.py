@@ -381,3 +381,49 @@ def test_page_locked_result_blocks_come_from_a_pool_and_go_back_with_the_last_vi
     H2 = np.empty(H1.shape)
     assert lib.mxe_chains_fetch(ctx._h, None, device._p(H2), None, None, None, None, None, None) == 0
     assert np.array_equal(H1, H2)
+
+
+@pytest.mark.parametrize('herm,cplx,ids', [(False, False, None), (True, False, None), (False, True, None), (True, True, None),
+                                           (False, False, (0, 0)), (True, True, (0, 0))])
+def test_elementwise_variants_assemble_the_same_arrays_every_way(herm, cplx, ids):
+    """hermiticity x complex elements x two contexts: the result arrays through the whole-array assembly (views of the
+    fetched block where the launch order allows), through the element-by-element assembly and from a run with contexts
+    of its own are the same bits; every record equals its slice"""
+    from maxent_amd.maxent_result import MaxEntResult
+    n_orb = 3
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(n_orb, 40, 60, seed=11)
+    if cplx:
+        G2 = synthetic.matrix_G(n_orb, 40, 60, seed=12)[3]
+        sgn = np.sign(np.arange(n_orb)[None, :] - np.arange(n_orb)[:, None]).astype(float)
+        Gmat = Gmat + 0.3j * sgn[:, :, None] * G2                # hermitian in the orbital indices
+
+    def run():
+        ew = mx.ElementwiseMaxEnt(use_hermiticity=herm, use_complex=cplx, device_ids=ids)
+        ew.set_verbosity(mx.VerbosityFlags.Quiet)
+        ew.set_G_tau_data(tau, Gmat)
+        ew.omega = omega
+        ew.alpha_mesh = mx.LogAlphaMesh(alpha_min=1e-1, alpha_max=1e3, n_points=9)
+        ew.set_error(synthetic.SIGMA)
+        return ew.run()
+    res = run()
+    names = ('H', 'A', 'chi2', 'S', 'Q', 'A_out')
+    got = {name: np.array(getattr(res, name)) for name in names}
+    assert np.all(np.isfinite(got['A_out'])) and got['A_out'].shape == (n_orb, n_orb, 60)
+    assert np.iscomplexobj(got['A_out']) == cplx
+    for key, rec in res._records.items():
+        assert np.array_equal(np.asarray(rec['H']), got['H'][key]) and np.array_equal(np.asarray(rec['chi2']), got['chi2'][key])
+    orig = MaxEntResult._assemble_whole
+    MaxEntResult._assemble_whole = lambda self, *a: None
+    try:
+        res2 = run()
+        for name in names:
+            assert np.array_equal(np.asarray(getattr(res2, name)), got[name], equal_nan=True), name
+    finally:
+        MaxEntResult._assemble_whole = orig
+    keep, BatchSolver.POOL_SIZE = BatchSolver.POOL_SIZE, 0
+    try:
+        res3 = run()
+        for name in names:
+            assert np.array_equal(np.asarray(getattr(res3, name)), got[name], equal_nan=True), name
+    finally:
+        BatchSolver.POOL_SIZE = keep
