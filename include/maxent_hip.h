@@ -133,6 +133,13 @@ typedef struct mxe_opts {
                                 sections of one overlap the streaming passes of the other), 1, 2   */
     double  chi2_factor;     /* eta in Q = eta chi2 / 2 - alpha S (CostFunction(chi2_factor=...),
                                 cost_function.py:60, bryan_cost_function.py:71); default 1       */
+    int32_t lds_basis;       /* lock-step layout with V^T resident in the LDS as binary32 (chain_kernel_lv; it needs
+                                n_s * (n_omega_pad + 4) * 4 B + 47 KB <= 160 KB: the BASELINE grids just fit).
+                                0 = auto: it IS the launch for precision = MXE_PRECISION_F32, and the first pass of a
+                                binary64 launch that does not fill the GPU (every alpha to 1e-5 in binary32, then one
+                                binary64 Newton step per alpha in the lock-step kernel, all alphas side by side);
+                                1 = also for binary64 launches that do fill it; 2 = never                        */
+    int32_t reserved_;       /* (keeps the struct a multiple of eight bytes; must be 0)                          */
 } mxe_opts;
 
 /* ---- library / device ------------------------------------------------- */

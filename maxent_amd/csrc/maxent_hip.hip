@@ -8,6 +8,7 @@
 #include "../../include/maxent_hip.h"
 #include "mxe_kernel.hip.h"
 #include "mxe_kernel_mc.hip.h"
+#include "mxe_kernel_lv.hip.h"
 #include "mxe_eval.hip.h"
 
 #include <algorithm>
@@ -104,7 +105,12 @@ struct PinnedPair {
         return true;
     }
 };
-PinnedPair g_pinned;
+// one pair per device: an event belongs to the device it was created on, and d2h_pipelined records it on the stream of
+// whichever context is fetching (with one process-wide pair, created on the device of the first context, a fetch
+// on another device failed with hipErrorInvalidHandle -- BatchSolver(device_ids = (0, 1, ...)) from ~22 scans of 500
+// frequencies on)
+constexpr int MXE_MAX_DEVICES = 64;
+PinnedPair g_pinned_dev[MXE_MAX_DEVICES];
 
 // Pinned host memory for the callers' result arrays (mxe_host_alloc / mxe_host_free): a copy into it runs at the rate of the
 // link (102 MB: 2-3 ms) where one into pageable memory takes 11-22 ms even through the staging pair above -- page faults of
@@ -157,8 +163,18 @@ hipError_t d2h_pipelined(void* dst, const void* src, size_t bytes, hipStream_t s
     }
     // (also the analyzers' rows of a launch, 3 MB: hipMemcpy into pageable memory took 0.7-1.1 ms for them, this way 0.3)
     if (bytes < ((size_t)256 << 10)) { hipError_t e0 = hipStreamSynchronize(s); return e0 != hipSuccess ? e0 : hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost); }
-    std::unique_lock<std::mutex> lk(g_pinned.mu, std::try_to_lock);
-    if (!lk.owns_lock() || !g_pinned.ready()) return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);    // (another thread's copy is in flight)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MXE_MAX_DEVICES) dev = -1;
+    PinnedPair* pp = dev >= 0 ? &g_pinned_dev[dev] : nullptr;
+    std::unique_lock<std::mutex> lk;
+    if (pp) lk = std::unique_lock<std::mutex>(pp->mu, std::try_to_lock);
+    if (!pp || !lk.owns_lock() || !pp->ready()) {
+        // (another thread's copy through this device's pair is in flight, or no pinned memory: a plain copy -- which runs on the
+        //  null stream and does NOT wait for work queued on the non-blocking stream s: wait for it first)
+        hipError_t e0 = hipStreamSynchronize(s);
+        return e0 != hipSuccess ? e0 : hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+    }
+    PinnedPair& g_pinned = *pp;
     const size_t C = PinnedPair::CHUNK, n = (bytes + C - 1) / C;
     hipError_t e = hipSuccess;
     for (size_t k = 0; k <= n && e == hipSuccess; ++k) {
@@ -217,6 +233,12 @@ struct mxe_ctx {
     std::vector<int> excluded;          // problems no piece of the lock-step launch covers (more than 32 coupled directions): mxe_chains_finish
     DevBuf<int> dexcluded;
     bool mc_gst = false;              // lock-step layout with u, H, sw in device memory (frequency meshes beyond the LDS)
+    // chain_kernel_lv (V^T resident in LDS as binary32, mxe_kernel_lv.hip.h): 0 = not used, 1 = it IS the launch
+    // (mxe_opts.precision = F32), 2 = first pass of a binary64 launch that does not fill the GPU -- chain_kernel_mc then
+    // takes every alpha as a piece of its own from the v it left (the arrays of that second pass: d2_*)
+    int lv_mode = 0;
+    int n_wg2 = 0, wgpc2 = 1;
+    DevBuf<int> d2_elem, d2_prob0, d2_len, d2_v0, d2_queue, dcnt1_niter, dcnt1_nevals;
     DevBuf<double> dgstate_mc;
     std::vector<int> queue;
     std::vector<int> sub_pre;                                           // leading alpha of a piece: entries before its first alpha (0: none)
@@ -502,6 +524,7 @@ void mxe_opts_default(mxe_opts* o)
     o->waves_per_chain = 0; o->chains_per_wg = 0; o->alpha_split = 0; o->stop_estimate = 1;
     o->precision = MXE_PRECISION_F64; o->wg_per_cu = 0;
     o->chi2_factor = 1.0;
+    o->lds_basis = 0; o->reserved_ = 0;
 }
 
 int mxe_ctx_create(int device, int n_tau, int n_omega, int n_s,
@@ -529,7 +552,9 @@ try {
     ctx->S.assign(S, S + n_s);
     ctx->V.assign(V, V + (size_t)n_omega * n_s);
     mxe_opts_default(&ctx->opts);
-    { std::lock_guard<std::mutex> lk(g_pinned.mu); g_pinned.ready(); }      // (the staging buffers of d2h_pipelined: once per process)
+    if (device >= 0 && device < MXE_MAX_DEVICES) {      // (the staging buffers of d2h_pipelined: once per device -- the current one is this context's)
+        std::lock_guard<std::mutex> lk(g_pinned_dev[device].mu); g_pinned_dev[device].ready();
+    }
     *out = ctx;
     return MXE_OK;
 }
@@ -792,6 +817,13 @@ try {
     for (size_t i = 0; i < (size_t)n_chain * n_alpha; ++i)
         if (!(alpha_scaled[i] > 0.0) || !std::isfinite(alpha_scaled[i])) return MXE_ERR_ARG;
     const size_t P = (size_t)n_chain * n_alpha;
+    // chain_kernel_lv (V^T resident in LDS as binary32): possible where the basis fits beside the state of four slots
+    const bool lv_fits = NP == 64 && ctx->nwp <= 512 && o.lds_basis != 2 && !getenv("MXE_NO_LDS_BASIS") &&
+                         o.chains_per_wg != 1 && o.tol_d <= 0.0 && o.decouple_tol > 0.0 &&
+                         mxe::lv_lds_bytes(ns, ctx->nwp) + mxe::LV_STATIC_LDS <= (size_t)160 * 1024;
+    // (binary32 launches in that kernel are scheduled like binary64 ones: lock-step pieces, one workgroup per CU)
+    const bool f32_lv = o.precision == MXE_PRECISION_F32 && lv_fits;
+    ctx->lv_mode = 0;
     // ---- (sub-)chains: an alpha scan may be cut into pieces that are cold-started
     //      from the same v0 (the minimiser of each alpha does not depend on the path)
     int split = o.alpha_split;
@@ -807,7 +839,7 @@ try {
         HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
         // (two workgroups per CU where the lock-step kernel has a build for it: n_omega_pad <= 512)
         const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        int wgpc_guess = (o.wg_per_cu != 1 && ctx->nwp <= 512 && NP == 64 && o.chains_per_wg != 1) ? 2 : 1;
+        int wgpc_guess = (o.wg_per_cu != 1 && ctx->nwp <= 512 && NP == 64 && o.chains_per_wg != 1 && !f32_lv) ? 2 : 1;
         for (;;) {
             const int n_slots = 4 * wgpc_guess * n_cu;
             // A piece of a normal-entropy scan costs about twice one of a plus-minus scan of the same length (10-18
@@ -820,7 +852,7 @@ try {
             split = std::max(1, std::min(want, n_alpha / 2));
             // (the binary32 streaming variant stops an alpha at its rounding floor, which a cold start reaches
             //  from further away: it keeps pieces of at least six alphas, at most 16 per scan)
-            if (o.precision == MXE_PRECISION_F32) split = std::max(1, std::min(std::min(want, 16), n_alpha / 6));
+            if (o.precision == MXE_PRECISION_F32 && !f32_lv) split = std::max(1, std::min(std::min(want, 16), n_alpha / 6));
             // two workgroups per CU pay when there is work for two rounds of them; a batch that cannot be cut
             // into that many pieces runs at one per CU, where a round of a workgroup takes 45 k instead of 73 k
             // cycles (the 3 200-problem shard of cfg4 / 8: 0.48 against 0.59 ms)
@@ -833,7 +865,7 @@ try {
         // and the time the one-chain kernel spends on one (cfg3, 16 scans: 1.9 ms with 256 pieces in the
         // one-chain layout, 0.7 ms with 768 pieces of two alphas in the lock-step layout)
         if ((long long)n_chain * split < 768 && n_alpha >= 4 && (long long)n_chain * (n_alpha / 2) >= 768 &&
-            NP == 64 && o.chains_per_wg != 1 && o.tol_d <= 0.0 && o.decouple_tol > 0.0 && o.precision == MXE_PRECISION_F64)
+            NP == 64 && o.chains_per_wg != 1 && o.tol_d <= 0.0 && o.decouple_tol > 0.0 && (o.precision == MXE_PRECISION_F64 || f32_lv))
             split = (768 + n_chain - 1) / n_chain;
     }
     if (split > n_alpha) split = n_alpha;
@@ -898,7 +930,7 @@ try {
     int layout = o.chains_per_wg;
     ctx->mc_na = 0;
     if (layout == 0) layout = 4;
-    if (layout == 4 && (NP != 64 || o.tol_d > 0.0 || o.decouple_tol <= 0.0 || o.precision != MXE_PRECISION_F64)) layout = 1;
+    if (layout == 4 && (NP != 64 || o.tol_d > 0.0 || o.decouple_tol <= 0.0 || (o.precision != MXE_PRECISION_F64 && !f32_lv))) layout = 1;
     if (layout == 4) {
         // capacity of the active block: the kernel clamps n_act to NA, and the
         // first neglected direction couples with relative strength
@@ -994,6 +1026,11 @@ try {
             }
         }
     }
+    if (layout == 4 && f32_lv) {
+        // the binary32 launch: only the plain 32-row layout with nothing cut has a build in chain_kernel_lv
+        if (ctx->mc_na == 32 && ctx->excluded.empty() && !ctx->mc_gst) { ctx->lv_mode = 1; ctx->mc_wgpc = 1; }
+        else { layout = 1; ctx->mc_na = 0; ctx->excluded.clear(); }          // (the one-chain binary32 kernel, as before r04)
+    }
     if (layout != 4 && ctx->has_pre) {
         size_t w = 0;
         for (size_t sc = 0; sc < ctx->sub_elem.size(); ++sc) {
@@ -1043,6 +1080,30 @@ try {
                         ctx->sub_prob0[sc] + ctx->sub_len[sc] == (ctx->sub_v0[sc] + 1) * n_alpha) ++n_tail;
                 ctx->n_solo = std::min((n_tail + 3) / 4, n_cu / 32);
             }
+            // A binary64 launch that does not fill the GPU (one workgroup per CU by the rule above) is as long as its
+            // deepest chain of rounds: its first pass runs in chain_kernel_lv -- binary32, V^T in LDS, a round in a
+            // fraction of the time --, every alpha to LV_TOL1, and the binary64 kernel then takes every alpha as a piece
+            // of its own from that v: P pieces of one alpha, start vector = the record of the first pass
+            if (lv_fits && o.precision == MXE_PRECISION_F64 && ctx->mc_na == 32 && !ctx->mc_gst && ctx->excluded.empty() &&
+                o.lds_basis == 1) {
+                ctx->lv_mode = 2;
+                ctx->mc_wgpc = 1; ctx->n_solo = 0;
+                ctx->n_wg = std::min((ctx->n_sub + 3) / 4, n_cu);
+                const int P2 = (int)P;
+                std::vector<int> e2(P2), p2(P2), l2(P2, 1);
+                for (int i = 0; i < P2; ++i) { e2[i] = elem_of_chain[i / n_alpha]; p2[i] = i; }
+                ctx->wgpc2 = (o.wg_per_cu != 1 && (P2 + 3) / 4 >= 2 * n_cu && mc_lds_bytes(32, ctx->nwp, 2) <= 80 * 1024 - 2048) ? 2 : 1;
+                ctx->n_wg2 = std::min((P2 + 3) / 4, n_cu * ctx->wgpc2);
+                HIPCHK(ctx, ctx->d2_elem.ensure(P2)); HIPCHK(ctx, ctx->d2_prob0.ensure(P2));
+                HIPCHK(ctx, ctx->d2_len.ensure(P2)); HIPCHK(ctx, ctx->d2_v0.ensure(P2)); HIPCHK(ctx, ctx->d2_queue.ensure(P2));
+                HIPCHK(ctx, ctx->dcnt1_niter.ensure(P2)); HIPCHK(ctx, ctx->dcnt1_nevals.ensure(P2));
+                HIPCHK(ctx, hipMemcpyAsync(ctx->d2_elem.p, e2.data(), (size_t)P2 * 4, hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(ctx->d2_prob0.p, p2.data(), (size_t)P2 * 4, hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(ctx->d2_v0.p, p2.data(), (size_t)P2 * 4, hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(ctx->d2_queue.p, p2.data(), (size_t)P2 * 4, hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(ctx->d2_len.p, l2.data(), (size_t)P2 * 4, hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(ctx, stream_wait(ctx->stream));          // (the host vectors go out of scope)
+            }
         } else {
             // static layout: group by data set, four per workgroup, -1 pads
             std::vector<std::vector<int>> by_ds(ctx->ds.size());
@@ -1056,7 +1117,7 @@ try {
         ctx->n_wg = ctx->n_sub;
     }
     HIPCHK(ctx, ctx->dqueue.ensure(std::max<size_t>(ctx->queue.size(), 1)));
-    HIPCHK(ctx, ctx->dcounter.ensure(1));
+    HIPCHK(ctx, ctx->dcounter.ensure(2));
     if (!ctx->queue.empty())
         HIPCHK(ctx, hipMemcpyAsync(ctx->dqueue.p, ctx->queue.data(), ctx->queue.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, ctx->dchain_elem.ensure(ctx->n_sub));
@@ -1150,7 +1211,18 @@ void clear_excluded_kernel(const int* __restrict__ idx, int n_alpha, int n_omega
     for (int k = threadIdx.x; k < NP; k += blockDim.x) v[pidx * NP + k] = v0[chain * NP + k];
     if (threadIdx.x == 0) { chi2[pidx] = nan; S[pidx] = nan; Q[pidx] = nan; niter[pidx] = 0; conv[pidx] = 0; nevals[pidx] = 0; nact[pidx] = 0; }
 }
+// the iteration counts of a two-pass launch (chain_kernel_lv, then chain_kernel_mc per alpha): both passes
+__global__ __launch_bounds__(256)
+void add_counts_kernel(int* __restrict__ niter, int* __restrict__ nevals, const int* __restrict__ niter1, const int* __restrict__ nevals1, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { niter[i] += niter1[i]; nevals[i] += nevals1[i]; }
+}
 }  // namespace
+
+// tolerance of the binary32 first pass of a two-pass launch: far enough above the rounding floor of h = V^T H in binary32
+// (~2e-7 of |H|) to be reached without crawling, close enough for ONE binary64 Newton step to land below 1e-9
+constexpr double LV_TOL1 = 1e-5;
 
 int mxe_chains_launch(mxe_ctx* ctx)
 try {
@@ -1171,6 +1243,58 @@ try {
         // Eight waves per workgroup (four helpers for the streaming passes) where the launch runs one workgroup per
         // CU, i.e. does not fill the GPU and is as long as its deepest chain of rounds; mxe_opts.waves_per_chain = 4 / 8
         // overrides (the passes of that build want n_omega_pad in units of 256)
+        if (ctx->lv_mode != 0) {
+            // V^T resident in LDS as binary32 (mxe_kernel_lv.hip.h): the launch itself (precision = F32) or the first pass
+            // of a binary64 launch that does not fill the GPU
+            const size_t lds1 = mxe::lv_lds_bytes(ctx->n_s, ctx->nwp);
+            mxe::MCExtra ex; ex.wg_chains = ctx->dwg_chains.p; ex.n_wg = ctx->n_wg;
+            ex.gstate = nullptr; ex.gstate_stride = 0; ex.stagger = 0; ex.n_solo = 0;
+            ex.queue = ctx->dqueue.p; ex.n_queue = ctx->n_queue; ex.counter = ctx->dcounter.p;
+            HIPCHK(ctx, hipMemsetAsync(ctx->dcounter.p, 0, 2 * sizeof(int), ctx->stream));
+            KParams k1 = kp;
+            if (ctx->lv_mode == 2) {
+                k1.tol_h = std::max(kp.tol_h, LV_TOL1);
+                k1.out_H = nullptr;
+                k1.out_niter = ctx->dcnt1_niter.p; k1.out_nevals = ctx->dcnt1_nevals.p;
+            }
+            ctx->last_nw = mxe::LV_NWV; ctx->last_lds = (int)lds1;
+            ctx->last_kernel = "mxe::chain_kernel_lv";
+            HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+            e = hipFuncSetAttribute((const void*)mxe::chain_kernel_lv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+            HIPCHK(ctx, e);
+            hipLaunchKernelGGL(mxe::chain_kernel_lv, dim3(ctx->n_wg), dim3(64 * mxe::LV_NWV), lds1, ctx->stream, k1, ex);
+            HIPCHK(ctx, hipGetLastError());
+            if (ctx->lv_mode == 2) {
+                // second pass: every alpha a piece of its own in the binary64 lock-step kernel, from the v of the first
+                const size_t Pn = (size_t)ctx->n_chain * ctx->n_alpha;
+                const int W2 = ctx->wgpc2;
+                const int NWV2 = (W2 == 1 && ctx->nwp % 256 == 0 && mc_lds_bytes(32, ctx->nwp, 1, 8) <= 160 * 1024 - 6144) ? 8 : 4;
+                const size_t lds = mc_lds_bytes(32, ctx->nwp, W2, NWV2);
+                if (lds > 160 * 1024 - 6144) return MXE_ERR_LIMIT;
+                KParams k2 = kp;
+                k2.chain_elem = ctx->d2_elem.p; k2.chain_prob0 = ctx->d2_prob0.p; k2.chain_len = ctx->d2_len.p;
+                k2.chain_v0 = ctx->d2_v0.p; k2.v0 = ctx->dout_v.p;
+                k2.chain_lead = nullptr; k2.init_tab = nullptr; k2.chain_init = nullptr;
+                k2.n_chain = (int)Pn;
+                k2.prof = nullptr;                  // (diagnostic build: the stamps of the first pass stay)
+                mxe::MCExtra e2 = ex;
+                e2.wg_chains = nullptr; e2.n_wg = ctx->n_wg2;
+                e2.queue = ctx->d2_queue.p; e2.n_queue = (int)Pn; e2.counter = ctx->dcounter.p + 1;
+#define MXE_LAUNCH_MC2(WG_, NWV_) do { \
+                e = hipFuncSetAttribute((const void*)mxe::chain_kernel_mc<32, WG_, false, NWV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<32, WG_, false, NWV_>), dim3(ctx->n_wg2), dim3(64 * NWV_), lds, ctx->stream, k2, e2); e = hipGetLastError(); } } while (0)
+                if (W2 == 2) MXE_LAUNCH_MC2(2, 4); else if (NWV2 == 8) MXE_LAUNCH_MC2(1, 8); else MXE_LAUNCH_MC2(1, 4);
+#undef MXE_LAUNCH_MC2
+                HIPCHK(ctx, e);
+                hipLaunchKernelGGL(add_counts_kernel, dim3((unsigned)((Pn + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   ctx->dout_niter.p, ctx->dout_nevals.p, ctx->dcnt1_niter.p, ctx->dcnt1_nevals.p, (int)Pn);
+                HIPCHK(ctx, hipGetLastError());
+                ctx->last_kernel += " + mxe::chain_kernel_mc<32, " + std::to_string(W2) + (NWV2 == 8 ? ", 8 waves>" : ">") + " per alpha";
+            }
+            HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+            ctx->launched = true;
+            return MXE_OK;
+        }
         const int NA = ctx->mc_na, WGPC = ctx->mc_wgpc;
         const bool GST = ctx->mc_gst;
         const int NWV = (NA == 32 && WGPC == 1 && ctx->nwp % 256 == 0 && o.waves_per_chain != 4 &&
@@ -1904,8 +2028,8 @@ try {
     const size_t nc = ctx->n_chain, nw = ctx->n_omega;
     ctx->h_sel3.resize(3 * nc);
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_sel3.data(), ctx->dsel3.p, 3 * nc * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));       // (the selection kernel has finished before any path of the row copy starts)
     if (out_H_selected) HIPCHK(ctx, d2h_pipelined(out_H_selected, ctx->dsel3.p + 3 * nc, 3 * nc * nw * 8, ctx->stream));
-    HIPCHK(ctx, stream_wait(ctx->stream));
     for (size_t i = 0; i < 3 * nc; ++i) out_index[i] = (int32_t)ctx->h_sel3[i];
     return MXE_OK;
 }

@@ -45,7 +45,9 @@ class MxeOpts(ctypes.Structure):
                 ('stop_estimate', ctypes.c_int32),
                 ('precision', ctypes.c_int32),
                 ('wg_per_cu', ctypes.c_int32),
-                ('chi2_factor', ctypes.c_double)]
+                ('chi2_factor', ctypes.c_double),
+                ('lds_basis', ctypes.c_int32),
+                ('reserved_', ctypes.c_int32)]
 
 
 _dp = ctypes.POINTER(ctypes.c_double)

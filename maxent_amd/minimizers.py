@@ -248,7 +248,8 @@ class LevenbergMinimizer(Minimizer):
 
         1. ``mu`` grows by factors ``nu`` until the step does not increase the function (a NaN counts as an increase);
         2. the neighbour ``nu mu`` is tried: the search then walks in the direction that lowers the function --
-           up while the neighbour is better, else down --, as long as it keeps falling and ``mu`` stays inside
+           up while the neighbour is better, else DOWN (``mu / nu``, ``mu / nu^2`` ...: after a rejected step ``mu``
+           falls back as soon as smaller values do better) --, as long as it keeps falling and ``mu`` stays inside
            ``(nu eps, max_mu)``; the last step before it rose again is taken.
 
         ``mu`` carries over to the next iteration."""
@@ -289,11 +290,17 @@ class LevenbergMinimizer(Minimizer):
                 mu *= nu
                 step, Q = trial(mu)
             step_up, Q_up = trial(nu * mu)                                    # 2. which way does mu want to go?
+            # The walk of levenberg_minimizer.py:209-233 with its pairings: going up, the first candidate (the step of
+            # nu mu) is measured against the value at mu itself (:216-218); going down, mu is first raised by nu and the
+            # step of mu is seeded with the value the neighbour nu mu gave (:222-224), so that the loop's first pass
+            # re-evaluates mu and its second the real candidate mu / nu.  The step taken is the last one before the
+            # function rose again; mu ends on the value that made it rise and carries over to the next iteration.
             if Q_up < Q:
-                factor, mu, best_step, best_Q, next_step, next_Q = nu, nu * mu, step, Q, step_up, Q_up
+                factor, next_step, next_Q = nu, step_up, Q
             else:
-                factor, best_step, best_Q, next_step, next_Q = 1.0 / nu, step, np.inf, step, Q
-                mu *= nu                                                      # (the walk below starts by undoing this)
+                factor, next_step, next_Q = 1.0 / nu, step, Q_up
+            mu *= nu
+            best_step, best_Q = step, np.inf
             while next_Q < best_Q and tiny < mu < self.max_mu:
                 best_step, best_Q = next_step, next_Q
                 mu *= factor

@@ -254,6 +254,44 @@ def kat_srvo3():
                         alps_maxspec=ms)
 
 
+
+def record_solves(ew):
+    """every minimisation of an element-wise run as the reference set it up -- the data its cost function held (kernel as
+    rotated / blurred for that element, G, err, default model, V) and the v its minimiser ended at -- keyed by matrix element,
+    complex index and alpha index: what the truth rows of the element-wise fixtures are polished from"""
+    log, cur = [], {}
+    for worker in (ew.maxent_diagonal, ew.maxent_offdiagonal):
+        loop = worker.maxent_loop
+
+        def run(*a, _o=loop.run, **k):
+            cur['elem'], cur['ci'], cur['ia'] = k.get('matrix_element'), k.get('complex_index'), 0
+            return _o(*a, **k)
+
+        def minimize(f, v, _o=loop.minimizer.minimize):
+            r = _o(f, v)
+            log.append(dict(elem=tuple(cur['elem']), ci=cur['ci'], ia=cur['ia'], alpha=float(f._alpha),
+                            K=np.array(f.chi2.K.K), G=np.array(f.chi2.G),
+                            err=np.array(f.chi2.err, dtype=float) * np.ones(len(f.chi2.G)),
+                            D=np.array(f.S.D.D), V=np.array(f.H_of_v.K.V), v=np.array(r, copy=True),
+                            entropy='plusminus' if 'PlusMinus' in type(f.S).__name__ else 'normal'))
+            cur['ia'] += 1
+            return r
+        loop.run = run
+        loop.minimizer.minimize = minimize
+    return log
+
+
+def truth_of(log, shape, D_of=None):
+    """H_truth in the layout of MaxEntResult.H (NaN where the run solved nothing): every recorded solve polished in extended
+    precision from the reference's own iterate (oracle/hp_truth.py), with the reference's data"""
+    Ht = np.full(shape, np.nan)
+    for s in log:
+        D = s['D'] if D_of is None else D_of(s)
+        _, H = hp_truth.polish(s['K'], s['G'], s['err'], D, s['V'], None, s['alpha'], s['v'], s['entropy'], iters=6)
+        Ht[s['elem'] + ((s['ci'] or 0,) if len(shape) == 5 else ()) + (s['ia'],)] = H
+    return Ht
+
+
 def elementwise_case():
     """reference test/python/elementwise_maxent.py:101-188 on its own fixture
     elementwise_g_tau.npz (2x2x201, beta=400)."""
@@ -271,7 +309,29 @@ def elementwise_case():
         ew.omega = HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=80)
         ew.alpha_mesh = LogAlphaMesh(alpha_min=0.05, alpha_max=500, n_points=8)
         ew.set_error(noise)
+        log = record_solves(ew)
         res = ew.run()
+        lf = np.array([[res.analyzer_results[i][j]['LineFitAnalyzer']['alpha_index'] for j in range(2)] for i in range(2)])
+        delta = ew.omega.delta
+        if name == 'ew':
+            out[name + '_H_truth'] = truth_of(log, np.array(res.H).shape)
+        else:
+            # Poorman (elementwise_maxent.py:637-652): the default model of an off-diagonal element is sqrt(A_ii A_jj) + 1e-6
+            # of the diagonal elements' LineFit spectra.  The truth of the whole procedure takes the TRUTH of those spectra
+            # (the reference's own differ from it by its stopping slack, 1e-5 relative, and so would every off-diagonal H)
+            diag = truth_of([q for q in log if q['elem'][0] == q['elem'][1]], np.array(res.H).shape)
+
+            def D_pm(q):
+                i, j = q['elem']
+                if i == j:
+                    return q['D']
+                A1, A2 = diag[i, i, lf[i, i]] / delta, diag[j, j, lf[j, j]] / delta
+                D = (np.sqrt(A1 * A2) + 1e-6) * delta
+                assert np.allclose(D, q['D'], rtol=1e-3, atol=1e-9), np.max(np.abs(D - q['D']) / q['D'])          # (the reference's, up to its slack)
+                return D
+            out[name + '_H_truth'] = truth_of(log, np.array(res.H).shape, D_pm)
+        e = np.linalg.norm(np.array(res.H) - out[name + '_H_truth'], axis=-1) / np.linalg.norm(out[name + '_H_truth'], axis=-1)
+        print('   %s: reference vs truth, rel L2 of H: max %.2e' % (name, np.nanmax(e)))
         out[name + '_A'] = np.array(res.A)
         out[name + '_H'] = np.array(res.H)
         out[name + '_chi2'] = np.array(res.chi2)
@@ -445,8 +505,10 @@ def complex_elementwise_case():
         ew.omega = HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=60)
         ew.alpha_mesh = LogAlphaMesh(alpha_min=0.05, alpha_max=500, n_points=6)
         ew.set_error(1e-3)
+        log = record_solves(ew)
         res = ew.run()
         tag = 'herm%d_' % int(herm)
+        out[tag + 'H_truth'] = truth_of(log, np.array(res.H).shape)
         for k in ('H', 'A', 'chi2', 'S', 'Q', 'alpha', 'A_out'):
             out[tag + k] = np.array(getattr(res, k))
         out[tag + 'zero_elements'] = np.array(res.zero_elements, dtype=int)
@@ -480,8 +542,10 @@ def elementwise_cov_case():
             ew.maxent_offdiagonal.K = PreblurKernel(K=ew.maxent_offdiagonal.K, b=0.3)
         ew.alpha_mesh = LogAlphaMesh(alpha_min=0.05, alpha_max=500, n_points=6)
         ew.set_cov(cov)
+        log = record_solves(ew)
         res = ew.run()
         tag = 'blur%d_' % int(blur)
+        out[tag + 'H_truth'] = truth_of(log, np.array(res.H).shape)
         for k in ('H', 'A', 'chi2', 'S', 'Q', 'alpha', 'A_out'):
             out[tag + k] = np.array(getattr(res, k))
         out['omega'] = np.array(ew.omega)
@@ -514,8 +578,10 @@ def elementwise_shared_cov_case():
     ew.omega = HyperbolicOmegaMesh(omega_min=-10, omega_max=10, n_points=60)
     ew.alpha_mesh = LogAlphaMesh(alpha_min=0.05, alpha_max=500, n_points=6)
     ew.set_cov(cov)
+    log = record_solves(ew)
     res = ew.run()
     out = dict(tau=tau, G_tau=G, cov=cov, omega=np.array(ew.omega))
+    out['H_truth'] = truth_of(log, np.array(res.H).shape)
     for k in ('H', 'A', 'chi2', 'S', 'Q', 'alpha', 'A_out'):
         out[k] = np.array(getattr(res, k))
     print('%-28s' % 'elementwise_shared_cov')

@@ -45,9 +45,9 @@ def test_opts_defaults_and_struct_layout():
     assert o.stop_estimate == 1
     assert o.precision == device.PRECISION_F64 and o.wg_per_cu == 0
     assert o.chi2_factor == 1.0
-    # the struct of include/maxent_hip.h: 2 int32, 8 double, 6 int32, 1 double, no padding holes
+    # the struct of include/maxent_hip.h: 2 int32, 8 double, 6 int32, 1 double, 2 int32 (lds_basis, reserved), no padding holes
     import ctypes
-    assert ctypes.sizeof(device.MxeOpts) == 2 * 4 + 8 * 8 + 6 * 4 + 8
+    assert ctypes.sizeof(device.MxeOpts) == 2 * 4 + 8 * 8 + 6 * 4 + 8 + 2 * 4
     assert device.MxeOpts.precision.offset == 2 * 4 + 8 * 8 + 4 * 4
     assert device.MxeOpts.chi2_factor.offset == 2 * 4 + 8 * 8 + 6 * 4
     with pytest.raises(TypeError):

@@ -74,6 +74,20 @@ class Coupled(DoublyDerivableFunction):
         return np.dot(self.A.T * (6 * np.dot(self.A, v)), self.A)
 
 
+class Rosenbrock(DoublyDerivableFunction):
+    @cached
+    def f(self, v):
+        return (1 - v[0]) ** 2 + 100 * (v[1] - v[0] ** 2) ** 2
+
+    @cached
+    def d(self, v):
+        return np.array([-2 * (1 - v[0]) - 400 * v[0] * (v[1] - v[0] ** 2), 200 * (v[1] - v[0] ** 2)])
+
+    @cached
+    def dd(self, v):
+        return np.array([[2 - 400 * (v[1] - 3 * v[0] ** 2), -400 * v[0]], [-400 * v[0], 200.0]])
+
+
 FLAGS = [(j, m) for j in (True, False) for m in (True, False)]
 
 
@@ -112,7 +126,9 @@ def test_the_flags_change_the_iterates(J_squared, marquardt):
     lines = []
     lm = LevenbergMinimizer(J_squared=J_squared, marquardt=marquardt, mu0=1.0, nu=2.0, maxiter=3,
                             convergence=MaxDerivativeConvergenceMethod(1e-300), verbose_callback=lines.append)
-    v = lm.minimize(Coupled(), np.array([3.0, 5.0]))
+    # (a function whose full Newton step goes uphill from here, so that the damping stays in the step: where the walk of mu
+    #  ends at its floor -- Coupled() from (3, 5): every smaller mu is better -- all four variants take the Newton step)
+    v = lm.minimize(Rosenbrock(), np.array([-1.2, 1.0]))
     test_the_flags_change_the_iterates.seen = getattr(test_the_flags_change_the_iterates, 'seen', {})
     test_the_flags_change_the_iterates.seen[(J_squared, marquardt)] = tuple(np.round(v, 10))
     seen = test_the_flags_change_the_iterates.seen
@@ -158,3 +174,45 @@ def test_nu_below_one_is_refused_and_miniter_is_kept():
     lm = LevenbergMinimizer(miniter=7, convergence=NullConvergenceMethod())
     lm.minimize(Sin(), np.array([0.3]))
     assert lm.n_iter_last == 8
+
+
+def _reference_style_search(fun, v0, mu0=1e-18, nu=1.3, max_mu=1e20, maxiter=1000, tol=1e-4):
+    """the search of levenberg_minimizer.py:155-243 written down independently for this test (plain loops, the
+    reference's stopping rule max|d| < 1e-4): iteration count and the damping it ends with"""
+    v, mu = np.array(v0, float), mu0
+    for it in range(maxiter):
+        g, J = fun(v).d(), fun(v).dd()
+        if np.max(np.abs(g)) < tol:
+            return v, it + 1, mu
+        Q0 = fun(v).f()
+        q = lambda m: fun(v - np.linalg.solve(J + m * np.eye(2), g)).f()
+        Q1 = q(mu)
+        while (Q1 > Q0 or np.isnan(Q1)) and mu < max_mu:
+            mu *= nu
+            Q1 = q(mu)
+        Q2 = q(nu * mu)
+        if Q2 < Q1:
+            f, take, Q2 = nu, nu * mu, Q1
+        else:
+            f, take = 1 / nu, mu
+        use = mu
+        mu *= nu
+        Qb = np.inf
+        while Q2 < Qb and nu * np.finfo(float).eps < mu < max_mu:
+            Qb, use = Q2, take
+            mu *= f
+            take, Q2 = mu, q(mu)
+        v = v - np.linalg.solve(J + use * np.eye(2), g)
+    return v, maxiter, mu
+
+
+def test_the_damping_falls_back_after_a_rejected_step():
+    """once a step had been rejected the damping could only grow (the walk towards smaller mu re-evaluated
+    the same trial and stopped): Rosenbrock's valley from (-1.2, 1) then took 1000 iterations with mu stuck near 65.
+    With the reference's walk it converges in a few dozen iterations and mu is back at its floor."""
+    m = LevenbergMinimizer(convergence=MaxDerivativeConvergenceMethod(1e-4))
+    v = m.minimize(Rosenbrock(), np.array([-1.2, 1.0]))
+    v_ref, n_ref, mu_ref = _reference_style_search(Rosenbrock(), [-1.2, 1.0])
+    assert m.converged and np.allclose(v, [1.0, 1.0], atol=1e-5)
+    assert n_ref < 60 and abs(m.n_iter_last - n_ref) <= 1, (m.n_iter_last, n_ref)
+    assert np.allclose(v, v_ref, atol=1e-9)
