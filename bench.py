@@ -306,7 +306,7 @@ def scaling_projection(batch, opts, k_ms_full, n_alpha, n_launch=30):
     out = dict(whole_batch_kernel_ms=k_ms_full, method='one GPU solves each rank\'s shard in turn (HIP events over %d launches '
                'back to back); speedup = whole-batch kernel time / slowest shard' % n_launch)
     for N in (2, 4, 8):
-        times, kern = [], None
+        times, kern, depths = [], None, []
         for r in range(N):
             which = [e for e in range(n_elem) if e % N == r]
             c = stage(batch, 0, which)
@@ -319,23 +319,62 @@ def scaling_projection(batch, opts, k_ms_full, n_alpha, n_launch=30):
                 c.launch()
             times.append(c.ms_since_mark() / n_launch)
             kern = c.last_launch_info()['kernel']
+            depths.append(c.launch_depth())
             c.close()
+        slow = int(np.argmax(times))
         out['N=%d' % N] = dict(shard_kernel_ms=[round(t, 4) for t in times], slowest_ms=max(times), fastest_ms=min(times),
-                               slowest_rank=int(np.argmax(times)), kernel=kern, alpha_solves_per_rank=len(which) * n_alpha,
-                               speedup_before_gather=k_ms_full / max(times))
+                               slowest_rank=slow, kernel=kern, alpha_solves_per_rank=len(which) * n_alpha,
+                               speedup_before_gather=k_ms_full / max(times),
+                               rounds_deepest_workgroup=[d['max_rounds'][0] for d in depths],
+                               us_per_round_slowest_rank=1e3 * times[slow] / max(1, depths[slow]['max_rounds'][0]))
+    # the bound, from this run: a shard that does not fill the GPU is as long as its deepest workgroup (rounds counted by the
+    # kernel, mxe_launch_depth) times what a round takes there (the shard's kernel time / that depth)
+    deep = [out['N=%d' % N]['rounds_deepest_workgroup'][out['N=%d' % N]['slowest_rank']] for N in (2, 4, 8)]
+    usr = [out['N=%d' % N]['us_per_round_slowest_rank'] for N in (2, 4, 8)]
     out['bound'] = dict(
-        text='A shard that does not fill the GPU is as long as its deepest chain of Newton rounds, not as its work: the tail '
-             'of a normal-entropy scan cannot be cold-started (the last 6 % of the alpha range take 50-390 evaluations from '
-             'the default model), so its pieces solve the last alpha above that range cold -- 14-16 rounds to the 2e-2 the walk '
-             'needs at the smallest alphas: Newton moves u = log(H / D) by 1-2.5 per step where the spectrum has to vanish, and '
-             'it has to fall by ~11 --, walk down the mesh at one round per alpha (up to 6) and take 3-4 rounds for their own '
-             'alpha: 23-27 rounds whatever N is.  A round of a workgroup that has its CU to itself takes ~37 k cycles (15.6 us, '
-             'eight waves, stamps of profiles/r03_h_phases_mc_wg1_8waves.txt): binary32 Gauss-Jordan + step 12.5 k on one wave per '
-             'slot, accept 4.6 k, the two streaming passes 20 k of which the 448 KB of V and V^T at the 32-64 B per cycle one CU '
-             'gets out of its L2 are 7-15 k (more waves do not change that: profiles/r03_a_phases_wg1_*waves.txt, '
-             'profiles/r03_a_l2_stream_rate.txt).',
-        rounds_deepest_chain=[23, 27], us_per_round_one_workgroup_per_cu=15.6, floor_ms=[0.36, 0.42],
-        speedup_ceiling_at_this_round_structure=k_ms_full / 0.36)
+        rounds_deepest_chain=[min(deep), max(deep)], us_per_round_one_workgroup_per_cu=float(np.mean(usr[1:])),
+        floor_ms=[1e-3 * min(deep) * float(np.mean(usr[1:])), 1e-3 * max(deep) * float(np.mean(usr[1:]))],
+        speedup_ceiling_at_this_round_structure=k_ms_full / (1e-3 * min(deep) * float(np.mean(usr[1:]))),
+        measured='rounds: mxe_launch_depth of the slowest rank\'s shard; us per round: that shard\'s kernel time / its rounds (N = 4, 8: '
+                 'one workgroup per CU); floor = rounds x us; the why is in DESIGN.md section 7')
+    return out
+
+
+def underfilled_block(n_launch=40):
+    """The BASELINE configurations that do not fill one GPU, in the same run: cfg2 (one scan of 100 alpha) and cfg3 (4 x 4: 16
+    scans), binary64 and binary32 (mxe_opts.precision: the LDS-resident kernel), kernel time by HIP events over launches back to
+    back, depth in rounds, every problem audited; and the binary32 kernel time on the cfg4 batch."""
+    out = {}
+    for name, n_orb in (('cfg2', 1), ('cfg3', 4), ('cfg4', 16)):
+        batch = build_batch(max(n_orb, 2), 200, 500, 100, 0)
+        if n_orb == 1:
+            _, _, _, G1 = synthetic.single_G(200, 500)
+            batch['Gmat'] = G1[None, None, :]
+            batch['elems'], batch['kinds'], batch['v0'] = [(0, 0)], batch['kinds'][:1], batch['v0'][:1]
+        n = len(batch['elems'])
+        for tag, o in (('', {}), ('_f32', dict(precision=device.PRECISION_F32))):
+            if name == 'cfg4' and not tag:
+                continue                                  # (the headline itself)
+            c = stage(batch, 0)
+            c.upload_chains(np.arange(n, dtype=np.int32), batch['alphas'], batch['v0'], device.default_opts(**o))
+            for _ in range(3):
+                c.launch()
+            c.sync()
+            c.timing_mark()
+            for _ in range(n_launch):
+                c.launch()
+            ms = c.ms_since_mark() / n_launch
+            c.launch()
+            info, depth, left = c.last_launch_info(), c.launch_depth(), c.finish()
+            res = c.fetch(want_v=False, want_H=False)
+            aud = c.audit()['corr'].ravel()
+            c.close()
+            out[name + tag] = dict(kernel_ms=ms, alpha_solves=int(res['converged'].size), converged=int(res['converged'].sum()),
+                                   left_to_finish=int(left), kernel=info['kernel'], workgroups=info['n_workgroups'],
+                                   rounds_deepest_workgroup=depth['max_rounds'][0], evals_per_solve=float(res['n_evals'].mean()),
+                                   audit_max=float(np.nanmax(aud)), audit_p99=float(np.nanpercentile(aud, 99)))
+    out['cfg2_ms'], out['cfg3_ms'] = out['cfg2']['kernel_ms'], out['cfg3']['kernel_ms']
+    out['cfg2_f32_ms'], out['cfg3_f32_ms'], out['cfg4_f32_ms'] = out['cfg2_f32']['kernel_ms'], out['cfg3_f32']['kernel_ms'], out['cfg4_f32']['kernel_ms']
     return out
 
 
@@ -633,6 +672,8 @@ def main():
                     lds_bytes=info['lds_bytes'], converged_on_rank0=n_conv, alphas_left_to_mxe_chains_finish=n_left_to_finish,
                     svd_seconds_host=batch['t_svd'], host_split=host_split,
                     gather_checked=gather_checked,
+                    self_check='with --gpus N rank 0 solves the whole batch itself and compares the chi2 of every rank as gathered: '
+                               'gather_checked, exit code 3 on a mismatch',
                     multi_gpu_note='N > 1 has not been run by the builders (one-GPU boxes); the RCCL calls of the gather '
                                    '(group start / send / recv / all-reduce) are executed with one rank (--force-comm, '
                                    'tests/test_gpu_multi.py) and several contexts on one device go through device copies; '
@@ -649,12 +690,29 @@ def main():
             line['parity_per_alpha'] = parity_per_alpha()
             if args.shard_of <= 1:
                 line['scaling_projection'] = scaling_projection(batch, opts, k_ms, args.n_alpha)
+                # weak scaling (--scaling weak: one such batch per GPU): no shard gets smaller, every rank runs the step timed above
+                # and the root additionally receives N compact packs.  A projection from this run's step time; the link rate
+                # is the guide's figure (7 xGMI links x ~153 GB/s per GPU, ~76 GB/s per direction and link), not a measurement
+                pack = (3 * P_rank + n_elem * (args.n_omega + 1)) * 8
+                step_ms = 1e3 * elapsed / args.steps
+                line['scaling_projection']['weak'] = {
+                    'step_ms_one_gpu_measured': step_ms, 'compact_pack_bytes_per_rank': pack,
+                    'assumed_link_GBs_per_direction': 76.0,
+                    **{'N=%d' % N: dict(gather_ms_projected=1e3 * pack / 76e9,
+                                        alpha_solves_per_s_projected=N * P_rank / (1e-3 * step_ms + pack / 76e9))
+                       for N in (2, 4, 8)}}
     if use_comm:
         ctx.comm_destroy()
     ctx.close()
     if world == 1 and not args.no_extras:
         line['end_to_end'] = end_to_end_block(batch, args.n_orb, args.n_alpha)
+        if default_workload and args.shard_of <= 1:
+            line['underfilled'] = underfilled_block()
     print(json.dumps(line))
+    if gather_checked is False:
+        # every rank's chi2 as gathered must be what rank 0 gets when it solves the whole batch itself
+        print('bench.py: the gathered results of the ranks differ from the one-GPU solve of the same batch', file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == '__main__':

@@ -275,6 +275,20 @@ const char* mxe_last_kernel_name(mxe_ctx* ctx);
 /* kernel geometry of the last launch: waves per chain, workgroups, LDS bytes */
 int  mxe_last_launch_info(mxe_ctx* ctx, int* waves_per_chain, int* n_workgroups,
                           int* lds_bytes);
+/* Depth of the last lock-step launch in ROUNDS (one Newton iteration of the four chain slots of a workgroup): maximum and mean over
+ * its workgroups.  The reference's scan is one serial chain of n_alpha x ~16 iterations (maxent_loop.py:241-245 around
+ * levenberg_minimizer.py:155); here a launch that does not fill the GPU is as long as its deepest workgroup, and this is that depth
+ * as the kernel counted it (bench.py: scaling_projection.bound divides the measured time by it).  [0]: the launch, or the binary32
+ * first pass of a two-pass launch (mxe_opts.lds_basis); [1]: the second pass (0 when there is none).  One-chain layout: zeros.
+ * Blocking. */
+int  mxe_launch_depth(mxe_ctx* ctx, int32_t* max_rounds /*[2]*/, double* mean_rounds /*[2]*/);
+/* The schedule of the staged chains (after mxe_chains_upload): n_solo = workgroups of a two-per-CU lock-step launch that get a CU to
+ * themselves for the longest pieces (the tails of the normal-entropy scans; the serial alpha loop they replace: maxent_loop.py:241-245).
+ * That schedule rests on which workgroups share a CU -- b and b + gridDim / 2 --, an observed placement that HIP does not promise: the
+ * library probes it once per device (a 25 us kernel that records XCC_ID / HW_ID) and drops the solo workgroups where it does not
+ * hold.  placement_rule: 0 = the upload wanted none, 1 = probed and holds, 2 = does not hold (n_solo = 0).  Results never depend
+ * on it; MXE_FORCE_NO_SOLO_RULE in the environment forces 2. */
+int  mxe_schedule_info(mxe_ctx* ctx, int* n_solo, int* placement_rule);
 
 /* ---- the cost function and its derivatives at caller-supplied points --- */
 /* Device side of CostFunction.__call__ / f / d / dd (cost_function.py:73-85),

@@ -239,6 +239,9 @@ struct mxe_ctx {
     int lv_mode = 0;
     int n_wg2 = 0, wgpc2 = 1;
     DevBuf<int> d2_elem, d2_prob0, d2_len, d2_v0, d2_queue, dcnt1_niter, dcnt1_nevals;
+    DevBuf<int> drounds;                // rounds per workgroup of the last lock-step launch: [n_wg] | [n_wg2] (mxe_launch_depth)
+    int rounds_n[2] = {0, 0};
+    int placement_checked = 0;          // the last upload that wanted solo workgroups: 0 none did, 1 the placement rule holds, 2 it does not
     DevBuf<double> dgstate_mc;
     std::vector<int> queue;
     std::vector<int> sub_pre;                                           // leading alpha of a piece: entries before its first alpha (0: none)
@@ -769,6 +772,54 @@ int build_init_table(mxe_ctx* ctx, int n_chain, const int32_t* elem_of_chain, co
     ctx->has_init = true;
     return MXE_OK;
 }
+// Which workgroups of a launch of two per CU share a CU?  The solo schedule of the lock-step kernel (the longest pieces get a
+// CU to themselves: workgroup b's partner b + gridDim / 2 leaves at once) rests on an OBSERVED placement -- the dispatcher fills
+// every CU with one workgroup before any gets its second, in order -- that HIP does not promise.  Probed once per device with
+// the launch shape of that kernel (256 threads, LDS for exactly two workgroups per CU, every workgroup resident at once):
+// every workgroup records XCC_ID / HW_ID; the rule holds when b and b + n_cu report the same CU for every b.  Where it does
+// not, n_solo stays 0: the schedule is a speed-up only, results never depend on it.
+__global__ __launch_bounds__(256)
+void placement_probe_kernel(unsigned* out)
+{
+    extern __shared__ char probe_lds[];
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = hw; out[2 * blockIdx.x + 1] = xcc; probe_lds[0] = 1; }
+    const long long t0 = clock64();
+    while (clock64() - t0 < 60000) { }           // ~25 us: every workgroup of the grid is resident before the first one leaves
+}
+int g_placement[MXE_MAX_DEVICES];                // 0: not probed, 1: the rule holds, 2: it does not
+std::mutex g_placement_mu;
+
+int placement_rule_holds(mxe_ctx* ctx, int n_cu, bool* holds)
+{
+    *holds = false;
+    if (getenv("MXE_FORCE_NO_SOLO_RULE")) return MXE_OK;              // (tests: the branch a different dispatcher would take)
+    const int dev = ctx->device;
+    if (dev < 0 || dev >= MXE_MAX_DEVICES) return MXE_OK;
+    std::lock_guard<std::mutex> lk(g_placement_mu);
+    if (g_placement[dev] == 0) {
+        const int n = 2 * n_cu;
+        DevBuf<unsigned> d;
+        HIPCHK(ctx, d.ensure((size_t)2 * n));
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)placement_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
+        std::vector<unsigned> h((size_t)2 * n);
+        bool ok = true;
+        for (int rep = 0; rep < 2 && ok; ++rep) {          // (twice: the rule has to hold on every launch, not on the first)
+            hipLaunchKernelGGL(placement_probe_kernel, dim3(n), dim3(256), 73728, ctx->stream, d.p);
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipMemcpyAsync(h.data(), d.p, h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, stream_wait(ctx->stream));
+            for (int b = 0; b < n_cu && ok; ++b)
+                ok = ((h[2 * b] >> 8) & 0xff) == ((h[2 * (b + n_cu)] >> 8) & 0xff) && (h[2 * b + 1] & 0xf) == (h[2 * (b + n_cu) + 1] & 0xf);      // (HW_ID: CU 11:8, SH 12, SE 15:13; XCC_ID 3:0)
+        }
+        d.release();
+        g_placement[dev] = ok ? 1 : 2;
+    }
+    *holds = g_placement[dev] == 1;
+    return MXE_OK;
+}
 }  // namespace
 
 constexpr double MC_COUPLING_MAX = 1e-3;     // relative coupling of the first direction the 32-row active block leaves out (see below)
@@ -1042,7 +1093,7 @@ try {
         ctx->sub_pre.assign(w, 0); ctx->has_pre = false;
         ctx->n_sub = (int)w;
     }
-    ctx->wg_chains.clear(); ctx->queue.clear(); ctx->n_queue = 0; ctx->n_solo = 0;
+    ctx->wg_chains.clear(); ctx->queue.clear(); ctx->n_queue = 0; ctx->n_solo = 0; ctx->placement_checked = 0;
     if (layout == 4) {
         bool one_ds = true;
         for (int sc = 1; sc < ctx->n_sub; ++sc)
@@ -1079,6 +1130,11 @@ try {
                     if (ctx->elem_kind[ctx->sub_elem[sc]] == MXE_ENTROPY_NORMAL &&
                         ctx->sub_prob0[sc] + ctx->sub_len[sc] == (ctx->sub_v0[sc] + 1) * n_alpha) ++n_tail;
                 ctx->n_solo = std::min((n_tail + 3) / 4, n_cu / 32);
+                // (only where workgroups b and b + n_wg / 2 do share a CU on this device: probed once, see placement_rule_holds)
+                bool holds = false;
+                if (ctx->n_solo > 0) { const int rp = placement_rule_holds(ctx, n_cu, &holds); if (rp != MXE_OK) return rp; }
+                ctx->placement_checked = holds ? 1 : 2;
+                if (!holds) ctx->n_solo = 0;
             }
             // A binary64 launch that does not fill the GPU (one workgroup per CU by the rule above) is as long as its
             // deepest chain of rounds: its first pass runs in chain_kernel_lv -- binary32, V^T in LDS, a round in a
@@ -1251,6 +1307,11 @@ try {
             ex.gstate = nullptr; ex.gstate_stride = 0; ex.stagger = 0; ex.n_solo = 0;
             ex.queue = ctx->dqueue.p; ex.n_queue = ctx->n_queue; ex.counter = ctx->dcounter.p;
             HIPCHK(ctx, hipMemsetAsync(ctx->dcounter.p, 0, 2 * sizeof(int), ctx->stream));
+            ctx->rounds_n[0] = ctx->n_wg; ctx->rounds_n[1] = (ctx->lv_mode == 2) ? ctx->n_wg2 : 0;
+            HIPCHK(ctx, ctx->drounds.ensure((size_t)ctx->rounds_n[0] + ctx->rounds_n[1]));
+            HIPCHK(ctx, hipMemsetAsync(ctx->drounds.p, 0, ((size_t)ctx->rounds_n[0] + ctx->rounds_n[1]) * sizeof(int), ctx->stream));
+            if (ex.n_queue > 0) ex.wg_chains = ctx->drounds.p;          // (dynamic layout: the rounds of every workgroup come back here)
+            else ctx->rounds_n[0] = 0;
             KParams k1 = kp;
             if (ctx->lv_mode == 2) {
                 k1.tol_h = std::max(kp.tol_h, LV_TOL1);
@@ -1278,8 +1339,9 @@ try {
                 k2.n_chain = (int)Pn;
                 k2.prof = nullptr;                  // (diagnostic build: the stamps of the first pass stay)
                 mxe::MCExtra e2 = ex;
-                e2.wg_chains = nullptr; e2.n_wg = ctx->n_wg2;
+                e2.n_wg = ctx->n_wg2;
                 e2.queue = ctx->d2_queue.p; e2.n_queue = (int)Pn; e2.counter = ctx->dcounter.p + 1;
+                e2.wg_chains = ctx->drounds.p + ctx->rounds_n[0];
 #define MXE_LAUNCH_MC2(WG_, NWV_) do { \
                 e = hipFuncSetAttribute((const void*)mxe::chain_kernel_mc<32, WG_, false, NWV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                 if (e == hipSuccess) { hipLaunchKernelGGL((mxe::chain_kernel_mc<32, WG_, false, NWV_>), dim3(ctx->n_wg2), dim3(64 * NWV_), lds, ctx->stream, k2, e2); e = hipGetLastError(); } } while (0)
@@ -1309,6 +1371,16 @@ try {
             ex.gstate = ctx->dgstate_mc.p;
         }
         ex.queue = ctx->dqueue.p; ex.n_queue = ctx->n_queue; ex.counter = ctx->dcounter.p;
+        // rounds per workgroup (mxe_launch_depth): the builds for launches that do not fill the GPU write them, in the dynamic
+        // layout (MCExtra: the pointer is the table of chain ids in the static one).  Not <32, 2> without led pieces -- the batch
+        // that fills the GPU: the memset node alone is 1.5 us of its 812 (A/B: profiles/r04_experiments.txt)
+        ctx->rounds_n[0] = ctx->rounds_n[1] = 0;
+        if (ex.n_queue > 0 && (kp.chain_lead != nullptr || WGPC == 1)) {
+            ctx->rounds_n[0] = ctx->n_wg;
+            HIPCHK(ctx, ctx->drounds.ensure((size_t)ctx->n_wg));
+            HIPCHK(ctx, hipMemsetAsync(ctx->drounds.p, 0, (size_t)ctx->n_wg * sizeof(int), ctx->stream));
+            ex.wg_chains = ctx->drounds.p;
+        }
         ex.stagger = 0;              // (a late start of the second half of the grid never paid: 0 ... 14 units measured; 5 cost 0.4 %; with the wave priorities of r03: 0 ... 24 units all within 0.5 %)
         ex.n_solo = 0;
         int counter0 = 0;
@@ -1343,6 +1415,7 @@ try {
 #undef MXE_LAUNCH_MC
         HIPCHK(ctx, e);
     } else {
+        ctx->rounds_n[0] = ctx->rounds_n[1] = 0;
         int NW = std::min(o.waves_per_chain, 4);     // (eight waves per chain: two per SIMD at 256 registers each spilled; not built)
         if (NW == 0) {
             // fill the 256 CUs x 4 SIMDs: few chains -> more waves per chain
@@ -1464,6 +1537,14 @@ try {
     kp.chain_v0 = ctx->dfin_v0.p; kp.v0 = ctx->dfin_start.p;
     kp.chain_lead = nullptr; kp.init_tab = nullptr; kp.chain_init = nullptr;
     kp.n_chain = nr;
+    {
+        // the caller's maxiter bounds the iterations of an alpha over BOTH passes (the reference caps them per alpha,
+        // levenberg_minimizer.py:155): this pass gets what the lock-step pass left of it (one budget per launch: that of the
+        // open alpha with the most iterations behind it)
+        int spent = 0;
+        for (size_t i = 0; i < P; ++i) if (open[i]) spent = std::max(spent, nit[i]);
+        kp.maxiter = std::max(1, o.maxiter - spent);
+    }
     const int NW = 4;
     size_t lds = lds_bytes(NP, ctx->nwp, NW, false);
     hipError_t e;
@@ -1630,6 +1711,37 @@ int mxe_last_launch_info(mxe_ctx* ctx, int* waves_per_chain, int* n_workgroups, 
     if (lds_bytes) *lds_bytes = ctx->last_lds;
     return MXE_OK;
 }
+
+int mxe_schedule_info(mxe_ctx* ctx, int* n_solo, int* placement_rule)
+{
+    if (!ctx) return MXE_ERR_ARG;
+    if (n_solo) *n_solo = ctx->n_solo;
+    if (placement_rule) *placement_rule = ctx->placement_checked;
+    return MXE_OK;
+}
+
+// depth of the last lock-step launch in rounds (a round = one Newton iteration of the four slots of a workgroup): maximum and
+// mean over its workgroups, [0] the launch (or its first pass), [1] the second pass of a two-pass launch (0 when there is none;
+// both 0 after a launch of the one-chain layout).  Blocking.
+int mxe_launch_depth(mxe_ctx* ctx, int32_t* max_rounds, double* mean_rounds)
+try {
+    if (!ctx || !max_rounds || !mean_rounds) return MXE_ERR_ARG;
+    if (!ctx->launched) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, stream_wait(ctx->stream));
+    const size_t n = (size_t)ctx->rounds_n[0] + ctx->rounds_n[1];
+    std::vector<int> h(n ? n : 1, 0);
+    if (n) HIPCHK(ctx, hipMemcpy(h.data(), ctx->drounds.p, n * sizeof(int), hipMemcpyDeviceToHost));
+    size_t off = 0;
+    for (int k = 0; k < 2; ++k) {
+        int mx = 0; double sum = 0.0; int busy = 0;
+        for (int i = 0; i < ctx->rounds_n[k]; ++i) { mx = std::max(mx, h[off + i]); sum += h[off + i]; busy += h[off + i] > 0; }
+        max_rounds[k] = mx; mean_rounds[k] = busy ? sum / busy : 0.0;
+        off += ctx->rounds_n[k];
+    }
+    return MXE_OK;
+}
+MXE_CATCH_ALL
 
 } // extern "C"
 
@@ -2166,6 +2278,19 @@ try {
         if (!g_rccl.load()) { ctxs[0]->hip_err = "librccl.so.1 could not be loaded"; return MXE_ERR_NODEVICE; }
         std::vector<int> devs(n);
         for (int r = 0; r < n; ++r) devs[r] = ctxs[r]->device;
+        // xGMI peers reach each other directly; where a pair cannot (hipDeviceCanAccessPeer), RCCL stages through the host --
+        // slower, still correct.  Said once on stderr; an error only when the caller insists (MXE_REQUIRE_PEER_ACCESS)
+        for (int a = 0; a < n; ++a) for (int b = 0; b < n; ++b) {
+            int can = 1;
+            if (a != b && hipDeviceCanAccessPeer(&can, devs[a], devs[b]) == hipSuccess && !can) {
+                if (getenv("MXE_REQUIRE_PEER_ACCESS")) {
+                    ctxs[0]->hip_err = "device " + std::to_string(devs[a]) + " cannot access device " + std::to_string(devs[b]) + " directly (hipDeviceCanAccessPeer)";
+                    return MXE_ERR_HIP;
+                }
+                static bool said = false;
+                if (!said) { said = true; fprintf(stderr, "[mxe] devices %d and %d have no direct peer access: the gather goes through host memory\n", devs[a], devs[b]); }
+            }
+        }
         NCCLCHK(ctxs[0], g_rccl.CommInitAll(comms.data(), n, devs.data()));
     }
     for (int r = 0; r < n; ++r) {
@@ -2228,9 +2353,8 @@ static int gather_enqueue(mxe_ctx* ctx, int root, int what, const int64_t* count
     if ((int64_t)n_mine != counts[cm->rank]) return MXE_ERR_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (cm->rank == root) {
-        size_t total = 0;
-        for (int r = 0; r < cm->n_ranks; ++r) total += (size_t)counts[r];
-        HIPCHK(ctx, cm->recv.ensure(total));
+        // (the root's receive buffer was sized by the caller BEFORE ncclGroupStart: gather_reserve -- an allocation, i.e. a
+        //  possible device synchronisation, has no place between the calls of a group)
         size_t off = 0;
         for (int r = 0; r < cm->n_ranks; ++r) {
             if (r == root && cm->loopback && !cm->copy_transport) {
@@ -2248,6 +2372,16 @@ static int gather_enqueue(mxe_ctx* ctx, int root, int what, const int64_t* count
     return MXE_OK;
 }
 
+// the root's receive buffer for a gather of these counts (outside any RCCL group)
+static int gather_reserve(mxe_ctx* root_ctx, int n_ranks, const int64_t* counts)
+{
+    size_t total = 0;
+    for (int r = 0; r < n_ranks; ++r) { if (counts[r] < 0) return MXE_ERR_ARG; total += (size_t)counts[r]; }
+    HIPCHK(root_ctx, hipSetDevice(root_ctx->device));
+    HIPCHK(root_ctx, root_ctx->comm->recv.ensure(total));
+    return MXE_OK;
+}
+
 extern "C" int mxe_gather(mxe_ctx* ctx, int root, int what, const int64_t* counts, double* recv_host)
 try {
     if (!ctx || !counts || (what != MXE_GATHER_COMPACT && what != MXE_GATHER_FULL)) return MXE_ERR_ARG;
@@ -2255,6 +2389,7 @@ try {
     mxe_comm_state* cm = ctx->comm;
     if (root < 0 || root >= cm->n_ranks) return MXE_ERR_ARG;
     if (!cm->local.empty()) return MXE_ERR_STATE;            // ranks of one process gather together: mxe_gather_local
+    if (cm->rank == root) { const int rr = gather_reserve(ctx, cm->n_ranks, counts); if (rr != MXE_OK) return rr; }
     const bool grouped = cm->n_ranks > 1 || cm->loopback;
     if (grouped) NCCLCHK(ctx, g_rccl.GroupStart());
     const int rc = gather_enqueue(ctx, root, what, counts);
@@ -2277,6 +2412,7 @@ try {
         if (!ctxs[r] || !ctxs[r]->comm || ctxs[r]->comm->n_ranks != n || ctxs[r]->comm->rank != r || !ctxs[r]->launched) return MXE_ERR_STATE;
     mxe_ctx* rt = ctxs[root];
     const bool copy = rt->comm->copy_transport;
+    { const int rr = gather_reserve(rt, n, counts); if (rr != MXE_OK) return rr; }
     if (copy) {
         // ranks that share a device (or a single rank): the root waits for the others' launches with events
         // and copies their packs itself

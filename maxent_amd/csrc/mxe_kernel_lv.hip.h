@@ -751,6 +751,7 @@ void chain_kernel_lv(const KParams p, const MCExtra x)
         ++prof_rounds;
 #endif
     }
+    if (dynamic && x.wg_chains && tid == 0) const_cast<int*>(x.wg_chains)[blockIdx.x] = (int)guard - 1;      // (MCExtra: the rounds of this workgroup)
 #ifdef MXE_PROFILE
     if (lane == 0 && p.prof && blockIdx.x < 1024) {
         long long* pr = p.prof + ((size_t)blockIdx.x * 8 + wave) * 8;

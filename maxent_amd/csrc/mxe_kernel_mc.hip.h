@@ -32,7 +32,7 @@ namespace mxe {
 constexpr int MCC = 4;            // chain slots per workgroup == wavefronts per workgroup
 
 struct MCExtra {
-    const int* wg_chains;         // static layout: [n_wg][MCC] chain ids, -1 = empty slot
+    const int* wg_chains;         // static layout: [n_wg][MCC] chain ids, -1 = empty slot (dynamic layout: see below)
     int n_wg;
     const int* queue;             // dynamic layout: chain ids in the order they are handed out
     int n_queue;                  //   (0 = static layout)
@@ -43,6 +43,9 @@ struct MCExtra {
                                   //   their partners leave at once -- and the first pieces of the queue (the most expensive)
     double* gstate;               // GSTATE builds: the omega-space state of the workgroups, gstate_stride doubles each
     size_t gstate_stride;         //   (mc_gstate_doubles)
+    // (dynamic layout, n_queue > 0: wg_chains is not a table of chain ids but, when not null, [n_wg] ints that RECEIVE the rounds --
+    //  Newton iterations of its four slots in lock-step -- every workgroup ran: the depth of a launch that does not fill the GPU,
+    //  mxe_launch_depth.  A field of its own changed the kernel-argument layout and cost the <32, 2> build 0.25 %.)
 };
 
 // omega-space state of one workgroup of a GSTATE build, in doubles: u [nwp][4] | H [nwp][4] + look-ahead | sw [nwp][4] floats + look-ahead
@@ -1162,6 +1165,10 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         ++prof_rounds;
 #endif
     }
+    // (not in the build of the batch that fills the GPU, <32, 2> without led pieces: its depth is not what bounds it, and the
+    //  store cost that kernel 0.6 % -- 0.8173 against 0.8127 ms on one box, register allocation: profiles/r04_experiments.txt)
+    if constexpr (LEAD || WGPC == 1)
+        if (dynamic && x.wg_chains && tid == 0) const_cast<int*>(x.wg_chains)[blockIdx.x] = (int)guard - 1;      // (the last entry of the loop left it before its passes)
 #ifdef MXE_PROFILE
     if (lane == 0 && p.prof && blockIdx.x < 1024) {
         long long* pr = p.prof + ((size_t)blockIdx.x * 8 + wave) * 8;

@@ -98,6 +98,8 @@ SYMBOLS = [
     ('mxe_last_launch_info', ctypes.c_int, [_vp] +
      [ctypes.POINTER(ctypes.c_int)] * 3),
     ('mxe_apply_output_map', ctypes.c_int, [_vp, _dp, _dp]),
+    ('mxe_launch_depth', ctypes.c_int, [_vp, _ip, _dp]),
+    ('mxe_schedule_info', ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     ('mxe_eval_batch', ctypes.c_int, [_vp, ctypes.c_int, _ip, _dp, _dp, ctypes.c_int, ctypes.c_double] + [_dp] * 11),
     ('mxe_entropy', ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp]),
     ('mxe_audit', ctypes.c_int, [_vp, _dp, _dp]),
@@ -595,6 +597,20 @@ class DeviceContext(object):
         return dict(waves_per_chain=a.value, n_workgroups=b.value,
                     lds_bytes=c.value,
                     kernel=self._lib.mxe_last_kernel_name(self._h).decode())
+
+    def schedule_info(self):
+        """``mxe_schedule_info``: dict(n_solo, placement_rule) of the staged chains (placement_rule 0: not needed, 1: probed and
+        holds, 2: does not hold -- no solo workgroups)"""
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        self._check(self._lib.mxe_schedule_info(self._h, ctypes.byref(a), ctypes.byref(b)), 'mxe_schedule_info')
+        return dict(n_solo=a.value, placement_rule=b.value)
+
+    def launch_depth(self):
+        """``mxe_launch_depth``: rounds of the deepest workgroup and the mean over the workgroups of the last lock-step launch,
+        per pass: dict(max_rounds=[a, b], mean_rounds=[a, b])"""
+        mx, mean = np.zeros(2, dtype=np.int32), np.zeros(2)
+        self._check(self._lib.mxe_launch_depth(self._h, _p(mx), _p(mean)), 'mxe_launch_depth')
+        return dict(max_rounds=[int(mx[0]), int(mx[1])], mean_rounds=[float(mean[0]), float(mean[1])])
 
     def set_result_buffer(self, which):
         self._check(self._lib.mxe_set_result_buffer(self._h, int(which)),

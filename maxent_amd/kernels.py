@@ -32,6 +32,55 @@ class _one_blas_thread(object):
         return False
 
 
+def _fingerprint(a):
+    """64-bit content hash of a contiguous float array (xxhash where the package is there, zlib.crc32 + adler32 otherwise)"""
+    a = np.ascontiguousarray(a)
+    try:
+        import xxhash
+        return xxhash.xxh3_64_intdigest(memoryview(a).cast('B'))
+    except Exception:
+        import zlib
+        m = memoryview(a).cast('B')
+        return (zlib.crc32(m) << 32) | zlib.adler32(m)
+
+
+class _Recent(object):
+    """the few most recently used results of an expensive function of array CONTENTS (kernel fill, SVD): a new TauMaxEnt /
+    ElementwiseMaxEnt on the grids of an earlier one -- every iteration of a self-consistency loop, both workers of an
+    element-wise run -- fills and decomposes the same 200 x 500 matrix again (reference elementwise_maxent.py:170-221: one fresh
+    SVD per ELEMENT; here it was one per object, 6.5-7.7 ms of the 13-15 ms a fresh object took).  Entries are found by a content
+    hash and confirmed by comparing the arrays; what they hand out is shared and read-only."""
+
+    def __init__(self, size=4):
+        import collections
+        import threading
+        self._d, self._size, self._lock = collections.OrderedDict(), size, threading.Lock()
+
+    def get(self, key, confirm):
+        with self._lock:
+            hit = self._d.get(key)
+            if hit is not None and confirm(hit[0]):
+                self._d.move_to_end(key)
+                return hit[1]
+        return None
+
+    def put(self, key, witness, value):
+        with self._lock:
+            self._d[key] = (witness, value)
+            while len(self._d) > self._size:
+                self._d.popitem(last=False)
+
+
+def _frozen(a):
+    a = np.asarray(a)
+    a.setflags(write=False)
+    return a
+
+
+_recent_svd = _Recent()
+_recent_fill = _Recent()
+
+
 class KernelSVD(object):
     """Matrix with a lazily computed thin SVD ``K = U diag(S) V^T``.
 
@@ -65,9 +114,15 @@ class KernelSVD(object):
                 #  slower than 1 in BASELINE.md -- and a BLAS pool that spins up on every core of the host burns the
                 #  CPU quota of a container: the process then stalls for most of a scheduler period, 70 ms, at some
                 #  later point of the run)
-                with _one_blas_thread():
-                    U, S, Vh = np.linalg.svd(self.K, full_matrices=False)
-                self._U, self._S, self._V = U, S, Vh.transpose()
+                K = np.ascontiguousarray(self.K, dtype=float)
+                key = (K.shape, _fingerprint(K))
+                hit = _recent_svd.get(key, lambda K0: K0.shape == K.shape and np.array_equal(K0, K))
+                if hit is None:
+                    with _one_blas_thread():
+                        U, S, Vh = np.linalg.svd(K, full_matrices=False)
+                    hit = (_frozen(U), _frozen(S), _frozen(Vh.transpose()))
+                    _recent_svd.put(key, K.copy(), hit)
+                self._U, self._S, self._V = hit
             else:
                 raise ValueError("svd_backend must be 'host' or 'device'")
         return (self._U, self._S, self._V)
@@ -203,6 +258,15 @@ class TauKernel(Kernel):
         tau = np.asarray(self.tau, dtype=float)
         w = np.asarray(self.omega, dtype=float)
         beta = tau[-1] if self.beta is None else self.beta
+        delta = np.asarray(self.omega.delta, dtype=float)
+        key = (tau.tobytes(), w.tobytes(), delta.tobytes(), float(beta))
+        hit = _recent_fill.get(key, lambda _: True)               # (the key IS the contents)
+        if hit is not None:
+            self._K, self._K_delta = hit
+            T = self._T
+            self._T = None
+            self.transform(T)
+            return
         ww = w[np.newaxis, :] * np.ones((len(tau), 1))
         tt = tau[:, np.newaxis] * np.ones((1, len(w)))
         pos = ww >= 0.0
@@ -212,8 +276,9 @@ class TauKernel(Kernel):
         neg = np.logical_not(pos)
         K[neg] = -np.exp(ww[neg] * (beta - tt[neg])) / \
             (1.0 + np.exp(beta * ww[neg]))
-        self._K = K
-        self._K_delta = K * self.omega.delta[np.newaxis, :]
+        self._K = _frozen(K)
+        self._K_delta = _frozen(K * self.omega.delta[np.newaxis, :])
+        _recent_fill.put(key, None, (self._K, self._K_delta))
         T = self._T
         self._T = None
         self.transform(T)

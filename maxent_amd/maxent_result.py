@@ -636,7 +636,10 @@ class MaxEntResult(MaxEntResultData):
         if nb and v0.flags.c_contiguous:
             p0 = v0.__array_interface__['data'][0]
             if all(v.flags.c_contiguous and v.__array_interface__['data'][0] == p0 + i * nb for i, v in enumerate(vals)):
-                whole = np.lib.stride_tricks.as_strided(v0, shape=(len(vals),) + v0.shape, strides=(nb,) + v0.strides)
+                # (a VIEW of what came off the device, shared with the records and with every field derived later: read-only, so
+                #  that an in-place edit of result.H fails loudly instead of silently changing them -- ``np.array(result.H)``
+                #  gives a private copy, as every field of the reference is)
+                whole = np.lib.stride_tricks.as_strided(v0, shape=(len(vals),) + v0.shape, strides=(nb,) + v0.strides, writeable=False)
                 return whole.reshape(shape)
         arr = np.empty(shape)
         flat = arr.reshape((len(vals),) + v0.shape)

@@ -16,6 +16,7 @@ import pytest
 import maxent_amd as mx
 
 pytestmark = pytest.mark.gpu
+os.environ['MAXENT_AMD_AUDIT'] = '1'          # every launch of the drivers is audited on the device (BatchSolver.solve: info['audit_max'])
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 GATE = 1e-6
 REF_SPREAD = 5e-5
@@ -211,7 +212,19 @@ def test_elementwise_drivers():
             if i == j:
                 np.testing.assert_allclose(r_di.A[i, i], r_ew.A[i, i], rtol=1e-12)
                 np.testing.assert_allclose(r_di.A[i, i], r_pm.A[i, i], rtol=1e-12)
-    # against the reference's outputs (its own spread)
+    # the gate: every element and alpha against the fixed point the reference's own iterates polish to (make_golden.py:
+    # truth_of; Poorman's off-diagonal default models from the truth of the diagonal spectra), and the exact Newton
+    # correction of every problem of every launch on the device
+    delta = g['delta']
+    for name, r in (('ew', r_ew), ('pm', r_pm), ('ew', r_herm), ('pm', r_pm_herm), ('ew', r_two)):
+        Ht = g[name + '_H_truth']
+        e = rel_l2(np.asarray(r.H), Ht)
+        assert np.all(np.isfinite(e)) and e.max() < GATE, (name, e.max())
+        assert rel_l2(np.asarray(r.A), Ht / delta).max() < GATE
+    for obj in (ew1, pm_h, ew2):
+        for info in obj.last_launches:
+            assert info['audit_max'] < GATE, info['audit_max']
+    # against the reference's raw outputs (its own stopping slack)
     assert r_ew.A.shape == g['ew_A'].shape == (2, 2, 8, 80)
     for name, r in (('ew', r_ew), ('pm', r_pm)):
         assert rel_l2(r.A, g[name + '_A']).max() < 2e-4

@@ -11,6 +11,8 @@ import maxent_amd as mx
 from maxent_amd import device, synthetic
 
 pytestmark = pytest.mark.gpu
+os.environ['MAXENT_AMD_AUDIT'] = '1'          # every launch of the drivers is audited on the device (BatchSolver.solve: info['audit_max'])
+GATE = 1e-6
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
@@ -35,6 +37,13 @@ def test_complex_elements_match_the_reference():
         assert sorted(tuple(z) for z in res.zero_elements) == sorted(tuple(z) for z in g[tag + 'zero_elements'])
         ref_H, mask = g[tag + 'H'], ~np.isnan(g[tag + 'H'])
         assert np.array_equal(np.isnan(res.H), ~mask)
+        # the gate: real and imaginary parts of every element against the fixed point of the reference's own iterates
+        # (make_golden.py: truth_of), and the device's audit of every launch
+        Ht = g[tag + 'H_truth']
+        solved = np.isfinite(Ht).all(axis=-1)
+        e = rel_l2(np.asarray(res.H)[solved], Ht[solved])
+        assert solved.sum() == (24 if herm else 36) and e.max() < GATE, e.max()
+        assert all(info['audit_max'] < GATE for info in ew.last_launches) and len(ew.last_launches) >= 1
         # against the reference's outputs: its own stopping slack (3e-5 of H at small alpha)
         for idx in np.ndindex(2, 2, 2):
             if mask[idx].all():
@@ -63,9 +72,13 @@ def test_one_covariance_per_element_matches_the_reference(blur):
     tag = 'blur%d_' % int(blur)
     assert res.A.shape == g[tag + 'A'].shape == (2, 2, 6, 60)
     np.testing.assert_allclose(res.alpha, g[tag + 'alpha'], rtol=1e-13)
+    # the gate: rotated data sets (one per element) against the fixed point of the reference's own iterates, device audit
+    e = rel_l2(np.asarray(res.H), g[tag + 'H_truth'])
+    assert np.all(np.isfinite(e)) and e.max() < GATE, e.max()
+    assert all(info['audit_max'] < GATE for info in ew.last_launches) and len(ew.last_launches) >= 1
     for i in range(2):
         for j in range(2):
-            assert rel_l2(res.A[i, j], g[tag + 'A'][i, j]).max() < 2e-4, (i, j)
+            assert rel_l2(res.A[i, j], g[tag + 'A'][i, j]).max() < 2e-4, (i, j)       # (the reference's raw output: its slack)
             np.testing.assert_allclose(res.chi2[i, j], g[tag + 'chi2'][i, j], rtol=1e-4)
     assert rel_l2(res.A_out, g[tag + 'A_out']).max() < 2e-4
     # one decomposition serves every element: the rotated kernels share S and V
@@ -86,6 +99,9 @@ def test_one_covariance_for_all_elements_matches_the_reference_and_is_one_data_s
     ew.set_cov(g['cov'])
     res = ew.run()
     assert res.A.shape == g['A'].shape == (2, 2, 6, 60)
+    e = rel_l2(np.asarray(res.H), g['H_truth'])
+    assert np.all(np.isfinite(e)) and e.max() < GATE, e.max()
+    assert all(info['audit_max'] < GATE for info in ew.last_launches)
     for i in range(2):
         for j in range(2):
             assert rel_l2(res.A[i, j], g['A'][i, j]).max() < 2e-4, (i, j)

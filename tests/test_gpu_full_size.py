@@ -155,3 +155,27 @@ def test_cfg3_elementwise_api_matches_direct_batch():
     w = np.asarray(batch['omega'])
     for i in range(4):
         assert abs(np.trapezoid(res.A_out[i, i], w) - 1) < 2e-2
+
+
+def test_the_solo_schedule_is_dropped_where_the_placement_rule_does_not_hold(cfg4, monkeypatch):
+    """the workgroups that get a CU to themselves rest on an observed placement (workgroups b and
+    b + gridDim / 2 share a CU).  The library probes it per device; forced to 'does not hold' the schedule has no solo
+    workgroups and the batch still passes the audit."""
+    batch, ctx0, out0, info0 = cfg4
+    ctx = bench.stage(batch, 0)
+    ctx.upload_chains(np.arange(256, dtype=np.int32), batch['alphas'], batch['v0'])
+    normal = ctx.schedule_info()
+    assert normal['placement_rule'] in (1, 2) and (normal['n_solo'] > 0) == (normal['placement_rule'] == 1), normal
+    monkeypatch.setenv('MXE_FORCE_NO_SOLO_RULE', '1')
+    ctx.upload_chains(np.arange(256, dtype=np.int32), batch['alphas'], batch['v0'])
+    forced = ctx.schedule_info()
+    assert forced == dict(n_solo=0, placement_rule=2), forced
+    ctx.launch()
+    assert ctx.finish() == 0
+    out = ctx.fetch(want_v=False, want_H=False)
+    depth = ctx.launch_depth()
+    c = ctx.audit()['corr']
+    ctx.close()
+    assert out['converged'].all() and c.max() < 1e-6 and np.percentile(c, 99) < 1e-8
+    np.testing.assert_allclose(out['chi2'], out0['chi2'], rtol=1e-7)
+    assert depth['max_rounds'] == [0, 0]       # (the build of the batch that fills the GPU does not count its rounds: see mxe_launch_depth)

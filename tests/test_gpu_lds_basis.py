@@ -1,0 +1,80 @@
+"""chain_kernel_lv (mxe_kernel_lv.hip.h): the lock-step layout with V^T resident in the LDS as binary32.  It IS the launch
+for mxe_opts.precision = F32 where the basis fits the LDS (reference path: the alpha scan of maxent_loop.py:241-245 with the
+minimiser of levenberg_minimizer.py:123-248; BASELINE config 5 asks for the binary32 leg), and on request
+(mxe_opts.lds_basis = 1) the first pass of a binary64 launch."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench                                                 # noqa: E402
+from maxent_amd import device                                # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    return np.linalg.norm(a - b, axis=-1) / np.linalg.norm(b, axis=-1)
+
+
+def solve(batch, **opts):
+    ctx = bench.stage(batch, 0)
+    n = len(batch['elems'])
+    ctx.upload_chains(np.arange(n, dtype=np.int32), batch['alphas'], batch['v0'], device.default_opts(**opts))
+    ctx.launch()
+    info = ctx.last_launch_info()
+    left = ctx.finish()
+    out = ctx.fetch(want_v=False, want_H=True)
+    out['H'] = np.array(out['H'])
+    out['audit'] = ctx.audit()['corr']
+    out['depth'] = ctx.launch_depth()
+    ctx.close()
+    return out, info, left
+
+
+@pytest.mark.parametrize('n_omega,n_alpha', [(200, 20), (500, 40)])
+def test_binary32_launch_runs_in_the_lds_resident_kernel(n_omega, n_alpha):
+    batch = bench.build_batch(3, 100 if n_omega == 200 else 200, n_omega, n_alpha, 0)      # 3 normal + 6 plus-minus scans
+    ref, info64, _ = solve(batch)
+    out, info, left = solve(batch, precision=device.PRECISION_F32)
+    assert info['kernel'] == 'mxe::chain_kernel_lv' and info['waves_per_chain'] == 8, info
+    assert info['lds_bytes'] <= 160 * 1024 - 2304
+    assert out['converged'].all() and left == 0
+    e = rel_l2(out['H'], ref['H'])
+    # binary32 classes: everything within 1e-4, nearly everything within 1e-5 -- and the device's own audit
+    # (exact binary64 Newton correction at the returned v) says the same
+    assert e.max() < 1e-4 and np.mean(e < 1e-5) > 0.97, (e.max(), np.mean(e < 1e-5))
+    assert np.nanmax(out['audit']) < 1e-4
+    np.testing.assert_allclose(out['chi2'], ref['chi2'], rtol=2e-3)
+    # the one-chain binary32 kernel is still there (lds_basis = 2), and agrees
+    old, info_old, _ = solve(batch, precision=device.PRECISION_F32, lds_basis=2)
+    assert info_old['kernel'].startswith('mxe::chain_kernel<') and 'float' in info_old['kernel']
+    assert rel_l2(old['H'], out['H']).max() < 2e-4
+
+
+def test_a_basis_that_does_not_fit_the_lds_keeps_the_one_chain_binary32_kernel():
+    batch = bench.build_batch(2, 100, 1000, 10, 0)           # n_omega_pad = 1024: 56 x 1028 floats are 230 KB
+    out, info, _ = solve(batch, precision=device.PRECISION_F32)
+    assert info['kernel'].startswith('mxe::chain_kernel<') and 'float' in info['kernel'], info
+    assert out['converged'].all()
+
+
+def test_binary32_first_pass_then_one_binary64_step_per_alpha():
+    """mxe_opts.lds_basis = 1: every alpha to 1e-5 in chain_kernel_lv, then every alpha as a piece of its own in the binary64
+    lock-step kernel from that v.  Same fixed points as the single binary64 pass, iteration counts of both passes added."""
+    batch = bench.build_batch(3, 200, 500, 40, 0)
+    ref, info64, _ = solve(batch, lds_basis=2)
+    out, info, left = solve(batch, lds_basis=1)
+    assert info['kernel'].startswith('mxe::chain_kernel_lv + mxe::chain_kernel_mc<32'), info
+    assert 'chain_kernel_lv' not in info64['kernel']
+    assert out['converged'].all() and left == 0
+    assert rel_l2(out['H'], ref['H']).max() < 1e-7
+    assert np.nanmax(out['audit']) < 1e-6 and np.nanpercentile(out['audit'], 99) < 1e-8
+    np.testing.assert_allclose(out['chi2'], ref['chi2'], rtol=1e-7)
+    assert np.all(out['n_iter'] >= 2) and np.all(out['n_evals'] >= out['n_iter'])      # (first pass + at least the step and its check)
+    # the depth of both passes as the kernels counted it (mxe_launch_depth): the second pass is a few rounds per alpha
+    d, d64 = out['depth'], ref['depth']
+    assert d['max_rounds'][0] >= 10 and 2 <= d['max_rounds'][1] <= 12 and d64['max_rounds'][0] >= 10 and d64['max_rounds'][1] == 0, (d, d64)
+    assert all(0 < m <= x for m, x in zip(d['mean_rounds'], d['max_rounds']))
