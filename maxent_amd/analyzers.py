@@ -337,34 +337,62 @@ class Deferred(object):
         return self.picks.rows[self.n]
 
 
+def _scan_picks(maxent_result, keys):
+    """one pass over the records of ``keys`` for all three analyzers of a batch (it was three): the parameters the device used,
+    the launch's arrays and the chains of the elements in them, the A maps -- or None when some element has no choice of the
+    device (no fit, a record made some other way).  Kept on the result for the ``keys`` list object at hand."""
+    held = maxent_result.__dict__.get('_picks_scan')
+    if held is not None and held[0] is keys and held[1] == len(keys):
+        return held[2]
+    recs = getattr(maxent_result, '_records', {})
+    sels, maps = [], []
+    params, uniform_params = None, True
+    out = None
+    for k in keys:
+        rec = recs.get(k)
+        sel = None if rec is None else rec.get('device_select')
+        A = None if rec is None else rec.get('A')
+        if sel is None or not hasattr(A, 'from_H_row'):
+            break
+        if params is None:
+            params = sel['params']
+        elif sel['params'] is not params and sel['params'] != params:
+            uniform_params = False
+        maps.append(A)
+        sels.append(sel)
+    else:
+        batch = sels[0].get('batch') if sels else None
+        if batch is not None and not all(s.get('batch') is batch for s in sels):
+            batch = None
+        cs = np.fromiter((s['chain'] for s in sels), dtype=np.intp, count=len(sels)) if batch is not None else None
+        first = maps[0]._map if maps else None
+        same_map = bool(maps) and first.matrix() is None and all(m._map is first for m in maps)
+        out = dict(sels=sels, maps=maps, params=params if uniform_params else None, batch=batch, cs=cs,
+                   first=first, same_map=same_map)
+    maxent_result.__dict__['_picks_scan'] = (keys, len(keys), out)
+    return out
+
+
 def _device_picks(maxent_result, keys, which, matches):
     """What the device chose for these elements (``mxe_select3_launch``, one launch behind the solve; the indices and
     the three H rows of every scan came back in one copy): (indices, A rows), or None when any element has no such
     choice -- another parameter than the device used (``matches(params)``), no fit, a record made some other way.
     ``which``: 0 line fit, 1 chi2 curvature, 2 entropy."""
-    recs = getattr(maxent_result, '_records', {})
-    sels, maps = [], []
-    ok_params = None
-    for k in keys:
-        rec = recs.get(k)
-        sel = None if rec is None else rec.get('device_select')
-        if sel is None:
-            return None
-        if sel['params'] is not ok_params:
-            if not matches(sel['params']):
-                return None
-            ok_params = sel['params']
-        A = rec.get('A')
-        if not hasattr(A, 'from_H_row'):
-            return None
-        maps.append(A)
-        sels.append(sel)
+    scan = _scan_picks(maxent_result, keys)
+    if scan is None:
+        return None
+    sels, maps = scan['sels'], scan['maps']
     if not sels:
         return [], []
-    batch = sels[0].get('batch')
-    if batch is not None and all(s.get('batch') is batch for s in sels):
+    if scan['params'] is not None:
+        if not matches(scan['params']):
+            return None
+    elif not all(matches(s['params']) for s in sels):
+        return None
+    batch = scan['batch']
+    if batch is not None:
         # the launch's arrays as they came off the device: [3][n_chain] indices, [3][n_chain][n_omega] rows
-        cs = np.fromiter((s['chain'] for s in sels), dtype=np.intp, count=len(sels))
+        cs = scan['cs']
         idx = batch[0][which][cs]
         H = batch[1][which][cs]
     else:
@@ -372,10 +400,9 @@ def _device_picks(maxent_result, keys, which, matches):
         H = np.array([s['H'][which] for s in sels])
     if np.any(idx < 0):
         return None
-    first = maps[0]._map
-    if first.matrix() is None and all(m._map is first for m in maps):
+    if scan['same_map']:
         # A = H / delta for everybody: one division for all rows (elementwise: the same bits as row by row)
-        rows = list(first.f(H))
+        rows = list(scan['first'].f(H))
     else:
         rows = [m.from_H_row(r) for m, r in zip(maps, H)]
     return idx.tolist(), rows

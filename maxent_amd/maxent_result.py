@@ -27,7 +27,7 @@ from itertools import product
 import numpy as np
 
 from .alpha_meshes import DataAlphaMesh
-from .analyzers import Deferred
+from .analyzers import Deferred, Picks
 from .omega_meshes import DataOmegaMesh
 
 _ALL_FIELDS = ['alpha', 'v', 'chi2', 'S', 'A', 'Q', 'omega', 'probability',
@@ -262,12 +262,18 @@ class ElementAnalysis(OrderedDict):
     device picked the alpha, nobody has looked at the result object yet --: it is built when it is first read;
     ``raw(name)`` reads without building (``MaxEntResult.A_out`` takes the A row straight from the batch)."""
 
+    _n = None        # position of this element in the batches whose Picks stand for its entries
+
     def raw(self, name, default=None):
-        return OrderedDict.get(self, name, default)
+        val = OrderedDict.get(self, name, default)
+        return Deferred(val, self._n) if isinstance(val, Picks) else val
 
     def __getitem__(self, name):
         val = OrderedDict.__getitem__(self, name)
-        if isinstance(val, Deferred):
+        if isinstance(val, Picks):                 # (the whole batch's choice of one analyzer: this element's result, built now)
+            val = val.build(self._n)
+            OrderedDict.__setitem__(self, name, val)
+        elif isinstance(val, Deferred):
             val = val.build()
             OrderedDict.__setitem__(self, name, val)
         return val
@@ -479,21 +485,27 @@ class MaxEntResult(MaxEntResultData):
         """:meth:`analyze` for many elements (``keys``: tuples as :meth:`_key` makes them); the rows of A
         the analyzers pick are fetched from the device in ONE go at the end"""
         self._deferred_rows = []
+        self.__dict__.pop('_picks_scan', None)
         try:
             many = {}
             for analyzer in analyzers:
                 if len(keys) > 1 and hasattr(analyzer, 'pick_many'):
                     picks = analyzer.pick_many(self, keys)        # the device chose: result objects when somebody looks
                     if picks is not None:
-                        many[analyzer.name] = [Deferred(picks, n) for n in range(len(keys))]
+                        many[analyzer.name] = picks               # (ONE object for the batch; an element finds its own through its position)
                         continue
                 if hasattr(analyzer, 'analyze_many') and len(keys) > 1:
                     many[analyzer.name] = analyzer.analyze_many(self, keys)
             for n, key in enumerate(keys):
                 out = ElementAnalysis()
+                out._n = n
                 for analyzer in analyzers:
                     try:
-                        res = many[analyzer.name][n] if analyzer.name in many else analyzer.analyze(self, key)
+                        got = many.get(analyzer.name)
+                        if isinstance(got, Picks):
+                            OrderedDict.__setitem__(out, analyzer.name, got)
+                            continue
+                        res = got[n] if got is not None else analyzer.analyze(self, key)
                         if isinstance(res, Deferred):
                             OrderedDict.__setitem__(out, analyzer.name, res)
                             continue
@@ -509,6 +521,7 @@ class MaxEntResult(MaxEntResultData):
             pending = self._deferred_rows
         finally:
             self._deferred_rows = None
+            self.__dict__.pop('_picks_scan', None)
         if pending:
             owner = None
             for ph in pending:
