@@ -878,6 +878,7 @@ try {
     // ---- (sub-)chains: an alpha scan may be cut into pieces that are cold-started
     //      from the same v0 (the minimiser of each alpha does not depend on the path)
     int split = o.alpha_split;
+    int split_pm = 0;                 // pieces per plus-minus scan where that differs from the normal-entropy scans' (0: the same)
     if (split <= 0) {
         // about two pieces per chain slot of the GPU (CUs x workgroups per CU x 4 slots): the persistent grid
         // then balances (pieces have unequal costs and are handed out most expensive first), and a batch that
@@ -911,6 +912,23 @@ try {
             break;
         }
         ctx->wgpc_auto = wgpc_guess;
+        // A launch that does not fill the GPU (one workgroup per CU: pieces at the cap of two alphas) is as long as its deepest slot,
+        // and a slot that takes a second piece pays a second cold start.  Where the uniform cut gives more pieces than slots, the
+        // plus-minus scans -- cold start 5 rounds against 12-16, 2 rounds per alpha against 2.75: a piece of twice the alphas costs
+        // what a normal-entropy piece does -- are cut into fewer, longer pieces, so that every slot gets ONE piece (the 3 200-problem
+        // shard of cfg4 / 8: 1 600 pieces on 1 024 slots -> 1 012; profiles/r04_experiments.txt).  MXE_NO_SPLIT_BY_KIND: the old cut
+        if (wgpc_guess == 1 && o.wg_per_cu == 0 && !getenv("MXE_NO_SPLIT_BY_KIND") && n_alpha >= 4) {
+            const long long n_slots = 4LL * n_cu, s_n = n_alpha / 2;
+            long long n_normal = 0;
+            for (int c = 0; c < n_chain; ++c) n_normal += ctx->elem_kind[elem_of_chain[c]] == MXE_ENTROPY_NORMAL;
+            const long long n_pm = n_chain - n_normal;
+            if ((long long)n_chain * split > n_slots && n_pm > 0 && n_normal * s_n + n_pm <= n_slots) {
+                // (normal-entropy scans at the cap of two alphas per piece, the plus-minus scans share the slots that are left)
+                const long long sp = std::max(1LL, std::min(s_n, (n_slots - n_normal * s_n) / n_pm));
+                split = (int)s_n;
+                split_pm = (int)sp;
+            }
+        }
         // a small batch that cannot fill the lock-step layout (>= 768 pieces) with pieces of six alphas,
         // but can with shorter ones, takes those: the lock-step kernel serves four pieces with the loads
         // and the time the one-chain kernel spends on one (cfg3, 16 scans: 1.9 ms with 256 pieces in the
@@ -940,8 +958,9 @@ try {
             for (int i = 0; i < n_alpha; ++i) if (std::log(ac[i]) >= lguard && ac[i] < best) { best = ac[i]; pre_index = i; }
             if (lmax > lmin && best < 1e300) pre_alpha = best;
         }
-        for (int sidx = 0; sidx < split; ++sidx) {
-            const int a0 = (int)((long long)n_alpha * sidx / split), a1 = (int)((long long)n_alpha * (sidx + 1) / split);
+        const int split_c = (split_pm > 0 && ctx->elem_kind[elem_of_chain[c]] != MXE_ENTROPY_NORMAL) ? std::min(split_pm, n_alpha) : split;
+        for (int sidx = 0; sidx < split_c; ++sidx) {
+            const int a0 = (int)((long long)n_alpha * sidx / split_c), a1 = (int)((long long)n_alpha * (sidx + 1) / split_c);
             if (a1 <= a0) continue;
             const bool guarded = pre_alpha > 0.0 && sidx > 0 && std::log(ac[a0]) < lguard && pre_index < a0;
             // (the warm step from the leading alpha is safe over a factor of 1.5 in alpha -- measured: at most 11
@@ -1108,7 +1127,7 @@ try {
                 for (int i = 0; i < ctx->sub_len[sc]; ++i) amin = std::min(amin, alpha_dev[ctx->sub_prob0[sc] + i]);
                 cost[sc] = ctx->sub_len[sc] * (ctx->elem_kind[e] == MXE_ENTROPY_NORMAL ? 4.0 : 3.0) +
                            (ctx->elem_kind[e] == MXE_ENTROPY_NORMAL ? 16.0 : 6.0) - 1e-3 * std::log10(amin) +
-                           2.0 * ctx->sub_pre[sc];                    // (the walk of a led piece)
+                           0.7 * ctx->sub_pre[sc];                    // (the walk of a led piece: a landing every ~third alpha, MXE_X_WALK_RATIO)
             }
             ctx->queue.resize(ctx->n_sub);
             for (int sc = 0; sc < ctx->n_sub; ++sc) ctx->queue[sc] = sc;

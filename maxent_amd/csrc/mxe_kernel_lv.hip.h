@@ -349,6 +349,7 @@ void chain_kernel_lv(const KParams p, const MCExtra x)
                     const double Qt = 0.5 * chi2t - t.alpha * St;
                     const bool finite = fabs(Qt) <= 1.7e308;
                     bool finish_alpha = false, failed = false; int conv = 0;
+                    bool on_path = false;      // (a landing of the walk that ended well inside its tolerance: the next step may be long)
                     const bool fresh = t.scratch == 2;
                     if (t.scratch == 1 || (fresh && !t.okprev)) {
                         ++t.nevals;
@@ -404,6 +405,7 @@ void chain_kernel_lv(const KParams p, const MCExtra x)
                         t.slow = 0;
                         t.dHp = full ? sdH : 0.0;
                         t.bt = 0;
+                        on_path = newton_step && t.niter == 1 && relH2_min < (MXE_X_WALK_SKIP_TOL * MXE_X_WALK_SKIP_TOL) * t.Hn2;
                         if (newton_step && p.tol_h > 0.0 && relH2_min < tol2Hn && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                         else if (at_floor && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                         else if (p.tol_relq > 0.0 && fabs(fabs(t.Qprev - t.Q) / t.Q) < p.tol_relq && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
@@ -439,6 +441,14 @@ void chain_kernel_lv(const KParams p, const MCExtra x)
                             ecor[q * NP + k] = e; eacc[q * NP + k] = 0.0f;
                         }
                         ++t.ia;
+                        if (t.ia < -1 && on_path) {         // (the walk: landings a factor MXE_X_WALK_RATIO apart, as in chain_kernel_mc)
+                            const double lo = t.alpha * (1.0 / MXE_X_WALK_RATIO), hi = t.alpha * MXE_X_WALK_RATIO;
+                            while (t.ia < -1) {
+                                const double an = alpha_at(t, t.ia + 1);
+                                if (!(an >= lo && an <= hi)) break;
+                                ++t.ia;
+                            }
+                        }
                         if (!conv && p.mc_abandon) {
                             for (int i = max(t.ia, 0) + lane; i < t.clen; i += 64) {
                                 const size_t pr = (size_t)t.prob0 + i;

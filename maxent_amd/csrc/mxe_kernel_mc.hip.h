@@ -83,8 +83,19 @@ constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
                                 // cfg2, cfg3): 1e-3 0.492 / 0.434 / 0.465 ms, 1e-2 0.473 / 0.418 / 0.445, 3e-2 0.454 / 0.386 / 0.414, 6e-2 runs away
                                 // on the scan with the hardest tail (rank 5 of cfg4 / 8: 1.6 ms, as in r02); 2e-2 keeps a factor 3 to that
 #endif
-#ifndef MXE_X_WALK_STRIDE
-#define MXE_X_WALK_STRIDE 1
+// The walk of a led piece does not visit every alpha of the mesh: it lands where alpha has fallen by at most this factor since the
+// last landing -- one corrector round per landing.  Measured safe over a factor 1.5 (r02: at most 11 evaluations for such a warm
+// step; over a factor 2 single scans took 100-300).  On the BASELINE mesh that is every third alpha: cfg2 0.389 -> 0.344 ms,
+// cfg3 0.411 -> 0.372 ms (profiles/r04_experiments.txt: fixed strides 2 and 3 on one box); 1.0 = every alpha, as until r04
+#ifndef MXE_X_WALK_RATIO
+#define MXE_X_WALK_RATIO 1.55
+#endif
+// ... but only from a landing that is ON the path: ONE corrector round that ended with an estimated next correction below this (the
+// walk's own tolerance is MXE_X_WALK_TOL = 1e-1).  Without the condition the scan with the hardest tail of the BASELINE batch
+// (element 221: rank 5 of cfg4 / 8) ran away at every stride > 1: 0.39 -> 0.91 ms for that rank; with it (1e-2: never taken, 3e-2
+// and 1e-1: the same) that rank stays at 0.40 ms and cfg2 / cfg3 go 0.389 / 0.415 -> 0.359 / 0.379 ms (profiles/r04_experiments.txt)
+#ifndef MXE_X_WALK_SKIP_TOL
+#define MXE_X_WALK_SKIP_TOL 3e-2
 #endif
 #ifndef MXE_X_WALK_ITERS
 #define MXE_X_WALK_ITERS 4
@@ -567,6 +578,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     const double Qt = 0.5 * chi2t - t.alpha * St;
                     const bool finite = fabs(Qt) <= 1.7e308;
                     bool finish_alpha = false, failed = false; int conv = 0;
+                    bool on_path = false;      // (a landing of the walk that ended well inside its tolerance: the next step may be long)
                     // (fresh: the piece's start state came from the table and this round evaluated its first Newton step
                     //  v0 - delta from scratch: a trial point like any other, except that the row pass has no old state to
                     //  measure the step against -- no convergence test on it)
@@ -654,6 +666,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                             t.dHp = full ? sdH : 0.0;
                         }
                         t.bt = 0;
+                        on_path = newton_step && t.niter == 1 && relH2_min < (MXE_X_WALK_SKIP_TOL * MXE_X_WALK_SKIP_TOL) * t.Hn2;
                         if (newton_step && p.tol_h > 0.0 && relH2_min < tol2Hn && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                         else if (p.tol_relq > 0.0 && fabs(fabs(t.Qprev - t.Q) / t.Q) < p.tol_relq && t.niter > p.miniter) { conv = 1; finish_alpha = true; }
                         else if (t.niter >= ((LEAD && t.ia < 0 && t.ia > -t.lead) ? MXE_X_WALK_ITERS : p.mc_maxiter)) finish_alpha = true;   // (an alpha of a walk is a starting point: a few rounds, then on)
@@ -700,9 +713,18 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                             ecor[q * NP + k] = e; eacc[q * NP + k] = 0.0;
                         }
                         ++t.ia;
-    #if MXE_X_WALK_STRIDE > 1
-                        if (LEAD && t.ia < -1) t.ia = min(t.ia + (MXE_X_WALK_STRIDE - 1), -1);      // (the walk: every MXE_X_WALK_STRIDE-th alpha of the mesh)
-    #endif
+                        if constexpr (LEAD) {
+                            // the walk lands on every alpha that is a factor MXE_X_WALK_RATIO below the last landing (and on the
+                            // last one before the piece's own): on the BASELINE mesh (ratio 0.87) every third alpha
+                            if (t.ia < -1 && on_path) {
+                                const double lo = t.alpha * (1.0 / MXE_X_WALK_RATIO), hi = t.alpha * MXE_X_WALK_RATIO;
+                                while (t.ia < -1) {
+                                    const double an = alpha_at(t, t.ia + 1);
+                                    if (!(an >= lo && an <= hi)) break;
+                                    ++t.ia;
+                                }
+                            }
+                        }
                         if (!conv && p.mc_abandon) {
                             // An alpha this layout gave up on: the rest of the piece would start from a point that is not a
                             // solution and go the same way.  Its alphas are marked open -- mxe_chains_finish solves every run of

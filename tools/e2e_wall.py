@@ -24,6 +24,15 @@ wrap(batch_solver.BatchSolver, 'solve'); wrap(batch_solver.BatchSolver, '_stage'
 wrap(maxent_result.MaxEntResult, 'analyze_batch'); wrap(maxent_result.MaxEntResult, 'add_element_results')
 wrap(maxent_loop.MaxEntLoop, 'make_record'); wrap(maxent_loop.MaxEntLoop, 'make_spec')
 wrap(elementwise_maxent.ElementwiseMaxEnt, '_run_batch'); wrap(elementwise_maxent.ElementwiseMaxEnt, '_load_element'); wrap(elementwise_maxent.ElementwiseMaxEnt, 'prepare_maxent_result')
+for n in ('_prepare_batch', '_solve_batches', '_finish_batch', '_offdiag_jobs'):
+    if hasattr(elementwise_maxent.ElementwiseMaxEnt, n): wrap(elementwise_maxent.ElementwiseMaxEnt, n)
+for n in ('make_records', 'spec_like', 'note_minimizer_state'):
+    if hasattr(maxent_loop.MaxEntLoop, n) and not isinstance(maxent_loop.MaxEntLoop.__dict__.get(n), staticmethod): wrap(maxent_loop.MaxEntLoop, n)
+wrap(maxent_result.MaxEntResult, 'add_batch_results')
+for n in ('finish', 'select3_launch', 'select3_fetch'):
+    if hasattr(device.DeviceContext, n): wrap(device.DeviceContext, n, 'ctx.' + n)
+for cls in (analyzers.LineFitAnalyzer, analyzers.Chi2CurvatureAnalyzer, analyzers.EntropyAnalyzer):
+    if hasattr(cls, 'pick_many'): wrap(cls, 'pick_many', cls.__name__ + '.pick_many')
 for cls in (analyzers.LineFitAnalyzer, analyzers.Chi2CurvatureAnalyzer, analyzers.EntropyAnalyzer):
     if hasattr(cls, 'analyze_many'): wrap(cls, 'analyze_many', cls.__name__ + '.analyze_many')
 batch = bench.build_batch(16, 200, 500, 100, 0)
