@@ -879,6 +879,9 @@ try {
     //      from the same v0 (the minimiser of each alpha does not depend on the path)
     int split = o.alpha_split;
     int split_pm = 0;                 // pieces per plus-minus scan where that differs from the normal-entropy scans' (0: the same)
+    bool cut_by_cost = false;         // launches that do not fill the GPU: pieces of equal COST, one per slot (see below)
+    bool cost_needs_short_pm = false; //   at two workgroups per CU: only when the plus-minus pieces stay within the depth target too
+    long long slots_by_cost = 0;
     if (split <= 0) {
         // about two pieces per chain slot of the GPU (CUs x workgroups per CU x 4 slots): the persistent grid
         // then balances (pieces have unequal costs and are handed out most expensive first), and a batch that
@@ -917,17 +920,10 @@ try {
         // plus-minus scans -- cold start 5 rounds against 12-16, 2 rounds per alpha against 2.75: a piece of twice the alphas costs
         // what a normal-entropy piece does -- are cut into fewer, longer pieces, so that every slot gets ONE piece (the 3 200-problem
         // shard of cfg4 / 8: 1 600 pieces on 1 024 slots -> 1 012; profiles/r04_experiments.txt).  MXE_NO_SPLIT_BY_KIND: the old cut
+        // (one workgroup per CU only.  At two per CU -- the two-GPU shard of cfg4, whose plus-minus pieces would stay short enough --
+        //  the cut by cost LOST: 0.565 -> 0.617 ms; two workgroups per CU are the throughput regime, profiles/r04_experiments.txt)
         if (wgpc_guess == 1 && o.wg_per_cu == 0 && !getenv("MXE_NO_SPLIT_BY_KIND") && n_alpha >= 4) {
-            const long long n_slots = 4LL * n_cu, s_n = n_alpha / 2;
-            long long n_normal = 0;
-            for (int c = 0; c < n_chain; ++c) n_normal += ctx->elem_kind[elem_of_chain[c]] == MXE_ENTROPY_NORMAL;
-            const long long n_pm = n_chain - n_normal;
-            if ((long long)n_chain * split > n_slots && n_pm > 0 && n_normal * s_n + n_pm <= n_slots) {
-                // (normal-entropy scans at the cap of two alphas per piece, the plus-minus scans share the slots that are left)
-                const long long sp = std::max(1LL, std::min(s_n, (n_slots - n_normal * s_n) / n_pm));
-                split = (int)s_n;
-                split_pm = (int)sp;
-            }
+            cut_by_cost = true; slots_by_cost = 4LL * n_cu; cost_needs_short_pm = false;
         }
         // a small batch that cannot fill the lock-step layout (>= 768 pieces) with pieces of six alphas,
         // but can with shorter ones, takes those: the lock-step kernel serves four pieces with the loads
@@ -946,21 +942,90 @@ try {
     // where it is cheap and safe, then one warm step down to the piece's first alpha (lock-step kernel: chain_pre);
     // in the other layouts, and where that step would be long, the piece is joined to the one before it.
     ctx->sub_pre.clear(); ctx->has_pre = false;
+    // Launches that do not fill the GPU (cut_by_cost): such a launch is as long as its deepest slot, so the pieces are cut to equal
+    // COST and every slot gets one.  The cost of a normal-entropy piece is its cold start -- 9-10 evaluations in the upper third of
+    // the logarithmic alpha range, rising to 17-19 just above the guarded tail (profiles/r04_b_depth_by_piece.txt; the same numbers
+    // as the cold-start profile of r02) -- plus ~3 per further alpha: with the uniform pieces of two alphas the deepest slot of the
+    // 8-GPU shards was a piece at alpha index 88-92 (19 + 5 evaluations), not the led tail pieces (~22 rounds with their walk).
+    // Pieces of a normal-entropy scan therefore get as many alphas as fit MC_DEPTH_TARGET evaluations (4 at the top of the mesh, 1
+    // next to the tail) and end where the guarded range begins; the plus-minus scans (cold start ~4.5, ~2.2 per alpha) share the
+    // slots the normal-entropy pieces leave.
+    double MC_DEPTH_TARGET = 20.0;
+    bool cost_cut_normal_only = false;           // (experiment: the normal-entropy scans of a batch that fills the GPU, MXE_X_COST_CUT_FULL = target)
+    if (!cut_by_cost && o.alpha_split == 0 && getenv("MXE_X_COST_CUT_FULL") && split > 1) {
+        MC_DEPTH_TARGET = atof(getenv("MXE_X_COST_CUT_FULL"));
+        cost_cut_normal_only = MC_DEPTH_TARGET > 10.0;
+    }
+    auto scan_range = [&](const double* ac, double& lmax, double& lmin) {
+        lmax = -1e300; lmin = 1e300;
+        for (int i = 0; i < n_alpha; ++i) { const double l = std::log(ac[i]); lmax = std::max(lmax, l); lmin = std::min(lmin, l); }
+    };
+    auto cost_cuts = [&](const double* ac, std::vector<int>& cuts) {          // piece starts of one normal-entropy scan (+ n_alpha)
+        double lmax, lmin;
+        scan_range(ac, lmax, lmin);
+        const double lguard = lmax - 0.94 * (lmax - lmin);
+        int lead = -1;                               // the smallest alpha above the guarded range: what leads the tail pieces
+        { double best = 1e300; for (int i = 0; i < n_alpha; ++i) if (std::log(ac[i]) >= lguard && ac[i] < best) { best = ac[i]; lead = i; } }
+        cuts.clear();
+        int a0 = 0;
+        while (a0 < n_alpha) {
+            cuts.push_back(a0);
+            const double la = std::log(ac[a0]);
+            if (lmax > lmin && la < lguard && lead >= 0 && lead < a0) break;     // (the guarded tail: one range, cut into led single alphas below)
+            if (cost_cut_normal_only && lead >= 0 && a0 == lead) break;          // (experiment: the last piece starts AT the leading alpha and stays whole, as the uniform cut's)
+            const double xpos = (lmax > lmin) ? (lmax - la) / (lmax - lmin) : 0.0;
+            const double cold = 9.5 + 13.0 * std::max(0.0, xpos - 0.3);
+            int L = 1 + (int)std::floor(std::max(0.0, (MC_DEPTH_TARGET - cold) / 3.0));
+            L = std::max(1, std::min(L, cost_cut_normal_only ? 16 : 6));
+            int a1 = std::min(n_alpha, a0 + L);
+            for (int j = a0 + 1; j < a1; ++j) if (lmax > lmin && std::log(ac[j]) < lguard && lead >= 0 && lead < j) { a1 = j; break; }
+            if (cost_cut_normal_only && lead > a0 && a1 > lead) a1 = lead;
+            a0 = a1;
+        }
+        cuts.push_back(n_alpha);
+    };
+    if (cut_by_cost) {
+        long long n_normal = 0, pieces_normal = 0;
+        std::vector<int> cuts;
+        for (int c = 0; c < n_chain; ++c)
+            if (ctx->elem_kind[elem_of_chain[c]] == MXE_ENTROPY_NORMAL) {
+                ++n_normal;
+                cost_cuts(alpha_dev.data() + (size_t)c * n_alpha, cuts);
+                pieces_normal += (long long)cuts.size() - 2 + (n_alpha - cuts[cuts.size() - 2]);      // (the last range: one piece per alpha if it is the guarded tail -- an upper bound otherwise)
+            }
+        const long long n_pm = n_chain - n_normal;
+        // (a plus-minus piece of eight alphas costs ~4.5 + 7 x 2.5 = 22 evaluations: the depth of the led tail pieces.  A launch of
+        //  two workgroups per CU -- a batch that can fill the GPU twice over with uniform pieces -- only takes this cut when its
+        //  plus-minus pieces stay that short: the two-GPU shard of cfg4 does, cfg4 itself -- six pieces of 17 alphas -- does not)
+        const long long min_pm = cost_needs_short_pm ? (n_alpha + 7) / 8 : 1;
+        if (pieces_normal + n_pm * min_pm <= slots_by_cost) {
+            if (n_pm > 0) split_pm = (int)std::max(1LL, std::min<long long>(n_alpha / 2, (slots_by_cost - pieces_normal) / n_pm));
+        } else cut_by_cost = false;                  // (more scans than slots can take one piece of each: the uniform cut)
+    }
     for (int c = 0; c < n_chain; ++c) {
         const double* ac = alpha_dev.data() + (size_t)c * n_alpha;
         double pre_alpha = 0.0, lguard = 0.0;
         int pre_index = -1;
-        if (ctx->elem_kind[elem_of_chain[c]] == MXE_ENTROPY_NORMAL && split > 1) {
-            double lmax = -1e300, lmin = 1e300;
-            for (int i = 0; i < n_alpha; ++i) { const double l = std::log(ac[i]); lmax = std::max(lmax, l); lmin = std::min(lmin, l); }
+        const bool normal_c = ctx->elem_kind[elem_of_chain[c]] == MXE_ENTROPY_NORMAL;
+        if (normal_c && split > 1) {
+            double lmax, lmin;
+            scan_range(ac, lmax, lmin);
             lguard = lmax - 0.94 * (lmax - lmin);
             double best = 1e300;                     // the smallest alpha of the scan that is still above the guarded range
             for (int i = 0; i < n_alpha; ++i) if (std::log(ac[i]) >= lguard && ac[i] < best) { best = ac[i]; pre_index = i; }
             if (lmax > lmin && best < 1e300) pre_alpha = best;
         }
-        const int split_c = (split_pm > 0 && ctx->elem_kind[elem_of_chain[c]] != MXE_ENTROPY_NORMAL) ? std::min(split_pm, n_alpha) : split;
-        for (int sidx = 0; sidx < split_c; ++sidx) {
-            const int a0 = (int)((long long)n_alpha * sidx / split_c), a1 = (int)((long long)n_alpha * (sidx + 1) / split_c);
+        std::vector<int> cuts;
+        if ((cut_by_cost || cost_cut_normal_only) && normal_c && split > 1) cost_cuts(ac, cuts);
+        else {
+            const int split_c = (split_pm > 0 && !normal_c) ? std::min(split_pm, n_alpha) : split;
+            for (int sidx = 0; sidx <= split_c; ++sidx) {
+                const int a = (int)((long long)n_alpha * sidx / split_c);
+                if (cuts.empty() || a > cuts.back()) cuts.push_back(a);
+            }
+        }
+        for (size_t sidx = 0; sidx + 1 < cuts.size(); ++sidx) {
+            const int a0 = cuts[sidx], a1 = cuts[sidx + 1];
             if (a1 <= a0) continue;
             const bool guarded = pre_alpha > 0.0 && sidx > 0 && std::log(ac[a0]) < lguard && pre_index < a0;
             // (the warm step from the leading alpha is safe over a factor of 1.5 in alpha -- measured: at most 11
