@@ -950,12 +950,9 @@ try {
     // Pieces of a normal-entropy scan therefore get as many alphas as fit MC_DEPTH_TARGET evaluations (4 at the top of the mesh, 1
     // next to the tail) and end where the guarded range begins; the plus-minus scans (cold start ~4.5, ~2.2 per alpha) share the
     // slots the normal-entropy pieces leave.
-    double MC_DEPTH_TARGET = 20.0;
-    bool cost_cut_normal_only = false;           // (experiment: the normal-entropy scans of a batch that fills the GPU, MXE_X_COST_CUT_FULL = target)
-    if (!cut_by_cost && o.alpha_split == 0 && getenv("MXE_X_COST_CUT_FULL") && split > 1) {
-        MC_DEPTH_TARGET = atof(getenv("MXE_X_COST_CUT_FULL"));
-        cost_cut_normal_only = MC_DEPTH_TARGET > 10.0;
-    }
+    // (the same cut for the normal-entropy scans of the batch that FILLS the GPU -- targets of 34 / 38 / 42 evaluations instead of 15
+    //  uniform pieces -- was 10-13 % slower, 0.814 -> 0.894 / 0.893 / 0.917 ms: there the queue balances, profiles/r04_experiments.txt)
+    constexpr double MC_DEPTH_TARGET = 20.0;
     auto scan_range = [&](const double* ac, double& lmax, double& lmin) {
         lmax = -1e300; lmin = 1e300;
         for (int i = 0; i < n_alpha; ++i) { const double l = std::log(ac[i]); lmax = std::max(lmax, l); lmin = std::min(lmin, l); }
@@ -972,14 +969,12 @@ try {
             cuts.push_back(a0);
             const double la = std::log(ac[a0]);
             if (lmax > lmin && la < lguard && lead >= 0 && lead < a0) break;     // (the guarded tail: one range, cut into led single alphas below)
-            if (cost_cut_normal_only && lead >= 0 && a0 == lead) break;          // (experiment: the last piece starts AT the leading alpha and stays whole, as the uniform cut's)
             const double xpos = (lmax > lmin) ? (lmax - la) / (lmax - lmin) : 0.0;
             const double cold = 9.5 + 13.0 * std::max(0.0, xpos - 0.3);
             int L = 1 + (int)std::floor(std::max(0.0, (MC_DEPTH_TARGET - cold) / 3.0));
-            L = std::max(1, std::min(L, cost_cut_normal_only ? 16 : 6));
+            L = std::max(1, std::min(L, 6));
             int a1 = std::min(n_alpha, a0 + L);
             for (int j = a0 + 1; j < a1; ++j) if (lmax > lmin && std::log(ac[j]) < lguard && lead >= 0 && lead < j) { a1 = j; break; }
-            if (cost_cut_normal_only && lead > a0 && a1 > lead) a1 = lead;
             a0 = a1;
         }
         cuts.push_back(n_alpha);
@@ -1016,7 +1011,7 @@ try {
             if (lmax > lmin && best < 1e300) pre_alpha = best;
         }
         std::vector<int> cuts;
-        if ((cut_by_cost || cost_cut_normal_only) && normal_c && split > 1) cost_cuts(ac, cuts);
+        if (cut_by_cost && normal_c && split > 1) cost_cuts(ac, cuts);
         else {
             const int split_c = (split_pm > 0 && !normal_c) ? std::min(split_pm, n_alpha) : split;
             for (int sidx = 0; sidx <= split_c; ++sidx) {
