@@ -979,6 +979,33 @@ try {
         }
         cuts.push_back(n_alpha);
     };
+    // plus-minus scans: cold start ~4.5 evaluations, then 2 per alpha at the top of the mesh and 3 at its bottom -- with uniform pieces of
+    // seven alphas the deepest slot of the four-GPU shards was a plus-minus piece at the smallest alphas (4.6 + 7 x 3.0 = 26 rounds).
+    // At most `pieces` pieces of equal cost: the smallest cost per piece that needs no more (bisection)
+    auto pm_cuts = [&](const double* ac, int pieces, std::vector<int>& cuts) {
+        double lmax, lmin;
+        scan_range(ac, lmax, lmin);
+        auto w = [&](int a) { return 2.0 + ((lmax > lmin) ? (lmax - std::log(ac[a])) / (lmax - lmin) : 0.0); };
+        auto cut = [&](double T, std::vector<int>* out) {
+            int n = 0, a0 = 0;
+            while (a0 < n_alpha) {
+                if (out) out->push_back(a0);
+                double cost = 4.5 + w(a0);
+                int a1 = a0 + 1;
+                while (a1 < n_alpha && cost + w(a1) <= T) { cost += w(a1); ++a1; }
+                a0 = a1; ++n;
+            }
+            return n;
+        };
+        double lo = 6.0, hi = 4.5 + 3.0 * n_alpha + 1.0;
+        for (int it = 0; it < 40 && hi - lo > 0.05; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (cut(mid, nullptr) <= pieces) hi = mid; else lo = mid;
+        }
+        cuts.clear();
+        cut(hi, &cuts);
+        cuts.push_back(n_alpha);
+    };
     if (cut_by_cost) {
         long long n_normal = 0, pieces_normal = 0;
         std::vector<int> cuts;
@@ -1012,6 +1039,7 @@ try {
         }
         std::vector<int> cuts;
         if (cut_by_cost && normal_c && split > 1) cost_cuts(ac, cuts);
+        else if (cut_by_cost && !normal_c && split_pm > 1 && split_pm < n_alpha / 2) pm_cuts(ac, split_pm, cuts);      // (at the cap of two alphas there is nothing to balance)
         else {
             const int split_c = (split_pm > 0 && !normal_c) ? std::min(split_pm, n_alpha) : split;
             for (int sidx = 0; sidx <= split_c; ++sidx) {
