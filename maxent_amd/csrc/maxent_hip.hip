@@ -923,7 +923,10 @@ try {
         // (one workgroup per CU only.  At two per CU -- the two-GPU shard of cfg4, whose plus-minus pieces would stay short enough --
         //  the cut by cost LOST: 0.565 -> 0.617 ms; two workgroups per CU are the throughput regime, profiles/r04_experiments.txt)
         if (wgpc_guess == 1 && o.wg_per_cu == 0 && !getenv("MXE_NO_SPLIT_BY_KIND") && n_alpha >= 4) {
-            cut_by_cost = true; slots_by_cost = 4LL * n_cu; cost_needs_short_pm = false;
+            // (one workgroup per CU is not always a launch that does not fill the GPU -- a binary32 launch runs that way whatever its
+            //  size --: the cut is only taken when the plus-minus pieces it leaves are short, see min_pm below.  Without that test
+            //  the 25 600-problem batch in binary32 got ONE piece per plus-minus scan: 1.24 -> 3.18 ms)
+            cut_by_cost = true; slots_by_cost = 4LL * n_cu; cost_needs_short_pm = true;
         }
         // a small batch that cannot fill the lock-step layout (>= 768 pieces) with pieces of six alphas,
         // but can with shorter ones, takes those: the lock-step kernel serves four pieces with the loads
@@ -1016,10 +1019,10 @@ try {
                 pieces_normal += (long long)cuts.size() - 2 + (n_alpha - cuts[cuts.size() - 2]);      // (the last range: one piece per alpha if it is the guarded tail -- an upper bound otherwise)
             }
         const long long n_pm = n_chain - n_normal;
-        // (a plus-minus piece of eight alphas costs ~4.5 + 7 x 2.5 = 22 evaluations: the depth of the led tail pieces.  A launch of
-        //  two workgroups per CU -- a batch that can fill the GPU twice over with uniform pieces -- only takes this cut when its
-        //  plus-minus pieces stay that short: the two-GPU shard of cfg4 does, cfg4 itself -- six pieces of 17 alphas -- does not)
-        const long long min_pm = cost_needs_short_pm ? (n_alpha + 7) / 8 : 1;
+        // (a plus-minus piece of eight or nine alphas costs ~4.5 + 8 x 2.5 = 24 evaluations: the depth of the led tail pieces.  The
+        //  cut is for launches whose plus-minus pieces stay that short: the four-GPU shard of cfg4 -- 14 pieces per scan -- does,
+        //  cfg4 itself does not)
+        const long long min_pm = cost_needs_short_pm ? (n_alpha + 8) / 9 : 1;       // (at most nine alphas per plus-minus piece)
         if (pieces_normal + n_pm * min_pm <= slots_by_cost) {
             if (n_pm > 0) split_pm = (int)std::max(1LL, std::min<long long>(n_alpha / 2, (slots_by_cost - pieces_normal) / n_pm));
         } else cut_by_cost = false;                  // (more scans than slots can take one piece of each: the uniform cut)

@@ -78,3 +78,14 @@ def test_binary32_first_pass_then_one_binary64_step_per_alpha():
     d, d64 = out['depth'], ref['depth']
     assert d['max_rounds'][0] >= 10 and 2 <= d['max_rounds'][1] <= 12 and d64['max_rounds'][0] >= 10 and d64['max_rounds'][1] == 0, (d, d64)
     assert all(0 < m <= x for m, x in zip(d['mean_rounds'], d['max_rounds']))
+
+
+def test_a_binary32_batch_that_fills_the_gpu_keeps_the_uniform_pieces():
+    """One workgroup per CU is not always 'a launch that does not fill the GPU': the binary32 kernel runs that way whatever the
+    batch size.  The cut of the pieces by cost (one piece per slot) is for small launches -- applied to the 25 600-problem batch
+    it left ONE piece of 100 alphas per plus-minus scan (227 rounds deep, 3.2 ms instead of 1.2)."""
+    batch = bench.build_batch(16, 200, 500, 100, 0)
+    out, info, left = solve(batch, precision=device.PRECISION_F32)
+    assert info['kernel'] == 'mxe::chain_kernel_lv' and out['converged'].all() and left == 0
+    assert 40 <= out['depth']['max_rounds'][0] <= 130, out['depth']
+    assert np.nanmax(out['audit']) < 1e-4
