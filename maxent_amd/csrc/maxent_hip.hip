@@ -873,7 +873,19 @@ try {
                          o.chains_per_wg != 1 && o.tol_d <= 0.0 && o.decouple_tol > 0.0 &&
                          mxe::lv_lds_bytes(ns, ctx->nwp) + mxe::LV_STATIC_LDS <= (size_t)160 * 1024;
     // (binary32 launches in that kernel are scheduled like binary64 ones: lock-step pieces, one workgroup per CU)
-    const bool f32_lv = o.precision == MXE_PRECISION_F32 && lv_fits;
+    bool f32_lv = o.precision == MXE_PRECISION_F32 && lv_fits;
+    if (f32_lv && ns > 32) {
+        // (chain_kernel_lv has the plain 32-row build only: a job with an alpha that couples more than 32 directions -- the criterion
+        //  of the layout decision below, per scan -- keeps the one-chain binary32 kernel AND its pieces of six alphas)
+        for (int c = 0; c < n_chain && f32_lv; ++c) {
+            const int e = elem_of_chain[c];
+            if (e < 0 || e >= ctx->n_elem) return MXE_ERR_ARG;
+            const DataSet& DS = ctx->ds[ctx->elem_ds[e]];
+            double amin = 1e300;
+            for (int i = 0; i < n_alpha; ++i) amin = std::min(amin, alpha_dev[(size_t)c * n_alpha + i]);
+            if (!(DS.c[32] * DS.c[32] * std::max(1.0, ctx->h_sumD[e]) / amin <= MC_COUPLING_MAX)) f32_lv = false;
+        }
+    }
     ctx->lv_mode = 0;
     // ---- (sub-)chains: an alpha scan may be cut into pieces that are cold-started
     //      from the same v0 (the minimiser of each alpha does not depend on the path)
@@ -1116,6 +1128,7 @@ try {
         (void)worst48;
         ctx->excluded.clear();
         if (worst32 <= MC_COUPLING_MAX) ctx->mc_na = 32;
+        else if (f32_lv) layout = 1;      // (chain_kernel_lv has the plain 32-row build only: the one-chain binary32 kernel, BEFORE any piece is cut or dropped below)
         else {
             // Some alphas couple more than 32 directions (very small error bars: sigma = 1e-6 on the BASELINE grids does at
             // the 27 smallest of 100 alphas).  Until r03 the whole launch then went to the one-chain layout (7 x slower).
@@ -1189,8 +1202,11 @@ try {
     }
     if (layout == 4 && f32_lv) {
         // the binary32 launch: only the plain 32-row layout with nothing cut has a build in chain_kernel_lv
+        // (anything else was sent to the one-chain layout above, before the pieces were touched: r04's first form of this fell back
+        //  HERE, after pieces of a 64-row launch had been cut -- the alphas behind the cuts were never solved, their records garbage:
+        //  STRESS_F32=1 tools/stress.py, cases 24 / 25 / 42)
         if (ctx->mc_na == 32 && ctx->excluded.empty() && !ctx->mc_gst) { ctx->lv_mode = 1; ctx->mc_wgpc = 1; }
-        else { layout = 1; ctx->mc_na = 0; ctx->excluded.clear(); }          // (the one-chain binary32 kernel, as before r04)
+        else return MXE_ERR_STATE;
     }
     if (layout != 4 && ctx->has_pre) {
         size_t w = 0;

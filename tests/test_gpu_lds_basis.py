@@ -89,3 +89,37 @@ def test_a_binary32_batch_that_fills_the_gpu_keeps_the_uniform_pieces():
     assert info['kernel'] == 'mxe::chain_kernel_lv' and out['converged'].all() and left == 0
     assert 40 <= out['depth']['max_rounds'][0] <= 130, out['depth']
     assert np.nanmax(out['audit']) < 1e-4
+
+
+def test_binary32_with_more_than_32_coupled_directions_solves_every_alpha_in_the_one_chain_kernel():
+    """chain_kernel_lv has the plain 32-row build only.  A job whose smallest alphas couple more directions (error bars far below
+    the noise) keeps the one-chain binary32 kernel -- decided BEFORE the scans are cut: the first form of this fell back after the
+    lock-step schedule had dropped the alphas behind its cuts, whose records then were garbage (STRESS_F32=1 tools/stress.py)."""
+    from maxent_amd import synthetic, hostprep
+    import maxent_amd as mx
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(2, 200, 500, seed=11)
+    K.reduce_singular_space(1e-14)
+    D = synthetic.flat_D(omega)
+    alphas = np.array(mx.LogAlphaMesh(alpha_min=1.2e-2, alpha_max=1.6e4, n_points=20)) * 200
+    elems = [(0, 0), (0, 1), (1, 0), (1, 1)]
+    kinds = [device.ENTROPY_NORMAL if i == j else device.ENTROPY_PLUSMINUS for i, j in elems]
+    v0 = np.stack([hostprep.initial_v(K.V, D, omega.delta, k) for k in kinds])
+    outs = {}
+    for prec in (device.PRECISION_F64, device.PRECISION_F32):
+        ctx = device.DeviceContext(K.U, K.S, K.V)
+        ds = ctx.add_dataset(2e-5 * np.ones(200))
+        ctx.set_elements([ds] * 4, [Gmat[i, j] for i, j in elems], np.tile(D, (4, 1)), kinds)
+        ctx.upload_chains(np.arange(4), alphas, v0, device.default_opts(precision=prec, maxiter=300))
+        ctx.launch()
+        kernel = ctx.last_launch_info()['kernel']
+        ctx.finish()
+        outs[prec] = (ctx.fetch(want_v=False, want_H=True), kernel)
+        ctx.close()
+    o32, k32 = outs[device.PRECISION_F32]
+    o64, _ = outs[device.PRECISION_F64]
+    assert k32.startswith('mxe::chain_kernel<') and 'float' in k32, k32
+    assert np.isin(o32['converged'], (0, 1)).all() and o32['n_evals'].min() >= 1 and o32['n_evals'].max() < 100000
+    both = (o32['converged'] == 1) & (o64['converged'] == 1)
+    assert both.sum() >= 40
+    e = np.linalg.norm(o32['H'][both] - o64['H'][both], axis=-1) / np.linalg.norm(o64['H'][both], axis=-1)
+    assert np.all(np.isfinite(e)) and e.max() < 1e-3

@@ -1,6 +1,6 @@
 """Randomised shapes and alpha meshes through the default schedule, checked with the device audit (exact Newton
 correction at the returned v of EVERY problem): convergence, accuracy and the cost of the most expensive alpha.
-    python tools/stress.py [n_cases] [seed]"""
+    python tools/stress.py [n_cases] [seed]        (STRESS_F32=1: the binary32 launches, mxe_opts.precision)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -52,7 +52,7 @@ def main():
         n = len(elems)
         ctx.set_elements([ds] * n, [Gmat[i, j] for i, j in elems], np.tile(D, (n, 1)), kinds)
         t0 = time.perf_counter()
-        ctx.upload_chains(np.arange(n), alphas, v0)
+        ctx.upload_chains(np.arange(n), alphas, v0, device.default_opts(precision=device.PRECISION_F32) if os.environ.get('STRESS_F32') else None)
         ctx.launch()
         n_fin = ctx.finish()
         out = ctx.fetch(want_v=False, want_H=True)
