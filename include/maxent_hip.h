@@ -347,6 +347,11 @@ int  mxe_select_fetch(mxe_ctx* ctx, int32_t* out_index, double* out_H_selected);
  * NULL), both in ONE device-to-host copy. */
 int  mxe_select3_launch(mxe_ctx* ctx, int p2_deg, double gamma);
 int  mxe_select3_fetch(mxe_ctx* ctx, int32_t* out_index, double* out_H_selected);
+/* The same, the rows of the analyzers first .. first + count - 1 only (out_H_selected [count][n_chain][n_omega]; out_index
+ * [3][n_chain] or NULL): a caller whose default analyzer is the line fit takes its row behind the launch and those of the
+ * other two when somebody looks at them (result.analyzer_results[...]['A_out'], maxent_result.py:600-640 of the reference
+ * reads one analyzer's A_out at a time).  The rows stay valid until the next mxe_select3_launch / mxe_chains_upload. */
+int  mxe_select3_fetch_rows(mxe_ctx* ctx, int32_t* out_index, int first, int count, double* out_H_selected);
 /* n_rows hidden images of the last launch by problem index (chain * n_alpha + i), [n_rows][n_omega]:
  * what an analyzer needs (one row per scan) without moving all of H */
 int  mxe_fetch_rows(mxe_ctx* ctx, int n_rows, const int32_t* problem_index, double* out_H);

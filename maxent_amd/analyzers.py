@@ -394,18 +394,50 @@ def _device_picks(maxent_result, keys, which, matches):
         # the launch's arrays as they came off the device: [3][n_chain] indices, [3][n_chain][n_omega] rows
         cs = scan['cs']
         idx = batch[0][which][cs]
-        H = batch[1][which][cs]
+        if np.any(idx < 0):
+            return None
+        src = batch[1][which]
+        if not getattr(src, 'on_host', True):
+            # (the rows of an analyzer that is not the result's default are still on the device: 1 MB that comes when somebody
+            #  looks at this analyzer's A_out)
+            return idx.tolist(), DeferredRows(src, cs, scan['first'] if scan['same_map'] else None, maps)
+        H = src[cs]
     else:
         idx = np.array([s['index'][which] for s in sels])
+        if np.any(idx < 0):
+            return None
         H = np.array([s['H'][which] for s in sels])
-    if np.any(idx < 0):
-        return None
-    if scan['same_map']:
+    return idx.tolist(), _rows_of_H(H, scan['first'] if scan['same_map'] else None, maps)
+
+
+def _rows_of_H(H, shared_map, maps):
+    if shared_map is not None:
         # A = H / delta for everybody: one division for all rows (elementwise: the same bits as row by row)
-        rows = list(scan['first'].f(H))
-    else:
-        rows = [m.from_H_row(r) for m, r in zip(maps, H)]
-    return idx.tolist(), rows
+        return list(shared_map.f(H))
+    return [m.from_H_row(r) for m, r in zip(maps, H)]
+
+
+class DeferredRows(object):
+    """the A rows of one analyzer for the elements of a batch, formed from the device's H rows when first looked at"""
+
+    def __init__(self, src, cs, shared_map, maps):
+        self._src, self._cs, self._shared, self._maps = src, cs, shared_map, maps
+        self._rows = None
+
+    def _build(self):
+        if self._rows is None:
+            self._rows = _rows_of_H(np.asarray(self._src)[self._cs], self._shared, self._maps)
+            self._src = self._maps = None
+        return self._rows
+
+    def __len__(self):
+        return len(self._cs)
+
+    def __getitem__(self, n):
+        return self._build()[n]
+
+    def __iter__(self):
+        return iter(self._build())
 
 
 class LineFitAnalyzer(Analyzer):

@@ -77,6 +77,51 @@ class LazyV(LazyH):
         return self.materialize()[item]
 
 
+class LazyRows(object):
+    """the H rows ONE of the three device analyzers chose for the scans of a launch ([n_chain][n_omega]), on the device until
+    somebody looks (``mxe_select3_fetch_rows``): a result shows the rows of its default analyzer, which come with the solve;
+    those of the other two are 1 MB each for a 16 x 16 job"""
+    _what = 'rows'
+
+    def __init__(self, owner, rank, which, n_chain, n_omega):
+        self._owner, self._rank, self._which = owner, rank, which
+        self.shape, self.dtype, self.ndim = (n_chain, n_omega), np.dtype(float), 2
+        self._val = None
+
+    def materialize(self):
+        if self._val is None:
+            self._owner._materialize_rows(self)
+        return self._val
+
+    def __array__(self, dtype=None, copy=None):
+        val = self.materialize()
+        return val if dtype is None else val.astype(dtype, copy=False)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, item):
+        return self.materialize()[item]
+
+    @property
+    def on_host(self):
+        return self._val is not None
+
+
+class PickedRows(object):
+    """``device_select['H']`` of one scan: [which] -> the H row analyzer ``which`` chose for it"""
+    __slots__ = ('_rows', '_chain')
+
+    def __init__(self, rows, chain):
+        self._rows, self._chain = rows, chain
+
+    def __getitem__(self, which):
+        return self._rows[which][self._chain]
+
+    def __len__(self):
+        return len(self._rows)
+
+
 class LazyA(object):
     """A = A_of_H(H) of one alpha scan (H / delta, or B H with a preblur), formed when looked at"""
 
@@ -235,9 +280,10 @@ class BatchSolver(object):
     def solve(self, K, specs, opts, want_logdet=False, want_H='lazy', output_map=None, select=(0, 0.2)):
         """``specs``: dicts with G, err, U_rot (or None), D, kind, v0, alpha (equal lengths).  Returns
         (list of per-spec result dicts in the order of ``specs``, info).  ``want_H``: 'lazy' (default),
-        True (fetched now) or False.  ``select`` = (linefit_deg, gamma): the three default analyzers' alphas are picked
-        on the device behind the solve (``mxe_select3_launch``) and come back with their H rows as ``device_select``
-        of every result; None: not."""
+        True (fetched now) or False.  ``select`` = (linefit_deg, gamma[, default]): the three default analyzers' alphas are
+        picked on the device behind the solve (``mxe_select3_launch``) and come back as ``device_select`` of every result
+        -- the indices of all three and the H rows of analyzer ``default`` (0 line fit, 1 chi2 curvature, 2 entropy: the one
+        ``result.A_out`` shows) at once, the rows of the other two when somebody looks at them; None: not."""
         self.materialize_pending()                  # the result buffers are about to be overwritten
         n_alpha = len(specs[0]['alpha'])
         for s in specs:
@@ -251,12 +297,31 @@ class BatchSolver(object):
         gather = len(active) == N and N > 1
         outs = [None] * N
         picks = [None] * N
+        conv = {}
+        eager = int(select[2]) if select is not None and len(select) > 2 else 0
+        sel_params = (int(select[0]), float(select[1])) if select is not None else None
 
         def begin(r):
             # stage -> launch of ONE device (the launch returns at once)
             c = self.ctxs[r]
             self._stage(c, K, [specs[i] for i in per_rank[r]], opts)
             c.launch()
+
+        def destinations(r):
+            # the host arrays the results of device r come into -- made BEFORE the device is waited for, so that the per-scan views
+            # of them can be cut while the kernel runs
+            c = self.ctxs[r]
+            if not gather:
+                outs[r] = c.result_arrays()
+                conv[r] = np.empty(outs[r]['converged'].shape, dtype=bool)
+            if select is not None:
+                idx, row = c.select3_arrays(1)
+                rows = [LazyRows(self, r, w, c._n_chain, self.n_omega) for w in range(3)]
+                rows[eager]._val = row[0]
+                for w in range(3):
+                    if w != eager:
+                        self._pending.append(weakref.ref(rows[w]))
+                picks[r] = (idx, rows, row)
 
         def end(r):
             # finish -> (fetch) of ONE device
@@ -267,9 +332,12 @@ class BatchSolver(object):
             elif gather:
                 c.select_launch(0)
             if not gather:
-                outs[r] = c.fetch(want_v=False, want_H=False)
+                c.fetch(want_v=False, want_H=False, out=outs[r])
+                np.not_equal(outs[r]['converged'], 0, out=conv[r])
             if select is not None:
-                picks[r] = c.select3_fetch()
+                # (the indices of all three analyzers and the rows of the result's default analyzer; the rows of the other two when
+                #  somebody looks at them)
+                c.select3_fetch_rows(first=eager, count=1, idx=picks[r][0], rows=picks[r][2])
 
         def skeleton():
             # what of the results does not wait for the device: built while the kernel runs
@@ -283,16 +351,36 @@ class BatchSolver(object):
                 out.append(dict(alpha=np.asarray(s['alpha'], dtype=float), H=H, A=None, v=v))
             return out
 
+        def attach(res):
+            # the per-scan views of the arrays of ``destinations`` (filled by ``end``: with one device while the kernel runs)
+            for i, d in enumerate(res):
+                r, c = int(rank_of[i]), int(local_of[i])
+                o = outs[r]
+                if o is not None:
+                    d.update(chi2=o['chi2'][c], S=o['S'][c], Q=o['Q'][c],
+                             n_iter=o['n_iter'][c], converged=conv[r][c], n_evals=o['n_evals'][c])
+                if picks[r] is not None:
+                    idx, rows = picks[r][0], picks[r][1]
+                    d['device_select'] = dict(params=sel_params, index=idx[:, c], H=PickedRows(rows, c), batch=picks[r], chain=c)
+
         # with several devices each runs on a thread of its own (ctypes releases the GIL, the library promises one
         # thread per context: include/maxent_hip.h)
         if len(active) == 1:
             begin(active[0])
             res = skeleton()
+            destinations(active[0])
+            attach(res)
             end(active[0])
         else:
-            waiting = self._on_devices(lambda r: (begin(r), end(r)), active, wait=False)
+            def one(r):
+                begin(r)
+                destinations(r)         # (after the staging: the context knows its chains)
+                end(r)
+            waiting = self._on_devices(one, active, wait=False)
             res = skeleton()
             waiting()
+            if not gather:
+                attach(res)
         info = None
         if gather:
             # ONE gather of the per-alpha scalars (and of the analyzer's rows) to the first device
@@ -306,7 +394,13 @@ class BatchSolver(object):
                 extra = self.ctxs[r].fetch(want_v=False, want_H=False)
                 for k in ('n_iter', 'converged', 'n_evals'):
                     outs[r][k] = extra[k]
+                conv[r] = outs[r]['converged'].astype(bool)
             self._on_devices(rest, list(range(N)))
+            attach(res)
+            for i, d in enumerate(res):
+                r, c = int(rank_of[i]), int(local_of[i])
+                d['device_linefit_index'] = int(outs[r]['linefit_index'][c])
+                d['device_linefit_H'] = outs[r]['linefit_H'][c]
         logdets = {r: self.ctxs[r].logdet() for r in active} if want_logdet else {}
         maps = {r: self.ctxs[r].apply_output_map(output_map) for r in active} if output_map is not None else {}
         ms = [self.ctxs[r].last_kernel_ms() for r in active]
@@ -321,28 +415,17 @@ class BatchSolver(object):
             info['audit_max'] = float(np.nanmax(corr[conv_all])) if conv_all.any() else 0.0
             info['audit_problems'] = int(conv_all.sum())
         self.last_info = info
-        conv = {r: outs[r]['converged'].astype(bool) for r in active}
-        sel_params = (int(select[0]), float(select[1])) if select is not None else None
-        for i, d in enumerate(res):
-            r, c = int(rank_of[i]), int(local_of[i])
-            o = outs[r]
-            if r in maps:
-                d['A'] = maps[r][c]
-            d.update(chi2=o['chi2'][c], S=o['S'][c], Q=o['Q'][c],
-                     n_iter=o['n_iter'][c], converged=conv[r][c], n_evals=o['n_evals'][c])
-            if 'linefit_index' in o:
-                d['device_linefit_index'] = int(o['linefit_index'][c])
-                d['device_linefit_H'] = o['linefit_H'][c]
-            if picks[r] is not None:
-                d['device_select'] = dict(params=sel_params, index=picks[r][0][:, c], H=picks[r][1][:, c], batch=picks[r], chain=c)
-                if 'device_linefit_index' not in d:
-                    d['device_linefit_index'], d['device_linefit_H'] = int(picks[r][0][0, c]), picks[r][1][0, c]
-            if r in logdets:
-                d['logdet'] = logdets[r][c]
+        if maps or logdets:
+            for i, d in enumerate(res):
+                r, c = int(rank_of[i]), int(local_of[i])
+                if r in maps:
+                    d['A'] = maps[r][c]
+                if r in logdets:
+                    d['logdet'] = logdets[r][c]
         if want_H is True:
             self.materialize_pending()
         elif want_H is False:
-            self._pending = [ref for ref in self._pending if isinstance(ref(), LazyV)]
+            self._pending = [ref for ref in self._pending if getattr(ref(), '_what', 'H') != 'H']
             for d in res:
                 d['H'] = None
         return res, info
@@ -462,12 +545,23 @@ class BatchSolver(object):
     @_one_at_a_time
     def _materialize_rank(self, rank):
         alive = self._alive()
-        mine = [h for h in alive if h._rank == rank]
+        mine = [h for h in alive if h._rank == rank and h._what != 'rows']
         if mine:
             got = self.ctxs[rank].fetch(want_v=any(h._what == 'v' for h in mine), want_H=any(h._what == 'H' for h in mine))
             for h in mine:
                 h._val = got[h._what][h._chain]
+        for h in alive:
+            if h._rank == rank and h._what == 'rows':
+                h._val = self.ctxs[rank].select3_fetch_rows(first=h._which, count=1, want_index=False)[1][0]
         self._pending = [weakref.ref(h) for h in alive if h._val is None]
+
+    @_one_at_a_time
+    def _materialize_rows(self, lazy):
+        """the rows of ONE analyzer of the last launch of its device (nothing else moves)"""
+        if lazy._val is None:
+            if not any(ref() is lazy for ref in self._pending):
+                raise RuntimeError('the rows of this analyzer are no longer on the device')      # (cannot happen: materialize_pending runs before every launch)
+            lazy._val = self.ctxs[lazy._rank].select3_fetch_rows(first=lazy._which, count=1, want_index=False)[1][0]
 
     @_one_at_a_time
     def materialize_pending(self):

@@ -262,7 +262,8 @@ struct mxe_ctx {
     DevBuf<int> dparent_elem;
     int result_buffer = 0;        // which of the two result allocations launches write to
     struct View { double* p = nullptr; } dout_H, dout_chi2, dout_S, dout_Q;
-    DevBuf<int> dout_niter, dout_conv, dout_nevals, dout_nact;
+    DevBuf<int> dout_niter, dout_nact;       // dout_niter: niter [P] | converged [P] | nevals [P] in ONE block (mxe_chains_fetch: one copy)
+    struct IView { int* p = nullptr; } dout_conv, dout_nevals;
     DevBuf<long long> dprof;
     DevBuf<int> dqueue, dcounter;
     DevBuf<int> dsub_pre, dsub_init;
@@ -270,6 +271,7 @@ struct mxe_ctx {
     DevBuf<double> dgstate;             // omega-space state of the chains when it does not fit LDS (KParams::gstate)
     DevBuf<int> dfin_elem, dfin_prob0, dfin_len, dfin_v0;       // mxe_chains_finish: one piece per alpha that is solved again
     DevBuf<double> dfin_start;          //   and its start vector (the state the lock-step kernel left)
+    int sel3_nc = 0;                    // scans of the launch the last mxe_select3_launch chose for (0: none since the chains were uploaded)
     int last_finished = 0;              // alphas the last mxe_chains_finish solved again
     bool has_init = false;
     // mxe_eval_batch / mxe_audit scratch
@@ -577,7 +579,7 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
     ctx->dghat.release(); ctx->dcperp.release(); ctx->dD.release(); ctx->dsumD.release();
     ctx->dalpha.release(); ctx->dv0.release(); ctx->delem_ds.release(); ctx->delem_kind.release();
     ctx->dchain_elem.release(); ctx->dsub_prob0.release(); ctx->dsub_len.release(); ctx->dsub_v0.release(); ctx->dwg_chains.release(); ctx->dqueue.release(); ctx->dcounter.release(); ctx->dsub_pre.release(); ctx->dsub_init.release(); ctx->dinit_tab.release(); ctx->dout_v.release(); ctx->dout_pack.release(); ctx->dout_pack2.release();
-    ctx->dout_niter.release(); ctx->dout_conv.release(); ctx->dout_nevals.release(); ctx->dout_nact.release(); ctx->dexcluded.release();
+    ctx->dout_niter.release(); ctx->dout_conv.p = ctx->dout_nevals.p = nullptr; ctx->dout_nact.release(); ctx->dexcluded.release();
     ctx->dB.release(); ctx->dA.release(); ctx->dprof.release();
     ctx->rows_out.release(); ctx->rows_idx.release();
     ctx->ev_x.release(); ctx->ev_alpha.release(); ctx->ev_scal.release(); ctx->ev_vecw.release(); ctx->ev_vecs.release();
@@ -1319,9 +1321,9 @@ try {
     ctx->dout_chi2.p = ctx->dout_pack.p + P * nw;
     ctx->dout_S.p = ctx->dout_chi2.p + P;
     ctx->dout_Q.p = ctx->dout_S.p + P;
-    HIPCHK(ctx, ctx->dout_niter.ensure(P));
-    HIPCHK(ctx, ctx->dout_conv.ensure(P));
-    HIPCHK(ctx, ctx->dout_nevals.ensure(P));
+    HIPCHK(ctx, ctx->dout_niter.ensure(3 * P));
+    ctx->dout_conv.p = ctx->dout_niter.p + P;
+    ctx->dout_nevals.p = ctx->dout_conv.p + P;
     HIPCHK(ctx, ctx->dout_nact.ensure(P));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dchain_elem.p, ctx->sub_elem.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_prob0.p, ctx->sub_prob0.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1342,7 +1344,7 @@ try {
     ctx->n_chain = n_chain; ctx->n_alpha = n_alpha;
     ctx->has_init = false;
     { const int rc_init = build_init_table(ctx, n_chain, elem_of_chain, hv0); if (rc_init != MXE_OK) return rc_init; }
-    ctx->chains_ready = true; ctx->launched = false;
+    ctx->chains_ready = true; ctx->launched = false; ctx->sel3_nc = 0;
     return MXE_OK;
 }
 MXE_CATCH_ALL
@@ -1710,15 +1712,24 @@ try {
     const size_t P = (size_t)ctx->n_chain * ctx->n_alpha;
     const int ns = ctx->n_s, NP = ctx->NP, nw = ctx->n_omega;
     if (out_H) HIPCHK(ctx, d2h_pipelined(out_H, ctx->dout_H.p, P * nw * 8, ctx->stream));
-    if (out_chi2) HIPCHK(ctx, hipMemcpy(out_chi2, ctx->dout_chi2.p, P * 8, hipMemcpyDeviceToHost));
-    if (out_S) HIPCHK(ctx, hipMemcpy(out_S, ctx->dout_S.p, P * 8, hipMemcpyDeviceToHost));
-    if (out_Q) {
-        HIPCHK(ctx, hipMemcpy(out_Q, ctx->dout_Q.p, P * 8, hipMemcpyDeviceToHost));
-        if (ctx->chi2_factor != 1.0) for (size_t i = 0; i < P; ++i) out_Q[i] *= ctx->chi2_factor;
+    // (chi2 | S | Q and niter | converged | nevals are one block each on the device: a caller whose arrays lie the same way --
+    //  maxent_amd.device.DeviceContext.fetch allocates them so -- gets each block in ONE copy; six copies of 100-200 KB
+    //  cost 0.15 ms behind a launch of 0.8 ms)
+    if (out_chi2 && out_S == out_chi2 + P && out_Q == out_S + P)
+        HIPCHK(ctx, hipMemcpy(out_chi2, ctx->dout_chi2.p, 3 * P * 8, hipMemcpyDeviceToHost));
+    else {
+        if (out_chi2) HIPCHK(ctx, hipMemcpy(out_chi2, ctx->dout_chi2.p, P * 8, hipMemcpyDeviceToHost));
+        if (out_S) HIPCHK(ctx, hipMemcpy(out_S, ctx->dout_S.p, P * 8, hipMemcpyDeviceToHost));
+        if (out_Q) HIPCHK(ctx, hipMemcpy(out_Q, ctx->dout_Q.p, P * 8, hipMemcpyDeviceToHost));
     }
-    if (out_niter) HIPCHK(ctx, hipMemcpy(out_niter, ctx->dout_niter.p, P * 4, hipMemcpyDeviceToHost));
-    if (out_converged) HIPCHK(ctx, hipMemcpy(out_converged, ctx->dout_conv.p, P * 4, hipMemcpyDeviceToHost));
-    if (out_nevals) HIPCHK(ctx, hipMemcpy(out_nevals, ctx->dout_nevals.p, P * 4, hipMemcpyDeviceToHost));
+    if (out_Q && ctx->chi2_factor != 1.0) for (size_t i = 0; i < P; ++i) out_Q[i] *= ctx->chi2_factor;
+    if (out_niter && out_converged == out_niter + P && out_nevals == out_converged + P)
+        HIPCHK(ctx, hipMemcpy(out_niter, ctx->dout_niter.p, 3 * P * 4, hipMemcpyDeviceToHost));
+    else {
+        if (out_niter) HIPCHK(ctx, hipMemcpy(out_niter, ctx->dout_niter.p, P * 4, hipMemcpyDeviceToHost));
+        if (out_converged) HIPCHK(ctx, hipMemcpy(out_converged, ctx->dout_conv.p, P * 4, hipMemcpyDeviceToHost));
+        if (out_nevals) HIPCHK(ctx, hipMemcpy(out_nevals, ctx->dout_nevals.p, P * 4, hipMemcpyDeviceToHost));
+    }
     if (out_v) {
         std::vector<double> hv(P * NP);
         HIPCHK(ctx, hipMemcpy(hv.data(), ctx->dout_v.p, P * NP * 8, hipMemcpyDeviceToHost));
@@ -2254,24 +2265,35 @@ try {
                        ctx->dalpha.p, ctx->dout_chi2.p, ctx->dout_H.p, ctx->n_alpha, ctx->n_omega, p2_deg, sel, idx,
                        ctx->dout_S.p, gamma, ctx->dsel3.p, ctx->dsel3.p + 3 * nc);
     HIPCHK(ctx, hipGetLastError());
+    ctx->sel3_nc = ctx->n_chain;
+    return MXE_OK;
+}
+MXE_CATCH_ALL
+
+extern "C" int mxe_select3_fetch_rows(mxe_ctx* ctx, int32_t* out_index /*[3][n_chain] or NULL*/, int first, int count,
+                                      double* out_H_selected /*[count][n_chain][n_omega] or NULL*/)
+try {
+    if (!ctx || first < 0 || count < 0 || first + count > 3 || (!out_index && !out_H_selected)) return MXE_ERR_ARG;
+    if (!ctx->launched || !ctx->dsel3.p || ctx->sel3_nc != ctx->n_chain) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t nc = ctx->n_chain, nw = ctx->n_omega;
+    if (out_index) {
+        ctx->h_sel3.resize(3 * nc);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_sel3.data(), ctx->dsel3.p, 3 * nc * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, stream_wait(ctx->stream));       // (the selection kernel has finished before any path of the row copy starts)
+    if (out_H_selected && count > 0)
+        HIPCHK(ctx, d2h_pipelined(out_H_selected, ctx->dsel3.p + 3 * nc + (size_t)first * nc * nw, (size_t)count * nc * nw * 8, ctx->stream));
+    if (out_index) for (size_t i = 0; i < 3 * nc; ++i) out_index[i] = (int32_t)ctx->h_sel3[i];
     return MXE_OK;
 }
 MXE_CATCH_ALL
 
 extern "C" int mxe_select3_fetch(mxe_ctx* ctx, int32_t* out_index /*[3][n_chain]*/, double* out_H_selected /*[3][n_chain][n_omega]*/)
-try {
+{
     if (!ctx || !out_index) return MXE_ERR_ARG;
-    if (!ctx->launched || !ctx->dsel3.p) return MXE_ERR_STATE;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    const size_t nc = ctx->n_chain, nw = ctx->n_omega;
-    ctx->h_sel3.resize(3 * nc);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_sel3.data(), ctx->dsel3.p, 3 * nc * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, stream_wait(ctx->stream));       // (the selection kernel has finished before any path of the row copy starts)
-    if (out_H_selected) HIPCHK(ctx, d2h_pipelined(out_H_selected, ctx->dsel3.p + 3 * nc, 3 * nc * nw * 8, ctx->stream));
-    for (size_t i = 0; i < 3 * nc; ++i) out_index[i] = (int32_t)ctx->h_sel3[i];
-    return MXE_OK;
+    return mxe_select3_fetch_rows(ctx, out_index, 0, out_H_selected ? 3 : 0, out_H_selected);
 }
-MXE_CATCH_ALL
 
 extern "C" int mxe_select_fetch(mxe_ctx* ctx, int32_t* out_index, double* out_H_selected)
 try {

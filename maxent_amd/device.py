@@ -107,6 +107,7 @@ SYMBOLS = [
     ('mxe_select_fetch', ctypes.c_int, [_vp, _ip, _dp]),
     ('mxe_select3_launch', ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double]),
     ('mxe_select3_fetch', ctypes.c_int, [_vp, _ip, _dp]),
+    ('mxe_select3_fetch_rows', ctypes.c_int, [_vp, _ip, ctypes.c_int, ctypes.c_int, _dp]),
     ('mxe_fetch_rows', ctypes.c_int, [_vp, ctypes.c_int, _ip, _dp]),
     ('mxe_shard_plan', ctypes.c_int, [ctypes.c_int, ctypes.c_int, _ip, _ip, _ip]),
     ('mxe_comm_unique_id', ctypes.c_int, [ctypes.c_char_p]),
@@ -441,13 +442,21 @@ class DeviceContext(object):
         self._check(self._lib.mxe_chains_finish(self._h, ctypes.byref(n)), 'mxe_chains_finish')
         return int(n.value)
 
-    def fetch(self, want_v=True, want_H=True):
+    def result_arrays(self):
+        """the per-alpha arrays :meth:`fetch` fills, uninitialised: chi2 / S / Q and n_iter / converged / n_evals as the
+        rows of ONE block each -- the library then brings each block in one copy"""
         nc, na = self._n_chain, self._n_alpha
-        out = dict(
-            chi2=np.empty((nc, na)), S=np.empty((nc, na)), Q=np.empty((nc, na)),
-            n_iter=np.empty((nc, na), dtype=np.int32),
-            converged=np.empty((nc, na), dtype=np.int32),
-            n_evals=np.empty((nc, na), dtype=np.int32))
+        d = np.empty((3, nc, na))
+        i = np.empty((3, nc, na), dtype=np.int32)
+        return dict(chi2=d[0], S=d[1], Q=d[2], n_iter=i[0], converged=i[1], n_evals=i[2])
+
+    def fetch(self, want_v=True, want_H=True, out=None):
+        """``out``: the arrays of :meth:`result_arrays`, made by the caller before the launch"""
+        nc, na = self._n_chain, self._n_alpha
+        if out is None:
+            out = self.result_arrays()
+        elif out['chi2'].shape != (nc, na):
+            raise ValueError('result arrays of another launch')
         v = np.empty((nc, na, self.n_s)) if want_v else None
         H = pinned_empty((nc, na, self.n_omega)) if want_H else None
         self._check(self._lib.mxe_chains_fetch(
@@ -528,6 +537,24 @@ class DeviceContext(object):
         Hs = np.empty((3, self._n_chain, self.n_omega)) if want_H else None
         self._check(self._lib.mxe_select3_fetch(self._h, _p(idx), _p(Hs)), 'mxe_select3_fetch')
         return idx, Hs
+
+    def select3_arrays(self, count=1):
+        """uninitialised destinations of :meth:`select3_fetch_rows`: indices [3][n_chain], rows [count][n_chain][n_omega]
+        (page-locked when large: one DMA)"""
+        return np.empty((3, self._n_chain), dtype=np.int32), pinned_empty((count, self._n_chain, self.n_omega))
+
+    def select3_fetch_rows(self, first=0, count=1, idx=None, rows=None, want_index=True):
+        """``mxe_select3_fetch_rows``: the indices of all three analyzers (``want_index``) and the rows of analyzers
+        ``first`` .. ``first + count - 1`` -- the others stay on the device until the next selection"""
+        if want_index and idx is None:
+            idx = np.empty((3, self._n_chain), dtype=np.int32)
+        if rows is None and count > 0:
+            rows = pinned_empty((count, self._n_chain, self.n_omega))
+        if rows is not None and rows.shape != (count, self._n_chain, self.n_omega):
+            raise ValueError('rows of another launch')
+        self._check(self._lib.mxe_select3_fetch_rows(self._h, _p(idx) if want_index else None, int(first), int(count),
+                                                     _p(rows) if count > 0 else None), 'mxe_select3_fetch_rows')
+        return idx, rows
 
     def fetch_rows(self, problem_index):
         pi = _c(np.atleast_1d(problem_index), np.int32)

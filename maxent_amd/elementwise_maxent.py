@@ -142,12 +142,22 @@ class ElementwiseMaxEnt(object):
         self._share_decomposition()
         direct = self._direct_input(worker) and per_job_D is None
         template = None
-        big = err_same = None
+        big = err_same = g_rows = None
         if direct and len(jobs) > 1:
-            # (all elements at once: which of them are below the threshold; one error array when it is the same for all)
+            # (all elements at once: the data vectors as the rows of ONE array -- real part, or imaginary part of an off-diagonal
+            #  element's second scan --, which of them are below the threshold; one error array when it is the same for all)
             Gm = self.G_mat[1]
+            ii = np.fromiter((e[0] for e, _ in jobs), dtype=np.intp, count=len(jobs))
+            jj = np.fromiter((e[1] for e, _ in jobs), dtype=np.intp, count=len(jobs))
+            Gsel = Gm[ii, jj]
+            real_part = np.fromiter((bool(re) for _, re in jobs), dtype=bool, count=len(jobs)) | (ii == jj)
+            if np.iscomplexobj(Gsel):
+                g_rows = np.where(real_part[:, None], Gsel.real, Gsel.imag).astype(float, copy=False)
+            else:
+                g_rows = np.array(Gsel, dtype=float)
+                g_rows[~real_part] = 0.0             # (the imaginary part of real data)
             with np.errstate(all='ignore'):
-                big = (np.max(np.abs(np.real(Gm)), axis=-1), np.max(np.abs(np.imag(Gm)), axis=-1) if np.iscomplexobj(Gm) else None)
+                big = np.max(np.abs(g_rows), axis=-1)
             e0 = self.get_error(tuple(jobs[0][0]))
             if isinstance(self.error, float) or len(np.shape(self.error)) == self.error_dimension:
                 err_same = np.asarray(e0, dtype=float) * np.ones(np.shape(Gm)[-1])
@@ -156,23 +166,25 @@ class ElementwiseMaxEnt(object):
             if direct and n > 0:
                 # array input, plain errors, unrotated kernel: the spec of every further element straight
                 # from the arrays (the worker keeps the first element's state until the last is loaded below)
-                g = self.G_mat[1][tuple(element)]
-                real_part = re or element[0] == element[1]
-                g = np.real(g) if real_part else np.imag(g)
-                if (big[0] if real_part else big[1])[tuple(element)] < loop.G_threshold:
+                if big[n] < loop.G_threshold:
                     res._zero_elements.append(tuple(element) + ((cidx,) if self.use_complex else ()))
                     worker.logtaker.error_message('G below threshold, not performing the calculation.')
                     continue
+                g = g_rows[n]
                 if template is None:
                     template = loop.make_spec(G=g, err=self.get_error(tuple(element)))
                     template['A_map'] = loop.A_of_H
+                    template['G'] = template['G_orig'] = g
                     if err_same is not None:
                         # (ONE error array for every spec of the batch, the first included: BatchSolver._stage then stages one
                         #  row instead of stacking 256 -- it was 1 ms of the 4.7 ms of a run on an object that has run before)
                         template['err'] = err_same
                     spec = template
+                elif err_same is not None:
+                    spec = dict(template)
+                    spec['G'] = spec['G_orig'] = g
                 else:
-                    spec = loop.spec_like(template, g, self.get_error(tuple(element)) if err_same is None else err_same)
+                    spec = loop.spec_like(template, g, self.get_error(tuple(element)))
                 specs.append(spec)
                 live.append((element, cidx))
                 if n == len(jobs) - 1:
@@ -193,7 +205,8 @@ class ElementwiseMaxEnt(object):
             spec['A_map'] = loop.A_of_H
             specs.append(spec)
             live.append((element, cidx))
-        return dict(worker=worker, specs=specs, live=live)
+        # (the keys of the result's records, made once: they were made three times per element -- 0.2 ms of a 16 x 16 run)
+        return dict(worker=worker, specs=specs, live=live, keys=[res._key(element, cidx) for (element, cidx) in live])
 
     def _solve_batches(self, batches):
         """one launch for all batches whose workers share the decomposition of the kernel, the minimiser settings
@@ -213,7 +226,7 @@ class ElementwiseMaxEnt(object):
             loop = g[0]['worker'].maxent_loop
             # the scans of the launch in the order of the result's matrix (row major): what comes off the device in one
             # copy then IS the (M, N, n_alpha, n_omega) array of the result -- MaxEntResult._assemble takes it as a view
-            where = [(res._key(element, cidx), n, k) for n, b in enumerate(g) for k, (element, cidx) in enumerate(b['live'])]
+            where = [(key, n, k) for n, b in enumerate(g) for k, key in enumerate(b['keys'])]
             try:
                 where.sort(key=lambda t: t[0])
             except TypeError:
@@ -221,7 +234,7 @@ class ElementwiseMaxEnt(object):
             specs = [g[n]['specs'][k] for (_, n, k) in where]
             t0 = datetime.now()
             for b in g:
-                res._start.update(dict.fromkeys([res._key(element, cidx) for (element, cidx) in b['live']], t0))
+                res._start.update(dict.fromkeys(b['keys'], t0))
             sols, info = solve_elements(loop.K, specs, loop.minimizer,
                                         device_id=loop.device_id, device_ids=self.device_ids,
                                         want_logdet=loop.probability is not None,
@@ -277,7 +290,7 @@ class ElementwiseMaxEnt(object):
             if X not in times:
                 times[X] = (per_alpha,) * X        # (one immutable tuple for the records of a launch; MaxEntResult.run_times hands out lists)
             rec['run_times'] = times[X]
-        keys = res.add_batch_results(records, live, t_end=t1)
+        keys = res.add_batch_results(records, live, t_end=t1, keys=batch.get('keys'))
         if not talk and sols:
             # (one reduction over the rows of the launch's count array, not one numpy call per element: 1.2 ms for 256 elements)
             loop.note_minimizer_state(sols[-1], int(np.asarray([x['n_iter'] for x in sols]).sum()))

@@ -73,18 +73,23 @@ def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0,
 
 
 def select_params(analyzers):
-    """(linefit_deg, gamma) for ``mxe_select3_launch`` from a list of analyzers -- the device then picks the alphas of
-    the LineFit / Chi2Curvature / Entropy analyzers in the list behind the solve --, None when none of them is there"""
+    """(linefit_deg, gamma, default) for ``mxe_select3_launch`` from a list of analyzers -- the device then picks the alphas
+    of the LineFit / Chi2Curvature / Entropy analyzers in the list behind the solve; ``default``: which of the three (0, 1,
+    2) comes first in the list: its rows come with the solve, the others' when looked at --, None when none of them is there"""
     from .analyzers import LineFitAnalyzer, Chi2CurvatureAnalyzer, EntropyAnalyzer
-    deg, gamma, any_ = 0, 0.2, False
+    deg, gamma, first = 0, 0.2, None
     for a in analyzers or ():
         if isinstance(a, LineFitAnalyzer):
-            deg, any_ = int(a.linefit_deg), True
+            deg, which = int(a.linefit_deg), 0
         elif isinstance(a, Chi2CurvatureAnalyzer):
-            gamma, any_ = float(a.gamma), True
+            gamma, which = float(a.gamma), 1
         elif isinstance(a, EntropyAnalyzer):
-            any_ = True
-    return (deg, gamma) if any_ and deg in (0, 1) and gamma > 0 else None
+            which = 2
+        else:
+            continue
+        if first is None:
+            first = which
+    return (deg, gamma, first) if first is not None and deg in (0, 1) and gamma > 0 else None
 
 
 def solve_single(cost_function, v0, minimizer, device_id=0):

@@ -340,12 +340,13 @@ class MaxEntResult(MaxEntResultData):
         self._records[key] = record
         self._cache = dict()
 
-    def add_batch_results(self, records, elements, t_start=None, t_end=None):
+    def add_batch_results(self, records, elements, t_start=None, t_end=None, keys=None):
         """:meth:`add_element_results` (+ :meth:`start_timing` / :meth:`end_timing` when the times are given) for the
-        scans of one launch; ``elements``: (matrix_element, complex_index) pairs.  Returns their keys"""
-        keys = [self._key(element, cidx) for (element, cidx) in elements]
-        for key, rec in zip(keys, records):
-            self._records[key] = rec
+        scans of one launch; ``elements``: (matrix_element, complex_index) pairs (``keys``: their keys, where the caller
+        has made them already).  Returns their keys"""
+        if keys is None:
+            keys = [self._key(element, cidx) for (element, cidx) in elements]
+        self._records.update(zip(keys, records))
         if t_start is not None:
             self._start.update(dict.fromkeys(keys, t_start))
         if t_end is not None:
@@ -552,10 +553,12 @@ class MaxEntResult(MaxEntResultData):
     def _reference_record(self):
         if not self._records:
             raise AttributeError('no results have been added yet')
-        best = None
-        for rec in self._records.values():
-            if best is None or len(rec['alpha']) > len(best['alpha']):
-                best = rec
+        best = self._cache.get(('reference record',))       # (the cache is dropped whenever a record is added)
+        if best is None:
+            for rec in self._records.values():
+                if best is None or len(rec['alpha']) > len(best['alpha']):
+                    best = rec
+            self._cache[('reference record',)] = best
         return best
 
     @property
