@@ -23,6 +23,8 @@ import weakref
 
 import os
 
+import operator
+
 import numpy as np
 
 from . import device
@@ -277,13 +279,16 @@ class BatchSolver(object):
 
     # ---- one batch -----------------------------------------------------------
     @_one_at_a_time
-    def solve(self, K, specs, opts, want_logdet=False, want_H='lazy', output_map=None, select=(0, 0.2)):
+    def solve(self, K, specs, opts, want_logdet=False, want_H='lazy', output_map=None, select=(0, 0.2), while_waiting=None):
         """``specs``: dicts with G, err, U_rot (or None), D, kind, v0, alpha (equal lengths).  Returns
         (list of per-spec result dicts in the order of ``specs``, info).  ``want_H``: 'lazy' (default),
         True (fetched now) or False.  ``select`` = (linefit_deg, gamma[, default]): the three default analyzers' alphas are
         picked on the device behind the solve (``mxe_select3_launch``) and come back as ``device_select`` of every result
         -- the indices of all three and the H rows of analyzer ``default`` (0 line fit, 1 chi2 curvature, 2 entropy: the one
-        ``result.A_out`` shows) at once, the rows of the other two when somebody looks at them; None: not."""
+        ``result.A_out`` shows) at once, the rows of the other two when somebody looks at them; None: not.
+        ``while_waiting(results)``: called while the kernel runs, with the result dicts complete but for their VALUES (the
+        arrays are there and are filled behind it) -- a caller builds its records from them then; only with one device and
+        neither ``want_logdet`` nor ``output_map`` (which add keys later): who passes it checks that it was called."""
         self.materialize_pending()                  # the result buffers are about to be overwritten
         n_alpha = len(specs[0]['alpha'])
         for s in specs:
@@ -370,6 +375,8 @@ class BatchSolver(object):
             res = skeleton()
             destinations(active[0])
             attach(res)
+            if while_waiting is not None and not want_logdet and output_map is None and want_H == 'lazy':
+                while_waiting(res)
             end(active[0])
         else:
             def one(r):
@@ -432,12 +439,29 @@ class BatchSolver(object):
 
     @staticmethod
     def _rows_of(specs, key):
-        """the vectors ``key`` of the specs as rows -- ONE row when every spec holds the same array object (the
-        element-wise drivers hand one default model, alpha mesh, start vector and error array to every element)"""
-        first = specs[0][key]
-        if isinstance(first, np.ndarray) and all(s[key] is first for s in specs):
-            return np.array(first, dtype=float).reshape(1, -1)       # (a copy: what is staged must not follow an edit in place)
-        rows = [np.asarray(s[key], dtype=float).ravel() for s in specs]
+        """the vectors ``key`` of the specs as rows -- ONE row when every spec holds the same array (the element-wise drivers
+        hand one default model, alpha mesh, start vector and error array to every element of a worker: a handful of
+        distinct objects per launch, compared by contents once each)"""
+        vals = list(map(operator.itemgetter(key), specs))
+        uniq = {}
+        for i in map(id, vals):
+            if i not in uniq:
+                uniq[i] = len(uniq)
+                if len(uniq) > 8:
+                    break
+        if len(uniq) <= 8 and all(isinstance(v, np.ndarray) for v in (vals[0], vals[-1])):
+            firsts = {}
+            for v in vals:                          # (the distinct objects, in the order of their first appearance)
+                if len(firsts) == len(uniq):
+                    break
+                firsts.setdefault(id(v), v)
+            rows = [np.asarray(v, dtype=float).ravel() for v in firsts.values()]
+            if all(r.shape == rows[0].shape for r in rows):
+                if all(np.array_equal(rows[0], r) for r in rows[1:]):
+                    return np.array(rows[0], dtype=float).reshape(1, -1)       # (a copy: what is staged must not follow an edit in place)
+                sel = np.fromiter(map(uniq.__getitem__, map(id, vals)), dtype=np.intp, count=len(vals))
+                return np.stack(rows)[sel]
+        rows = [np.asarray(v, dtype=float).ravel() for v in vals]
         return np.concatenate(rows).reshape(len(rows), -1)          # (np.stack costs 1 us per row)
 
     def _stage(self, ctx, K, specs, opts):

@@ -142,7 +142,7 @@ class ElementwiseMaxEnt(object):
         self._share_decomposition()
         direct = self._direct_input(worker) and per_job_D is None
         template = None
-        big = err_same = g_rows = None
+        below = err_same = g_rows = first_spec = None
         if direct and len(jobs) > 1:
             # (all elements at once: the data vectors as the rows of ONE array -- real part, or imaginary part of an off-diagonal
             #  element's second scan --, which of them are below the threshold; one error array when it is the same for all)
@@ -157,39 +157,15 @@ class ElementwiseMaxEnt(object):
                 g_rows = np.array(Gsel, dtype=float)
                 g_rows[~real_part] = 0.0             # (the imaginary part of real data)
             with np.errstate(all='ignore'):
-                big = np.max(np.abs(g_rows), axis=-1)
+                below = (np.max(np.abs(g_rows), axis=-1) < loop.G_threshold).tolist()
+            g_rows = list(g_rows)                    # (row views, made in one go)
             e0 = self.get_error(tuple(jobs[0][0]))
             if isinstance(self.error, float) or len(np.shape(self.error)) == self.error_dimension:
                 err_same = np.asarray(e0, dtype=float) * np.ones(np.shape(Gm)[-1])
         for n, (element, re) in enumerate(jobs):
             cidx = 0 if re else 1
             if direct and n > 0:
-                # array input, plain errors, unrotated kernel: the spec of every further element straight
-                # from the arrays (the worker keeps the first element's state until the last is loaded below)
-                if big[n] < loop.G_threshold:
-                    res._zero_elements.append(tuple(element) + ((cidx,) if self.use_complex else ()))
-                    worker.logtaker.error_message('G below threshold, not performing the calculation.')
-                    continue
-                g = g_rows[n]
-                if template is None:
-                    template = loop.make_spec(G=g, err=self.get_error(tuple(element)))
-                    template['A_map'] = loop.A_of_H
-                    template['G'] = template['G_orig'] = g
-                    if err_same is not None:
-                        # (ONE error array for every spec of the batch, the first included: BatchSolver._stage then stages one
-                        #  row instead of stacking 256 -- it was 1 ms of the 4.7 ms of a run on an object that has run before)
-                        template['err'] = err_same
-                    spec = template
-                elif err_same is not None:
-                    spec = dict(template)
-                    spec['G'] = spec['G_orig'] = g
-                else:
-                    spec = loop.spec_like(template, g, self.get_error(tuple(element)))
-                specs.append(spec)
-                live.append((element, cidx))
-                if n == len(jobs) - 1:
-                    self._load_element(worker, element, re)      # the state the reference leaves behind
-                continue
+                break               # (array input, plain errors, unrotated kernel: every further element below, straight from the arrays)
             if per_job_D is not None:
                 worker.set_D(per_job_D[n])
             self._load_element(worker, element, re)
@@ -203,10 +179,42 @@ class ElementwiseMaxEnt(object):
                 continue
             spec = loop.make_spec()
             spec['A_map'] = loop.A_of_H
+            if n == 0:
+                first_spec = spec
             specs.append(spec)
             live.append((element, cidx))
+        if direct and len(jobs) > 1:
+            # the specs of the further elements: copies of ONE template with their rows of the data array (the worker keeps the
+            # first element's state until the last is loaded, the state the reference leaves behind)
+            rest = []
+            for n in range(1, len(jobs)):
+                if below[n]:
+                    element, re = jobs[n]
+                    res._zero_elements.append(tuple(element) + (((0 if re else 1),) if self.use_complex else ()))
+                    worker.logtaker.error_message('G below threshold, not performing the calculation.')
+                else:
+                    rest.append(n)
+            if rest:
+                n0 = rest[0]
+                g, e0 = g_rows[n0], self.get_error(tuple(jobs[n0][0]))
+                # (everything but the data is what the first element's spec holds, when that was made a moment ago)
+                template = loop.make_spec(G=g, err=e0) if first_spec is None else loop.spec_like(first_spec, g, e0)
+                template['A_map'] = loop.A_of_H
+                template['G'] = template['G_orig'] = g
+                if err_same is not None:
+                    # (ONE error array for every spec of the batch: BatchSolver._stage then stages one row instead of stacking
+                    #  256 -- it was 1 ms of the 4.7 ms of a run on an object that has run before)
+                    template['err'] = err_same
+                    specs.append(template)
+                    specs.extend([{**template, 'G': g_rows[n], 'G_orig': g_rows[n]} for n in rest[1:]])
+                else:
+                    specs.append(template)
+                    specs.extend([loop.spec_like(template, g_rows[n], self.get_error(tuple(jobs[n][0]))) for n in rest[1:]])
+                live.extend([(jobs[n][0], 0 if jobs[n][1] else 1) for n in rest])
+                if rest[-1] == len(jobs) - 1:
+                    self._load_element(worker, jobs[-1][0], jobs[-1][1])
         # (the keys of the result's records, made once: they were made three times per element -- 0.2 ms of a 16 x 16 run)
-        return dict(worker=worker, specs=specs, live=live, keys=[res._key(element, cidx) for (element, cidx) in live])
+        return dict(worker=worker, specs=specs, live=live, keys=res._keys(live))
 
     def _solve_batches(self, batches):
         """one launch for all batches whose workers share the decomposition of the kernel, the minimiser settings
@@ -235,18 +243,32 @@ class ElementwiseMaxEnt(object):
             t0 = datetime.now()
             for b in g:
                 res._start.update(dict.fromkeys(b['keys'], t0))
+            for b in g:
+                b['sols'] = [None] * len(b['specs'])
+
+            def hand_out(sols, g=g, where=where):
+                for sol, (_, n, k) in zip(sols, where):
+                    g[n]['sols'][k] = sol
+
+            def records_while_the_kernel_runs(sols, g=g):
+                # (the result dicts hold their arrays already, the device fills them behind this: the records of the scans --
+                #  0.3 ms of dictionaries for 256 elements -- cost nothing next to a kernel of 0.8 ms)
+                hand_out(sols)
+                for b in g:
+                    b['records'] = b['worker'].maxent_loop.make_records(b['specs'], b['sols'])
+            plain = all(b['worker'].maxent_loop.probability is None for b in g)
             sols, info = solve_elements(loop.K, specs, loop.minimizer,
                                         device_id=loop.device_id, device_ids=self.device_ids,
                                         want_logdet=loop.probability is not None,
                                         chi2_factor=loop.cost_function.chi2_factor,
-                                        select=select_params(loop.analyzers))
+                                        select=select_params(loop.analyzers),
+                                        while_waiting=records_while_the_kernel_runs if plain else None)
             t1 = datetime.now()
             self.last_launches.append(info)
             for b in g:
-                b.update(sols=[None] * len(b['specs']), info=info, t0=t0, t1=t1,
-                         per_alpha=(t1 - t0) / max(1, len(specs) * len(specs[0]['alpha'])))
-            for sol, (_, n, k) in zip(sols, where):
-                g[n]['sols'][k] = sol
+                b.update(info=info, t0=t0, t1=t1, per_alpha=(t1 - t0) / max(1, len(specs) * len(specs[0]['alpha'])))
+            if not all('records' in b for b in g):
+                hand_out(sols)
 
     def _same_launch(self, a, b):
         la, lb = a['worker'].maxent_loop, b['worker'].maxent_loop
@@ -283,7 +305,9 @@ class ElementwiseMaxEnt(object):
                     'Element {} {}{}'.format(element[0], element[1],
                                              '' if cidx == 0 else ' (imaginary part)'))
                 loop.log_alpha_lines(sol)
-        records = loop.make_records(specs, sols)
+        records = batch.pop('records', None)
+        if records is None:
+            records = loop.make_records(specs, sols)
         times = {}
         for rec in records:
             X = len(rec['alpha'])

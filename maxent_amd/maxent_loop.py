@@ -47,7 +47,7 @@ class _LazyProduct(object):
 
 
 def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0,
-                   want_logdet=False, chi2_factor=1.0, device_ids=None, want_H='lazy', select=(0, 0.2)):
+                   want_logdet=False, chi2_factor=1.0, device_ids=None, want_H='lazy', select=(0, 0.2), while_waiting=None):
     """Solve the alpha scans of several elements in ONE kernel launch per device.
 
     ``K``: kernel whose singular space has been reduced (U, S, V are staged once per device and kept,
@@ -69,7 +69,7 @@ def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0,
     from .batch_solver import BatchSolver
     solver = BatchSolver.for_kernel(K, (device_id,) if device_ids is None else device_ids)
     opts = minimizer.to_opts(waves_per_chain=waves_per_chain, chi2_factor=float(chi2_factor))
-    return solver.solve(K, specs, opts, want_logdet=want_logdet, want_H=want_H, select=select)
+    return solver.solve(K, specs, opts, want_logdet=want_logdet, want_H=want_H, select=select, while_waiting=while_waiting)
 
 
 def select_params(analyzers):

@@ -329,6 +329,14 @@ class MaxEntResult(MaxEntResultData):
             key = key + (complex_index,)
         return key
 
+    def _keys(self, elements):
+        """:meth:`_key` for many (matrix_element, complex_index) pairs"""
+        if self.matrix_structure is None or not self.element_wise:
+            return [None] * len(elements)
+        if self.complex_elements:
+            return [self._key(element, cidx) for (element, cidx) in elements]
+        return [tuple(element) for (element, _) in elements]
+
     def add_element_results(self, record, matrix_element=None,
                             complex_index=None):
         """Store the arrays of one finished alpha scan.  ``record`` needs the

@@ -621,7 +621,13 @@ def test_staging_is_skipped_by_contents_and_shared_arrays_are_compared_as_one_ro
     specs = [dict(G=rng.rand(12), err=err, D=D, alpha=al, v0=v0, kind=device.ENTROPY_NORMAL, U_rot=None) for _ in range(n)]
     rows = BatchSolver._rows_of(specs, 'D')
     assert rows.shape == (1, 30)                               # shared: one row
-    assert BatchSolver._rows_of([dict(D=D), dict(D=D.copy())], 'D').shape == (2, 30)
+    assert BatchSolver._rows_of([dict(D=D), dict(D=D.copy())], 'D').shape == (1, 30)       # two workers' copies of one default model: one row
+    D2 = 2.0 * D
+    mixed = BatchSolver._rows_of([dict(D=D), dict(D=D2), dict(D=D), dict(D=D2.copy())], 'D')      # a few distinct objects: rows by object
+    assert mixed.shape == (4, 30) and np.array_equal(mixed[0], D) and np.array_equal(mixed[1], D2) and \
+        np.array_equal(mixed[2], D) and np.array_equal(mixed[3], D2)
+    many = [dict(D=rng.rand(30)) for _ in range(12)]                                              # more than a handful: the general way
+    assert np.array_equal(BatchSolver._rows_of(many, 'D'), np.array([m['D'] for m in many]))
     bs = BatchSolver.__new__(BatchSolver)
     ctx, opts = Ctx(), device.default_opts()
     bs._stage(ctx, K, specs, opts)
@@ -636,9 +642,12 @@ def test_staging_is_skipped_by_contents_and_shared_arrays_are_compared_as_one_ro
     D[5] *= 2.0                                                # the shared default model edited in place
     bs._stage(ctx, K, again, opts)
     assert ctx.calls == 3 and ctx.D[0, 5] == D[5]
-    own = [dict(s, D=D.copy()) for s in again]                 # every element its own copy, equal contents: shapes differ (5 rows / 1) -> staged again
+    own = [dict(s, D=D.copy()) for s in again]                 # every element its own copy, equal contents: still one row, nothing staged
     bs._stage(ctx, K, own, opts)
-    assert ctx.calls == 4
+    assert ctx.calls == 3
+    own[2]['D'] = own[2]['D'] * 1.5                            # one of them differs: rows per element, staged again
+    bs._stage(ctx, K, own, opts)
+    assert ctx.calls == 4 and ctx.D.shape == (5, 30) and ctx.D[2, 0] == 1.5 * D[0] and ctx.D[1, 0] == D[0]
     bs._stage(ctx, K, [dict(s) for s in own], opts)
     assert ctx.calls == 4
     opts2 = device.default_opts(); opts2.maxiter = opts.maxiter + 1
