@@ -575,6 +575,8 @@ class BatchSolver(object):
             for h in mine:
                 h._val = got[h._what][h._chain]
         for h in alive:
+            # (the rows of the analyzers go with the arrays: 1 MB each next to H's 100, and what has been brought over has no claim
+            #  on the device buffers any more -- a new object on the same grids may take the contexts over)
             if h._rank == rank and h._what == 'rows':
                 h._val = self.ctxs[rank].select3_fetch_rows(first=h._which, count=1, want_index=False)[1][0]
         self._pending = [weakref.ref(h) for h in alive if h._val is None]

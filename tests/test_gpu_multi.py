@@ -330,6 +330,48 @@ def test_elementwise_result_from_device_picks_equals_host_analyzers():
     assert r2.analyzer_results[0][0]['Chi2CurvatureAnalyzer']['gamma'] == 0.5
 
 
+def test_rows_of_the_other_analyzers_stay_on_the_device_until_somebody_looks():
+    """the rows of the result's default analyzer come with the solve, those of the other two device analyzers by
+    ``mxe_select3_fetch_rows`` when their A_out is read -- also after the same solver has run another job (they are brought
+    to the host before its buffers are overwritten); the default is the first of the three in the analyzer list"""
+    from maxent_amd.batch_solver import LazyRows
+    from maxent_amd.analyzers import LineFitAnalyzer, Chi2CurvatureAnalyzer, EntropyAnalyzer
+    ew = job(n_orb=3, n_alpha=20)
+    res = ew.run()
+    rows = res._records[(0, 0)]['device_select']['batch'][1]
+    assert all(isinstance(r, LazyRows) for r in rows) and [r.on_host for r in rows] == [True, False, False]
+    res.A_out                                                    # (the line fit's rows: nothing else moves)
+    assert [r.on_host for r in rows] == [True, False, False]
+    got = res.analyzer_results[0][1]['Chi2CurvatureAnalyzer']
+    assert [r.on_host for r in rows] == [True, True, False]
+    # the same object again, on other data: everything the first result still had on the device is brought over first
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(3, 60, 120, noise_seed=77)
+    ew.set_G_tau_data(tau, 1.3 * Gmat)
+    res2 = ew.run()
+    assert rows[2].on_host
+    A = np.asarray(res.A)
+    assert np.array_equal(np.asarray(got['A_out']), A[0, 1, got['alpha_index']])
+    for (i, j) in ((i, j) for i in range(3) for j in range(3)):
+        e = res.analyzer_results[i][j]['EntropyAnalyzer']
+        assert np.array_equal(np.asarray(e['A_out']), A[i, j, e['alpha_index']])
+    A2 = np.asarray(res2.A)
+    assert all(r.on_host for r in res2._records[(0, 0)]['device_select']['batch'][1])       # (they came with H)
+    e2 = res2.analyzer_results[1][1]['EntropyAnalyzer']
+    assert np.array_equal(np.asarray(e2['A_out']), A2[1, 1, e2['alpha_index']]) and not np.array_equal(A2, A)
+    # another default analyzer: its rows are the ones that come with the solve
+    ew3 = job(n_orb=2, n_alpha=20)
+    ew3.maxent_diagonal.analyzers = [Chi2CurvatureAnalyzer(), LineFitAnalyzer(), EntropyAnalyzer()]
+    ew3.maxent_offdiagonal.analyzers = [Chi2CurvatureAnalyzer(), LineFitAnalyzer(), EntropyAnalyzer()]
+    r3 = ew3.run()
+    rows3 = r3._records[(0, 0)]['device_select']['batch'][1]
+    assert [r.on_host for r in rows3] == [False, True, False]
+    c3 = r3.analyzer_results[0][1]['Chi2CurvatureAnalyzer']
+    assert np.array_equal(r3.A_out[0, 1], np.asarray(c3['A_out']))
+    assert np.array_equal(np.asarray(c3['A_out']), np.asarray(r3.A)[0, 1, c3['alpha_index']])
+    l3 = r3.analyzer_results[1][0]['LineFitAnalyzer']
+    assert np.array_equal(np.asarray(l3['A_out']), np.asarray(r3.A)[1, 0, l3['alpha_index']]) and rows3[0].on_host
+
+
 def test_result_arrays_of_a_full_matrix_are_views_of_what_came_off_the_device():
     """ElementwiseMaxEnt launches its scans in the order of the result's matrix and MaxEntResult assembles H as a view of
     the ONE fetched array (A = H / delta in one division); the values are those of the element-by-element assembly, and a
