@@ -1665,6 +1665,13 @@ try {
     kp.chain_v0 = ctx->dfin_v0.p; kp.v0 = ctx->dfin_start.p;
     kp.chain_lead = nullptr; kp.init_tab = nullptr; kp.chain_init = nullptr;
     kp.n_chain = nr;
+#ifdef MXE_PROFILE
+    // (diagnostic build: the stamps of THIS pass, rows 0 .. nr - 1 -- tools/finish_phases.py; those of the lock-step launch are gone)
+    if (ctx->dprof.p && (size_t)nr <= (size_t)ctx->n_sub + 8 * 1024) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->dprof.p, 0, ((size_t)ctx->n_sub + 8 * 1024) * 64, ctx->stream));
+        kp.prof = ctx->dprof.p;
+    }
+#endif
     {
         // the caller's maxiter bounds the iterations of an alpha over BOTH passes (the reference caps them per alpha,
         // levenberg_minimizer.py:155): this pass gets what the lock-step pass left of it (one budget per launch: that of the

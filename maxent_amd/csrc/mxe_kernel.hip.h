@@ -599,21 +599,23 @@ void chain_kernel(const KParams p)
             block_sync<SYNCW>();
             vs = vecs;
         }
+        // (rows k >= n_s of V^T are zero and so are the entries of the vector there: the loop runs over whole blocks of 16 rows with
+        //  all their loads in flight -- one wave per SIMD and nothing else on the CU, the pass waits for L2, and a remainder loop
+        //  would wait once per row)
+        const int ns16 = min(NP, (ns + 15) & ~15);
         for (int i = 2 * tid; i < nwp; i += 2 * T) {
             TS a0 = 0, a1 = 0, b0 = 0, b1 = 0;
             const TS* col = Vt + i;
-            int k = 0;
-#pragma unroll 8
-            for (; k + 1 < ns; k += 2) {
-                const TS2 x0 = *reinterpret_cast<const TS2*>(col + (size_t)k * nwp);
-                const TS2 x1 = *reinterpret_cast<const TS2*>(col + (size_t)(k + 1) * nwp);
-                const TS q0 = vs[k], q1 = vs[k + 1];
-                a0 = fma(x0.x, q0, a0); b0 = fma(x0.y, q0, b0);
-                a1 = fma(x1.x, q1, a1); b1 = fma(x1.y, q1, b1);
-            }
-            if (k < ns) {
-                const TS2 x0 = *reinterpret_cast<const TS2*>(col + (size_t)k * nwp);
-                a0 = fma(x0.x, vs[k], a0); b0 = fma(x0.y, vs[k], b0);
+            for (int k = 0; k < ns16; k += 16) {
+                TS2 x[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) x[e] = *reinterpret_cast<const TS2*>(col + (size_t)(k + e) * nwp);
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const TS q0 = vs[k + e], q1 = vs[k + e + 1];
+                    a0 = fma(x[e].x, q0, a0); b0 = fma(x[e].y, q0, b0);
+                    a1 = fma(x[e + 1].x, q1, a1); b1 = fma(x[e + 1].y, q1, b1);
+                }
             }
             const TS vd2[2] = {a0 + a1, b0 + b1};
 #pragma unroll
@@ -653,27 +655,26 @@ void chain_kernel(const KParams p)
         // lanes 32-63 odd rows, each lane two adjacent singular columns
         // (16-B loads); the two half-waves are summed with one shuffle.
         {
-            const int rows_per = (((nw + NW - 1) / NW) + 1) & ~1;
+            // (the rows of V beyond n_omega are zero and so is H there: every wave takes n_omega_pad / NW rows -- a multiple of 16 --,
+            //  its half-waves alternate rows, eight loads of 16 B per lane in flight, no remainder)
+            const int rows_per = nwp / NW;
             const int r0 = wave * rows_per;
-            const int r1 = min(nwp, r0 + rows_per);
+            const int r1 = r0 + rows_per;
             const int half = lane >> 5, cl = lane & 31;
 #pragma unroll
             for (int cb = 0; cb < NP / 64; ++cb) {
                 TS s0 = 0, s1 = 0, t0 = 0, t1 = 0;
                 const TS* Vc = V + 64 * cb + 2 * cl;
-                int i = r0 + half;
-#pragma unroll 4
-                for (; i + 2 < r1; i += 4) {
-                    const TS2 x0 = *reinterpret_cast<const TS2*>(Vc + (size_t)i * NP);
-                    const TS2 x1 = *reinterpret_cast<const TS2*>(Vc + (size_t)(i + 2) * NP);
-                    const TS h0 = Hs[i], h1 = Hs[i + 2];
-                    s0 = fma(x0.x, h0, s0); s1 = fma(x0.y, h0, s1);
-                    t0 = fma(x1.x, h1, t0); t1 = fma(x1.y, h1, t1);
-                }
-                for (; i < r1; i += 2) {
-                    const TS2 x0 = *reinterpret_cast<const TS2*>(Vc + (size_t)i * NP);
-                    const TS h0 = Hs[i];
-                    s0 = fma(x0.x, h0, s0); s1 = fma(x0.y, h0, s1);
+                for (int i = r0 + half; i < r1; i += 16) {
+                    TS2 x[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = *reinterpret_cast<const TS2*>(Vc + (size_t)(i + 2 * e) * NP);
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const TS h0 = Hs[i + 2 * e], h1 = Hs[i + 2 * e + 2];
+                        s0 = fma(x[e].x, h0, s0); s1 = fma(x[e].y, h0, s1);
+                        t0 = fma(x[e + 1].x, h1, t0); t1 = fma(x[e + 1].y, h1, t1);
+                    }
                 }
                 s0 += t0; s1 += t1;
                 s0 += __shfl_xor(s0, 32, WAVE);
@@ -1078,6 +1079,105 @@ void chain_kernel(const KParams p)
         return ok;
     };
 
+    // ------------------------------------------------------------------
+    // all four waves, active block of 33 .. 64 rows (binary64 build, NP = 64): Gauss-Jordan elimination on pivot PAIRS
+    // with the matrix in registers -- lane i of wave w holds the columns 16 w .. 16 w + 15 of row i of A = c W c + a I,
+    // every wave a copy of the right-hand side.  A step for the pivots (p, q = p + 1): the wave that owns their columns
+    // gives every row its two multipliers [A_ip A_iq] P^-1 (P: the 2 x 2 pivot block), every wave the rows p and q of
+    // its own columns, both through LDS behind ONE barrier (two buffers in turn); then 34 FMAs per lane.  Rows p and q
+    // are left as they are: at the end the matrix is block diagonal and every pair solves its 2 x 2 system.  No
+    // pivoting (the matrix is positive definite; a pivot block that is not ends the solve like a failed Cholesky).
+    // ~600 cycles per pair against the 2 400 per COLUMN of chol_solve on one wave (profiles/r04_f_onechain_phases.txt).
+    // ------------------------------------------------------------------
+    auto gj_solve_4w = [&](double a, int n_act) -> bool {
+        bool ok = true;
+        if constexpr (F64 && NW == 4 && NAB == 2) {
+            const int i = lane;
+            const bool live = i < n_act;
+            const double ci_ = live ? cc[i] : 0.0;
+            double A[16];
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int k = 16 * wave + kk;
+                double x = 0.0;
+                if (live && k < n_act) x = ci_ * Wm[min(k, i) * LD + max(k, i)] * cc[k];
+                if (k == i) x = live ? x + a : 1.0;
+                A[kk] = x;
+            }
+            double b = live ? rhs[i] : 0.0;
+            double* mult = stage;                       // [2][64][2]: (m_p, m_q) of row i
+            double* rowb = stage + 256;                 // [2][4 waves][17][2]: (A_pk, A_qk) of the wave's columns k, then (b_p, b_q)
+            int* flag = reinterpret_cast<int*>(rowb + 2 * 4 * 34);      // [2]
+            int step = 0;
+            for (int blk = 0; blk < 4; ++blk) {
+                if (16 * blk >= n_act) break;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int p = 16 * blk + 2 * kk;
+                    if (ok && p < n_act) {
+                        const int buf = step & 1;
+                        double* mb = mult + buf * 128;
+                        double* rb = rowb + (buf * 4 + wave) * 34;
+                        if (lane == p || lane == p + 1) {
+                            const int r = lane - p;
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) rb[2 * k + r] = A[k];
+                            rb[32 + r] = b;
+                        }
+                        if (wave == blk) {
+                            const double pp = wave_bcast(A[2 * kk], p), pq = wave_bcast(A[2 * kk + 1], p);
+                            const double qp = wave_bcast(A[2 * kk], p + 1), qq = wave_bcast(A[2 * kk + 1], p + 1);
+                            const double det = fma(pp, qq, -pq * qp);
+                            const bool good = pp > 0.0 && det > 0.0;
+                            const double inv = 1.0 / det;
+                            double mp = fma(A[2 * kk], qq, -A[2 * kk + 1] * qp) * inv;
+                            double mq = fma(A[2 * kk + 1], pp, -A[2 * kk] * pq) * inv;
+                            if (lane == p || lane == p + 1) { mp = 0.0; mq = 0.0; }
+                            *reinterpret_cast<double2*>(mb + 2 * lane) = make_double2(mp, mq);
+                            if (lane == 0) flag[buf] = good ? 1 : 0;
+                        }
+                        __syncthreads();
+                        {
+                            // (all the reads in flight before the first FMA: left to itself the compiler reuses one register
+                            //  quadruple and waits for every read in turn -- 17 LDS latencies, 2 400 cycles per step; the flag
+                            //  comes with them: after a failed pivot the update is wasted, not wrong)
+                            const double2 m = *reinterpret_cast<const double2*>(mb + 2 * lane);
+                            double2 r[17];
+#pragma unroll
+                            for (int k = 0; k < 17; ++k) r[k] = *reinterpret_cast<const double2*>(rb + 2 * k);
+                            const int fl = flag[buf];
+                            __builtin_amdgcn_sched_barrier(0);
+                            double t[17];
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) t[k] = fma(-m.x, r[k].x, A[k]);
+                            t[16] = fma(-m.x, r[16].x, b);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) A[k] = fma(-m.y, r[k].y, t[k]);
+                            b = fma(-m.y, r[16].y, t[16]);
+                            if (__builtin_amdgcn_readfirstlane(fl) == 0) ok = false;
+                        }
+                        ++step;
+                    }
+                }
+            }
+            if (ok) {
+                // the 2 x 2 systems of the pairs, each in the wave that holds its columns
+                double d = 0.0, off = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if ((lane & 15) == k) d = A[k];
+                    if (((lane & 15) ^ 1) == k) off = A[k];
+                }
+                const double d2 = __shfl_xor(d, 1, WAVE), off2 = __shfl_xor(off, 1, WAVE), b2 = __shfl_xor(b, 1, WAVE);
+                const double z = fma(d2, b, -off * b2) / fma(d, d2, -off * off2);
+                if ((lane >> 4) == wave && live) zz[i] = z;
+            }
+            __syncthreads();
+        }
+        return ok;
+    };
+
     // symmetric mat-vec on the active block: out = W_aa x_a  (threads < NP)
     auto symv = [&](const double* x, double* out, int n_act) {
         for (int i = tid; i < NP; i += T) {
@@ -1158,6 +1258,7 @@ void chain_kernel(const KParams p)
                 if (n_act0 <= 16) okc = gj_solve_reg(std::integral_constant<int, 16>{}, a, n_act0);
                 else if (n_act0 <= 24) okc = gj_solve_reg(std::integral_constant<int, 24>{}, a, n_act0);
                 else if (n_act0 <= 32) okc = gj_solve_reg(std::integral_constant<int, 32>{}, a, n_act0);
+                else if (F64 && NW == 4 && NAB == 2) okc = gj_solve_4w(a, n_act0);
                 else okc = chol_solve(a, n_act0);
                 MXE_STAMP(2);
                 bool good = okc;
