@@ -124,9 +124,15 @@ typedef struct mxe_opts {
                                 exp, h = V^T H and the Gram matrix in binary32 (fp32 MFMA); the
                                 n_act x n_act Newton system, the residual and all scalars stay
                                 binary64.  An alpha also stops when its Newton correction has
-                                reached the rounding floor (it no longer shrinks).  n_s <= 64,
-                                one chain per workgroup.  For the fp32-vs-fp64 tolerance sweep of
-                                BASELINE config 5 (tools/cfg5_tolerance_sweep.py)              */
+                                reached the rounding floor (it no longer shrinks).  n_s <= 64.
+                                Where V^T fits the LDS as binary32 the launch runs in the lock-step
+                                kernel chain_kernel_lv (mxe_opts.lds_basis), else one chain per
+                                workgroup.  A request, not a promise: a job with an alpha that couples
+                                more than 32 directions (error bars far below the noise of the data) is
+                                PROMOTED to binary64 -- the lock-step build with the 64-row block is the
+                                cheaper arithmetic there; mxe_last_launch_info names the kernel that
+                                ran.  For the fp32-vs-fp64 tolerance sweep of BASELINE config 5
+                                (tools/cfg5_tolerance_sweep.py)                                 */
     int32_t wg_per_cu;       /* lock-step layout: workgroups per CU.  0 = auto (2 where the kernel has a
                                 build for it: n_s <= 64 active block 32, n_omega <= 512 -- u then lives in
                                 registers and two workgroups of 73 KB share a CU, so that the serial

@@ -887,6 +887,13 @@ try {
             for (int i = 0; i < n_alpha; ++i) amin = std::min(amin, alpha_dev[(size_t)c * n_alpha + i]);
             if (!(DS.c[32] * DS.c[32] * std::max(1.0, ctx->h_sumD[e]) / amin <= MC_COUPLING_MAX)) f32_lv = false;
         }
+        if (!f32_lv) {
+            // Binary32 is asked for as the cheaper arithmetic; for such a job the cheaper arithmetic is the binary64 lock-step
+            // build with the 64-row block (and the hand-over of what it leaves): the one-chain binary32 kernel took 0.7-1.5 s
+            // where that takes 4-5 ms, and stops at its rounding floor besides (STRESS_F32=1 tools/stress.py, cases 24 / 25:
+            // profiles/r04_e_stress_f32.txt).  The launch is promoted; mxe_last_launch_info names the kernel that ran.
+            ctx->opts.precision = MXE_PRECISION_F64;
+        }
     }
     ctx->lv_mode = 0;
     // ---- (sub-)chains: an alpha scan may be cut into pieces that are cold-started

@@ -103,10 +103,16 @@ struct KParams {
 #else
 #define MXE_STAMP_E(idx) do {} while (0)
 #endif
-#ifdef MXE_PROFILE
+#if defined(MXE_PROFILE) && defined(MXE_PROFILE_GJ)
+// (diagnostic build of the four-wave elimination alone: the ordinary stamps only move the clock)
+#define MXE_STAMP(idx) do { prof_t = clock64(); } while (0)
+#define MXE_STAMP_G(idx) do { const long long t__ = clock64(); if (tid == 0) prof_acc[idx] += t__ - prof_t; prof_t = t__; } while (0)
+#elif defined(MXE_PROFILE)
 #define MXE_STAMP(idx) do { const long long t__ = clock64(); if (tid == 0) prof_acc[idx] += t__ - prof_t; prof_t = t__; } while (0)
+#define MXE_STAMP_G(idx) do {} while (0)
 #else
 #define MXE_STAMP(idx) do {} while (0)
+#define MXE_STAMP_G(idx) do {} while (0)
 #endif
 
 __device__ __forceinline__ void wave_sync() {
@@ -1083,11 +1089,13 @@ void chain_kernel(const KParams p)
     // all four waves, active block of 33 .. 64 rows (binary64 build, NP = 64): Gauss-Jordan elimination on pivot PAIRS
     // with the matrix in registers -- lane i of wave w holds the columns 16 w .. 16 w + 15 of row i of A = c W c + a I,
     // every wave a copy of the right-hand side.  A step for the pivots (p, q = p + 1): the wave that owns their columns
-    // gives every row its two multipliers [A_ip A_iq] P^-1 (P: the 2 x 2 pivot block), every wave the rows p and q of
-    // its own columns, both through LDS behind ONE barrier (two buffers in turn); then 34 FMAs per lane.  Rows p and q
-    // are left as they are: at the end the matrix is block diagonal and every pair solves its 2 x 2 system.  No
-    // pivoting (the matrix is positive definite; a pivot block that is not ends the solve like a failed Cholesky).
-    // ~600 cycles per pair against the 2 400 per COLUMN of chol_solve on one wave (profiles/r04_f_onechain_phases.txt).
+    // gives every row its two multipliers [A_ip A_iq] P^-1 (P: the 2 x 2 pivot block) through LDS (two buffers in turn,
+    // ONE barrier per step); every wave broadcasts the rows p and q of its own columns with v_readlane; then 34 FMAs per
+    // lane.  Rows p and q are left as they are: at the end the matrix is block diagonal and every pair solves its 2 x 2
+    // system.  No pivoting (the matrix is positive definite; a pivot block that is not ends the solve like a failed
+    // Cholesky).  47.5 k cycles for 56 rows against the 139 k of chol_solve on one wave (profiles/r04_f_onechain_phases.txt)
+    // -- 1 700 cycles per step for ~100 instructions: on a lone wave a dependent instruction costs 20-26 cycles and a
+    // v_readlane 20-24 (profiles/r04_f_dep_latency.txt); three other arrangements of the step came out within 10 %.
     // ------------------------------------------------------------------
     auto gj_solve_4w = [&](double a, int n_act) -> bool {
         bool ok = true;
@@ -1106,8 +1114,9 @@ void chain_kernel(const KParams p)
             }
             double b = live ? rhs[i] : 0.0;
             double* mult = stage;                       // [2][64][2]: (m_p, m_q) of row i
-            double* rowb = stage + 256;                 // [2][4 waves][17][2]: (A_pk, A_qk) of the wave's columns k, then (b_p, b_q)
-            int* flag = reinterpret_cast<int*>(rowb + 2 * 4 * 34);      // [2]
+            int* flag = reinterpret_cast<int*>(stage + 256);            // [2] (+ padding up to rowb)
+            // (unrolled over the eight pairs of a column block: the owner's two columns are then static registers; ONE loop body
+            //  with the columns picked by conditional moves was measured and is 10 % slower, 52.9 k against 47.5 k cycles)
             int step = 0;
             for (int blk = 0; blk < 4; ++blk) {
                 if (16 * blk >= n_act) break;
@@ -1117,46 +1126,36 @@ void chain_kernel(const KParams p)
                     if (ok && p < n_act) {
                         const int buf = step & 1;
                         double* mb = mult + buf * 128;
-                        double* rb = rowb + (buf * 4 + wave) * 34;
-                        if (lane == p || lane == p + 1) {
-                            const int r = lane - p;
-#pragma unroll
-                            for (int k = 0; k < 16; ++k) rb[2 * k + r] = A[k];
-                            rb[32 + r] = b;
-                        }
                         if (wave == blk) {
                             const double pp = wave_bcast(A[2 * kk], p), pq = wave_bcast(A[2 * kk + 1], p);
                             const double qp = wave_bcast(A[2 * kk], p + 1), qq = wave_bcast(A[2 * kk + 1], p + 1);
                             const double det = fma(pp, qq, -pq * qp);
                             const bool good = pp > 0.0 && det > 0.0;
-                            const double inv = 1.0 / det;
+                            // 1 / det: hardware estimate + two Newton steps (full binary64 accuracy, a shorter chain than the division)
+                            double inv = __builtin_amdgcn_rcp(det);
+                            inv = fma(fma(-det, inv, 1.0), inv, inv);
+                            inv = fma(fma(-det, inv, 1.0), inv, inv);
                             double mp = fma(A[2 * kk], qq, -A[2 * kk + 1] * qp) * inv;
                             double mq = fma(A[2 * kk + 1], pp, -A[2 * kk] * pq) * inv;
                             if (lane == p || lane == p + 1) { mp = 0.0; mq = 0.0; }
                             *reinterpret_cast<double2*>(mb + 2 * lane) = make_double2(mp, mq);
                             if (lane == 0) flag[buf] = good ? 1 : 0;
                         }
+                        // the rows p and q of the wave's own columns, lane to all lanes (v_readlane); the owner does this behind its
+                        // multipliers, the other waves while they wait for them.  (Through LDS instead -- two lanes write, a barrier,
+                        // all read 17 x 16 B, the pivot block taken from those reads, a second barrier for the multipliers --: 50.9 k
+                        // cycles; one barrier with rows and multipliers together: 52.7 k.)
+                        double rp[17], rq[17];
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) { rp[k] = wave_bcast(A[k], p); rq[k] = wave_bcast(A[k], p + 1); }
+                        rp[16] = wave_bcast(b, p); rq[16] = wave_bcast(b, p + 1);
                         __syncthreads();
-                        {
-                            // (all the reads in flight before the first FMA: left to itself the compiler reuses one register
-                            //  quadruple and waits for every read in turn -- 17 LDS latencies, 2 400 cycles per step; the flag
-                            //  comes with them: after a failed pivot the update is wasted, not wrong)
-                            const double2 m = *reinterpret_cast<const double2*>(mb + 2 * lane);
-                            double2 r[17];
+                        const double2 m = *reinterpret_cast<const double2*>(mb + 2 * lane);
+                        const int fl = flag[buf];
 #pragma unroll
-                            for (int k = 0; k < 17; ++k) r[k] = *reinterpret_cast<const double2*>(rb + 2 * k);
-                            const int fl = flag[buf];
-                            __builtin_amdgcn_sched_barrier(0);
-                            double t[17];
-#pragma unroll
-                            for (int k = 0; k < 16; ++k) t[k] = fma(-m.x, r[k].x, A[k]);
-                            t[16] = fma(-m.x, r[16].x, b);
-                            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int k = 0; k < 16; ++k) A[k] = fma(-m.y, r[k].y, t[k]);
-                            b = fma(-m.y, r[16].y, t[16]);
-                            if (__builtin_amdgcn_readfirstlane(fl) == 0) ok = false;
-                        }
+                        for (int k = 0; k < 16; ++k) A[k] = fma(-m.y, rq[k], fma(-m.x, rp[k], A[k]));
+                        b = fma(-m.y, rq[16], fma(-m.x, rp[16], b));
+                        if (__builtin_amdgcn_readfirstlane(fl) == 0) ok = false;
                         ++step;
                     }
                 }

@@ -91,10 +91,12 @@ def test_a_binary32_batch_that_fills_the_gpu_keeps_the_uniform_pieces():
     assert np.nanmax(out['audit']) < 1e-4
 
 
-def test_binary32_with_more_than_32_coupled_directions_solves_every_alpha_in_the_one_chain_kernel():
+def test_binary32_with_more_than_32_coupled_directions_is_promoted_to_the_binary64_lock_step_build():
     """chain_kernel_lv has the plain 32-row build only.  A job whose smallest alphas couple more directions (error bars far below
-    the noise) keeps the one-chain binary32 kernel -- decided BEFORE the scans are cut: the first form of this fell back after the
-    lock-step schedule had dropped the alphas behind its cuts, whose records then were garbage (STRESS_F32=1 tools/stress.py)."""
+    the noise) is promoted to binary64 -- the lock-step build with the 64-row block is the cheaper arithmetic there (the one-chain
+    binary32 kernel took 300 times as long) -- and that is decided BEFORE the scans are cut: the first form of the fallback came
+    after the lock-step schedule had dropped the alphas behind its cuts, whose records then were garbage (STRESS_F32=1
+    tools/stress.py)."""
     from maxent_amd import synthetic, hostprep
     import maxent_amd as mx
     tau, omega, K, Gmat, _ = synthetic.matrix_G(2, 200, 500, seed=11)
@@ -117,9 +119,7 @@ def test_binary32_with_more_than_32_coupled_directions_solves_every_alpha_in_the
         ctx.close()
     o32, k32 = outs[device.PRECISION_F32]
     o64, _ = outs[device.PRECISION_F64]
-    assert k32.startswith('mxe::chain_kernel<') and 'float' in k32, k32
+    assert k32 == outs[device.PRECISION_F64][1] and k32.startswith('mxe::chain_kernel_mc<64'), k32
     assert np.isin(o32['converged'], (0, 1)).all() and o32['n_evals'].min() >= 1 and o32['n_evals'].max() < 100000
-    both = (o32['converged'] == 1) & (o64['converged'] == 1)
-    assert both.sum() >= 40
-    e = np.linalg.norm(o32['H'][both] - o64['H'][both], axis=-1) / np.linalg.norm(o64['H'][both], axis=-1)
-    assert np.all(np.isfinite(e)) and e.max() < 1e-3
+    assert np.array_equal(o32['converged'], o64['converged']) and o32['converged'].sum() >= 40
+    assert np.array_equal(o32['H'], o64['H'])                 # (the same launch)
