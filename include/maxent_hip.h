@@ -127,11 +127,14 @@ typedef struct mxe_opts {
                                 reached the rounding floor (it no longer shrinks).  n_s <= 64.
                                 Where V^T fits the LDS as binary32 the launch runs in the lock-step
                                 kernel chain_kernel_lv (mxe_opts.lds_basis), else one chain per
-                                workgroup.  A request, not a promise: a job with an alpha that couples
-                                more than 32 directions (error bars far below the noise of the data) is
-                                PROMOTED to binary64 -- the lock-step build with the 64-row block is the
-                                cheaper arithmetic there; mxe_last_launch_info names the kernel that
-                                ran.  For the fp32-vs-fp64 tolerance sweep of BASELINE config 5
+                                workgroup.  A request, not a promise: binary32 is asked for as the cheaper
+                                arithmetic, and a launch for which it is not is PROMOTED to binary64 -- a
+                                job with an alpha that couples more than 32 directions (error bars far
+                                below the noise of the data: the lock-step build with the 64-row block),
+                                and, with wg_per_cu = 0, a batch that fills the GPU at two workgroups per
+                                CU (the binary64 kernel that runs that way: 0.81 against 1.24 ms on the
+                                16 x 16 x 100 batch; wg_per_cu = 1 keeps chain_kernel_lv);
+                                mxe_last_launch_info names the kernel that ran.  For the fp32-vs-fp64 tolerance sweep of BASELINE config 5
                                 (tools/cfg5_tolerance_sweep.py)                                 */
     int32_t wg_per_cu;       /* lock-step layout: workgroups per CU.  0 = auto (2 where the kernel has a
                                 build for it: n_s <= 64 active block 32, n_omega <= 512 -- u then lives in

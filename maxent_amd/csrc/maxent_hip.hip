@@ -915,6 +915,16 @@ try {
         HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
         // (two workgroups per CU where the lock-step kernel has a build for it: n_omega_pad <= 512)
         const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (f32_lv && o.wg_per_cu == 0 && ctx->nwp <= 512) {
+            // A binary32 launch runs in chain_kernel_lv at ONE workgroup per CU.  A batch that fills the GPU at two per CU (the test
+            // of the loop below) is faster in the binary64 kernel that runs that way: the 25 600-problem batch 0.81 ms against
+            // 1.24 ms -- binary32 is asked for as the cheaper arithmetic, and there it is not.  Such a launch is promoted like the
+            // one that couples more than 32 directions; wg_per_cu = 1 keeps it in chain_kernel_lv.
+            long long weight = 0;
+            for (int c = 0; c < n_chain; ++c) weight += (ctx->elem_kind[elem_of_chain[c]] == MXE_ENTROPY_NORMAL) ? 2 : 1;
+            const int want2 = (int)std::max(1LL, (2LL * 8 * n_cu) / std::max(1LL, weight));
+            if (std::max(1, std::min(want2, n_alpha / 2)) >= want2) { f32_lv = false; ctx->opts.precision = MXE_PRECISION_F64; }
+        }
         int wgpc_guess = (o.wg_per_cu != 1 && ctx->nwp <= 512 && NP == 64 && o.chains_per_wg != 1 && !f32_lv) ? 2 : 1;
         for (;;) {
             const int n_slots = 4 * wgpc_guess * n_cu;

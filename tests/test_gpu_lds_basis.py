@@ -80,12 +80,18 @@ def test_binary32_first_pass_then_one_binary64_step_per_alpha():
     assert all(0 < m <= x for m, x in zip(d['mean_rounds'], d['max_rounds']))
 
 
-def test_a_binary32_batch_that_fills_the_gpu_keeps_the_uniform_pieces():
-    """One workgroup per CU is not always 'a launch that does not fill the GPU': the binary32 kernel runs that way whatever the
-    batch size.  The cut of the pieces by cost (one piece per slot) is for small launches -- applied to the 25 600-problem batch
-    it left ONE piece of 100 alphas per plus-minus scan (227 rounds deep, 3.2 ms instead of 1.2)."""
+def test_a_binary32_batch_that_fills_the_gpu():
+    """A binary32 request on a batch that fills the GPU at two workgroups per CU is promoted to the binary64 kernel that runs that
+    way (0.81 ms against 1.24 ms in chain_kernel_lv: binary32 is asked for as the cheaper arithmetic).  Held in chain_kernel_lv
+    (wg_per_cu = 1) it keeps the uniform pieces: one workgroup per CU is not always 'a launch that does not fill the GPU' -- the cut of
+    the pieces by cost (one piece per slot) is for small launches; applied to the 25 600-problem batch it left ONE piece of 100
+    alphas per plus-minus scan (227 rounds deep, 3.2 ms instead of 1.2)."""
     batch = bench.build_batch(16, 200, 500, 100, 0)
+    ref, info64, _ = solve(batch)
     out, info, left = solve(batch, precision=device.PRECISION_F32)
+    assert info['kernel'] == info64['kernel'] == 'mxe::chain_kernel_mc<32, 2>' and out['converged'].all() and left == 0
+    assert rel_l2(out['H'], ref['H']).max() < 1e-7 and np.nanmax(out['audit']) < 1e-6      # (the binary64 kernel: binary64 answers)
+    out, info, left = solve(batch, precision=device.PRECISION_F32, wg_per_cu=1)
     assert info['kernel'] == 'mxe::chain_kernel_lv' and out['converged'].all() and left == 0
     assert 40 <= out['depth']['max_rounds'][0] <= 130, out['depth']
     assert np.nanmax(out['audit']) < 1e-4
