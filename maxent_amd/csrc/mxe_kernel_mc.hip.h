@@ -25,6 +25,9 @@
 // the slot is restored from its v (evaluation from scratch) in the next round
 // and retries with a larger damping.
 #pragma once
+#ifndef MXE_X_KERNARG_RELOAD
+#define MXE_X_KERNARG_RELOAD 0       // (measured, not taken: see chain_kernel_mc)
+#endif
 #include "mxe_kernel.hip.h"
 
 namespace mxe {
@@ -147,10 +150,43 @@ constexpr int MC_LOOKAHEAD_LDS = (8 + 2) * 4 * 4 * 4 + 64;       // entries
 //       LDS arrays have -- [row][slot], 512 contiguous bytes per tile in the row pass, 128 per row group in the fused pass
 //       -- and adds ~190 B per omega row and round to the 1024 B of V and V^T.  Waves of a workgroup share the CU's
 //       L1, the workgroup barriers order the accesses (as in chain_kernel<.., GST>).
+// the kernel's first argument, either as the compiler keeps it (RELOAD = false) or read through the kernarg segment pointer, which
+// refresh() makes opaque (see chain_kernel_mc)
+template <bool RELOAD> struct KernargRef;
+template <> struct KernargRef<false> {
+    const KParams& r;
+    __device__ __forceinline__ explicit KernargRef(const KParams& a) : r(a) {}
+    __device__ __forceinline__ const KParams& operator*() const { return r; }
+    __device__ __forceinline__ void refresh() {}
+};
+template <> struct KernargRef<true> {
+    typedef const KParams __attribute__((address_space(4))) K4;
+    K4* q;
+    __device__ __forceinline__ explicit KernargRef(const KParams&) : q((K4*)__builtin_amdgcn_kernarg_segment_ptr()) {}
+    __device__ __forceinline__ K4& operator*() const { return *q; }
+    __device__ __forceinline__ void refresh() { asm volatile("" : "+s"(q)); }
+};
+
 template <int NA, int WGPC, bool LEAD = false, int NWV = 4, bool GSTATE = false>
 __global__ __launch_bounds__(64 * NWV, WGPC)
+#if MXE_X_KERNARG_RELOAD
+void chain_kernel_mc(const KParams p_arg, const MCExtra x)
+#else
 void chain_kernel_mc(const KParams p, const MCExtra x)
+#endif
 {
+    // MXE_X_KERNARG_RELOAD (an experiment, off): at two workgroups per CU the kernel's arguments are read from the kernarg segment
+    // where they are used (scalar loads, re-issued every round: the pointer is made opaque at the top of the loop) instead of being
+    // held in scalar registers for the life of the kernel -- 175 of them are spilled to the lanes of three vector registers and come
+    // back through 461 v_readlane (static; whole tuples of eight for one option), a third of the vector instructions of the accept
+    // section.  Executed, that is 1.9 % of the kernel's vector instructions (SQ_INSTS_VALU 247.5 M -> 242.9 M per launch) and the
+    // full batch gains 0-0.25 % (0.8139 -> 0.8118, 0.8108 -> 0.8107 ms; the two-GPU shard 0.553 -> 0.547): the issue slots it frees
+    // are not what the kernel waits for.  A lone workgroup LOSES (it waits for the loads: cfg2 0.353 -> 0.359 ms).
+    // profiles/r04_experiments.txt 9.
+#if MXE_X_KERNARG_RELOAD
+    KernargRef<WGPC == 2> kargs(p_arg);
+#define p (*kargs)
+#endif
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int T = 64 * NWV;
     static_assert(WGPC == 1 || WGPC == 2, "one or two workgroups per CU");
@@ -542,6 +578,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 
     bool first_round = true;
     while (guard++ < guard_max) {
+#if MXE_X_KERNARG_RELOAD
+        kargs.refresh();
+#endif
         // (a slot that finishes its piece takes the next one from the queue right away, in step 4)
 
         // ---- 1. home wave: right-hand side, active block, factorise, solve, step ----
@@ -1199,5 +1238,9 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     }
 #endif
 }
+
+#if MXE_X_KERNARG_RELOAD
+#undef p
+#endif
 
 } // namespace mxe
