@@ -759,3 +759,58 @@ def test_result_arrays_are_views_of_one_fetched_array_where_they_can_be():
     assert np.all(np.isnan(gap.H[1, 0])) and np.array_equal(gap.H[1, 1], big[3])
     sh = result(short=(0, 1))
     assert np.array_equal(sh.H[0, 1][:3], big[1][:3]) and np.all(np.isnan(sh.H[0, 1][3:]))
+
+
+def test_rows_of_a_non_default_analyzer_are_formed_when_first_read():
+    """analyzers._device_picks with a source that is still 'on the device' (batch_solver.LazyRows stand-in): indices at once,
+    the A rows (H / delta for everybody, or map by map) when somebody reads one -- and then only once"""
+    from maxent_amd.analyzers import _device_picks, DeferredRows
+    from maxent_amd.maxent_result import MaxEntResult
+    from maxent_amd.batch_solver import LazyA, PickedRows
+
+    class Lazy(object):
+        fetched = 0
+
+        def __init__(self, val):
+            self._val, self.on_host = val, False
+
+        def __array__(self, dtype=None, copy=None):
+            Lazy.fetched += 1
+            self.on_host = True
+            return self._val
+
+        def __getitem__(self, item):
+            return np.asarray(self)[item]
+
+    class Map(object):
+        def matrix(self):
+            return None
+
+        def f(self, H):
+            return np.asarray(H) / 0.25
+    rng = np.random.RandomState(5)
+    n, nw = 4, 7
+    idx = np.array([[0, 1, 2, 1], [2, 2, 0, 1], [1, 0, 0, 2]], dtype=np.int32)
+    rows = rng.rand(3, n, nw)
+    srcs = [rows[0], Lazy(rows[1]), Lazy(rows[2])]           # analyzer 0 came with the solve
+    m = Map()
+    res = MaxEntResult(matrix_structure=(2, 2), element_wise=True, complex_elements=False, use_hermiticity=False)
+    keys = [(0, 0), (0, 1), (1, 0), (1, 1)]
+    batch = (idx, srcs, None)
+    for c, key in enumerate(keys):
+        H = rng.rand(3, nw)
+        res._records[key] = dict(alpha=np.array([4.0, 2.0, 1.0]), H=H, A=LazyA(H, m), chi2=rng.rand(3),
+                                 device_select=dict(params=(0, 0.2), index=idx[:, c], H=PickedRows(srcs, c), batch=batch, chain=c))
+    got0 = _device_picks(res, keys, 0, lambda p: True)
+    assert got0[0] == idx[0].tolist() and isinstance(got0[1], list) and np.array_equal(np.array(got0[1]), rows[0] / 0.25)
+    got1 = _device_picks(res, keys, 1, lambda p: True)
+    assert got1[0] == idx[1].tolist() and isinstance(got1[1], DeferredRows) and len(got1[1]) == n and Lazy.fetched == 0
+    assert np.array_equal(got1[1][2], rows[1][2] / 0.25) and Lazy.fetched == 1
+    assert np.array_equal(np.array(list(got1[1])), rows[1] / 0.25) and Lazy.fetched == 1       # (formed once)
+    # a subset of the launch's scans, in another order
+    res.__dict__.pop('_picks_scan', None)
+    sub = [(1, 1), (0, 1)]
+    got2 = _device_picks(res, sub, 2, lambda p: True)
+    assert got2[0] == [int(idx[2, 3]), int(idx[2, 1])] and np.array_equal(np.array(list(got2[1])), rows[2][[3, 1]] / 0.25)
+    # the per-scan view of the same rows
+    assert np.array_equal(res._records[(1, 0)]['device_select']['H'][1], rows[1][2])

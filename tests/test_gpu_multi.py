@@ -301,6 +301,27 @@ def test_device_analyzers_pick_the_alphas_the_host_analyzers_pick_on_the_referen
             for a in range(3):
                 if idx[a, c] >= 0:
                     assert np.array_equal(rows[a, c], out['H'][c, idx[a, c]])
+        # mxe_select3_fetch_rows: any part of the rows, with or without the indices, equals the whole
+        for first, count in ((0, 1), (1, 2), (2, 1), (0, 3)):
+            i2, r2 = ctx.select3_fetch_rows(first=first, count=count)
+            assert np.array_equal(i2, idx) and np.array_equal(r2, rows[first:first + count], equal_nan=True)     # (a scan without a choice: NaN row)
+            none, r3 = ctx.select3_fetch_rows(first=first, count=count, want_index=False)
+            assert none is None and np.array_equal(r3, r2, equal_nan=True)
+        i4, r4 = ctx.select3_fetch_rows(first=0, count=0)
+        assert np.array_equal(i4, idx) and r4 is None
+    # arguments and state: a part outside the three analyzers, neither indices nor rows, rows of another launch
+    for first, count in ((-1, 1), (2, 2), (0, 4)):
+        with pytest.raises(device.MaxEntDeviceError):
+            ctx.select3_fetch_rows(first=first, count=count)
+    with pytest.raises(device.MaxEntDeviceError):
+        ctx.select3_fetch_rows(first=0, count=0, want_index=False)
+    ctx.upload_chains([0, 1], alpha, np.tile(v0, (2, 1)))       # new chains: what the last selection chose is gone
+    ctx.launch()
+    ctx.sync()
+    with pytest.raises(device.MaxEntDeviceError):
+        ctx.select3_fetch_rows(first=1, count=1, want_index=False)
+    ctx.select3_launch(0, 0.2)
+    assert ctx.select3_fetch_rows(first=1, count=1)[1].shape == (1, 2, n_w)
     ctx.close()
 
 
