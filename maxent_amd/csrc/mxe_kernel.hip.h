@@ -671,7 +671,23 @@ void chain_kernel(const KParams p)
             for (int cb = 0; cb < NP / 64; ++cb) {
                 TS s0 = 0, s1 = 0, t0 = 0, t1 = 0;
                 const TS* Vc = V + 64 * cb + 2 * cl;
-                for (int i = r0 + half; i < r1; i += 16) {
+                int i = r0 + half;
+                // (sixteen loads in flight where the wave's rows allow it -- n_omega_pad a multiple of 128 --, else eight; the
+                //  NP = 128 build has no registers for them)
+                if (NAB == 2 && (rows_per & 31) == 0) {
+                    for (; i < r1; i += 32) {
+                        TS2 x[16];
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) x[e] = *reinterpret_cast<const TS2*>(Vc + (size_t)(i + 2 * e) * NP);
+#pragma unroll
+                        for (int e = 0; e < 16; e += 2) {
+                            const TS h0 = Hs[i + 2 * e], h1 = Hs[i + 2 * e + 2];
+                            s0 = fma(x[e].x, h0, s0); s1 = fma(x[e].y, h0, s1);
+                            t0 = fma(x[e + 1].x, h1, t0); t1 = fma(x[e + 1].y, h1, t1);
+                        }
+                    }
+                }
+                for (; i < r1; i += 16) {
                     TS2 x[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) x[e] = *reinterpret_cast<const TS2*>(Vc + (size_t)(i + 2 * e) * NP);
@@ -1086,6 +1102,44 @@ void chain_kernel(const KParams p)
     };
 
     // ------------------------------------------------------------------
+    // The same solve for FOUR dampings at once, one per wave (binary64 build with four waves): the damped Newton step tries
+    // mu = 0, then mu_1, mu_1 g, mu_1 g^2, ... until a step is accepted -- the sequence is known before the first trial, the
+    // matrix is the same, and three of the four waves idle during a solve.  Wave w solves (c W c + (alpha + mu_w) I) z = rhs
+    // into zzs[w]; the trial loop takes the solutions in turn.  The arithmetic of every solve is that of gj_solve_reg: the
+    // iterates do not change by a bit.  A chain that needs damping at every iteration (the chains that run into maxiter:
+    // 2.8 evaluations per iteration) pays one solve per iteration instead of one per evaluation.
+    // ------------------------------------------------------------------
+    constexpr bool SPEC = F64 && NW == 4 && NAB == 2;
+    double* zzs = stage + 272;                              // [4][NP]   (stage: free between the Gram sweeps)
+    int* spec_ok = reinterpret_cast<int*>(stage + 258);     // [4]
+    auto gj_solve_spec = [&](auto NTag, const double (&aw)[4], int n_act) {
+        constexpr int N = decltype(NTag)::value;
+        if constexpr (SPEC) {
+            const double a = wave == 0 ? aw[0] : wave == 1 ? aw[1] : wave == 2 ? aw[2] : aw[3];
+            const int i = lane & 31, h = lane >> 5;
+            const bool live = i < n_act;
+            const double ci_ = live ? cc[i] : 0.0;
+            double A[N / 2];
+            {
+                const int ic = min(i, N - 1);
+#pragma unroll
+                for (int kk = 0; kk < N / 2; ++kk) {
+                    const int k = 2 * kk + h;
+                    double x = 0.0;
+                    if (live && k < n_act) x = ci_ * Wm[min(k, ic) * LD + max(k, ic)] * cc[k];
+                    if (k == i) x = live ? x + a : 1.0;
+                    A[kk] = x;
+                }
+            }
+            double z;
+            const bool ok = gj2_solve64<N>(A, live ? rhs[i] : 0.0, i, z);
+            if (ok && live && h == 0) zzs[wave * NP + i] = z;
+            if (lane == 0) spec_ok[wave] = ok ? 1 : 0;
+            __syncthreads();
+        }
+    };
+
+    // ------------------------------------------------------------------
     // all four waves, active block of 33 .. 64 rows (binary64 build, NP = 64): Gauss-Jordan elimination on pivot PAIRS
     // with the matrix in registers -- lane i of wave w holds the columns 16 w .. 16 w + 15 of row i of A = c W c + a I,
     // every wave a copy of the right-hand side.  A step for the pivots (p, q = p + 1): the wave that owns their columns
@@ -1251,10 +1305,34 @@ void chain_kernel(const KParams p)
             double mu = 0.0;
             double chi2t = 0.0, St = 0.0, dH2t = 0.0, Hn2t = 0.0, wmaxt = 0.0, dumaxt = 0.0;
             bool accepted = false, scaled = false, predicted = false;
+            int spec_cnt = 0;                   // dampings of this iteration whose solutions are in zzs (gj_solve_spec)
+            double spec_mu[4] = {0.0, 0.0, 0.0, 0.0};
             while (true) {
                 const double a = alpha + mu;
                 bool okc;
-                if (n_act0 <= 16) okc = gj_solve_reg(std::integral_constant<int, 16>{}, a, n_act0);
+                const double* zsol = zz;
+                if (SPEC && n_act0 <= 32) {
+                    int hit = -1;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) if (w < spec_cnt && spec_mu[w] == mu) hit = w;
+                    if (hit < 0) {
+                        // this damping and the three the loop below would try next
+                        double aw[4];
+                        spec_mu[0] = mu;
+#pragma unroll
+                        for (int w = 1; w < 4; ++w)
+                            spec_mu[w] = (spec_mu[w - 1] == 0.0) ? fmax(p.mu_first * alpha, mu_hint / p.mu_grow) : spec_mu[w - 1] * p.mu_grow;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) aw[w] = alpha + spec_mu[w];
+                        if (n_act0 <= 16) gj_solve_spec(std::integral_constant<int, 16>{}, aw, n_act0);
+                        else if (n_act0 <= 24) gj_solve_spec(std::integral_constant<int, 24>{}, aw, n_act0);
+                        else gj_solve_spec(std::integral_constant<int, 32>{}, aw, n_act0);
+                        spec_cnt = 4; hit = 0;
+                    }
+                    okc = __builtin_amdgcn_readfirstlane(spec_ok[hit]) != 0;
+                    zsol = zzs + hit * NP;
+                }
+                else if (n_act0 <= 16) okc = gj_solve_reg(std::integral_constant<int, 16>{}, a, n_act0);
                 else if (n_act0 <= 24) okc = gj_solve_reg(std::integral_constant<int, 24>{}, a, n_act0);
                 else if (n_act0 <= 32) okc = gj_solve_reg(std::integral_constant<int, 32>{}, a, n_act0);
                 else if (F64 && NW == 4 && NAB == 2) okc = gj_solve_4w(a, n_act0);
@@ -1267,7 +1345,7 @@ void chain_kernel(const KParams p)
                     for (int k = tid; k < NP; k += T) {
                         double z = 0.0;
                         if (k < n_act0) {
-                            z = zz[k];
+                            z = zsol[k];
                             nrm += z * (rhs[k] - a * z);     // z^T (c W c) z = delta^T W delta
                         } else if (k < ns) {
                             z = rhs[k] / a;
