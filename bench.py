@@ -291,8 +291,29 @@ def end_to_end_block(batch, n_orb, n_alpha):
         t0 = time.perf_counter()
         np.asarray(res.A)
         t_A2 = time.perf_counter() - t0
+    # BASELINE config 2 through the API: TauMaxEnt.run() of ONE scan of n_alpha alphas (the reference's most common call)
+    tau1, omega1, _, G1 = synthetic.single_G(200, 500)
+
+    def single(k=0):
+        tm = mx.TauMaxEnt()
+        tm.set_verbosity(mx.VerbosityFlags.Quiet)
+        tm.set_G_tau_data(tau1, G1 * (1.0 + 1e-7 * k))
+        tm.set_error(synthetic.SIGMA)
+        tm.omega = omega1
+        tm.alpha_mesh = mx.LogAlphaMesh(alpha_min=1e-2, alpha_max=1e4, n_points=n_alpha)
+        return tm
+    tm = single(); tm.run()
+    one_fresh, one_warm = [], []
+    for k in range(1, 5):
+        t0 = time.perf_counter(); tm = single(k); r1 = tm.run(); one_fresh.append(time.perf_counter() - t0)
+    for _ in range(5):
+        r1 = None
+        t0 = time.perf_counter(); r1 = tm.run(); one_warm.append(time.perf_counter() - t0)
+    del r1, tm
     P = n_orb * n_orb * n_alpha
     return dict(api='ElementwiseMaxEnt(use_hermiticity=False).run()', problems=P,
+                single_scan=dict(api='TauMaxEnt.run(), one scan of %d alpha (BASELINE config 2)' % n_alpha,
+                                 same_object_ms=1e3 * min(one_warm), fresh_object_ms=1e3 * sorted(one_fresh)[1]),
                 fresh_object_ms=1e3 * min(cold), fresh_object_own_contexts_ms=1e3 * min(cold_own), same_object_ms=1e3 * min(warm),
                 alpha_solves_per_s_same_object=P / min(warm), alpha_solves_per_s_fresh_object=P / min(cold),
                 includes='fresh object: a new ElementwiseMaxEnt on new data of the same grids -- kernel fill + SVD + staging of the data; '

@@ -65,14 +65,25 @@ class Logtaker(object):
     def _passes(level, flags):
         return (level & flags) == flags
 
-    def message(self, message_verbosity, msg, *args, **kwargs):
-        text = msg.format(*args, **kwargs) if (args or kwargs) else msg
+    def wants(self, message_verbosity):
+        """would a message of this verbosity go anywhere (terminal or log file)?  Callers with many lines to format ask first"""
         if self._passes(self.verbose, message_verbosity):
+            return True
+        if self.logfile is None:
+            return False
+        return self._passes(self.verbose if self.logfile_verbose is None else self.logfile_verbose, message_verbosity)
+
+    def message(self, message_verbosity, msg, *args, **kwargs):
+        to_terminal = self._passes(self.verbose, message_verbosity)
+        to_file = self.logfile is not None and self._passes(
+            self.verbose if self.logfile_verbose is None else self.logfile_verbose, message_verbosity)
+        if not (to_terminal or to_file):
+            return                               # (nothing shows it: it is not formatted either)
+        text = msg.format(*args, **kwargs) if (args or kwargs) else msg
+        if to_terminal:
             self._terminal.show(text, overwrite=bool(message_verbosity & self.one_line))
-        if self.logfile is not None:
-            level = self.verbose if self.logfile_verbose is None else self.logfile_verbose
-            if self._passes(level, message_verbosity):
-                self.logfile.write(text + '\n')
+        if to_file:
+            self.logfile.write(text + '\n')
 
     def logged_message(self, msg, *args, **kwargs):
         """(deprecated in the reference: a message that always shows)"""

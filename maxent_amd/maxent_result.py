@@ -490,7 +490,7 @@ class MaxEntResult(MaxEntResultData):
 
     A_out = property(get_A_out)
 
-    def analyze_batch(self, analyzers, keys):
+    def analyze_batch(self, analyzers, keys, picks_for_one=False):
         """:meth:`analyze` for many elements (``keys``: tuples as :meth:`_key` makes them); the rows of A
         the analyzers pick are fetched from the device in ONE go at the end"""
         self._deferred_rows = []
@@ -498,7 +498,7 @@ class MaxEntResult(MaxEntResultData):
         try:
             many = {}
             for analyzer in analyzers:
-                if len(keys) > 1 and hasattr(analyzer, 'pick_many'):
+                if hasattr(analyzer, 'pick_many') and (len(keys) > 1 or picks_for_one):
                     picks = analyzer.pick_many(self, keys)        # the device chose: result objects when somebody looks
                     if picks is not None:
                         many[analyzer.name] = picks               # (ONE object for the batch; an element finds its own through its position)
