@@ -474,6 +474,9 @@ def main():
     ap.add_argument('--chains-per-wg', type=int, default=0)
     ap.add_argument('--alpha-split', type=int, default=0)
     ap.add_argument('--wg-per-cu', type=int, default=0)
+    ap.add_argument('--in-flight', type=int, default=2, choices=(1, 2),
+                    help='batches in flight on the GPU: 2 = two device contexts (two streams) take the steps in turn, so that a '
+                         'kernel starts on the CUs the one before it has already left (one rank only; 1: one batch at a time)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the audit / parity / end-to-end blocks')
     ap.add_argument('--shard-of', type=int, default=0,
@@ -526,14 +529,29 @@ def main():
             return n * args.n_alpha * (args.n_omega if full else 0) + 3 * n * args.n_alpha + n * (args.n_omega + 1)
         counts = [per(int(n_local[r]) if strong else n_elem) for r in range(world)]
 
-    def one_step():
-        ctx.launch()                 # enqueued back to back: no host synchronisation inside the timed region
-        ctx.select_launch(0)
+    # Two batches in flight (one rank): a second context -- its own stream, its own staging and result buffers -- takes every
+    # other step.  The persistent workgroups of a launch finish unevenly (the slowest takes 12 % longer than the mean:
+    # profiles/*_phases_mc_wg2.txt); the next launch of the SAME stream waits for the last of them, the launch of the other
+    # stream starts on the CUs that are free.  Every step is still one pass of the hot path over one batch.
+    in_flight = args.in_flight if (world == 1 and not use_comm) else 1
+    lanes = [ctx]
+    if in_flight == 2:
+        ctx_b = stage(batch, local_rank, mine)
+        ctx_b.upload_chains(np.arange(len(mine), dtype=np.int32), batch['alphas'], batch['v0'][mine], opts)
+        lanes.append(ctx_b)
+    turn = [0]
+
+    def one_step(only=None):
+        c = only if only is not None else lanes[turn[0] % len(lanes)]
+        turn[0] += 1
+        c.launch()                   # enqueued back to back: no host synchronisation inside the timed region
+        c.select_launch(0)
         if use_comm:
-            ctx.gather(0, counts, full=full)          # to rank 0's device, on the ctx stream
+            c.gather(0, counts, full=full)            # to rank 0's device, on the ctx stream
 
     def barrier():
-        ctx.sync()
+        for c in lanes:
+            c.sync()
         if use_comm:
             ctx.allreduce([0.0])
 
@@ -546,27 +564,42 @@ def main():
     t_settle = time.perf_counter()
     while time.perf_counter() - t_settle < (0.5 if use_comm else 0.25):
         one_step()
-        ctx.sync()
+        for c in lanes:
+            c.sync()
+    barrier()
+    # the dominant kernel's own duration: HIP events around launches on the library's stream, back to back, ONE launch at a time
+    # (taken in front of the timed region: behind two seconds of load the clocks of these boxes are 1-2 % lower, and the
+    #  rocprofv3 summary under profiles/ -- a short run -- is what this has to agree with)
+    ctx.timing_mark()
+    for _ in range(50):
+        ctx.launch()
+    k_ms = ctx.ms_since_mark() / 50
     barrier()
     ctx.timing_mark()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     t_enq = time.perf_counter()
-    ctx.sync()                       # on rank 0: every gather of the region has landed
+    for c in lanes:
+        c.sync()                     # on rank 0: every gather of the region has landed
     t_drained = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
     if use_comm:
         elapsed = float(ctx.allreduce([elapsed], 'max')[0])
     host_split = dict(enqueue_ms=1e3 * (t_enq - t0), wait_ms=1e3 * (t_drained - t_enq))
+    one_at_a_time = None
+    if len(lanes) > 1:
+        # the same number of steps with ONE batch at a time (rounds 1-3 timed this), in the same run
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step(only=ctx)
+        ctx.sync()
+        e1 = time.perf_counter() - t1
+        one_at_a_time = dict(ms_per_step=1e3 * e1 / args.steps, value=P_job * args.steps / e1)
+        ctx_b.close()
 
-    # the dominant kernel's own duration: HIP events around launches on the library's stream, back to back
-    ctx.sync()
-    ctx.timing_mark()
-    for _ in range(50):
-        ctx.launch()
-    k_ms = ctx.ms_since_mark() / 50
 
     gather_checked = None
     if use_comm and rank == 0:
@@ -702,6 +735,11 @@ def main():
                                                                n_elem * args.n_alpha, args.n_tau, args.n_omega, n_s)) +
                              ('the one batch sharded over %d GPU(s), element e on rank e mod N' % world if strong
                               else 'one such batch per GPU (%d GPUs, weak scaling)' % world),
+                    in_flight=len(lanes),
+                    in_flight_note=('two device contexts (two streams) take the steps in turn: a launch starts on the CUs whose '
+                                    'workgroups of the launch before have finished (the slowest workgroup of a launch runs 12 % '
+                                    'longer than the mean); one_at_a_time holds the same steps through one context, the figure of '
+                                    'rounds 1-3' if len(lanes) > 1 else 'one batch at a time'),
                     step='chain kernel + device line fit' + (' + one RCCL gather (%s) to rank 0: %.2f MB per step'
                                                             % (what, float(np.sum(counts)) * 8 / 1e6) if use_comm else ''),
                     problems_per_step=P_job, problems_on_rank0=P_rank,
@@ -716,6 +754,15 @@ def main():
                                    'tests/test_gpu_multi.py) and several contexts on one device go through device copies; '
                                    'scaling_projection holds every rank\'s shard timed on this GPU'),
                 roofline=roofline)
+    if one_at_a_time is not None:
+        line['one_at_a_time'] = one_at_a_time
+        # the issue slots that are busy over the TIMED REGION (launches overlapping), next to frac, which prices one launch alone
+        if achieved is not None:
+            roofline['frac_timed_region'] = (4 * pmc['valu_active_quadcycles'] + pmc['mfma_busy_cycles'] - pmc['coexec_cycles']) * \
+                args.steps / elapsed / 1e9 / peak
+            roofline['frac_timed_region_note'] = ('busy SIMD-cycles per launch (the same counters) x steps / the elapsed time of the timed '
+                                                  'region, in which two launches are in flight; frac, achieved and kernel_ms are those of '
+                                                  'ONE launch with the GPU to itself (what rocprofv3 records under profiles/ with --in-flight 1)')
     if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(batch, out)
         line['cpu_baseline']['all_cores'] = pool_baseline
