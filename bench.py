@@ -567,13 +567,26 @@ def main():
         for c in lanes:
             c.sync()
     barrier()
-    # the dominant kernel's own duration: HIP events around launches on the library's stream, back to back, ONE launch at a time
-    # (taken in front of the timed region: behind two seconds of load the clocks of these boxes are 1-2 % lower, and the
-    #  rocprofv3 summary under profiles/ -- a short run -- is what this has to agree with)
+    one_at_a_time = None
+    if len(lanes) > 1:
+        # first the same number of steps with ONE batch at a time (rounds 1-3 timed this), in the same run ...
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step(only=ctx)
+        ctx.sync()
+        e1 = time.perf_counter() - t1
+        one_at_a_time = dict(ms_per_step=1e3 * e1 / args.steps, value=P_job * args.steps / e1)
+    # ... and behind them (as in rounds 1-3) the dominant kernel's own duration: HIP events around launches on the library's
+    # stream, back to back, one launch at a time.  (Where it is taken matters by 1-3 % on these boxes: right behind the
+    # warm-up the clocks have not come up (0.84 ms), behind the region with two launches in flight they are lower (0.825).)
+    ctx.sync()
     ctx.timing_mark()
     for _ in range(50):
         ctx.launch()
     k_ms = ctx.ms_since_mark() / 50
+    if len(lanes) > 1:
+        for _ in range(20):
+            one_step()               # (the two contexts in turn again before the clock starts)
     barrier()
     ctx.timing_mark()
     t0 = time.perf_counter()
@@ -588,16 +601,7 @@ def main():
     if use_comm:
         elapsed = float(ctx.allreduce([elapsed], 'max')[0])
     host_split = dict(enqueue_ms=1e3 * (t_enq - t0), wait_ms=1e3 * (t_drained - t_enq))
-    one_at_a_time = None
     if len(lanes) > 1:
-        # the same number of steps with ONE batch at a time (rounds 1-3 timed this), in the same run
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            one_step(only=ctx)
-        ctx.sync()
-        e1 = time.perf_counter() - t1
-        one_at_a_time = dict(ms_per_step=1e3 * e1 / args.steps, value=P_job * args.steps / e1)
         ctx_b.close()
 
 
