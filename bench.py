@@ -474,9 +474,10 @@ def main():
     ap.add_argument('--chains-per-wg', type=int, default=0)
     ap.add_argument('--alpha-split', type=int, default=0)
     ap.add_argument('--wg-per-cu', type=int, default=0)
-    ap.add_argument('--in-flight', type=int, default=2, choices=(1, 2),
-                    help='batches in flight on the GPU: 2 = two device contexts (two streams) take the steps in turn, so that a '
-                         'kernel starts on the CUs the one before it has already left (one rank only; 1: one batch at a time)')
+    ap.add_argument('--in-flight', type=int, default=4, choices=(1, 2, 3, 4),
+                    help='batches in flight on the GPU: n device contexts (n streams) take the steps in turn -- a kernel starts on the '
+                         'CUs the ones before it have left, and every batch is cut into 1 / n as many cold-started pieces '
+                         '(mxe_opts.in_flight); one rank only; 1: one batch at a time')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the audit / parity / end-to-end blocks')
     ap.add_argument('--shard-of', type=int, default=0,
@@ -529,16 +530,15 @@ def main():
             return n * args.n_alpha * (args.n_omega if full else 0) + 3 * n * args.n_alpha + n * (args.n_omega + 1)
         counts = [per(int(n_local[r]) if strong else n_elem) for r in range(world)]
 
-    # Two batches in flight (one rank): a second context -- its own stream, its own staging and result buffers -- takes every
-    # other step.  The persistent workgroups of a launch finish unevenly (the slowest takes 12 % longer than the mean:
-    # profiles/*_phases_mc_wg2.txt); the next launch of the SAME stream waits for the last of them, the launch of the other
-    # stream starts on the CUs that are free.  Every step is still one pass of the hot path over one batch.
+    # Several batches in flight (one rank).  The persistent workgroups of a launch finish unevenly (the slowest takes 12 % longer
+    # than the mean: profiles/*_phases_mc_wg2.txt) and the next launch of the SAME stream waits for the last of them; a launch of
+    # another stream starts on the CUs that are free.  And a GPU that n batches share is full without most of the cold-started
+    # pieces one batch alone is cut into (mxe_opts.in_flight = n: 4 instead of 15 pieces per scan for n = 4, a cold start costs
+    # 4-17 evaluations).  --in-flight n: n device contexts -- each with its own stream, staging and result buffers, uploaded with
+    # mxe_opts.in_flight = n -- take the steps in turn; every step is still one pass of the hot path over one batch.  ``ctx`` (the
+    # library's choice for ONE batch: what rounds 1-3 timed) keeps the one-at-a-time steps, the kernel time, the roofline.
     in_flight = args.in_flight if (world == 1 and not use_comm) else 1
     lanes = [ctx]
-    if in_flight == 2:
-        ctx_b = stage(batch, local_rank, mine)
-        ctx_b.upload_chains(np.arange(len(mine), dtype=np.int32), batch['alphas'], batch['v0'][mine], opts)
-        lanes.append(ctx_b)
     turn = [0]
 
     def one_step(only=None):
@@ -555,40 +555,56 @@ def main():
         if use_comm:
             ctx.allreduce([0.0])
 
+    def settle():
+        # with only a few warm-up passes the first submission after a synchronisation was picked up 30-50 ms late in a quarter
+        # of the processes on the MI355X boxes; a quarter of a second of untimed passes (half a second with a communicator,
+        # whose first collectives finish initialising in the background)
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < (0.5 if use_comm else 0.25):
+            one_step()
+            for c in lanes:
+                c.sync()
+        barrier()
+
     for _ in range(args.warmup):
         one_step()
     barrier()
-    # settle: with only a few warm-up passes the first submission after a synchronisation was picked up
-    # 30-50 ms late in a quarter of the processes on the MI355X boxes; a quarter of a second of untimed
-    # passes (half a second with a communicator, whose first collectives finish initialising in the background)
-    t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < (0.5 if use_comm else 0.25):
-        one_step()
-        for c in lanes:
-            c.sync()
-    barrier()
+    settle()
     one_at_a_time = None
-    if len(lanes) > 1:
+    if in_flight > 1:
         # first the same number of steps with ONE batch at a time (rounds 1-3 timed this), in the same run ...
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            one_step(only=ctx)
+            one_step()
         ctx.sync()
         e1 = time.perf_counter() - t1
         one_at_a_time = dict(ms_per_step=1e3 * e1 / args.steps, value=P_job * args.steps / e1)
     # ... and behind them (as in rounds 1-3) the dominant kernel's own duration: HIP events around launches on the library's
     # stream, back to back, one launch at a time.  (Where it is taken matters by 1-3 % on these boxes: right behind the
-    # warm-up the clocks have not come up (0.84 ms), behind the region with two launches in flight they are lower (0.825).)
+    # warm-up the clocks have not come up (0.84 ms), behind the region with launches in flight they are lower (0.825).)
     ctx.sync()
     ctx.timing_mark()
     for _ in range(50):
         ctx.launch()
     k_ms = ctx.ms_since_mark() / 50
-    if len(lanes) > 1:
-        for _ in range(20):
-            one_step()               # (the two contexts in turn again before the clock starts)
+    if in_flight > 1:
+        # now the contexts of the batches in flight -- and ONLY they: the streams of a process share four hardware queues, a fifth
+        # stream halves the rate of the one it shares a queue with (0.98 instead of 0.65 ms per step); ``ctx`` comes back behind
+        # the timed region
+        ctx.close()
+        opts_fl = device.default_opts(waves_per_chain=args.waves_per_chain, chains_per_wg=args.chains_per_wg,
+                                      alpha_split=args.alpha_split, wg_per_cu=args.wg_per_cu, in_flight=in_flight)
+        lanes = []
+        for _ in range(in_flight):
+            c = stage(batch, local_rank, mine)
+            c.upload_chains(np.arange(len(mine), dtype=np.int32), batch['alphas'], batch['v0'][mine], opts_fl)
+            lanes.append(c)
+        for _ in range(max(args.warmup, 2 * in_flight)):
+            one_step()
+        barrier()
+        settle()
     barrier()
-    ctx.timing_mark()
+    lanes[0].timing_mark()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
@@ -601,8 +617,23 @@ def main():
     if use_comm:
         elapsed = float(ctx.allreduce([elapsed], 'max')[0])
     host_split = dict(enqueue_ms=1e3 * (t_enq - t0), wait_ms=1e3 * (t_drained - t_enq))
-    if len(lanes) > 1:
-        ctx_b.close()
+    in_flight_check = None
+    if in_flight > 1:
+        # what the batches in flight returned: every alpha converged, the exact Newton correction at the returned v of every problem
+        lanes[-1].launch()
+        left = lanes[-1].finish()
+        o_fl = lanes[-1].fetch(want_v=False, want_H=False)
+        a_fl = lanes[-1].audit()['corr'].ravel()
+        in_flight_check = dict(kernel=lanes[-1].last_launch_info()['kernel'], workgroups=lanes[-1].last_launch_info()['n_workgroups'],
+                               converged=int(o_fl['converged'].sum()), alpha_solves=int(o_fl['converged'].size),
+                               left_to_finish=int(left), evals_per_solve=float(o_fl['n_evals'].mean()),
+                               audit_max=float(np.nanmax(a_fl)), audit_p99=float(np.nanpercentile(a_fl, 99)))
+        for c in lanes:
+            c.close()
+        lanes = []
+        ctx = stage(batch, local_rank, mine)          # (the context of one batch at a time again, for what follows)
+        ctx.upload_chains(np.arange(len(mine), dtype=np.int32), batch['alphas'], batch['v0'][mine], opts)
+        lanes = [ctx]
 
 
     gather_checked = None
@@ -739,11 +770,15 @@ def main():
                                                                n_elem * args.n_alpha, args.n_tau, args.n_omega, n_s)) +
                              ('the one batch sharded over %d GPU(s), element e on rank e mod N' % world if strong
                               else 'one such batch per GPU (%d GPUs, weak scaling)' % world),
-                    in_flight=len(lanes),
-                    in_flight_note=('two device contexts (two streams) take the steps in turn: a launch starts on the CUs whose '
-                                    'workgroups of the launch before have finished (the slowest workgroup of a launch runs 12 % '
-                                    'longer than the mean); one_at_a_time holds the same steps through one context, the figure of '
-                                    'rounds 1-3' if len(lanes) > 1 else 'one batch at a time'),
+                    in_flight=in_flight,
+                    in_flight_note=('%d device contexts (%d streams), uploaded with mxe_opts.in_flight = %d, take the steps in turn: a '
+                                    'launch starts on the CUs whose workgroups of the launches before have finished (the slowest workgroup '
+                                    'of a launch runs 12 %% longer than the mean), and a GPU that %d batches share is full with a quarter '
+                                    'of the cold-started pieces one batch alone is cut into; one_at_a_time holds the same steps through '
+                                    'one context with the cut for one batch, the figure of rounds 1-3; in_flight_check: what a batch in '
+                                    'flight returned' % (in_flight, in_flight, in_flight, in_flight)
+                                    if in_flight > 1 else 'one batch at a time'),
+                    in_flight_check=in_flight_check,
                     step='chain kernel + device line fit' + (' + one RCCL gather (%s) to rank 0: %.2f MB per step'
                                                             % (what, float(np.sum(counts)) * 8 / 1e6) if use_comm else ''),
                     problems_per_step=P_job, problems_on_rank0=P_rank,
@@ -761,11 +796,14 @@ def main():
     if one_at_a_time is not None:
         line['one_at_a_time'] = one_at_a_time
         # the issue slots that are busy over the TIMED REGION (launches overlapping), next to frac, which prices one launch alone
-        if achieved is not None:
-            roofline['frac_timed_region'] = (4 * pmc['valu_active_quadcycles'] + pmc['mfma_busy_cycles'] - pmc['coexec_cycles']) * \
+        if achieved is not None and in_flight_check is not None:
+            # (the batches in flight are cut into fewer pieces and execute fewer evaluations per alpha than the launch the counters
+            #  were recorded on: the busy cycles are scaled with the evaluations)
+            scale = in_flight_check['evals_per_solve'] / float(out['n_evals'].mean())
+            roofline['frac_timed_region'] = scale *  (4 * pmc['valu_active_quadcycles'] + pmc['mfma_busy_cycles'] - pmc['coexec_cycles']) * \
                 args.steps / elapsed / 1e9 / peak
             roofline['frac_timed_region_note'] = ('busy SIMD-cycles per launch (the same counters) x steps / the elapsed time of the timed '
-                                                  'region, in which two launches are in flight; frac, achieved and kernel_ms are those of '
+                                                  'region, in which the launches of several contexts are in flight (scaled with the evaluations per alpha of their cut); frac, achieved and kernel_ms are those of '
                                                   'ONE launch with the GPU to itself (what rocprofv3 records under profiles/ with --in-flight 1)')
     if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(batch, out)

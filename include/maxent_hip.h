@@ -148,7 +148,12 @@ typedef struct mxe_opts {
                                 binary64 launch that does not fill the GPU (every alpha to 1e-5 in binary32, then one
                                 binary64 Newton step per alpha in the lock-step kernel, all alphas side by side);
                                 1 = also for binary64 launches that do fill it; 2 = never                        */
-    int32_t reserved_;       /* (keeps the struct a multiple of eight bytes; must be 0)                          */
+    int32_t in_flight;       /* batches of this size the caller keeps in flight on the GPU (launches of several
+                                contexts enqueued without waiting in between): 0 or 1 = one -- the scans are cut into
+                                enough cold-started pieces to fill the GPU on their own --, n > 1: into 1 / n as many
+                                (a cold start costs 4-17 evaluations: with n batches side by side the GPU is full
+                                without them; bench.py --in-flight 4: 0.83 -> 0.65 ms per batch of 25 600 alpha-solves).
+                                The latency of ONE batch grows (1.7 ms for n = 4)                                */
 } mxe_opts;
 
 /* ---- library / device ------------------------------------------------- */

@@ -529,7 +529,7 @@ void mxe_opts_default(mxe_opts* o)
     o->waves_per_chain = 0; o->chains_per_wg = 0; o->alpha_split = 0; o->stop_estimate = 1;
     o->precision = MXE_PRECISION_F64; o->wg_per_cu = 0;
     o->chi2_factor = 1.0;
-    o->lds_basis = 0; o->reserved_ = 0;
+    o->lds_basis = 0; o->in_flight = 0;
 }
 
 int mxe_ctx_create(int device, int n_tau, int n_omega, int n_s,
@@ -843,6 +843,7 @@ try {
     if (o.chains_per_wg != 0 && o.chains_per_wg != 1 && o.chains_per_wg != 4) return MXE_ERR_ARG;
     if (o.alpha_split < 0) return MXE_ERR_ARG;
     if (o.wg_per_cu < 0 || o.wg_per_cu > 2) return MXE_ERR_ARG;
+    if (o.in_flight < 0 || o.in_flight > 64) return MXE_ERR_ARG;
     if (o.precision != MXE_PRECISION_F64 && o.precision != MXE_PRECISION_F32) return MXE_ERR_ARG;
     if (o.precision == MXE_PRECISION_F32 && NP != 64) return MXE_ERR_LIMIT;
     if (!(o.chi2_factor > 0.0) || !std::isfinite(o.chi2_factor)) return MXE_ERR_ARG;
@@ -934,7 +935,13 @@ try {
             // 4096 pieces 14 % of the slots took a third --, 1.228 -> 1.171 ms; 14: 1.34 ms)
             long long weight = 0;
             for (int c = 0; c < n_chain; ++c) weight += (ctx->elem_kind[elem_of_chain[c]] == MXE_ENTROPY_NORMAL) ? 2 : 1;
-            const int want = (int)std::max(1LL, (2LL * n_slots) / std::max(1LL, weight));
+            // (mxe_opts.in_flight = n: the caller keeps n such batches in flight -- each fills 1 / n of the slots, with 1 / n of
+            //  the cold starts: 25 600 alpha-solves in 4 x 256 pieces of 25 alphas cost 0.65 ms side by side with three other
+            //  batches, in 15 x 256 pieces 0.83 ms alone and 0.74 ms next to one other; profiles/r04_experiments.txt 10.)
+            const long long nfl = std::max(1, o.in_flight);
+            weight *= nfl;
+            // (rounded UP when batches share the GPU: 4 pieces per scan x 4 batches 0.647 ms per batch, 3 x 4: 0.690)
+            const int want = (int)std::max(1LL, (2LL * n_slots + (nfl > 1 ? std::max(1LL, weight) - 1 : 0)) / std::max(1LL, weight));
             split = std::max(1, std::min(want, n_alpha / 2));
             // (the binary32 streaming variant stops an alpha at its rounding floor, which a cold start reaches
             //  from further away: it keeps pieces of at least six alphas, at most 16 per scan)

@@ -47,7 +47,7 @@ class MxeOpts(ctypes.Structure):
                 ('wg_per_cu', ctypes.c_int32),
                 ('chi2_factor', ctypes.c_double),
                 ('lds_basis', ctypes.c_int32),
-                ('reserved_', ctypes.c_int32)]
+                ('in_flight', ctypes.c_int32)]
 
 
 _dp = ctypes.POINTER(ctypes.c_double)

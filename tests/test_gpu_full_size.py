@@ -179,3 +179,38 @@ def test_the_solo_schedule_is_dropped_where_the_placement_rule_does_not_hold(cfg
     assert out['converged'].all() and c.max() < 1e-6 and np.percentile(c, 99) < 1e-8
     np.testing.assert_allclose(out['chi2'], out0['chi2'], rtol=1e-7)
     assert depth['max_rounds'] == [0, 0]       # (the build of the batch that fills the GPU does not count its rounds: see mxe_launch_depth)
+
+
+def test_batches_in_flight_are_cut_into_fewer_pieces_and_give_the_same_answers(cfg4):
+    """mxe_opts.in_flight = n: the caller keeps n batches of this size in flight (bench.py --in-flight n: n contexts take the
+    steps in turn), so each is cut into about 1 / n as many cold-started pieces -- fewer evaluations per alpha, the same fixed
+    points.  Two contexts launched without waiting in between both deliver."""
+    batch, ctx0, out0, info0 = cfg4
+    lanes = []
+    for _ in range(2):
+        c = bench.stage(batch, 0)
+        c.upload_chains(np.arange(256, dtype=np.int32), batch['alphas'], batch['v0'], device.default_opts(in_flight=4))
+        lanes.append(c)
+    for _ in range(3):
+        for c in lanes:
+            c.launch()                         # (no wait in between: the launches of the two contexts overlap)
+    outs = []
+    for c in lanes:
+        assert c.finish() == 0
+        info = c.last_launch_info()
+        assert info['kernel'] == info0['kernel'] and info['n_workgroups'] < info0['n_workgroups'], (info, info0)
+        o = c.fetch(want_v=False, want_H=True)
+        a = c.audit()['corr']
+        assert o['converged'].all() and a.max() < 1e-6 and np.percentile(a, 99) < 1e-8
+        outs.append(o)
+    for c in lanes:
+        c.close()
+    for o in outs:
+        assert o['n_evals'].mean() < out0['n_evals'].mean() - 0.15          # (4 cold starts per scan instead of 15)
+        np.testing.assert_allclose(o['chi2'], out0['chi2'], rtol=1e-7)
+        e = np.linalg.norm(o['H'] - out0['H'], axis=-1) / np.linalg.norm(out0['H'], axis=-1)
+        assert e.max() < 1e-7
+    with pytest.raises(device.MaxEntDeviceError):
+        ctx0.upload_chains(np.arange(256, dtype=np.int32), batch['alphas'], batch['v0'], device.default_opts(in_flight=-1))
+    ctx0.upload_chains(np.arange(256, dtype=np.int32), batch['alphas'], batch['v0'])       # (the fixture's state back)
+    ctx0.launch(); ctx0.finish()
