@@ -19,6 +19,10 @@ Contract: ``python bench.py --gpus N --steps K --warmup W`` (N > 1 under ``pytho
 torch.distributed.run``, which only serves as the process launcher); rank 0 prints ONE JSON line.
 """
 
+import os
+# (streams of one process share this many hardware queues; the default of four is what the four contexts in flight need -- with a
+#  communicator per context RCCL's own streams come on top and the steps in flight were SLOWER than one at a time, 1.77 against 0.85 ms)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 import argparse
 import json
 import os
@@ -357,6 +361,38 @@ def scaling_projection(batch, opts, k_ms_full, n_alpha, n_launch=30):
                                speedup_before_gather=k_ms_full / max(times),
                                rounds_deepest_workgroup=[d['max_rounds'][0] for d in depths],
                                us_per_round_slowest_rank=1e3 * times[slow] / max(1, depths[slow]['max_rounds'][0]))
+        # the slowest rank's shard with FOUR steps in flight on its GPU (four contexts, mxe_opts.in_flight = 4: what bench.py does on
+        # one rank; with --gpus N every rank keeps one context so far -- the gather would need a communicator per context): a
+        # shard alone does not fill the GPU and is bound by the depth of its chains, several of them side by side are not
+        which = [e for e in range(n_elem) if e % N == slow]
+        fl_opts = device.default_opts(in_flight=4)
+        lanes = []
+        for _ in range(4):
+            c = stage(batch, 0, which)
+            c.upload_chains(np.arange(len(which), dtype=np.int32), batch['alphas'], batch['v0'][which], fl_opts)
+            lanes.append(c)
+        for k in range(16):
+            lanes[k % 4].launch(); lanes[k % 4].select_launch(0)
+        for c in lanes:
+            c.sync()
+        t0 = time.perf_counter()
+        for k in range(4 * n_launch):
+            lanes[k % 4].launch(); lanes[k % 4].select_launch(0)
+        for c in lanes:
+            c.sync()
+        fl_ms = 1e3 * (time.perf_counter() - t0) / (4 * n_launch)
+        lanes[0].launch()
+        fl_left = lanes[0].finish()
+        fl_res = lanes[0].fetch(want_v=False, want_H=False)
+        fl_aud = float(np.nanmax(lanes[0].audit()['corr']))
+        fl_info = lanes[0].last_launch_info()
+        for c in lanes:
+            c.close()
+        out['N=%d' % N]['four_in_flight'] = dict(
+            ms_per_step_slowest_rank=fl_ms, speedup_before_gather=k_ms_full / fl_ms, kernel=fl_info['kernel'],
+            workgroups=fl_info['n_workgroups'], converged=int(fl_res['converged'].sum()), left_to_finish=int(fl_left), audit_max=fl_aud,
+            note='step = chain kernel + device line fit of the shard, four contexts in turn, timed by the host clock; speed-up against '
+                 'the one-batch kernel time of the whole batch, like the line above it')
     # the bound, from this run: a shard that does not fill the GPU is as long as its deepest workgroup (rounds counted by the
     # kernel, mxe_launch_depth) times what a round takes there (the shard's kernel time / that depth)
     deep = [out['N=%d' % N]['rounds_deepest_workgroup'][out['N=%d' % N]['slowest_rank']] for N in (2, 4, 8)]
@@ -418,10 +454,11 @@ def underfilled_block(n_launch=40):
 # ---------------------------------------------------------------------------------------------------
 #  ranks in separate processes
 # ---------------------------------------------------------------------------------------------------
-def comm_setup(ctx, rank, world):
-    """ncclUniqueId from rank 0 to the others through a file (single node: one /tmp)"""
+def comm_setup(ctx, rank, world, suffix=''):
+    """ncclUniqueId from rank 0 to the others through a file (single node: one /tmp); ``suffix``: one communicator per context
+    when a rank keeps several in flight"""
     tag = '%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'))
-    path = os.path.join('/tmp', 'mxe_bench_id_%s_%d' % (tag, os.getppid()))
+    path = os.path.join('/tmp', 'mxe_bench_id_%s_%d%s' % (tag, os.getppid(), suffix))
     if rank == 0:
         uid = device.comm_unique_id()
         with open(path + '.tmp', 'wb') as f:
@@ -455,6 +492,71 @@ def comm_setup(ctx, rank, world):
             os.remove(path)
         except OSError:
             pass
+
+
+def in_flight_comm_region(batch, mine, local_rank, rank, world, counts, full, args, n):
+    """The timed region with ``n`` steps in flight on EVERY rank (--gpus N): n contexts per rank, uploaded with mxe_opts.in_flight = n,
+    each with a communicator of its own (context k of all ranks form communicator k), take the steps in turn -- launch, device line
+    fit, gather to rank 0 on the context's stream.  All ranks issue the steps in the same order.  Returns (elapsed seconds, max
+    over the ranks; on rank 0 also what a step in flight returned).  A shard alone does not fill its GPU and is bound by the depth
+    of its chains (scaling_projection: 0.39 ms at N = 8); four of them side by side are not (0.16 ms)."""
+    opts_fl = device.default_opts(waves_per_chain=args.waves_per_chain, chains_per_wg=args.chains_per_wg,
+                                  alpha_split=args.alpha_split, wg_per_cu=args.wg_per_cu, in_flight=n)
+    lanes = []
+    for k in range(n):
+        c = stage(batch, local_rank, mine)
+        c.upload_chains(np.arange(len(mine), dtype=np.int32), batch['alphas'], batch['v0'][mine], opts_fl)
+        comm_setup(c, rank, world, suffix='_lane%d' % k)
+        lanes.append(c)
+
+    def step(k):
+        c = lanes[k % n]
+        c.launch()
+        c.select_launch(0)
+        c.gather(0, counts, full=full)
+
+    def barrier():
+        for c in lanes:
+            c.sync()
+        lanes[0].allreduce([0.0])
+
+    for k in range(max(args.warmup, 2 * n)):
+        step(k)
+    barrier()
+    t_settle, k = time.perf_counter(), 0
+    while True:
+        # (the ranks agree on the number of settling passes -- every step ends with a gather that pairs them up)
+        go = lanes[0].allreduce([1.0 if time.perf_counter() - t_settle < 0.5 else 0.0], 'max')[0] > 0.5
+        if not go:
+            break
+        for _ in range(n):
+            step(k)
+            k += 1
+        for c in lanes:
+            c.sync()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    for c in lanes:
+        c.sync()
+    barrier()
+    elapsed = float(lanes[0].allreduce([time.perf_counter() - t0], 'max')[0])
+    check = None
+    if rank == 0:
+        lanes[-1].launch()
+        left = lanes[-1].finish()
+        o = lanes[-1].fetch(want_v=False, want_H=False)
+        a = lanes[-1].audit()['corr'].ravel()
+        info = lanes[-1].last_launch_info()
+        check = dict(kernel=info['kernel'], workgroups=info['n_workgroups'], converged=int(o['converged'].sum()),
+                     alpha_solves=int(o['converged'].size), left_to_finish=int(left), evals_per_solve=float(o['n_evals'].mean()),
+                     audit_max=float(np.nanmax(a)), audit_p99=float(np.nanpercentile(a, 99)))
+    barrier()
+    for c in lanes:
+        c.comm_destroy()
+        c.close()
+    return elapsed, check
 
 
 def main():
@@ -529,6 +631,8 @@ def main():
         def per(n):
             return n * args.n_alpha * (args.n_omega if full else 0) + 3 * n * args.n_alpha + n * (args.n_omega + 1)
         counts = [per(int(n_local[r]) if strong else n_elem) for r in range(world)]
+        if args.shard_of > 1 and world == 1:
+            counts = [per(len(mine))]               # (--force-comm with one rank's shard of a bigger job: the pack of that shard)
 
     # Several batches in flight (one rank).  The persistent workgroups of a launch finish unevenly (the slowest takes 12 % longer
     # than the mean: profiles/*_phases_mc_wg2.txt) and the next launch of the SAME stream waits for the last of them; a launch of
@@ -560,7 +664,14 @@ def main():
         # of the processes on the MI355X boxes; a quarter of a second of untimed passes (half a second with a communicator,
         # whose first collectives finish initialising in the background)
         t_settle = time.perf_counter()
-        while time.perf_counter() - t_settle < (0.5 if use_comm else 0.25):
+        while True:
+            go = time.perf_counter() - t_settle < (0.5 if use_comm else 0.25)
+            if use_comm:
+                # (the ranks must agree on the number of passes -- each ends with a gather that pairs the ranks up: one clock
+                #  decides, not every rank its own)
+                go = bool(ctx.allreduce([1.0 if go else 0.0], 'max')[0] > 0.5)
+            if not go:
+                break
             one_step()
             for c in lanes:
                 c.sync()
@@ -668,9 +779,24 @@ def main():
     if use_comm:
         ctx.allreduce([0.0])
 
+    # --gpus N: behind the region above (one context per rank: what every round so far would have timed) the same steps with
+    # several in flight on every rank.  It is the LAST thing a rank does, under a watchdog: communicators per context have run
+    # on one GPU only (--force-comm); if the region does not come back, rank 0 prints the line of the region above and
+    # everybody leaves.
+    n_fl_comm = args.in_flight if (use_comm and args.in_flight > 1) else 1
     if rank != 0:
         ctx.comm_destroy()
         ctx.close()
+        if n_fl_comm > 1:
+            import threading
+            dog = threading.Timer(float(os.environ.get('MXE_BENCH_IN_FLIGHT_TIMEOUT', '180')), lambda: os._exit(0))
+            dog.daemon = True
+            dog.start()
+            try:
+                in_flight_comm_region(batch, mine, local_rank, rank, world, counts, full, args, n_fl_comm)
+            except Exception as exc:          # (rank 0 reports the region above)
+                print('bench.py: rank %d left the region with steps in flight: %r' % (rank, exc), file=sys.stderr)
+            dog.cancel()
         return
 
     ctx.launch()
@@ -791,7 +917,9 @@ def main():
                     multi_gpu_note='N > 1 has not been run by the builders (one-GPU boxes); the RCCL calls of the gather '
                                    '(group start / send / recv / all-reduce) are executed with one rank (--force-comm, '
                                    'tests/test_gpu_multi.py) and several contexts on one device go through device copies; '
-                                   'scaling_projection holds every rank\'s shard timed on this GPU'),
+                                   'scaling_projection holds every rank\'s shard timed on this GPU, alone and with four steps in flight.  '
+                                   'With --gpus N the region with one context per rank is timed first and kept as the line unless the region '
+                                   'behind it -- four contexts per rank, a communicator each, under a watchdog -- comes back faster'),
                 roofline=roofline)
     if one_at_a_time is not None:
         line['one_at_a_time'] = one_at_a_time
@@ -834,6 +962,38 @@ def main():
         line['end_to_end'] = end_to_end_block(batch, args.n_orb, args.n_alpha)
         if default_workload and args.shard_of <= 1:
             line['underfilled'] = underfilled_block()
+    if n_fl_comm > 1:
+        import threading
+
+        def give_up():
+            line['config']['in_flight_note'] = ('the region with %d steps in flight on every rank did not come back within the time '
+                                                'limit: this is the region with one context per rank' % n_fl_comm)
+            print(json.dumps(line))
+            sys.stdout.flush()
+            os._exit(0)
+        dog = threading.Timer(float(os.environ.get('MXE_BENCH_IN_FLIGHT_TIMEOUT', '180')), give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            e_fl, check_fl = in_flight_comm_region(batch, mine, local_rank, rank, world, counts, full, args, n_fl_comm)
+            dog.cancel()
+            fl = dict(ms_per_step=1e3 * e_fl / args.steps, value=P_job * args.steps / e_fl, contexts_per_rank=n_fl_comm, check=check_fl)
+            if fl['value'] > line['value']:
+                line['one_at_a_time'] = dict(ms_per_step=line['ms_per_step'], value=line['value'],
+                                             note='one context per rank: the region every round so far would have timed')
+                line['value'], line['ms_per_step'] = fl['value'], fl['ms_per_step']
+                line['config']['in_flight'] = n_fl_comm
+                line['config']['in_flight_check'] = check_fl
+                line['config']['in_flight_note'] = ('%d device contexts per rank, uploaded with mxe_opts.in_flight = %d and each with a '
+                                                    'communicator of its own, take the steps in turn (launch, device line fit, gather to rank 0 '
+                                                    'on the context\'s stream); one_at_a_time: one context per rank' % (n_fl_comm, n_fl_comm))
+            else:
+                # (the line stays that of one context per rank; what the steps in flight gave is beside it)
+                line['steps_in_flight'] = fl
+                line['config']['in_flight_note'] = 'one context per rank was faster than %d contexts in flight (steps_in_flight)' % n_fl_comm
+        except Exception as exc:
+            dog.cancel()
+            line['config']['in_flight_note'] = 'the region with steps in flight failed (%r): this is the region with one context per rank' % (exc,)
     print(json.dumps(line))
     if gather_checked is False:
         # every rank's chi2 as gathered must be what rank 0 gets when it solves the whole batch itself
