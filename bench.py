@@ -499,7 +499,7 @@ def in_flight_comm_region(batch, mine, local_rank, rank, world, counts, full, ar
     each with a communicator of its own (context k of all ranks form communicator k), take the steps in turn -- launch, device line
     fit, gather to rank 0 on the context's stream.  All ranks issue the steps in the same order.  Returns (elapsed seconds, max
     over the ranks; on rank 0 also what a step in flight returned).  A shard alone does not fill its GPU and is bound by the depth
-    of its chains (scaling_projection: 0.39 ms at N = 8); four of them side by side are not (0.16 ms)."""
+    of its chains (scaling_projection: 0.39 ms at N = 8); four of them side by side are not (0.2 ms)."""
     opts_fl = device.default_opts(waves_per_chain=args.waves_per_chain, chains_per_wg=args.chains_per_wg,
                                   alpha_split=args.alpha_split, wg_per_cu=args.wg_per_cu, in_flight=n)
     lanes = []
