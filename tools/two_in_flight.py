@@ -7,11 +7,12 @@ import bench
 from maxent_amd import device
 batch = bench.build_batch(16, 200, 500, 100, 0)
 n = len(batch['elems'])
+wgpc = int(sys.argv[4]) if len(sys.argv) > 4 else 0             # mxe_opts.wg_per_cu
 hint = int(sys.argv[3]) if len(sys.argv) > 3 else 0             # mxe_opts.in_flight
 split = int(sys.argv[1]) if len(sys.argv) > 1 else 0          # mxe_opts.alpha_split: pieces per scan (0: the library's choice)
 def make():
     c = bench.stage(batch, 0)
-    c.upload_chains(np.arange(n, dtype=np.int32), batch['alphas'], batch['v0'], device.default_opts(alpha_split=split, in_flight=hint))
+    c.upload_chains(np.arange(n, dtype=np.int32), batch['alphas'], batch['v0'], device.default_opts(alpha_split=split, in_flight=hint, wg_per_cu=wgpc))
     return c
 n_max = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 ctxs = [make() for _ in range(n_max)]
