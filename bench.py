@@ -442,6 +442,32 @@ def underfilled_block(n_launch=40):
                                    left_to_finish=int(left), kernel=info['kernel'], workgroups=info['n_workgroups'],
                                    rounds_deepest_workgroup=depth['max_rounds'][0], evals_per_solve=float(res['n_evals'].mean()),
                                    audit_max=float(np.nanmax(aud)), audit_p99=float(np.nanpercentile(aud, 99)))
+    # the same small jobs four in flight (four contexts take the launches in turn): a launch that does not fill the GPU leaves room for
+    # the others -- its latency is the depth of its chains, its throughput is not
+    for name, n_orb in (('cfg2', 1), ('cfg3', 4)):
+        batch = build_batch(max(n_orb, 2), 200, 500, 100, 0)
+        if n_orb == 1:
+            _, _, _, G1 = synthetic.single_G(200, 500)
+            batch['Gmat'] = G1[None, None, :]
+            batch['elems'], batch['kinds'], batch['v0'] = [(0, 0)], batch['kinds'][:1], batch['v0'][:1]
+        n = len(batch['elems'])
+        lanes = []
+        for _ in range(4):
+            c = stage(batch, 0)
+            c.upload_chains(np.arange(n, dtype=np.int32), batch['alphas'], batch['v0'], device.default_opts())
+            lanes.append(c)
+        for k in range(16):
+            lanes[k % 4].launch()
+        for c in lanes:
+            c.sync()
+        t0 = time.perf_counter()
+        for k in range(4 * n_launch):
+            lanes[k % 4].launch()
+        for c in lanes:
+            c.sync()
+        out[name + '_four_in_flight_ms'] = 1e3 * (time.perf_counter() - t0) / (4 * n_launch)
+        for c in lanes:
+            c.close()
     out['cfg2_ms'], out['cfg3_ms'] = out['cfg2']['kernel_ms'], out['cfg3']['kernel_ms']
     out['cfg2_f32_ms'], out['cfg3_f32_ms'], out['cfg4_f32_ms'] = out['cfg2_f32']['kernel_ms'], out['cfg3_f32']['kernel_ms'], out['cfg4_f32']['kernel_ms']
     out['cfg4_f32_lv_ms'] = out['cfg4_f32_lv']['kernel_ms']
