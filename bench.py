@@ -40,6 +40,12 @@ from maxent_amd import device, synthetic, hostprep   # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 L2_PEAK_GBS = 34500.0          # ... aggregate L2
 N_EVAL_NOMINAL = {'normal': 160, 'plusminus': 84}   # the reference's passes per alpha-solve
+# exit codes behind the printed line (0: everything checked out)
+EXIT_GATHER_MISMATCH = 3       # --gpus N: a rank's gathered chi2 differs from rank 0's one-GPU solve of the whole batch
+EXIT_IN_FLIGHT_CHECK = 4       # a batch in flight came back with an alpha not converged / left to finish / over the audit gate
+EXIT_WATCHDOG = 5              # --in-flight-comm: the region did not come back within the time limit
+EXIT_IN_FLIGHT_FAILED = 6      # --in-flight-comm: the region raised
+AUDIT_GATE = 1e-6
 
 # Counter values per launch of the default workload come from profiles/<tag>_pmc_summary.csv (rocprofv3 --pmc passes on
 # this very command, condensed by tools/summarize_pmc.py), whose first line records the source hash of the library
@@ -55,11 +61,17 @@ PMC_NAMES = dict(valu_active_quadcycles='SQ_ACTIVE_INST_VALU',      # (counts qu
                  l2_hit='TCC_HIT_sum', l2_miss='TCC_MISS_sum')
 
 
-def load_pmc(lib_hash):
+def load_pmc(lib_hash, which='one_launch'):
     """(counters, None) from the newest profiles/*_pmc_summary.csv recorded on this build, or (None, reason)"""
     import glob
     seen = []
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_summary.csv')), reverse=True):
+        # (``*_in_flight_pmc_summary.csv``: the counters of the cut for several batches in flight, launched alone;
+        #  ``*_lv_pmc_summary.csv``: chain_kernel_lv; the rest: the launch of one batch at a time)
+        base = os.path.basename(path)
+        kind = 'in_flight' if base.endswith('_in_flight_pmc_summary.csv') else 'lv' if base.endswith('_lv_pmc_summary.csv') else 'one_launch'
+        if kind != which:
+            continue
         with open(path) as f:
             lines = f.read().splitlines()
         if not lines or not lines[0].startswith('#source_hash,'):
@@ -524,7 +536,7 @@ def in_flight_comm_region(batch, mine, local_rank, rank, world, counts, full, ar
     """The timed region with ``n`` steps in flight on EVERY rank (--gpus N): n contexts per rank, uploaded with mxe_opts.in_flight = n,
     each with a communicator of its own (context k of all ranks form communicator k), take the steps in turn -- launch, device line
     fit, gather to rank 0 on the context's stream.  All ranks issue the steps in the same order.  Returns (elapsed seconds, max
-    over the ranks; on rank 0 also what a step in flight returned).  A shard alone does not fill its GPU and is bound by the depth
+    over the ranks; on rank 0 also what a step in flight returned; the seconds the n communicators took to initialise).  A shard alone does not fill its GPU and is bound by the depth
     of its chains (scaling_projection: 0.39 ms at N = 8); four of them side by side are not (0.2 ms)."""
     opts_fl = device.default_opts(waves_per_chain=args.waves_per_chain, chains_per_wg=args.chains_per_wg,
                                   alpha_split=args.alpha_split, wg_per_cu=args.wg_per_cu, in_flight=n)
@@ -532,8 +544,13 @@ def in_flight_comm_region(batch, mine, local_rank, rank, world, counts, full, ar
     for k in range(n):
         c = stage(batch, local_rank, mine)
         c.upload_chains(np.arange(len(mine), dtype=np.int32), batch['alphas'], batch['v0'][mine], opts_fl)
-        comm_setup(c, rank, world, suffix='_lane%d' % k)
         lanes.append(c)
+    # every communicator BEFORE any launch, one after the other (comm_setup ends with an all-reduce of its own: the ranks leave
+    # communicator k together before anybody starts on k + 1), timed apart from the region
+    t_comm0 = time.perf_counter()
+    for k, c in enumerate(lanes):
+        comm_setup(c, rank, world, suffix='_lane%d' % k)
+    t_comm = time.perf_counter() - t_comm0
 
     def step(k):
         c = lanes[k % n]
@@ -582,7 +599,7 @@ def in_flight_comm_region(batch, mine, local_rank, rank, world, counts, full, ar
     for c in lanes:
         c.comm_destroy()
         c.close()
-    return elapsed, check
+    return elapsed, check, t_comm
 
 
 def main():
@@ -602,10 +619,16 @@ def main():
     ap.add_argument('--chains-per-wg', type=int, default=0)
     ap.add_argument('--alpha-split', type=int, default=0)
     ap.add_argument('--wg-per-cu', type=int, default=0)
-    ap.add_argument('--in-flight', type=int, default=4, choices=(1, 2, 3, 4),
-                    help='batches in flight on the GPU: n device contexts (n streams) take the steps in turn -- a kernel starts on the '
-                         'CUs the ones before it have left, and every batch is cut into 1 / n as many cold-started pieces '
-                         '(mxe_opts.in_flight); one rank only; 1: one batch at a time')
+    ap.add_argument('--in-flight', type=int, default=4, choices=tuple(range(1, 9)),
+                    help='one rank: behind the timed region (ONE context, one batch at a time: value / ms_per_step) a second region with n '
+                         'batches in flight -- n device contexts (n streams) take the steps in turn, every batch cut into 1 / n as many '
+                         'cold-started pieces (mxe_opts.in_flight) -- reported as value_in_flight / ms_per_step_in_flight; 1: skip it')
+    ap.add_argument('--in-flight-comm', type=int, default=0, choices=tuple(range(0, 9)),
+                    help='--gpus N: behind the region with one context per rank, a region with n contexts per rank in flight, a communicator '
+                         'each (under a watchdog).  OFF by default: it has never run between two GPUs (ADVICE r04); 0 or 1: skip it')
+    ap.add_argument('--cut-for-in-flight', type=int, default=0,
+                    help='counter collection only (tools/round_profile.sh): the ONE context of the timed region is uploaded with '
+                         'mxe_opts.in_flight = n -- the launch the batches in flight consist of, alone on the GPU; not a bench line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the audit / parity / end-to-end blocks')
     ap.add_argument('--shard-of', type=int, default=0,
@@ -626,7 +649,7 @@ def main():
         if args.gpus > 1:
             sys.exit(2)
     use_comm = world > 1 or args.force_comm
-    default_workload = (args.n_orb, args.n_tau, args.n_omega, args.n_alpha) == (16, 200, 500, 100)
+    default_workload = (args.n_orb, args.n_tau, args.n_omega, args.n_alpha) == (16, 200, 500, 100) and args.cut_for_in_flight <= 1
 
     pool_baseline = None
     if world == 1 and not args.no_cpu_baseline:
@@ -645,7 +668,7 @@ def main():
         mine = [e for e in range(n_elem) if e % args.shard_of == args.shard_rank % args.shard_of]
     ctx = stage(batch, local_rank, mine)
     opts = device.default_opts(waves_per_chain=args.waves_per_chain, chains_per_wg=args.chains_per_wg,
-                               alpha_split=args.alpha_split, wg_per_cu=args.wg_per_cu)
+                               alpha_split=args.alpha_split, wg_per_cu=args.wg_per_cu, in_flight=max(args.cut_for_in_flight, 0))
     ctx.upload_chains(np.arange(len(mine), dtype=np.int32), batch['alphas'], batch['v0'][mine], opts)
     P_rank = len(mine) * args.n_alpha
     P_job = n_elem * args.n_alpha * (1 if strong else world)
@@ -707,27 +730,36 @@ def main():
         one_step()
     barrier()
     settle()
-    one_at_a_time = None
-    if in_flight > 1:
-        # first the same number of steps with ONE batch at a time (rounds 1-3 timed this), in the same run ...
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            one_step()
-        ctx.sync()
-        e1 = time.perf_counter() - t1
-        one_at_a_time = dict(ms_per_step=1e3 * e1 / args.steps, value=P_job * args.steps / e1)
-    # ... and behind them (as in rounds 1-3) the dominant kernel's own duration: HIP events around launches on the library's
+    # ---- THE timed region: K steps through ONE context, one batch at a time (what rounds 1-3 timed; ``value`` is this region
+    # again since round 5 -- ADVICE r04: rounds compare like with like; the steps-in-flight figure is value_in_flight) ----
+    barrier()
+    ctx.timing_mark()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    t_enq = time.perf_counter()
+    ctx.sync()                       # on rank 0: every gather of the region has landed
+    t_drained = time.perf_counter()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if use_comm:
+        elapsed = float(ctx.allreduce([elapsed], 'max')[0])
+    host_split = dict(enqueue_ms=1e3 * (t_enq - t0), wait_ms=1e3 * (t_drained - t_enq))
+    # ... and behind it (as in rounds 1-3) the dominant kernel's own duration: HIP events around launches on the library's
     # stream, back to back, one launch at a time.  (Where it is taken matters by 1-3 % on these boxes: right behind the
-    # warm-up the clocks have not come up (0.84 ms), behind the region with launches in flight they are lower (0.825).)
+    # warm-up the clocks have not come up (0.84 ms), behind a region with launches in flight they are lower (0.825).)
     ctx.sync()
     ctx.timing_mark()
     for _ in range(50):
         ctx.launch()
     k_ms = ctx.ms_since_mark() / 50
+
+    in_flight_region = None
+    in_flight_check = None
     if in_flight > 1:
-        # now the contexts of the batches in flight -- and ONLY they: the streams of a process share four hardware queues, a fifth
-        # stream halves the rate of the one it shares a queue with (0.98 instead of 0.65 ms per step); ``ctx`` comes back behind
-        # the timed region
+        # ---- a SECOND region, reported beside the line (value_in_flight): the same steps with ``in_flight`` batches in flight.
+        # Its contexts -- and ONLY they: the streams of a process share four hardware queues by default, a fifth stream halves the
+        # rate of the one it shares a queue with; ``ctx`` comes back behind the region
         ctx.close()
         opts_fl = device.default_opts(waves_per_chain=args.waves_per_chain, chains_per_wg=args.chains_per_wg,
                                       alpha_split=args.alpha_split, wg_per_cu=args.wg_per_cu, in_flight=in_flight)
@@ -736,26 +768,32 @@ def main():
             c = stage(batch, local_rank, mine)
             c.upload_chains(np.arange(len(mine), dtype=np.int32), batch['alphas'], batch['v0'][mine], opts_fl)
             lanes.append(c)
+        turn[0] = 0
         for _ in range(max(args.warmup, 2 * in_flight)):
             one_step()
         barrier()
         settle()
-    barrier()
-    lanes[0].timing_mark()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    t_enq = time.perf_counter()
-    for c in lanes:
-        c.sync()                     # on rank 0: every gather of the region has landed
-    t_drained = time.perf_counter()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_comm:
-        elapsed = float(ctx.allreduce([elapsed], 'max')[0])
-    host_split = dict(enqueue_ms=1e3 * (t_enq - t0), wait_ms=1e3 * (t_drained - t_enq))
-    in_flight_check = None
-    if in_flight > 1:
+        barrier()
+        # (a) as a driver's clock sees K steps: from an idle GPU to an idle GPU, filling and draining included
+        t0f = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        for c in lanes:
+            c.sync()
+        e_fl = time.perf_counter() - t0f
+        # (b) with the pipeline full at both ends: one un-timed step per lane, an event behind it on every lane's stream, K steps,
+        # the time to the end of every lane's last kernel (events; every lane's interval covers ~K steps of all lanes together)
+        steps_b = max(in_flight, (args.steps // in_flight) * in_flight)
+        turn[0] = 0
+        for _ in range(in_flight):
+            one_step()
+        for c in lanes:
+            c.timing_mark()
+        for _ in range(steps_b):
+            one_step()
+        lane_ms = [c.ms_since_mark() for c in lanes]
+        for c in lanes:
+            c.sync()
         # what the batches in flight returned: every alpha converged, the exact Newton correction at the returned v of every problem
         lanes[-1].launch()
         left = lanes[-1].finish()
@@ -765,13 +803,16 @@ def main():
                                converged=int(o_fl['converged'].sum()), alpha_solves=int(o_fl['converged'].size),
                                left_to_finish=int(left), evals_per_solve=float(o_fl['n_evals'].mean()),
                                audit_max=float(np.nanmax(a_fl)), audit_p99=float(np.nanpercentile(a_fl, 99)))
+        in_flight_region = dict(contexts=in_flight, steps=args.steps, ms_per_step=1e3 * e_fl / args.steps,
+                                value=P_job * args.steps / e_fl,
+                                ms_per_step_steady=float(np.mean(lane_ms)) / steps_b, steps_steady=steps_b,
+                                lane_interval_ms=[float(x) for x in lane_ms])
         for c in lanes:
             c.close()
         lanes = []
         ctx = stage(batch, local_rank, mine)          # (the context of one batch at a time again, for what follows)
         ctx.upload_chains(np.arange(len(mine), dtype=np.int32), batch['alphas'], batch['v0'][mine], opts)
         lanes = [ctx]
-
 
     gather_checked = None
     if use_comm and rank == 0:
@@ -809,19 +850,27 @@ def main():
     # several in flight on every rank.  It is the LAST thing a rank does, under a watchdog: communicators per context have run
     # on one GPU only (--force-comm); if the region does not come back, rank 0 prints the line of the region above and
     # everybody leaves.
-    n_fl_comm = args.in_flight if (use_comm and args.in_flight > 1) else 1
+    n_fl_comm = args.in_flight_comm if (use_comm and args.in_flight_comm > 1) else 1
     if rank != 0:
         ctx.comm_destroy()
         ctx.close()
         if n_fl_comm > 1:
             import threading
-            dog = threading.Timer(float(os.environ.get('MXE_BENCH_IN_FLIGHT_TIMEOUT', '180')), lambda: os._exit(0))
+
+            def bail():
+                print('bench.py: rank %d: the region with steps in flight did not come back within the time limit (watchdog); '
+                      'rank 0 prints the line of the region with one context per rank' % rank, file=sys.stderr)
+                sys.stderr.flush()
+                os._exit(EXIT_WATCHDOG)
+            dog = threading.Timer(float(os.environ.get('MXE_BENCH_IN_FLIGHT_TIMEOUT', '180')), bail)
             dog.daemon = True
             dog.start()
             try:
                 in_flight_comm_region(batch, mine, local_rank, rank, world, counts, full, args, n_fl_comm)
             except Exception as exc:          # (rank 0 reports the region above)
                 print('bench.py: rank %d left the region with steps in flight: %r' % (rank, exc), file=sys.stderr)
+                dog.cancel()
+                sys.exit(EXIT_IN_FLIGHT_FAILED)
             dog.cancel()
         return
 
@@ -922,14 +971,12 @@ def main():
                                                                n_elem * args.n_alpha, args.n_tau, args.n_omega, n_s)) +
                              ('the one batch sharded over %d GPU(s), element e on rank e mod N' % world if strong
                               else 'one such batch per GPU (%d GPUs, weak scaling)' % world),
-                    in_flight=in_flight,
-                    in_flight_note=('%d device contexts (%d streams), uploaded with mxe_opts.in_flight = %d, take the steps in turn: a '
-                                    'launch starts on the CUs whose workgroups of the launches before have finished (the slowest workgroup '
-                                    'of a launch runs 12 %% longer than the mean), and a GPU that %d batches share is full with a quarter '
-                                    'of the cold-started pieces one batch alone is cut into; one_at_a_time holds the same steps through '
-                                    'one context with the cut for one batch, the figure of rounds 1-3; in_flight_check: what a batch in '
-                                    'flight returned' % (in_flight, in_flight, in_flight, in_flight)
-                                    if in_flight > 1 else 'one batch at a time'),
+                    in_flight=1,
+                    in_flight_note=('value / ms_per_step: ONE device context, one batch at a time (the region of rounds 1-3).  '
+                                    'value_in_flight / ms_per_step_in_flight: a second region of the same run with %d contexts (%d streams), '
+                                    'uploaded with mxe_opts.in_flight = %d, taking the steps in turn -- what ElementwiseMaxEnt jobs reach through '
+                                    'maxent_amd.run_many (end_to_end.many_objects); in_flight_check: what a batch in flight returned'
+                                    % (in_flight, in_flight, in_flight) if in_flight > 1 else 'one batch at a time'),
                     in_flight_check=in_flight_check,
                     step='chain kernel + device line fit' + (' + one RCCL gather (%s) to rank 0: %.2f MB per step'
                                                             % (what, float(np.sum(counts)) * 8 / 1e6) if use_comm else ''),
@@ -947,18 +994,39 @@ def main():
                                    'With --gpus N the region with one context per rank is timed first and kept as the line unless the region '
                                    'behind it -- four contexts per rank, a communicator each, under a watchdog -- comes back faster'),
                 roofline=roofline)
-    if one_at_a_time is not None:
-        line['one_at_a_time'] = one_at_a_time
-        # the issue slots that are busy over the TIMED REGION (launches overlapping), next to frac, which prices one launch alone
-        if achieved is not None and in_flight_check is not None:
-            # (the batches in flight are cut into fewer pieces and execute fewer evaluations per alpha than the launch the counters
-            #  were recorded on: the busy cycles are scaled with the evaluations)
-            scale = in_flight_check['evals_per_solve'] / float(out['n_evals'].mean())
-            roofline['frac_timed_region'] = scale *  (4 * pmc['valu_active_quadcycles'] + pmc['mfma_busy_cycles'] - pmc['coexec_cycles']) * \
-                args.steps / elapsed / 1e9 / peak
-            roofline['frac_timed_region_note'] = ('busy SIMD-cycles per launch (the same counters) x steps / the elapsed time of the timed '
-                                                  'region, in which the launches of several contexts are in flight (scaled with the evaluations per alpha of their cut); frac, achieved and kernel_ms are those of '
-                                                  'ONE launch with the GPU to itself (what rocprofv3 records under profiles/ with --in-flight 1)')
+    # ---- flat scalars (the driver's record keeps top-level keys): kernel, one batch at a time, batches in flight ----
+    line['kernel_ms'] = k_ms
+    line['one_at_a_time_ms'] = line['ms_per_step']
+    line['one_at_a_time_value'] = line['value']
+    line['evals_per_solve'] = float(out['n_evals'].mean())
+    line['watchdog_fired'] = False
+    line['in_flight_ok'] = None
+    if in_flight_region is not None:
+        line['in_flight'] = in_flight_region
+        line['in_flight_contexts'] = in_flight_region['contexts']
+        line['value_in_flight'] = in_flight_region['value']
+        line['ms_per_step_in_flight'] = in_flight_region['ms_per_step']
+        line['ms_per_step_in_flight_steady'] = in_flight_region['ms_per_step_steady']
+        line['value_in_flight_steady'] = P_job / (1e-3 * in_flight_region['ms_per_step_steady'])
+        line['in_flight_converged'] = in_flight_check['converged']
+        line['in_flight_alpha_solves'] = in_flight_check['alpha_solves']
+        line['in_flight_left_to_finish'] = in_flight_check['left_to_finish']
+        line['in_flight_audit_max'] = in_flight_check['audit_max']
+        line['in_flight_evals_per_solve'] = in_flight_check['evals_per_solve']
+        line['in_flight_ok'] = bool(in_flight_check['converged'] == in_flight_check['alpha_solves'] and
+                                    in_flight_check['left_to_finish'] == 0 and in_flight_check['audit_max'] < AUDIT_GATE)
+        pmc_fl, why_fl = (load_pmc(lib_hash, 'in_flight') if (default_workload and world == 1 and args.shard_of <= 1)
+                          else (None, 'counters are collected for the default workload on one GPU only'))
+        if pmc_fl:
+            # the issue slots that are busy over the region with launches in flight: the counters of THAT cut (256 workgroups, four
+            # pieces per scan) launched alone -- profiles/*_in_flight_pmc_summary.csv, same source hash -- x steps / elapsed time
+            busy_fl = 4 * pmc_fl['valu_active_quadcycles'] + pmc_fl['mfma_busy_cycles'] - pmc_fl['coexec_cycles']
+            roofline['frac_in_flight_region'] = busy_fl / (1e-3 * in_flight_region['ms_per_step']) / 1e9 / peak
+            roofline['frac_in_flight_region_steady'] = busy_fl / (1e-3 * in_flight_region['ms_per_step_steady']) / 1e9 / peak
+            roofline['frac_in_flight_source'] = pmc_fl['source']
+        else:
+            roofline['frac_in_flight_region'] = None
+            roofline['frac_in_flight_null_reason'] = why_fl
     if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(batch, out)
         line['cpu_baseline']['all_cores'] = pool_baseline
@@ -988,43 +1056,51 @@ def main():
         line['end_to_end'] = end_to_end_block(batch, args.n_orb, args.n_alpha)
         if default_workload and args.shard_of <= 1:
             line['underfilled'] = underfilled_block()
+    exit_code = 0
     if n_fl_comm > 1:
         import threading
+        line['in_flight_comm_region'] = dict(ran=False, contexts_per_rank=n_fl_comm, ms_per_step=None, value=None, error=None)
 
         def give_up():
-            line['config']['in_flight_note'] = ('the region with %d steps in flight on every rank did not come back within the time '
-                                                'limit: this is the region with one context per rank' % n_fl_comm)
+            line['watchdog_fired'] = True
+            line['in_flight_comm_region']['error'] = 'did not come back within the time limit (watchdog)'
             print(json.dumps(line))
             sys.stdout.flush()
-            os._exit(0)
+            print('bench.py: the region with %d steps in flight on every rank did not come back within the time limit: the line is '
+                  'that of the region with one context per rank; exit code %d' % (n_fl_comm, EXIT_WATCHDOG), file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(EXIT_WATCHDOG)
         dog = threading.Timer(float(os.environ.get('MXE_BENCH_IN_FLIGHT_TIMEOUT', '180')), give_up)
         dog.daemon = True
         dog.start()
         try:
-            e_fl, check_fl = in_flight_comm_region(batch, mine, local_rank, rank, world, counts, full, args, n_fl_comm)
+            e_fl, check_fl, t_comm = in_flight_comm_region(batch, mine, local_rank, rank, world, counts, full, args, n_fl_comm)
             dog.cancel()
-            fl = dict(ms_per_step=1e3 * e_fl / args.steps, value=P_job * args.steps / e_fl, contexts_per_rank=n_fl_comm, check=check_fl)
-            if fl['value'] > line['value']:
-                line['one_at_a_time'] = dict(ms_per_step=line['ms_per_step'], value=line['value'],
-                                             note='one context per rank: the region every round so far would have timed')
-                line['value'], line['ms_per_step'] = fl['value'], fl['ms_per_step']
-                line['config']['in_flight'] = n_fl_comm
-                line['config']['in_flight_check'] = check_fl
-                line['config']['in_flight_note'] = ('%d device contexts per rank, uploaded with mxe_opts.in_flight = %d and each with a '
-                                                    'communicator of its own, take the steps in turn (launch, device line fit, gather to rank 0 '
-                                                    'on the context\'s stream); one_at_a_time: one context per rank' % (n_fl_comm, n_fl_comm))
-            else:
-                # (the line stays that of one context per rank; what the steps in flight gave is beside it)
-                line['steps_in_flight'] = fl
-                line['config']['in_flight_note'] = 'one context per rank was faster than %d contexts in flight (steps_in_flight)' % n_fl_comm
+            ok_fl = bool(check_fl['converged'] == check_fl['alpha_solves'] and check_fl['left_to_finish'] == 0 and
+                         check_fl['audit_max'] < AUDIT_GATE)
+            line['in_flight_comm_region'].update(ran=True, ms_per_step=1e3 * e_fl / args.steps, value=P_job * args.steps / e_fl,
+                                                 check=check_fl, ok=ok_fl, communicators_init_s=t_comm)
+            line['value_in_flight'] = line['in_flight_comm_region']['value']
+            line['ms_per_step_in_flight'] = line['in_flight_comm_region']['ms_per_step']
+            line['in_flight_contexts'] = n_fl_comm
+            line['in_flight_ok'] = ok_fl
+            if not ok_fl:
+                exit_code = EXIT_IN_FLIGHT_CHECK
         except Exception as exc:
             dog.cancel()
-            line['config']['in_flight_note'] = 'the region with steps in flight failed (%r): this is the region with one context per rank' % (exc,)
+            line['in_flight_comm_region']['error'] = repr(exc)
+            print('bench.py: the region with steps in flight failed: %r' % (exc,), file=sys.stderr)
+            exit_code = EXIT_IN_FLIGHT_FAILED
+    if line.get('in_flight_ok') is False and exit_code == 0:
+        print('bench.py: a batch in flight did not pass its check: %r' % (in_flight_check,), file=sys.stderr)
+        exit_code = EXIT_IN_FLIGHT_CHECK
     print(json.dumps(line))
     if gather_checked is False:
         # every rank's chi2 as gathered must be what rank 0 gets when it solves the whole batch itself
         print('bench.py: the gathered results of the ranks differ from the one-GPU solve of the same batch', file=sys.stderr)
-        sys.exit(3)
+        sys.exit(EXIT_GATHER_MISMATCH)
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == '__main__':

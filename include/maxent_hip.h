@@ -144,10 +144,12 @@ typedef struct mxe_opts {
                                 cost_function.py:60, bryan_cost_function.py:71); default 1       */
     int32_t lds_basis;       /* lock-step layout with V^T resident in the LDS as binary32 (chain_kernel_lv; it needs
                                 n_s * (n_omega_pad + 4) * 4 B + 47 KB <= 160 KB: the BASELINE grids just fit).
-                                0 = auto: it IS the launch for precision = MXE_PRECISION_F32, and the first pass of a
-                                binary64 launch that does not fill the GPU (every alpha to 1e-5 in binary32, then one
-                                binary64 Newton step per alpha in the lock-step kernel, all alphas side by side);
-                                1 = also for binary64 launches that do fill it; 2 = never                        */
+                                0 = auto: it IS the launch for precision = MXE_PRECISION_F32 (where the basis fits) and is
+                                NOT used by binary64 launches;
+                                1 = opt-in: also the first pass of every binary64 launch (every alpha to 1e-5 in binary32,
+                                then one binary64 Newton step per alpha in the lock-step kernel, all alphas side by side) --
+                                correct, measured NOT faster than the plain binary64 launch, hence not auto;
+                                2 = never                                                                        */
     int32_t in_flight;       /* batches of this size the caller keeps in flight on the GPU (launches of several
                                 contexts enqueued without waiting in between): 0 or 1 = one -- the scans are cut into
                                 enough cold-started pieces to fill the GPU on their own --, n > 1: into 1 / n as many

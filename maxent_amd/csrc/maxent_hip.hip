@@ -269,6 +269,7 @@ struct mxe_ctx {
     DevBuf<int> dsub_pre, dsub_init;
     DevBuf<double> dinit_tab;           // start states per class of pieces (KParams::init_tab)
     DevBuf<double> dgstate;             // omega-space state of the chains when it does not fit LDS (KParams::gstate)
+    DevBuf<int> dfin_budget;            // mxe_chains_finish: iterations every alpha may still spend
     DevBuf<int> dfin_elem, dfin_prob0, dfin_len, dfin_v0;       // mxe_chains_finish: one piece per alpha that is solved again
     DevBuf<double> dfin_start;          //   and its start vector (the state the lock-step kernel left)
     int sel3_nc = 0;                    // scans of the launch the last mxe_select3_launch chose for (0: none since the chains were uploaded)
@@ -1401,6 +1402,7 @@ static void fill_kparams(mxe_ctx* ctx, KParams& kp)
     kp.gstate = nullptr;
     kp.mc_maxiter = std::min(o.maxiter, std::max(MC_MAXITER, o.miniter + 8));     // (a caller's miniter above the limit moves it)
     kp.mc_abandon = 1;
+    kp.prob_maxiter = nullptr;
 }
 
 namespace {
@@ -1697,12 +1699,16 @@ try {
     }
 #endif
     {
-        // the caller's maxiter bounds the iterations of an alpha over BOTH passes (the reference caps them per alpha,
-        // levenberg_minimizer.py:155): this pass gets what the lock-step pass left of it (one budget per launch: that of the
-        // open alpha with the most iterations behind it)
-        int spent = 0;
-        for (size_t i = 0; i < P; ++i) if (open[i]) spent = std::max(spent, nit[i]);
-        kp.maxiter = std::max(1, o.maxiter - spent);
+        // the caller's maxiter bounds the iterations of an alpha over BOTH passes, alpha by alpha as the reference caps them
+        // (levenberg_minimizer.py:155): every open alpha gets what the lock-step pass left of ITS budget -- an alpha that pass
+        // never touched (the rest of an abandoned piece, an excluded alpha: nit = 0) the whole of it.  (Until round 5 the pass had
+        // ONE budget, that of the open alpha with the most iterations behind it: ADVICE r04.)
+        std::vector<int> budget(P, o.maxiter);
+        for (size_t i = 0; i < P; ++i) if (open[i]) budget[i] = std::max(1, o.maxiter - nit[i]);
+        HIPCHK(ctx, ctx->dfin_budget.ensure(P));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_budget.p, budget.data(), P * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, stream_wait(ctx->stream));          // (budget is a local)
+        kp.prob_maxiter = ctx->dfin_budget.p;
     }
     const int NW = 4;
     size_t lds = lds_bytes(NP, ctx->nwp, NW, false);

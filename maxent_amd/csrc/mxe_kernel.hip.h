@@ -96,6 +96,9 @@ struct KParams {
     // those alphas to the one-chain kernel (binary64 Gram matrix)
     int mc_maxiter;
     int mc_abandon;      // lock-step kernel: an alpha it gives up on ends its piece (the rest is left to mxe_chains_finish)
+    // (one-chain kernel) iterations problem p may still spend, or nullptr: maxiter for every alpha.  mxe_chains_finish sets it:
+    // the caller's maxiter caps the iterations of ONE alpha over both passes (levenberg_minimizer.py:155 caps per alpha)
+    const int* prob_maxiter;    // [P]
 };
 
 #if defined(MXE_PROFILE) && defined(MXE_PROFILE_EVAL)
@@ -1262,7 +1265,8 @@ void chain_kernel(const KParams p)
         double relH_prev = 1e300;
         double mu_hint = 0.0;       // damping the last damped step of this alpha needed
 
-        for (int it = 0; it < p.maxiter && !failed; ++it) {
+        const int maxit = p.prob_maxiter ? p.prob_maxiter[(size_t)prob0 + ia] : p.maxiter;
+        for (int it = 0; it < maxit && !failed; ++it) {
             for (int k = tid; k < NP; k += T) {
                 const double vv = v[k], r = rho[k];
                 g[k]   = (k < ns) ? fma(cc[k], r, alpha * vv) : 0.0;

@@ -49,7 +49,12 @@ class _Recent(object):
     ElementwiseMaxEnt on the grids of an earlier one -- every iteration of a self-consistency loop, both workers of an
     element-wise run -- fills and decomposes the same 200 x 500 matrix again (reference elementwise_maxent.py:170-221: one fresh
     SVD per ELEMENT; here it was one per object, 6.5-7.7 ms of the 13-15 ms a fresh object took).  Entries are found by a content
-    hash and confirmed by comparing the arrays; what they hand out is shared and read-only."""
+    hash and confirmed by comparing the arrays; what they hand out is shared and READ-ONLY.
+
+    Contract (differs from the reference, where ``K.K``, ``K.K_delta``, ``K.U``, ``K.S``, ``K.V`` are private writable arrays):
+    in-place edits such as ``K.K[...] *= x`` raise numpy's "assignment destination is read-only".  Code that wants to change
+    a kernel assigns a NEW array (``kernel._K = kernel.K * x``) or works on ``np.array(kernel.K)``; README.md, "Differences a
+    user of the reference will notice"."""
 
     def __init__(self, size=4):
         import collections

@@ -24,6 +24,9 @@ M = V^T K^T diag(1/err^2) K V, also in extended precision.
 import numpy as np
 
 LD = np.longdouble
+TOL = 1e-12            # relative Newton correction at which a polish counts as converged
+CAP = 2.0              # largest rise of u in one guarded step
+MAX_GUARDED = 400      # iterations of the guarded (line-search) form
 
 
 def _lu_solve(A, b):
@@ -46,11 +49,22 @@ def _lu_solve(A, b):
 
 
 def polish(K, G, err, D, V, S, alpha, v0, entropy='normal', iters=5,
-           history=None):
+           history=None, info=None):
     """Newton-polish ``v0`` (in the basis V, V^T V = 1) in extended precision.
 
     ``S``: unused (kept for call compatibility).  Returns
     ``(v, H)`` rounded to binary64.
+
+    ``info`` (a dict, optional) receives ``converged`` (the last Newton
+    correction, ``|w * V dv| / |H|``, is below ``TOL``), ``corr`` (that
+    correction), ``iterations`` and ``damped``.  The plain iteration -- ``iters``
+    full steps, what every committed fixture was made with -- runs first and its
+    result is returned unchanged when it converged.  Where it does not (a start
+    whose gradient has a large component along a direction in which H is ~0: the
+    full step lifts u there by hundreds and exp overflows -- element (15, 15) of
+    BASELINE config 4 at the smallest alpha), the iteration is repeated from
+    ``v0`` with the step scaled so that u rises by at most ``CAP`` anywhere
+    (full steps must also lower |g|), until the correction is below ``TOL``.
     """
     err = np.asarray(err, dtype=float) * np.ones(len(G))
     K_ = K.astype(LD)
@@ -58,11 +72,11 @@ def polish(K, G, err, D, V, S, alpha, v0, entropy='normal', iters=5,
     e_ = err.astype(LD)
     D_ = np.asarray(D).astype(LD)
     V_ = V.astype(LD)
-    v = np.asarray(v0).astype(LD)
     a = LD(alpha)
     # exact singular-space curvature of chi2/2:  M = V^T K^T diag(1/err^2) K V
     KV = K_ @ V_
     M = (KV / e_[:, None] ** 2).T @ KV
+    eye = np.eye(V_.shape[1], dtype=LD)
 
     def state(v):
         u = V_ @ v
@@ -76,19 +90,66 @@ def polish(K, G, err, D, V, S, alpha, v0, entropy='normal', iters=5,
             w = Hp + Hm
         return H, w
 
-    for it in range(iters):
-        H, w = state(v)
+    def grad(v, H):
         r = (K_ @ H - G_) / e_ ** 2
-        g = V_.T @ (K_.T @ r) + a * v
+        return V_.T @ (K_.T @ r) + a * v
+
+    def newton(v, H, w, g):
         W = (V_.T * w) @ V_
         # exact Newton step:  d g / d v = M W + alpha I  (row-equilibrated)
-        J = M @ W + a * np.eye(len(v), dtype=LD)
+        J = M @ W + a * eye
         sc = 1 / np.max(np.abs(J), axis=1)
         dl = _lu_solve(J * sc[:, None], g * sc)
-        if history is not None:
-            history.append((float(np.abs(g).max()),
-                            float(np.linalg.norm(w * (V_ @ dl)) /
-                                  np.linalg.norm(H))))
-        v = v - dl
-    H, _ = state(v)
+        return dl, float(np.linalg.norm(w * (V_ @ dl)) / np.linalg.norm(H))
+
+    def report(converged, corr, n, damped):
+        if info is not None:
+            info.update(converged=bool(converged), corr=float(corr), iterations=n, damped=damped)
+
+    # --- the plain iteration (bit for bit what made the fixtures) ---
+    v = np.asarray(v0).astype(LD)
+    corr = np.inf
+    with np.errstate(all='ignore'):
+        for it in range(iters):
+            H, w = state(v)
+            g = grad(v, H)
+            dl, corr = newton(v, H, w, g)
+            if history is not None:
+                history.append((float(np.abs(g).max()), corr))
+            v = v - dl
+        H, _ = state(v)
+    if np.all(np.isfinite(H)) and np.all(np.isfinite(v)) and corr < TOL:
+        report(True, corr, iters, False)
+        return v.astype(float), H.astype(float)
+
+    # --- guarded iteration: the same steps, capped in max(du) ---
+    v = np.asarray(v0).astype(LD)
+    H, w = state(v)
+    g = grad(v, H)
+    gn = np.linalg.norm(g)
+    corr, n = np.inf, 0
+    with np.errstate(all='ignore'):
+        for n in range(1, MAX_GUARDED + 1):
+            dl, corr = newton(v, H, w, g)
+            # H grows by at most e^CAP per step anywhere: the exponential is what the linear model misses
+            du = V_ @ dl
+            rise = float(np.max(-du if entropy == 'normal' else np.abs(du)))
+            t = LD(1) if rise <= CAP else LD(CAP / rise)
+            while True:
+                vt = v - t * dl
+                Ht, wt = state(vt)
+                gt = grad(vt, Ht)
+                gtn = np.linalg.norm(gt)
+                if np.isfinite(gtn) and (gtn < gn or t < 1):
+                    break
+                t = t / 2
+                if t < LD(2) ** -60:
+                    report(False, corr, n, True)
+                    return vt.astype(float), np.full(len(D_), np.nan)
+            if history is not None:
+                history.append((float(np.abs(g).max()), corr, float(t)))
+            v, H, w, g, gn = vt, Ht, wt, gt, gtn
+            if t == 1 and corr < TOL:
+                break
+    report(corr < TOL, corr, n, True)
     return v.astype(float), H.astype(float)

@@ -94,7 +94,8 @@ def _rank(rank, port, q):
             real = bench.time.perf_counter
             bench.time.perf_counter = lambda: real() * 1.7
         batch = dict(alphas=np.ones(5), v0=np.zeros((3, 4)))
-        elapsed, check = bench.in_flight_comm_region(batch, [0, 1, 2], 0, rank, WORLD, [10, 10], False, Args, 4)
+        elapsed, check, t_comm = bench.in_flight_comm_region(batch, [0, 1, 2], 0, rank, WORLD, [10, 10], False, Args, 4)
+        assert t_comm > 0                      # (the four communicators are made one after the other BEFORE any launch, timed apart)
         assert FakeCtx.made == 4 and log.count('destroyed') == 4 and log.count('closed') == 4
         assert elapsed > 0 and ((check is not None and check['converged'] == 15) if rank == 0 else check is None)
         # the hand-shake of ONE context (the first region of bench.py) with its own file, behind the four above

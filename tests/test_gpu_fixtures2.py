@@ -11,7 +11,18 @@ import maxent_amd as mx
 from maxent_amd import device, synthetic
 
 pytestmark = pytest.mark.gpu
-os.environ['MAXENT_AMD_AUDIT'] = '1'          # every launch of the drivers is audited on the device (BatchSolver.solve: info['audit_max'])
+
+
+@pytest.fixture(autouse=True, scope='module')
+def _audit_every_launch():
+    """every launch of the drivers is audited on the device (BatchSolver.solve: info['audit_max']) -- for THIS module only
+    (it used to be set at import and leaked into every later test of the process: ADVICE r04)"""
+    mp = pytest.MonkeyPatch()
+    mp.setenv('MAXENT_AMD_AUDIT', '1')
+    yield
+    mp.undo()
+
+
 GATE = 1e-6
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 

@@ -93,8 +93,10 @@ def test_cfg4_stationarity_and_truth_on_a_sample(cfg4):
             # gradient small against the size of its (cancelling) terms; the accuracy of H
             # itself is checked against the extended-precision truth below
             assert np.max(np.abs(d)) < 5e-3 * np.max(scale)
-            worst = max(worst, np.linalg.norm(out['H'][c, ia] - truth[ia]) / np.linalg.norm(truth[ia]))
-    assert worst < 1e-6, worst
+            e = anchor.rel_l2_checked(out['H'][c, ia], truth[ia])
+            assert e < 1e-6, (c, ia, e)
+            worst = max(worst, e)
+    assert 0 < worst < 1e-6, worst
 
 
 @pytest.mark.parametrize('opts', [dict(alpha_split=1, chains_per_wg=1), dict(alpha_split=4, chains_per_wg=1),

@@ -54,6 +54,61 @@ def test_binary32_launch_runs_in_the_lds_resident_kernel(n_omega, n_alpha):
     assert rel_l2(old['H'], out['H']).max() < 2e-4
 
 
+def test_chain_kernel_lv_against_the_reference_anchored_truth_cfg2():
+    """chain_kernel_lv against the ORACLE, not against the repo's own binary64 kernel: BASELINE config 2 (the
+    reference-generated fixture cfg2_normal.npz: n_tau = 200, n_omega = 500, 100 alpha) in precision = F32 -- the kernel that ran
+    is asserted by name --, class 1e-4 against ``H_truth`` (the reference's own iterate polished in extended precision,
+    tests/golden/make_golden.py), 5e-5 against the reference's raw H (its own stopping slack is 9e-6), device audit < 1e-4.
+    Reference path: levenberg_minimizer.py:123-248 around maxent_loop.py:241-245; BASELINE.json config 5 (fp32 leg)."""
+    from maxent_amd import hostprep
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cfg2_normal.npz')
+    with np.load(gold, allow_pickle=False) as d:
+        g = {k: d[k] for k in d.files}
+    ctx = device.DeviceContext(g['U'], g['S'], g['V'], device=0)          # the reference's own decomposition
+    ds = ctx.add_dataset(np.asarray(g['err']) * np.ones(len(g['tau'])))
+    D = np.asarray(g['D'])
+    ctx.set_elements([ds], [g['G']], D[None, :], [device.ENTROPY_NORMAL])
+    v0 = hostprep.initial_v(g['V'], D, np.asarray(g['delta']), device.ENTROPY_NORMAL)[None, :]
+    out = ctx.solve_chains([0], g['alpha'], v0, device.default_opts(precision=device.PRECISION_F32))      # g['alpha']: alpha * n_tau
+    info = ctx.last_launch_info()
+    audit = ctx.audit()['corr']
+    ctx.close()
+    assert info['kernel'] == 'mxe::chain_kernel_lv', info
+    assert out['converged'].all()
+    rows = g['rows']
+    e_truth = rel_l2(out['H'][0][rows], g['H_truth'])
+    assert np.all(np.isfinite(e_truth)) and 1e-9 < e_truth.max() < 1e-4, e_truth.max()
+    e_ref = rel_l2(out['H'][0][rows], g['H_ref'])
+    assert e_ref.max() < 5e-5, e_ref.max()
+    assert np.all(np.isfinite(audit)) and np.nanmax(audit) < 1e-4
+    np.testing.assert_allclose(out['chi2'][0], g['chi2_ref'], rtol=2e-3)
+
+
+def test_chain_kernel_lv_against_the_reference_anchored_truth_cfg3():
+    """BASELINE config 3 (4 x 4 matrix, 16 scans x 100 alpha) in precision = F32: chain_kernel_lv by name, one diagonal and one
+    off-diagonal element against the extended-precision truth reached from the ORACLE PORT's iterates (tests/anchor.py), class
+    1e-4; every problem's device audit < 1e-4."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import anchor
+    from oracle import ref_numpy as R
+    batch = bench.build_batch(4, 200, 500, 100, 0)
+    out, info, left = solve(batch, precision=device.PRECISION_F32)
+    assert info['kernel'] == 'mxe::chain_kernel_lv', info
+    assert out['converged'].all() and left == 0
+    assert np.all(np.isfinite(out['audit'])) and np.nanmax(out['audit']) < 1e-4
+    K = batch['K']
+    rows = (0, 40, 80, 99)
+    for c in (0, 1):                       # element (0, 0): normal entropy; (0, 1): plus-minus
+        i, j = batch['elems'][c]
+        ent = 'normal' if i == j else 'plusminus'
+        p = R.Problem(np.array(K.K), K.U, K.S, K.V, batch['Gmat'][i, j], batch['err'], batch['D'], entropy=ent)
+        truth, ref = anchor.truth_rows(p, batch['omega'].delta, batch['alphas'], len(batch['tau']), rows, ent)
+        for ia in rows:
+            e = anchor.rel_l2_checked(out['H'][c, ia], truth[ia])
+            assert e < 1e-4, (c, ia, e)
+        assert rel_l2(out['H'][c], ref['H']).max() < 1e-4
+
+
 def test_a_basis_that_does_not_fit_the_lds_keeps_the_one_chain_binary32_kernel():
     batch = bench.build_batch(2, 100, 1000, 10, 0)           # n_omega_pad = 1024: 56 x 1028 floats are 230 KB
     out, info, _ = solve(batch, precision=device.PRECISION_F32)
