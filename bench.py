@@ -307,6 +307,8 @@ def end_to_end_block(batch, n_orb, n_alpha):
         t0 = time.perf_counter()
         np.asarray(res.A)
         t_A2 = time.perf_counter() - t0
+    many = many_objects_block(make, res, n_orb, n_alpha)
+    del res
     # BASELINE config 2 through the API: TauMaxEnt.run() of ONE scan of n_alpha alphas (the reference's most common call)
     tau1, omega1, _, G1 = synthetic.single_G(200, 500)
 
@@ -340,8 +342,64 @@ def end_to_end_block(batch, n_orb, n_alpha):
                          'Entropy analyzers, D2H of chi2 / S / Q / flags, of the three analyzers\' indices and of the rows of the default '
                          'analyzer (v, H and the rows of the other two analyzers stay on the device until looked at: '
                          'other_analyzers_rows_ms), records (built while the kernel runs), the analysis batch',
+                many_objects=many,
                 other_analyzers_rows_ms=1e3 * t_other,
                 first_access_of_all_H_ms=1e3 * t_H, all_H_of_a_later_result_ms=1e3 * t_H2, all_A_of_it_ms=1e3 * t_A2, all_H_MB=nbytes / 1e6)
+
+
+def many_objects_block(make, res_one, n_orb, n_alpha, n_jobs=4, repeats=6):
+    """Jobs in flight behind the reference's API: ``n_jobs`` ElementwiseMaxEnt objects on DIFFERENT data of the
+    same grids through ``maxent_amd.run_many`` -- every object prepared, staged and launched before the first is waited for -- against
+    the same objects' ``run()`` one after the other.  A_out and chi2 of the two ways are compared."""
+    import maxent_amd as mx
+    jobs = [make(100 + k) for k in range(n_jobs)]
+    seq = [ew.run() for ew in jobs]                     # (first run of every object: contexts, staging)
+    seq_keep = [(np.array(r.A_out), np.array(r.chi2)) for r in seq]
+    del seq
+    P = n_orb * n_orb * n_alpha * n_jobs
+
+    def clear():
+        for ew in jobs:
+            ew.maxent_result = None
+    t_seq = []
+    for _ in range(repeats):
+        clear()
+        t0 = time.perf_counter()
+        out = [ew.run() for ew in jobs]
+        t_seq.append(time.perf_counter() - t0)
+        del out
+    t_many, out = [], None
+    for _ in range(repeats + 2):
+        clear()
+        out = None
+        t0 = time.perf_counter()
+        out = mx.run_many(jobs)
+        t_many.append(time.perf_counter() - t0)
+    t_many = t_many[2:]                                 # (the first passes re-cut the chains for mxe_opts.in_flight = n_jobs)
+    same_A = bool(all(np.array_equal(np.asarray(r.A_out), a) for r, (a, _) in zip(out, seq_keep)))
+    worst_A = float(max(np.max(np.abs(np.asarray(r.A_out) - a)) / np.max(np.abs(a)) for r, (a, _) in zip(out, seq_keep)))
+    worst_chi2 = float(max(np.nanmax(np.abs(np.asarray(r.chi2) - c) / np.abs(c)) for r, (_, c) in zip(out, seq_keep)))
+    conv = bool(all(np.all(np.asarray(r.converged)[~np.isnan(np.asarray(r.converged))] == 1) for r in out))
+    kernels = sorted(set(info['kernel'] for ew in jobs for info in ew.last_launches[-1:]))
+    # new data on the same objects before every pass (what a self-consistency loop does): the staging uploads G
+    t_new = []
+    for rep in range(repeats):
+        for k, ew in enumerate(jobs):
+            ew.set_G_tau_data(ew.G_mat[0], np.asarray(ew.G_mat[1]) * (1.0 + 1e-8 * (rep + 1)))
+        t0 = time.perf_counter()
+        out2 = mx.run_many(jobs)
+        t_new.append(time.perf_counter() - t0)
+        del out2
+    return dict(api='maxent_amd.run_many([ew0 .. ew%d]) -- ElementwiseMaxEnt.run_async() on every object, then .result() in turn' % (n_jobs - 1),
+                jobs=n_jobs, problems=P,
+                run_many_ms=1e3 * min(t_many), sequential_runs_ms=1e3 * min(t_seq), run_many_new_data_ms=1e3 * min(t_new),
+                alpha_solves_per_s=P / min(t_many), alpha_solves_per_s_sequential=P / min(t_seq),
+                alpha_solves_per_s_new_data=P / min(t_new),
+                A_out_bitwise_equal_to_sequential_runs=same_A, A_out_max_rel_diff=worst_A, chi2_max_rel_diff=worst_chi2,
+                all_converged=conv, kernels=kernels,
+                note='the jobs in flight are cut for mxe_opts.in_flight = %d (fewer cold-started pieces): their iterates differ from the '
+                     'one-at-a-time cut within the stopping tolerance (A_out_max_rel_diff); the analyzers pick the same alphas '
+                     'unless two candidates tie at that level' % n_jobs)
 
 
 def scaling_projection(batch, opts, k_ms_full, n_alpha, n_launch=30):

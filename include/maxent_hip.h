@@ -203,6 +203,12 @@ int  mxe_dataset_clear(mxe_ctx* ctx);
 int  mxe_elements_set(mxe_ctx* ctx, int n_elem, const int32_t* dataset_of_elem,
                       const double* G, const int64_t* G_offset,
                       const double* D, const int32_t* entropy);
+/* New DATA for the elements that are set (same number, same data sets, default models and entropies): G as above.  Only the
+ * projections of the data change on the device; the staged chains (mxe_chains_upload: their cut into pieces, the start
+ * states) do not depend on G and stay ready -- what every iteration of a self-consistency loop does to an
+ * ElementwiseMaxEnt on fixed grids (reference: set_G_tau_data again, elementwise_maxent.py:373-395, then run()).
+ * MXE_ERR_STATE when no elements are set, MXE_ERR_ARG when n_elem differs. */
+int  mxe_elements_update_data(mxe_ctx* ctx, int n_elem, const double* G, const int64_t* G_offset);
 
 /* ---- the hot path ------------------------------------------------------ */
 /* n_chain warm-started alpha scans of n_alpha values each.

@@ -34,7 +34,7 @@ from .maxent_result import MaxEntResult, MaxEntResultData   # noqa: F401
 from .maxent_loop import MaxEntLoop                 # noqa: F401
 from .tau_maxent import TauMaxEnt                   # noqa: F401
 from .elementwise_maxent import (ElementwiseMaxEnt, DiagonalMaxEnt,   # noqa: F401
-                                 PoormanMaxEnt)
+                                 PoormanMaxEnt, PendingRun, run_many)
 from .device import MaxEntDeviceError, device_count  # noqa: F401
 from . import _layout as _layout        # the reference's sub-module paths (analyzers.linefit_analyzer, ...)
 _layout.register(__name__)

@@ -30,21 +30,50 @@ import numpy as np
 from . import device
 
 
+class Claim(object):
+    """what ONE launch still holds in the result buffers of a device: all H, or all v, of its scans.  The lazy arrays of the
+    single scans (:class:`LazyH`, :class:`LazyV`) and the result object of the launch (``elementwise_maxent.DeferredLaunch``)
+    hold it strongly, the solver weakly: a result that was dropped takes its claim with it.  ``val``: the whole array
+    [n_chain][n_alpha][...] once it has come to the host."""
+    __slots__ = ('_owner', '_rank', '_what', 'val', 'shape', '__weakref__')
+
+    def __init__(self, owner, rank, what, shape):
+        self._owner, self._rank, self._what, self.val, self.shape = owner, rank, what, None, shape
+
+    def materialize(self):
+        if self.val is None:
+            # (everything this launch still holds on the device comes with it -- v: 13 MB next to H's 100 --: what has been
+            #  brought over has no claim on the buffers any more, a new object on the same grids may take the contexts over)
+            self._owner._materialize_rank(self._rank)
+        return self.val
+
+
 class LazyH(object):
     """hidden images of one alpha scan, still on the device until somebody looks"""
     _what = 'H'
+    __slots__ = ('_claim', '_chain', 'shape', '__weakref__')
+    dtype = np.dtype(float)
+    ndim = 2
 
-    def __init__(self, owner, rank, chain, n_alpha, n_omega):
-        self._owner, self._rank, self._chain = owner, rank, chain
+    def __init__(self, claim, chain, n_alpha, n_omega):
+        self._claim, self._chain = claim, chain
         self.shape = (n_alpha, n_omega)
-        self.dtype = np.dtype(float)
-        self.ndim = 2
-        self._val = None
+
+    @property
+    def _owner(self):
+        return self._claim._owner
+
+    @property
+    def _rank(self):
+        return self._claim._rank
+
+    @property
+    def _val(self):
+        whole = self._claim.val
+        return None if whole is None else whole[self._chain]
 
     def materialize(self):
-        if self._val is None:
-            self._owner._materialize_rank(self._rank)
-        return self._val
+        return self._claim.materialize()[self._chain]
 
     def __array__(self, dtype=None, copy=None):
         val = self.materialize()
@@ -74,6 +103,7 @@ class LazyV(LazyH):
     """the singular-space vectors v of one alpha scan (n_alpha x n_s), on the device until somebody looks: 13 MB of
     a 16 x 16 x 100 job that the result object hardly ever shows"""
     _what = 'v'
+    __slots__ = ()
 
     def __getitem__(self, item):
         return self.materialize()[item]
@@ -156,6 +186,47 @@ class LazyA(object):
         return np.asarray(self._map.f(row))
 
 
+class LazySols(object):
+    """the per-scan result dicts of ONE launch on ONE device -- what :meth:`BatchSolver.solve` returns as a list --, each built
+    when it is first asked for (256 dicts, lazy arrays and views cost 0.5 ms that a caller who reads ``result.A_out`` or
+    ``result.chi2`` never needs).  ``arrays``: chi2 / S / Q / n_iter / n_evals [n][n_alpha], ``conv`` the flags as bool,
+    ``picks`` = (indices [3][n], rows [LazyRows x 3], eager rows) or None"""
+
+    def __init__(self, n, alpha_tab, alpha_sel, claim_H, claim_v, arrays, conv, picks, sel_params, n_omega, n_s):
+        self.n, self.alpha_tab, self.alpha_sel = n, alpha_tab, alpha_sel
+        self.claim_H, self.claim_v, self.arrays, self.conv, self.picks, self.sel_params = claim_H, claim_v, arrays, conv, picks, sel_params
+        self.n_alpha, self.n_omega, self.n_s = alpha_tab.shape[1], n_omega, n_s
+        self._made = {}
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        return (self[i] for i in range(self.n))
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self.n))]
+        i = int(i)
+        if i < 0:
+            i += self.n
+        d = self._made.get(i)
+        if d is None:
+            if not 0 <= i < self.n:
+                raise IndexError(i)
+            o = self.arrays
+            d = dict(alpha=self.alpha_tab[self.alpha_sel[i] if self.alpha_sel is not None else 0],
+                     H=LazyH(self.claim_H, i, self.n_alpha, self.n_omega), A=None,
+                     v=LazyV(self.claim_v, i, self.n_alpha, self.n_s),
+                     chi2=o['chi2'][i], S=o['S'][i], Q=o['Q'][i], n_iter=o['n_iter'][i], converged=self.conv[i],
+                     n_evals=o['n_evals'][i])
+            if self.picks is not None:
+                idx, rows = self.picks[0], self.picks[1]
+                d['device_select'] = dict(params=self.sel_params, index=idx[:, i], H=PickedRows(rows, i), batch=self.picks, chain=i)
+            self._made[i] = d
+        return d
+
+
 def _one_at_a_time(method):
     """the solver's lock around a method: solvers are shared between kernel objects with the same decomposition, and
     the library wants one thread per context at a time"""
@@ -183,6 +254,7 @@ class BatchSolver(object):
         self._pending = []                          # weak references to the LazyH whose data still live in a result buffer
         self._layout = None
         self.last_info = None
+        self._busy = False                          # a batch is in flight (between solve_begin and the function it returned)
         self._lock = threading.RLock()              # (one job at a time on these contexts: include/maxent_hip.h)
 
     # ---- reuse -------------------------------------------------------------
@@ -203,7 +275,7 @@ class BatchSolver(object):
     # The few most recently used are kept (each holds the result buffers of its last job on the device).
     _pool_lock = threading.Lock()
     _pooled = []                                    # most recently used first
-    POOL_SIZE = 3
+    POOL_SIZE = 8                                   # (eight jobs in flight on one kernel: maxent_amd.run_many)
 
     def _same_contents(self, K, device_ids):
         if self.device_ids != device_ids or not self.ctxs[0]._h or (K.rotation is None) != self._token[3]:
@@ -223,10 +295,10 @@ class BatchSolver(object):
         if held is None:
             held = K.__dict__['_batch_solvers'] = {}
         s = held.get(device_ids)
-        if s is not None and cls._same_token(s._token, cls._kernel_token(K)) and s.ctxs[0]._h:
-            return s
+        if s is not None and cls._same_token(s._token, cls._kernel_token(K)) and s.ctxs[0]._h and not s._busy:
+            return s           # (a solver with a batch in flight -- solve_begin without its end -- is nobody else's)
         if cls.POOL_SIZE <= 0:                       # no pool: every kernel object its own contexts
-            if s is not None:
+            if s is not None and not s._busy:
                 s.close()
             s = held[device_ids] = cls(K, device_ids)
             return s
@@ -235,7 +307,7 @@ class BatchSolver(object):
             for cand in cls._pooled:
                 # (not one whose last results somebody still holds unfetched: they would have to come to the host
                 #  first -- 102 MB for a 16 x 16 x 100 job --, a context of its own is cheaper)
-                if cand._same_contents(K, device_ids) and not cand._alive():
+                if not cand._busy and cand._same_contents(K, device_ids) and not cand._alive():
                     found = cand
                     break
             if found is None:
@@ -244,8 +316,10 @@ class BatchSolver(object):
                 cls._pooled.remove(found)
                 found._token = cls._kernel_token(K)        # (equal arrays: the staged basis is that of K)
             cls._pooled.insert(0, found)
-            retired = cls._pooled[cls.POOL_SIZE:]
+            keep = [x for x in cls._pooled[cls.POOL_SIZE:] if x._busy]
+            retired = [x for x in cls._pooled[cls.POOL_SIZE:] if not x._busy]
             del cls._pooled[cls.POOL_SIZE:]
+            cls._pooled.extend(keep)
         for old in retired:
             if not old._alive():
                 old.close()                         # (one with results out lives as long as they do: they hold it)
@@ -278,9 +352,24 @@ class BatchSolver(object):
             c.close()
 
     # ---- one batch -----------------------------------------------------------
-    @_one_at_a_time
     def solve(self, K, specs, opts, want_logdet=False, want_H='lazy', output_map=None, select=(0, 0.2), while_waiting=None):
-        """``specs``: dicts with G, err, U_rot (or None), D, kind, v0, alpha (equal lengths).  Returns
+        """one batch, start to end: :meth:`solve_begin` and the function it returns"""
+        return self.solve_begin(K, specs, opts, want_logdet=want_logdet, want_H=want_H, output_map=output_map, select=select,
+                                while_waiting=while_waiting)()
+
+    def solve_begin(self, K, specs, opts, want_logdet=False, want_H='lazy', output_map=None, select=(0, 0.2), while_waiting=None,
+                    early_select=False, arrays=None):
+        """Stage and LAUNCH one batch; returns the function that waits for it and returns what :meth:`solve` returns.  Between
+        the two the solver is busy (``for_kernel`` hands it to nobody else) and the caller is free: it may begin the batches of
+        OTHER solvers -- several jobs in flight on the GPU, launched from one thread without a wait in between
+        (``ElementwiseMaxEnt.run_async``, ``maxent_amd.run_many``) -- and do its own host work.  ``early_select``: the selection
+        kernel of the analyzers is enqueued right behind the solve instead of behind ``mxe_chains_finish`` (which waits for the
+        device), and once more in the rare case that the finishing pass had something to do.  With several devices everything
+        happens in this call and the returned function only hands the results over.
+        ``arrays`` (instead of ``specs``, one device): the job as ARRAYS -- dict(G [n][n_tau], err [1 or n][n_tau], sel [n]: which
+        row of the small tables D [m][n_omega], alpha [m][n_alpha], v0 [m][n_s], kinds [m] a scan takes) for an unrotated kernel --;
+        the results then come as a :class:`LazySols` (per-scan dicts built when asked for), nothing per scan is done here.
+        ``specs``: dicts with G, err, U_rot (or None), D, kind, v0, alpha (equal lengths).  Returns
         (list of per-spec result dicts in the order of ``specs``, info).  ``want_H``: 'lazy' (default),
         True (fetched now) or False.  ``select`` = (linefit_deg, gamma[, default]): the three default analyzers' alphas are
         picked on the device behind the solve (``mxe_select3_launch``) and come back as ``device_select`` of every result
@@ -289,6 +378,28 @@ class BatchSolver(object):
         ``while_waiting(results)``: called while the kernel runs, with the result dicts complete but for their VALUES (the
         arrays are there and are filled behind it) -- a caller builds its records from them then; only with one device and
         neither ``want_logdet`` nor ``output_map`` (which add keys later): who passes it checks that it was called."""
+        self._lock.acquire()                        # (released by the returned function, or below if this call fails)
+        try:
+            if self._busy:
+                raise RuntimeError('this solver has a batch in flight: end it first')
+            if arrays is not None:
+                rest = self._solve_begin_arrays(K, arrays, opts, select, early_select)
+            else:
+                rest = self._solve_begin(K, specs, opts, want_logdet, want_H, output_map, select, while_waiting, early_select)
+            self._busy = True
+        except BaseException:
+            self._lock.release()
+            raise
+
+        def end():
+            try:
+                return rest()
+            finally:
+                self._busy = False
+                self._lock.release()
+        return end
+
+    def _solve_begin(self, K, specs, opts, want_logdet, want_H, output_map, select, while_waiting, early_select):
         self.materialize_pending()                  # the result buffers are about to be overwritten
         n_alpha = len(specs[0]['alpha'])
         for s in specs:
@@ -311,6 +422,8 @@ class BatchSolver(object):
             c = self.ctxs[r]
             self._stage(c, K, [specs[i] for i in per_rank[r]], opts)
             c.launch()
+            if early_select and select is not None:
+                c.select3_launch(select[0], select[1])
 
         def destinations(r):
             # the host arrays the results of device r come into -- made BEFORE the device is waited for, so that the per-scan views
@@ -331,9 +444,10 @@ class BatchSolver(object):
         def end(r):
             # finish -> (fetch) of ONE device
             c = self.ctxs[r]
-            c.finish()                              # (alphas the lock-step layout gave up on: one-chain layout)
+            left = c.finish()                       # (alphas the lock-step layout gave up on: one-chain layout)
             if select is not None:
-                c.select3_launch(select[0], select[1])
+                if not early_select or left:
+                    c.select3_launch(select[0], select[1])
             elif gather:
                 c.select_launch(0)
             if not gather:
@@ -347,13 +461,16 @@ class BatchSolver(object):
         def skeleton():
             # what of the results does not wait for the device: built while the kernel runs
             out = []
+            claims = {}
+            for r in active:
+                nc = len(per_rank[r])
+                claims[r] = (Claim(self, r, 'H', (nc, n_alpha, self.n_omega)), Claim(self, r, 'v', (nc, n_alpha, self.n_s)))
+                self._pending.append(weakref.ref(claims[r][0]))
+                self._pending.append(weakref.ref(claims[r][1]))
             for i, s in enumerate(specs):
                 r, c = int(rank_of[i]), int(local_of[i])
-                H = LazyH(self, r, c, n_alpha, self.n_omega)
-                v = LazyV(self, r, c, n_alpha, self.n_s)
-                self._pending.append(weakref.ref(H))
-                self._pending.append(weakref.ref(v))
-                out.append(dict(alpha=np.asarray(s['alpha'], dtype=float), H=H, A=None, v=v))
+                out.append(dict(alpha=np.asarray(s['alpha'], dtype=float), H=LazyH(claims[r][0], c, n_alpha, self.n_omega), A=None,
+                                v=LazyV(claims[r][1], c, n_alpha, self.n_s)))
             return out
 
         def attach(res):
@@ -368,6 +485,56 @@ class BatchSolver(object):
                     idx, rows = picks[r][0], picks[r][1]
                     d['device_select'] = dict(params=sel_params, index=idx[:, c], H=PickedRows(rows, c), batch=picks[r], chain=c)
 
+        def tail(res):
+            info = None
+            if gather:
+                # ONE gather of the per-alpha scalars (and of the analyzer's rows) to the first device
+                counts = [self.ctxs[r].compact_count() for r in range(N)]
+                recv = np.empty(int(np.sum(counts)))
+                device.gather_local(self.ctxs, 0, counts, full=False, recv=recv)
+                offs = np.concatenate([[0], np.cumsum(counts)]).astype(int)
+
+                def rest_of(r):
+                    outs[r] = self._unpack_compact(recv[offs[r]:offs[r] + counts[r]], len(per_rank[r]), n_alpha, eta)
+                    extra = self.ctxs[r].fetch(want_v=False, want_H=False)
+                    for k in ('n_iter', 'converged', 'n_evals'):
+                        outs[r][k] = extra[k]
+                    conv[r] = outs[r]['converged'].astype(bool)
+                self._on_devices(rest_of, list(range(N)))
+                attach(res)
+                for i, d in enumerate(res):
+                    r, c = int(rank_of[i]), int(local_of[i])
+                    d['device_linefit_index'] = int(outs[r]['linefit_index'][c])
+                    d['device_linefit_H'] = outs[r]['linefit_H'][c]
+            logdets = {r: self.ctxs[r].logdet() for r in active} if want_logdet else {}
+            maps = {r: self.ctxs[r].apply_output_map(output_map) for r in active} if output_map is not None else {}
+            ms = [self.ctxs[r].last_kernel_ms() for r in active]
+            info = dict(kernel_ms=max(ms), kernel_ms_per_device=ms, devices=[self.device_ids[r] for r in active],
+                        n_datasets=[self._n_datasets.get(id(self.ctxs[r]), 0) for r in active])
+            info.update(self.ctxs[active[0]].last_launch_info())
+            if os.environ.get('MAXENT_AMD_AUDIT'):
+                # on request (the parity tests): mxe_audit over every problem of this launch -- the exact binary64 Newton correction
+                # at the returned v, ||w * V delta|| / ||H||, to first order the distance of the returned H from the minimiser
+                corr = np.concatenate([self.ctxs[r].audit()['corr'].ravel() for r in active])
+                conv_all = np.concatenate([outs[r]['converged'].ravel() for r in active]).astype(bool)
+                info['audit_max'] = float(np.nanmax(corr[conv_all])) if conv_all.any() else 0.0
+                info['audit_problems'] = int(conv_all.sum())
+            self.last_info = info
+            if maps or logdets:
+                for i, d in enumerate(res):
+                    r, c = int(rank_of[i]), int(local_of[i])
+                    if r in maps:
+                        d['A'] = maps[r][c]
+                    if r in logdets:
+                        d['logdet'] = logdets[r][c]
+            if want_H is True:
+                self.materialize_pending()
+            elif want_H is False:
+                self._pending = [ref for ref in self._pending if getattr(ref(), '_what', 'H') != 'H']       # (claims on H given up)
+                for d in res:
+                    d['H'] = None
+            return res, info
+
         # with several devices each runs on a thread of its own (ctypes releases the GIL, the library promises one
         # thread per context: include/maxent_hip.h)
         if len(active) == 1:
@@ -377,7 +544,10 @@ class BatchSolver(object):
             attach(res)
             if while_waiting is not None and not want_logdet and output_map is None and want_H == 'lazy':
                 while_waiting(res)
-            end(active[0])
+
+            def rest():
+                end(active[0])
+                return tail(res)
         else:
             def one(r):
                 begin(r)
@@ -388,54 +558,130 @@ class BatchSolver(object):
             waiting()
             if not gather:
                 attach(res)
-        info = None
-        if gather:
-            # ONE gather of the per-alpha scalars (and of the analyzer's rows) to the first device
-            counts = [self.ctxs[r].compact_count() for r in range(N)]
-            recv = np.empty(int(np.sum(counts)))
-            device.gather_local(self.ctxs, 0, counts, full=False, recv=recv)
-            offs = np.concatenate([[0], np.cumsum(counts)]).astype(int)
+            done = tail(res)
 
-            def rest(r):
-                outs[r] = self._unpack_compact(recv[offs[r]:offs[r] + counts[r]], len(per_rank[r]), n_alpha, eta)
-                extra = self.ctxs[r].fetch(want_v=False, want_H=False)
-                for k in ('n_iter', 'converged', 'n_evals'):
-                    outs[r][k] = extra[k]
-                conv[r] = outs[r]['converged'].astype(bool)
-            self._on_devices(rest, list(range(N)))
-            attach(res)
-            for i, d in enumerate(res):
-                r, c = int(rank_of[i]), int(local_of[i])
-                d['device_linefit_index'] = int(outs[r]['linefit_index'][c])
-                d['device_linefit_H'] = outs[r]['linefit_H'][c]
-        logdets = {r: self.ctxs[r].logdet() for r in active} if want_logdet else {}
-        maps = {r: self.ctxs[r].apply_output_map(output_map) for r in active} if output_map is not None else {}
-        ms = [self.ctxs[r].last_kernel_ms() for r in active]
-        info = dict(kernel_ms=max(ms), kernel_ms_per_device=ms, devices=[self.device_ids[r] for r in active],
-                    n_datasets=[self._n_datasets.get(id(self.ctxs[r]), 0) for r in active])
-        info.update(self.ctxs[active[0]].last_launch_info())
-        if os.environ.get('MAXENT_AMD_AUDIT'):
-            # on request (the parity tests): mxe_audit over every problem of this launch -- the exact binary64 Newton correction
-            # at the returned v, ||w * V delta|| / ||H||, to first order the distance of the returned H from the minimiser
-            corr = np.concatenate([self.ctxs[r].audit()['corr'].ravel() for r in active])
-            conv_all = np.concatenate([outs[r]['converged'].ravel() for r in active]).astype(bool)
-            info['audit_max'] = float(np.nanmax(corr[conv_all])) if conv_all.any() else 0.0
-            info['audit_problems'] = int(conv_all.sum())
-        self.last_info = info
-        if maps or logdets:
-            for i, d in enumerate(res):
-                r, c = int(rank_of[i]), int(local_of[i])
-                if r in maps:
-                    d['A'] = maps[r][c]
-                if r in logdets:
-                    d['logdet'] = logdets[r][c]
-        if want_H is True:
-            self.materialize_pending()
-        elif want_H is False:
-            self._pending = [ref for ref in self._pending if getattr(ref(), '_what', 'H') != 'H']
-            for d in res:
-                d['H'] = None
-        return res, info
+            def rest():
+                return done
+        return rest
+
+    def _solve_begin_arrays(self, K, arrays, opts, select, early_select):
+        """:meth:`solve_begin` for a job given as arrays, on the one device of this solver: stage (nothing when the job is what
+        the context holds), launch, the selection kernel behind it; the returned function waits, brings the scalars and the
+        analyzers' choice and returns (:class:`LazySols`, info)"""
+        if len(self.ctxs) != 1:
+            raise ValueError('a job given as arrays runs on one device')
+        self.materialize_pending()                  # the result buffers are about to be overwritten
+        c = self.ctxs[0]
+        n, n_alpha = int(arrays['n']), arrays['alpha'].shape[1]
+        self._stage_arrays(c, K, arrays, opts)
+        c.launch()
+        if select is not None and early_select:
+            c.select3_launch(select[0], select[1])
+        eager = int(select[2]) if select is not None and len(select) > 2 else 0
+        sel_params = (int(select[0]), float(select[1])) if select is not None else None
+        claim_H, claim_v = Claim(self, 0, 'H', (n, n_alpha, self.n_omega)), Claim(self, 0, 'v', (n, n_alpha, self.n_s))
+        self._pending.append(weakref.ref(claim_H))
+        self._pending.append(weakref.ref(claim_v))
+        out = c.result_arrays()
+        conv = np.empty(out['converged'].shape, dtype=bool)
+        picks = None
+        if select is not None:
+            idx, row = c.select3_arrays(1)
+            rows = [LazyRows(self, 0, w, n, self.n_omega) for w in range(3)]
+            rows[eager]._val = row[0]
+            for w in range(3):
+                if w != eager:
+                    self._pending.append(weakref.ref(rows[w]))
+            picks = (idx, rows, row)
+        sols = LazySols(n, arrays['alpha'], arrays['sel'] if arrays['alpha'].shape[0] > 1 else None, claim_H, claim_v, out, conv,
+                        picks, sel_params, self.n_omega, self.n_s)
+
+        def rest():
+            if select is not None and early_select:
+                # the scalars first (the fetch waits for the stream): when every alpha converged -- the rule -- the finishing pass
+                # has nothing to do and is not called (it would copy the flags a second time and scan them: 0.05 ms per job)
+                c.fetch(want_v=False, want_H=False, out=out)
+                if not out['converged'].all():
+                    if c.finish():                  # (alphas the lock-step layout gave up on: one-chain layout)
+                        c.select3_launch(select[0], select[1])
+                    c.fetch(want_v=False, want_H=False, out=out)
+            else:
+                c.finish()
+                if select is not None:
+                    c.select3_launch(select[0], select[1])
+                c.fetch(want_v=False, want_H=False, out=out)
+            np.not_equal(out['converged'], 0, out=conv)
+            if select is not None:
+                c.select3_fetch_rows(first=eager, count=1, idx=picks[0], rows=picks[2])
+            ms = c.last_kernel_ms()
+            info = dict(kernel_ms=ms, kernel_ms_per_device=[ms], devices=[self.device_ids[0]],
+                        n_datasets=[self._n_datasets.get(id(c), 0)], eager=eager)
+            info.update(c.last_launch_info())
+            if os.environ.get('MAXENT_AMD_AUDIT'):
+                corr = c.audit()['corr'].ravel()
+                ok = conv.ravel()
+                info['audit_max'] = float(np.nanmax(corr[ok])) if ok.any() else 0.0
+                info['audit_problems'] = int(ok.sum())
+            self.last_info = info
+            return sols, info
+        return rest
+
+    def _stage_arrays(self, ctx, K, arrays, opts):
+        """:meth:`_stage` for a job that comes as arrays (unrotated kernel, no per-element rotation): the same record of what is
+        staged, so that a job given one way is recognised when it comes the other way"""
+        n = int(arrays['n'])
+        sel = arrays['sel']
+
+        def rows(tab):
+            tab = np.asarray(tab, dtype=float)
+            if tab.shape[0] == 1 or all(np.array_equal(tab[0], t) for t in tab[1:]):
+                return np.array(tab[:1])            # (a copy: what is staged must not follow an edit in place)
+            return tab[sel]
+        G = np.ascontiguousarray(arrays['G'], dtype=float)
+        err = np.asarray(arrays['err'], dtype=float)
+        staged = dict(n=n, G=G, err=(np.array(err[:1]) if err.shape[0] == 1 else err),
+                      D=rows(arrays['D']), alpha=rows(arrays['alpha']), v0=rows(arrays['v0']),
+                      kinds=np.asarray(arrays['kinds'])[sel], U_rot=[None] * n,
+                      opts=(bytes(opts) if opts is not None else b''), rotated=K.rotation is not None)
+        if staged['rotated']:
+            raise ValueError('a job given as arrays needs an unrotated kernel')
+        held = self.__dict__.setdefault('_staged', {})
+        old = held.get(id(ctx))
+        if old is not None and old['G'] is not None and old['n'] == n and ctx._n_chain == n and \
+                old['opts'] == staged['opts'] and old['rotated'] == staged['rotated'] and \
+                len(old['U_rot']) == n and all(u is None for u in old['U_rot']) and \
+                all(old[k].shape == staged[k].shape and np.array_equal(old[k], staged[k])
+                    for k in ('err', 'D', 'alpha', 'v0', 'kinds')) and old['G'].shape == G.shape:
+            if not np.array_equal(old['G'], G):
+                # new data on the same grids (every iteration of a self-consistency loop): only their projections change on the
+                # device -- data sets, default models, the cut of the chains and their start states stay (mxe_elements_update_data)
+                ctx.update_data(G)
+                old['G'] = G
+            return
+        held.pop(id(ctx), None)
+        ctx.clear_datasets()
+        self.__dict__.setdefault('_n_datasets', {})
+        full = lambda a: a if a.shape[0] == n else np.broadcast_to(a, (n, a.shape[1]))
+        if staged['err'].shape[0] == 1:
+            ds_ids = [ctx.add_dataset(staged['err'][0], None)] * n
+            self._n_datasets[id(ctx)] = 1
+        else:
+            ds_ids, seen = [], []
+            for e in staged['err']:
+                found = None
+                for (e0, i0) in seen:
+                    if np.array_equal(e0, e):
+                        found = i0
+                        break
+                if found is None:
+                    found = ctx.add_dataset(e, None)
+                    seen.append((e, found))
+                ds_ids.append(found)
+            self._n_datasets[id(ctx)] = len(seen)
+        ctx.set_elements(ds_ids, G, full(staged['D']), staged['kinds'])
+        ctx.upload_chains(np.arange(n, dtype=np.int32), np.ascontiguousarray(full(staged['alpha'])),
+                          np.ascontiguousarray(full(staged['v0'])), opts)
+        held[id(ctx)] = staged
 
     @staticmethod
     def _rows_of(specs, key):
@@ -499,7 +745,10 @@ class BatchSolver(object):
                 old['opts'] == staged['opts'] and old['rotated'] == staged['rotated'] and \
                 len(old['U_rot']) == len(staged['U_rot']) and all(a is b for a, b in zip(old['U_rot'], staged['U_rot'])) and \
                 all(old[k].shape == staged[k].shape and np.array_equal(old[k], staged[k])
-                    for k in ('G', 'err', 'D', 'alpha', 'v0', 'kinds')):
+                    for k in ('err', 'D', 'alpha', 'v0', 'kinds')) and old['G'].shape == staged['G'].shape:
+            if not np.array_equal(old['G'], staged['G']):
+                ctx.update_data(staged['G'])        # (new data, everything else as staged: mxe_elements_update_data)
+                old['G'] = staged['G']
             return
         held.pop(id(ctx), None)
         ctx.clear_datasets()
@@ -557,29 +806,32 @@ class BatchSolver(object):
 
     # ---- H on demand ----------------------------------------------------------
     def _alive(self):
-        """the LazyH somebody still holds and that have not been fetched (a result that was dropped takes
-        its claim on the device buffer with it)"""
+        """the claims on the result buffers (:class:`Claim`: all H / all v of a launch; :class:`LazyRows`) that somebody still
+        holds and that have not been fetched (a result that was dropped takes its claim on the device buffer with it)"""
         out = []
         for ref in self._pending:
             h = ref()
-            if h is not None and h._val is None:
+            if h is not None and (h.val if isinstance(h, Claim) else h._val) is None:
                 out.append(h)
         return out
 
     @_one_at_a_time
-    def _materialize_rank(self, rank):
+    def _materialize_rank(self, rank, only=None):
+        """everything of ``rank`` that is still claimed comes to the host (``only`` = 'H' / 'v': that array alone -- and the
+        analyzers' rows with H)"""
         alive = self._alive()
-        mine = [h for h in alive if h._rank == rank and h._what != 'rows']
+        mine = [h for h in alive if h._rank == rank and h._what != 'rows' and (only is None or h._what == only)]
         if mine:
             got = self.ctxs[rank].fetch(want_v=any(h._what == 'v' for h in mine), want_H=any(h._what == 'H' for h in mine))
             for h in mine:
-                h._val = got[h._what][h._chain]
-        for h in alive:
-            # (the rows of the analyzers go with the arrays: 1 MB each next to H's 100, and what has been brought over has no claim
-            #  on the device buffers any more -- a new object on the same grids may take the contexts over)
-            if h._rank == rank and h._what == 'rows':
-                h._val = self.ctxs[rank].select3_fetch_rows(first=h._which, count=1, want_index=False)[1][0]
-        self._pending = [weakref.ref(h) for h in alive if h._val is None]
+                h.val = got[h._what]
+        if only != 'v':
+            for h in alive:
+                # (the rows of the analyzers go with the arrays: 1 MB each next to H's 100, and what has been brought over has no
+                #  claim on the device buffers any more -- a new object on the same grids may take the contexts over)
+                if h._rank == rank and h._what == 'rows':
+                    h._val = self.ctxs[rank].select3_fetch_rows(first=h._which, count=1, want_index=False)[1][0]
+        self._pending = [weakref.ref(h) for h in alive if (h.val if isinstance(h, Claim) else h._val) is None]
 
     @_one_at_a_time
     def _materialize_rows(self, lazy):

@@ -22,6 +22,7 @@
 #include <map>
 #include <vector>
 #include <mutex>
+#include <thread>
 #include <tuple>
 
 using mxe::KParams;
@@ -616,27 +617,22 @@ int mxe_dataset_clear(mxe_ctx* ctx)
     return MXE_OK;
 }
 
-int mxe_elements_set(mxe_ctx* ctx, int n_elem, const int32_t* dataset_of_elem,
-                     const double* G, const int64_t* G_offset,
-                     const double* D, const int32_t* entropy)
-try {
-    if (!ctx || n_elem < 1 || !dataset_of_elem || !G || !G_offset || !D || !entropy) return MXE_ERR_ARG;
-    if (ctx->ds.empty()) return MXE_ERR_STATE;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    const int ns = ctx->n_s, NP = ctx->NP, nw = ctx->n_omega, nwp = ctx->nwp;
-    std::vector<double> hghat((size_t)n_elem * NP, 0.0), hcperp(n_elem), hD((size_t)n_elem * nwp, 0.0), hsumD(n_elem);
-    ctx->elem_ds.assign(n_elem, 0); ctx->elem_kind.assign(n_elem, 0);
+namespace {
+// ghat = Uhat^T (G / err) and c_perp = |G / err - Uhat ghat|^2 of elements [e0, e1): the data side of the whitened problem
+// (DESIGN.md section 2).  Both along the rows of Uhat (unit stride); the residual is formed term by term (a sum of squares: no
+// cancellation).  A batch of 256 elements is 5.7 M multiply-adds: on one host core 0.5-0.9 ms -- more than the kernel that solves
+// them takes --, so batches are cut over a handful of threads (the arithmetic of an element does not depend on the cut).
+void project_elements(const mxe_ctx* ctx, int e0, int e1, const int32_t* dataset_of_elem, const double* G, const int64_t* G_offset,
+                      double* hghat, double* hcperp)
+{
+    const int ns = ctx->n_s, NP = ctx->NP;
     std::vector<double> Gt;
-    for (int e = 0; e < n_elem; ++e) {
-        const int d = dataset_of_elem[e];
-        if (d < 0 || d >= (int)ctx->ds.size()) return MXE_ERR_ARG;
-        if (entropy[e] != MXE_ENTROPY_NORMAL && entropy[e] != MXE_ENTROPY_PLUSMINUS) return MXE_ERR_ARG;
-        const DataSet& DS = ctx->ds[d];
+    for (int e = e0; e < e1; ++e) {
+        const DataSet& DS = ctx->ds[dataset_of_elem[e]];
         const double* Ge = G + G_offset[e];
         Gt.assign(DS.n_rows, 0.0);
         for (int i = 0; i < DS.n_rows; ++i) Gt[i] = Ge[i] / DS.err[i];
-        // ghat = Uhat^T Gt ;  c_perp = |Gt - Uhat ghat|^2   (both along the rows of Uhat: unit stride)
-        double* gh = hghat.data() + (size_t)e * NP;
+        double* gh = hghat + (size_t)e * NP;
         for (int i = 0; i < DS.n_rows; ++i) {
             const double* ui = DS.Uhat.data() + (size_t)i * ns;
             const double gi = Gt[i];
@@ -650,11 +646,44 @@ try {
             cp += r * r;
         }
         hcperp[e] = cp;
+    }
+}
+
+void project_all(const mxe_ctx* ctx, int n_elem, const int32_t* dataset_of_elem, const double* G, const int64_t* G_offset,
+                 double* hghat, double* hcperp)
+{
+    int nt = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    nt = std::min(nt, n_elem / 32);
+    if (nt <= 1) { project_elements(ctx, 0, n_elem, dataset_of_elem, G, G_offset, hghat, hcperp); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t) {
+        const int e0 = (int)((long long)n_elem * t / nt), e1 = (int)((long long)n_elem * (t + 1) / nt);
+        pool.emplace_back(project_elements, ctx, e0, e1, dataset_of_elem, G, G_offset, hghat, hcperp);
+    }
+    for (auto& th : pool) th.join();
+}
+}
+
+int mxe_elements_set(mxe_ctx* ctx, int n_elem, const int32_t* dataset_of_elem,
+                     const double* G, const int64_t* G_offset,
+                     const double* D, const int32_t* entropy)
+try {
+    if (!ctx || n_elem < 1 || !dataset_of_elem || !G || !G_offset || !D || !entropy) return MXE_ERR_ARG;
+    if (ctx->ds.empty()) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int ns = ctx->n_s, NP = ctx->NP, nw = ctx->n_omega, nwp = ctx->nwp;
+    std::vector<double> hghat((size_t)n_elem * NP, 0.0), hcperp(n_elem), hD((size_t)n_elem * nwp, 0.0), hsumD(n_elem);
+    ctx->elem_ds.assign(n_elem, 0); ctx->elem_kind.assign(n_elem, 0);
+    for (int e = 0; e < n_elem; ++e) {
+        const int d = dataset_of_elem[e];
+        if (d < 0 || d >= (int)ctx->ds.size()) return MXE_ERR_ARG;
+        if (entropy[e] != MXE_ENTROPY_NORMAL && entropy[e] != MXE_ENTROPY_PLUSMINUS) return MXE_ERR_ARG;
         double sd = 0.0;
         for (int i = 0; i < nw; ++i) { hD[(size_t)e * nwp + i] = D[(size_t)e * nw + i]; sd += D[(size_t)e * nw + i]; }
         hsumD[e] = (entropy[e] == MXE_ENTROPY_PLUSMINUS) ? 2.0 * sd : sd;
         ctx->elem_ds[e] = d; ctx->elem_kind[e] = entropy[e];
     }
+    project_all(ctx, n_elem, dataset_of_elem, G, G_offset, hghat.data(), hcperp.data());
     ctx->n_elem = n_elem;
     ctx->h_sumD = hsumD;
     ctx->h_D = hD;
@@ -673,6 +702,23 @@ try {
     HIPCHK(ctx, stream_wait(ctx->stream));
     if (ctx->ds_dirty) { int rc = upload_bases(ctx); if (rc != MXE_OK) return rc; }
     ctx->chains_ready = false;
+    return MXE_OK;
+}
+MXE_CATCH_ALL
+
+int mxe_elements_update_data(mxe_ctx* ctx, int n_elem, const double* G, const int64_t* G_offset)
+try {
+    if (!ctx || !G || !G_offset) return MXE_ERR_ARG;
+    if (ctx->n_elem < 1 || ctx->ds.empty() || ctx->ds_dirty) return MXE_ERR_STATE;
+    if (n_elem != ctx->n_elem) return MXE_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int ns = ctx->n_s, NP = ctx->NP;
+    std::vector<double> hghat((size_t)n_elem * NP, 0.0), hcperp(n_elem);
+    project_all(ctx, n_elem, ctx->elem_ds.data(), G, G_offset, hghat.data(), hcperp.data());    // (as mxe_elements_set: the same bits)
+    // (behind whatever the stream still runs with the old data)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dghat.p, hghat.data(), hghat.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dcperp.p, hcperp.data(), (size_t)n_elem * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));
     return MXE_OK;
 }
 MXE_CATCH_ALL

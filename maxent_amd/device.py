@@ -74,6 +74,7 @@ SYMBOLS = [
     ('mxe_dataset_clear', ctypes.c_int, [_vp]),
     ('mxe_elements_set', ctypes.c_int, [_vp, ctypes.c_int, _ip, _dp, _lp, _dp,
                                         _ip]),
+    ('mxe_elements_update_data', ctypes.c_int, [_vp, ctypes.c_int, _dp, _lp]),
     ('mxe_solve_chains', ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _ip,
                                         _dp, _dp, ctypes.POINTER(MxeOpts),
                                         _dp, _dp, _dp, _dp, _dp, _ip, _ip,
@@ -412,6 +413,15 @@ class DeviceContext(object):
                                                _p(offs), _p(D), _p(ent)),
                     'mxe_elements_set')
         self.n_elem = n_elem
+
+    def update_data(self, G):
+        """``mxe_elements_update_data``: new data vectors (one row per element, all of one length) for the elements that
+        are set; data sets, default models, entropies and the staged chains stay"""
+        G = _c(G)
+        if G.ndim != 2 or G.shape[0] != self.n_elem:
+            raise ValueError('G has shape {}, {} elements are set'.format(G.shape, self.n_elem))
+        offs = np.arange(G.shape[0], dtype=np.int64) * G.shape[1]
+        self._check(self._lib.mxe_elements_update_data(self._h, G.shape[0], _p(G), _p(offs)), 'mxe_elements_update_data')
 
     # -- the hot path ----------------------------------------------------
     def upload_chains(self, elem_of_chain, alpha_scaled, v0, opts=None):

@@ -47,7 +47,8 @@ class _LazyProduct(object):
 
 
 def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0,
-                   want_logdet=False, chi2_factor=1.0, device_ids=None, want_H='lazy', select=(0, 0.2), while_waiting=None):
+                   want_logdet=False, chi2_factor=1.0, device_ids=None, want_H='lazy', select=(0, 0.2), while_waiting=None,
+                   defer=False, in_flight=0, arrays=None):
     """Solve the alpha scans of several elements in ONE kernel launch per device.
 
     ``K``: kernel whose singular space has been reduced (U, S, V are staged once per device and kept,
@@ -63,12 +64,24 @@ def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0,
     ``want_logdet``: also return log det(I + M W/alpha) per alpha (device kernel; the expensive term of
     NormalLogProbability).  ``want_H``: 'lazy' (H stays on the device until it is looked at), True, False.
     Returns (list of per-spec dicts(alpha, v, H, chi2, S, Q, n_iter, converged, n_evals[, logdet]), info).
+    ``defer``: stage and launch only; returns the function that waits for the device and returns the above (the caller launches
+    other jobs meanwhile: ``ElementwiseMaxEnt.run_async``).  ``in_flight``: how many such jobs the caller keeps on the GPU at a time
+    (``mxe_opts.in_flight``: each is cut into 1 / n as many cold-started pieces -- n jobs fill the GPU together).
     """
-    if not specs:
-        return [], dict(kernel_ms=0.0)
+    if not specs and arrays is None:
+        done = ([], dict(kernel_ms=0.0))
+        return (lambda: done) if defer else done
     from .batch_solver import BatchSolver
     solver = BatchSolver.for_kernel(K, (device_id,) if device_ids is None else device_ids)
-    opts = minimizer.to_opts(waves_per_chain=waves_per_chain, chi2_factor=float(chi2_factor))
+    extra = dict(in_flight=int(in_flight)) if in_flight and in_flight > 1 else {}
+    opts = minimizer.to_opts(waves_per_chain=waves_per_chain, chi2_factor=float(chi2_factor), **extra)
+    if arrays is not None:
+        # (the job as arrays -- BatchSolver.solve_begin --: results as a LazySols, nothing per scan built)
+        begun = solver.solve_begin(K, None, opts, select=select, early_select=True, arrays=arrays)
+        return begun if defer else begun()
+    if defer:
+        return solver.solve_begin(K, specs, opts, want_logdet=want_logdet, want_H=want_H, select=select,
+                                  while_waiting=while_waiting, early_select=True)
     return solver.solve(K, specs, opts, want_logdet=want_logdet, want_H=want_H, select=select, while_waiting=while_waiting)
 
 

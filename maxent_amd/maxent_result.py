@@ -312,11 +312,74 @@ class MaxEntResult(MaxEntResultData):
                  complex_elements=False, use_hermiticity=True):
         super(MaxEntResult, self).__init__(matrix_structure, element_wise,
                                            complex_elements, use_hermiticity)
+        self._deferred = []                 # launches whose per-element records have not been built (add_deferred)
         self._records = OrderedDict()       # key (tuple or None) -> dict
         self._analysis = OrderedDict()      # key -> {name: AnalyzerResult}
         self._start = dict()
         self._end = dict()
         self._cache = dict()
+
+    # ---- launches whose records are built when somebody looks -----------------
+    # ``ElementwiseMaxEnt.run()`` on array input hands the result ONE object per launch (``elementwise_maxent.DeferredLaunch``)
+    # instead of 256 records and 256 analyses: the fields a caller usually reads -- A_out, chi2, S, Q, alpha, omega, H, A,
+    # n_iter, converged -- are served from the launch's arrays as they came off the device; anything per element (a record,
+    # an analyzer result, G_rec, run_times, a pickle ...) first SETTLES the launch: it then builds its records and analyses
+    # exactly as run() used to, and everything goes the general way.  _records / _analysis / _start / _end are therefore
+    # properties that settle before they hand the tables out.
+    def _table(name):                                           # noqa: N805
+        store = '_' + name + '_store'
+
+        def get(self):
+            if self.__dict__.get('_deferred'):
+                self._settle()
+            return self.__dict__[store]
+
+        def put(self, value):
+            self.__dict__[store] = value
+        return property(get, put)
+    _records, _analysis, _start, _end = _table('records'), _table('analysis'), _table('start'), _table('end')
+    del _table
+
+    def add_deferred(self, launch):
+        """``launch``: keys (in launch order), ``settle(result)``, and the arrays the fast accessors read"""
+        if self.__dict__['_deferred'] or self.__dict__['_records_store']:
+            self._settle()                  # (something is there already: everything the general way)
+        self._deferred.append(launch)
+        self._cache = dict()
+        if self.__dict__['_records_store']:
+            self._settle()
+
+    def _settle(self):
+        pending, self.__dict__['_deferred'] = self.__dict__['_deferred'], []
+        for launch in pending:
+            launch.settle(self)
+        if pending:
+            self._cache = dict()
+
+    def _whole(self):
+        """the one unsettled launch that covers every element of the matrix in the order of the matrix, or None"""
+        d = self.__dict__.get('_deferred')
+        if not d or len(d) != 1:
+            return None
+        launch = d[0]
+        ok = launch.covers
+        if ok is None:
+            ok = launch.covers = bool(
+                self._matrix_structure is not None and self.element_wise and not self.complex_elements and
+                not self._zero_elements and launch.keys == list(product(*map(range, self._matrix_structure))))
+        return launch if ok else None
+
+    def _whole_field(self, name):
+        launch = self._whole()
+        if launch is None:
+            return None
+        val = self._cache.get(name)
+        if val is None:
+            val = launch.field(name, tuple(self._matrix_structure))
+            if val is None:
+                return None
+            self._cache[name] = val
+        return val
 
     # ---- filling -------------------------------------------------------
     def _key(self, matrix_element, complex_index):
@@ -458,6 +521,11 @@ class MaxEntResult(MaxEntResultData):
             analyzer = self.default_analyzer_name
         if analyzer is None:
             analyzer = 'LineFitAnalyzer'
+        launch = self._whole()
+        if launch is not None:
+            fast = launch.A_out(analyzer, tuple(self._matrix_structure))       # (the device's rows of that analyzer, one division)
+            if fast is not None:
+                return fast
 
         def chosen(elem):
             """A_out of the analyzer for this element, None where it has none (the rows of a batch the device picked
@@ -673,10 +741,16 @@ class MaxEntResult(MaxEntResultData):
 
     @property
     def alpha(self):
+        launch = self._whole()
+        if launch is not None:
+            return np.asarray(launch.alpha)
         return np.asarray(self._reference_record()['alpha'])
 
     @property
     def omega(self):
+        launch = self._whole()
+        if launch is not None:
+            return launch.omega
         return self._reference_record()['omega']
 
     @property
@@ -685,23 +759,28 @@ class MaxEntResult(MaxEntResultData):
 
     @property
     def chi2(self):
-        return self._assemble('chi2')
+        fast = self._whole_field('chi2')
+        return fast if fast is not None else self._assemble('chi2')
 
     @property
     def S(self):
-        return self._assemble('S')
+        fast = self._whole_field('S')
+        return fast if fast is not None else self._assemble('S')
 
     @property
     def Q(self):
-        return self._assemble('Q')
+        fast = self._whole_field('Q')
+        return fast if fast is not None else self._assemble('Q')
 
     @property
     def H(self):
-        return self._assemble('H', mirror=True)
+        fast = self._whole_field('H')
+        return fast if fast is not None else self._assemble('H', mirror=True)
 
     @property
     def A(self):
-        return self._assemble('A', mirror=True)
+        fast = self._whole_field('A')
+        return fast if fast is not None else self._assemble('A', mirror=True)
 
     @property
     def G_rec(self):
@@ -726,11 +805,13 @@ class MaxEntResult(MaxEntResultData):
     @property
     def n_iter(self):
         """Newton iterations per (element, alpha) (not in the reference)."""
-        return self._assemble('n_iter')
+        fast = self._whole_field('n_iter')
+        return fast if fast is not None else self._assemble('n_iter')
 
     @property
     def converged(self):
-        return self._assemble('converged')
+        fast = self._whole_field('converged')
+        return fast if fast is not None else self._assemble('converged')
 
     def _nested_from(self, table, fill):
         if self.matrix_structure is None or not self.element_wise:

@@ -614,6 +614,13 @@ def test_staging_is_skipped_by_contents_and_shared_arrays_are_compared_as_one_ro
             self._n_chain = len(el)
             self.alpha, self.v0 = np.array(alpha), np.array(v0)
 
+        data_updates = 0
+
+        def update_data(self, G):
+            # (mxe_elements_update_data: new data for the elements that are set, chains stay ready)
+            self.data_updates += 1
+            self.G = np.array(G)
+
     class K(object):
         rotation, U = None, None
     n, rng = 5, np.random.RandomState(0)
@@ -638,21 +645,38 @@ def test_staging_is_skipped_by_contents_and_shared_arrays_are_compared_as_one_ro
     again = [dict(s) for s in specs]
     again[3]['G'] = again[3]['G'] + 1e-9
     bs._stage(ctx, K, again, opts)
-    assert ctx.calls == 2 and np.array_equal(ctx.G[3], again[3]['G'])
+    # new DATA only: their projections are updated, the chains (cut, start states: they do not depend on G) stay (round 5)
+    assert ctx.calls == 1 and ctx.data_updates == 1 and np.array_equal(ctx.G[3], again[3]['G'])
+    bs._stage(ctx, K, [dict(s) for s in again], opts)
+    assert ctx.calls == 1 and ctx.data_updates == 1
     D[5] *= 2.0                                                # the shared default model edited in place
     bs._stage(ctx, K, again, opts)
-    assert ctx.calls == 3 and ctx.D[0, 5] == D[5]
+    assert ctx.calls == 2 and ctx.D[0, 5] == D[5]
     own = [dict(s, D=D.copy()) for s in again]                 # every element its own copy, equal contents: still one row, nothing staged
     bs._stage(ctx, K, own, opts)
-    assert ctx.calls == 3
+    assert ctx.calls == 2
     own[2]['D'] = own[2]['D'] * 1.5                            # one of them differs: rows per element, staged again
     bs._stage(ctx, K, own, opts)
-    assert ctx.calls == 4 and ctx.D.shape == (5, 30) and ctx.D[2, 0] == 1.5 * D[0] and ctx.D[1, 0] == D[0]
+    assert ctx.calls == 3 and ctx.D.shape == (5, 30) and ctx.D[2, 0] == 1.5 * D[0] and ctx.D[1, 0] == D[0]
     bs._stage(ctx, K, [dict(s) for s in own], opts)
-    assert ctx.calls == 4
+    assert ctx.calls == 3
     opts2 = device.default_opts(); opts2.maxiter = opts.maxiter + 1
     bs._stage(ctx, K, own, opts2)
-    assert ctx.calls == 5
+    assert ctx.calls == 4
+    # the same job given as ARRAYS (ElementwiseMaxEnt on array input, round 5) is recognised as what is staged, and the other way
+    # round; new data rows go through update_data there as well
+    Gm = np.stack([s['G'] for s in own])
+    arrays = dict(n=n, G=Gm, err=err.reshape(1, -1), sel=np.array([0, 0, 1, 0, 0]),
+                  D=np.stack([own[0]['D'], own[2]['D']]), alpha=np.stack([al, al]), v0=np.stack([v0, v0]),
+                  kinds=np.array([device.ENTROPY_NORMAL, device.ENTROPY_NORMAL]))
+    bs._stage_arrays(ctx, K, arrays, opts2)
+    assert ctx.calls == 4 and ctx.data_updates == 1
+    bs._stage_arrays(ctx, K, dict(arrays, G=Gm + 1e-9), opts2)
+    assert ctx.calls == 4 and ctx.data_updates == 2 and np.array_equal(ctx.G, Gm + 1e-9)
+    bs._stage(ctx, K, [dict(s, G=s['G'] + 1e-9) for s in own], opts2)
+    assert ctx.calls == 4 and ctx.data_updates == 2
+    bs._stage_arrays(ctx, K, dict(arrays, G=Gm, sel=np.array([0, 1, 1, 0, 0])), opts2)      # another default model for scan 1
+    assert ctx.calls == 5 and ctx.D[1, 0] == 1.5 * D[0]
 
 
 def test_records_and_picks_of_a_launch_are_made_in_one_go():
