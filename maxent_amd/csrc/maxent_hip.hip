@@ -238,6 +238,7 @@ struct mxe_ctx {
     // (mxe_opts.precision = F32), 2 = first pass of a binary64 launch that does not fill the GPU -- chain_kernel_mc then
     // takes every alpha as a piece of its own from the v it left (the arrays of that second pass: d2_*)
     int lv_mode = 0;
+    int mc_wgpc_hint = 1;               // workgroups per CU the auto rule of mxe_chains_upload expects (piece_taper)
     int n_wg2 = 0, wgpc2 = 1;
     DevBuf<int> d2_elem, d2_prob0, d2_len, d2_v0, d2_queue, dcnt1_niter, dcnt1_nevals;
     DevBuf<int> drounds;                // rounds per workgroup of the last lock-step launch: [n_wg] | [n_wg2] (mxe_launch_depth)
@@ -246,6 +247,9 @@ struct mxe_ctx {
     DevBuf<double> dgstate_mc;
     std::vector<int> queue;
     std::vector<int> sub_pre;                                           // leading alpha of a piece: entries before its first alpha (0: none)
+    std::vector<int> sub_walk0;                                         // led piece: its ladder starts at walk_alpha[sub_walk0] (-1: it walks the scan's mesh)
+    std::vector<double> walk_alpha;                                     // the ladders of the led pieces of a coarse mesh (mxe_chains_upload)
+    bool has_walk = false;
     bool has_pre = false;
     mxe_opts opts;
     bool chains_ready = false, launched = false;
@@ -267,7 +271,8 @@ struct mxe_ctx {
     struct IView { int* p = nullptr; } dout_conv, dout_nevals;
     DevBuf<long long> dprof;
     DevBuf<int> dqueue, dcounter;
-    DevBuf<int> dsub_pre, dsub_init;
+    DevBuf<int> dsub_pre, dsub_init, dsub_walk0;
+    DevBuf<double> dwalk_alpha;
     DevBuf<double> dinit_tab;           // start states per class of pieces (KParams::init_tab)
     DevBuf<double> dgstate;             // omega-space state of the chains when it does not fit LDS (KParams::gstate)
     DevBuf<int> dfin_budget;            // mxe_chains_finish: iterations every alpha may still spend
@@ -580,7 +585,7 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
     ctx->dlogdet.release(); ctx->dparent_elem.release(); ctx->dV.release(); ctx->dVt.release(); ctx->dVf.release(); ctx->dVtf.release(); ctx->dc.release(); ctx->dcinv.release();
     ctx->dghat.release(); ctx->dcperp.release(); ctx->dD.release(); ctx->dsumD.release();
     ctx->dalpha.release(); ctx->dv0.release(); ctx->delem_ds.release(); ctx->delem_kind.release();
-    ctx->dchain_elem.release(); ctx->dsub_prob0.release(); ctx->dsub_len.release(); ctx->dsub_v0.release(); ctx->dwg_chains.release(); ctx->dqueue.release(); ctx->dcounter.release(); ctx->dsub_pre.release(); ctx->dsub_init.release(); ctx->dinit_tab.release(); ctx->dout_v.release(); ctx->dout_pack.release(); ctx->dout_pack2.release();
+    ctx->dchain_elem.release(); ctx->dsub_prob0.release(); ctx->dsub_len.release(); ctx->dsub_v0.release(); ctx->dwg_chains.release(); ctx->dqueue.release(); ctx->dcounter.release(); ctx->dsub_pre.release(); ctx->dsub_init.release(); ctx->dsub_walk0.release(); ctx->dwalk_alpha.release(); ctx->dinit_tab.release(); ctx->dout_v.release(); ctx->dout_pack.release(); ctx->dout_pack2.release();
     ctx->dout_niter.release(); ctx->dout_conv.p = ctx->dout_nevals.p = nullptr; ctx->dout_nact.release(); ctx->dexcluded.release();
     ctx->dB.release(); ctx->dA.release(); ctx->dprof.release();
     ctx->rows_out.release(); ctx->rows_idx.release();
@@ -873,6 +878,16 @@ int placement_rule_holds(mxe_ctx* ctx, int n_cu, bool* holds)
 
 constexpr double MC_COUPLING_MAX = 1e-3;     // relative coupling of the first direction the 32-row active block leaves out (see below)
 
+namespace {
+// pieces of unequal length for launches that FILL the GPU (see mxe_chains_upload); MXE_TAPER overrides (A/B runs)
+double piece_taper(const mxe_opts& o, int wgpc)
+{
+    if (const char* e = getenv("MXE_TAPER")) return std::max(0.2, atof(e));
+    (void)o; (void)wgpc;
+    return 1.0;
+}
+}
+
 int mxe_chains_upload(mxe_ctx* ctx, int n_chain, int n_alpha,
                       const int32_t* elem_of_chain, const double* alpha_scaled,
                       const double* v0, const mxe_opts* opts)
@@ -1000,6 +1015,7 @@ try {
             break;
         }
         ctx->wgpc_auto = wgpc_guess;
+        ctx->mc_wgpc_hint = wgpc_guess;
         // A launch that does not fill the GPU (one workgroup per CU: pieces at the cap of two alphas) is as long as its deepest slot,
         // and a slot that takes a second piece pays a second cold start.  Where the uniform cut gives more pieces than slots, the
         // plus-minus scans -- cold start 5 rounds against 12-16, 2 rounds per alpha against 2.75: a piece of twice the alphas costs
@@ -1030,6 +1046,7 @@ try {
     // where it is cheap and safe, then one warm step down to the piece's first alpha (lock-step kernel: chain_pre);
     // in the other layouts, and where that step would be long, the piece is joined to the one before it.
     ctx->sub_pre.clear(); ctx->has_pre = false;
+    ctx->sub_walk0.clear(); ctx->walk_alpha.clear(); ctx->has_walk = false;
     // Launches that do not fill the GPU (cut_by_cost): such a launch is as long as its deepest slot, so the pieces are cut to equal
     // COST and every slot gets one.  The cost of a normal-entropy piece is its cold start -- 9-10 evaluations in the upper third of
     // the logarithmic alpha range, rising to 17-19 just above the guarded tail (profiles/r04_b_depth_by_piece.txt; the same numbers
@@ -1112,11 +1129,17 @@ try {
             if (n_pm > 0) split_pm = (int)std::max(1LL, std::min<long long>(n_alpha / 2, (slots_by_cost - pieces_normal) / n_pm));
         } else cut_by_cost = false;                  // (more scans than slots can take one piece of each: the uniform cut)
     }
+    constexpr double MC_LADDER_COARSE = 2.0;      // a step between neighbouring alphas beyond this factor is not taken in one go (measured: up to a factor ~1.5 a warm step is safe, over a factor 2 single scans took 100-300 evaluations; 1.6 here cost stress case 51 -- ratio 1.66, sigma 1e-5 -- two converged flags and 3 x the time)
+    const double MC_LADDER_RATIO = getenv("MXE_LADDER_RATIO") ? std::max(1.05, atof(getenv("MXE_LADDER_RATIO"))) : 1.56;      // ratio of the rungs (just above MXE_X_WALK_RATIO: the walk lands on every rung)
+    constexpr int MC_LADDER_MAX = 28;             // rungs per piece (the slot's alpha table holds 32 entries)
+    const bool ladder_ok = !getenv("MXE_NO_LADDER") && NP == 64 && o.chains_per_wg != 1 && o.tol_d <= 0.0 && o.decouple_tol > 0.0 &&
+                           (o.precision == MXE_PRECISION_F64 || f32_lv);
     for (int c = 0; c < n_chain; ++c) {
         const double* ac = alpha_dev.data() + (size_t)c * n_alpha;
         double pre_alpha = 0.0, lguard = 0.0;
         int pre_index = -1;
         const bool normal_c = ctx->elem_kind[elem_of_chain[c]] == MXE_ENTROPY_NORMAL;
+        const double hard_below = 0.25 * ctx->ds[ctx->elem_ds[elem_of_chain[c]]].n_rows;      // alpha~ below N_data / 4
         if (normal_c && split > 1) {
             double lmax, lmin;
             scan_range(ac, lmax, lmin);
@@ -1130,6 +1153,21 @@ try {
         else if (cut_by_cost && !normal_c && split_pm > 1 && split_pm < n_alpha / 2) pm_cuts(ac, split_pm, cuts);      // (at the cap of two alphas there is nothing to balance)
         else {
             const int split_c = (split_pm > 0 && !normal_c) ? std::min(split_pm, n_alpha) : split;
+            // (taper: the pieces of a scan grow from its first alpha to its last -- piece i of n has 1 + (taper - 1) i / (n - 1) parts --
+            //  so that what the queue hands out LAST, the cheap short pieces at the top of the mesh, evens the workgroups out;
+            //  1 = pieces of equal length)
+            const double taper = piece_taper(o, ctx->mc_wgpc_hint);
+            if (taper != 1.0 && split_c > 1) {
+                std::vector<double> wsum(split_c + 1, 0.0);
+                for (int i = 0; i < split_c; ++i) wsum[i + 1] = wsum[i] + 1.0 + (taper - 1.0) * i / (split_c - 1);
+                for (int sidx = 0; sidx <= split_c; ++sidx) {
+                    int a = (int)std::llround(n_alpha * wsum[sidx] / wsum[split_c]);
+                    a = std::max(a, sidx == 0 ? 0 : cuts.back() + 1);          // (no empty piece)
+                    a = std::min(a, n_alpha - (split_c - sidx));
+                    if (sidx == split_c) a = n_alpha;
+                    if (cuts.empty() || a > cuts.back()) cuts.push_back(a);
+                }
+            } else
             for (int sidx = 0; sidx <= split_c; ++sidx) {
                 const int a = (int)((long long)n_alpha * sidx / split_c);
                 if (cuts.empty() || a > cuts.back()) cuts.push_back(a);
@@ -1151,20 +1189,55 @@ try {
             // (a piece that starts above the range and runs into it stays whole: cutting it where it enters cost the
             //  batch that fills the GPU 6 % -- cfg4 on one GPU 0.947 -> 1.01 ms)
             const int g0 = guarded ? a0 : a1;
-            if (g0 > a0) {
+            auto emit = [&](int first, int len, int pre, int walk0) {
                 ctx->sub_elem.push_back(elem_of_chain[c]);
-                ctx->sub_prob0.push_back(c * n_alpha + a0);
-                ctx->sub_len.push_back(g0 - a0);
+                ctx->sub_prob0.push_back(c * n_alpha + first);
+                ctx->sub_len.push_back(len);
                 ctx->sub_v0.push_back(c);
-                ctx->sub_pre.push_back(0);
+                ctx->sub_pre.push_back(pre);
+                ctx->sub_walk0.push_back(walk0);
+                if (pre > 0) ctx->has_pre = true;
+            };
+            // A mesh too coarse to walk on (round 5).  The warm step into an alpha is safe over a factor ~1.5 in alpha; the reference's
+            // own tests and defaults use 3-20 alphas over 4-6 decades (alpha_meshes.py:81, test/python/tau_maxent.py:44), and
+            // where the entropy term no longer holds the solution (alpha~ below about N_data / 4) a step over a factor 2 ... 600 took
+            // 250-2 300 evaluations (profiles/r05_b_coarse_mesh.txt: smoke()'s last alpha 913 of the launch's 308 rounds).  Such an
+            // alpha is a piece of its own that starts cold where that is cheap -- at max(N_data / 4, its own alpha) -- and walks down a
+            // LADDER of alphas of its own (ratio MC_LADDER_RATIO, a few loose rounds per rung, no records) to its alpha: all hard
+            // alphas of a scan side by side, each as deep as one cold start + one walk.
+            auto hard = [&](int i) {
+                if (!ladder_ok || i < 0 || i >= n_alpha) return false;
+                const double a = ac[i];
+                if (!(a < hard_below)) return false;
+                if (i == 0) return false;                  // (the head of a scan starts from the default model as ever)
+                const double r = ac[i - 1] / a;
+                return r > MC_LADDER_COARSE || r < 1.0 / MC_LADDER_COARSE;
+            };
+            auto emit_ladder = [&](int i) {
+                const double a = ac[i];
+                const double top = std::max(hard_below, a * MC_LADDER_RATIO);
+                int rungs = (int)std::ceil(std::log(top / a) / std::log(MC_LADDER_RATIO) - 1e-9);
+                rungs = std::max(1, std::min(rungs, MC_LADDER_MAX));
+                const double ratio = std::pow(top / a, 1.0 / rungs);          // (equal rungs; more than MC_LADDER_MAX would not fit the slot's table)
+                const int w0 = (int)ctx->walk_alpha.size();
+                for (int k = 0; k < rungs; ++k) ctx->walk_alpha.push_back(a * std::pow(ratio, rungs - k));
+                emit(i, 1, rungs, w0);
+                ctx->has_walk = true;
+            };
+            {
+                // the part of the piece that is not led: cut at every hard alpha
+                int b = a0;
+                for (int i = a0; i < g0; ++i)
+                    if (hard(i)) {
+                        if (i > b) emit(b, i - b, 0, -1);
+                        emit_ladder(i);
+                        b = i + 1;
+                    }
+                if (g0 > b) emit(b, g0 - b, 0, -1);
             }
             for (int b0 = g0; b0 < a1; ++b0) {
-                ctx->sub_elem.push_back(elem_of_chain[c]);
-                ctx->sub_prob0.push_back(c * n_alpha + b0);
-                ctx->sub_len.push_back(1);
-                ctx->sub_v0.push_back(c);
-                ctx->sub_pre.push_back(b0 - pre_index);
-                ctx->has_pre = true;
+                if (hard(b0)) emit_ladder(b0);
+                else emit(b0, 1, b0 - pre_index, -1);
             }
         }
     }
@@ -1250,11 +1323,11 @@ try {
                     if (len == 0) continue;
                     for (int i = 0; i < len; ++i) covered[(size_t)p0 + i] = 1;
                     ctx->sub_elem[w] = ctx->sub_elem[sc]; ctx->sub_prob0[w] = p0; ctx->sub_len[w] = len;
-                    ctx->sub_v0[w] = ctx->sub_v0[sc]; ctx->sub_pre[w] = ctx->sub_pre[sc]; ++w;
+                    ctx->sub_v0[w] = ctx->sub_v0[sc]; ctx->sub_pre[w] = ctx->sub_pre[sc]; ctx->sub_walk0[w] = ctx->sub_walk0[sc]; ++w;
                 }
                 if (w == 0) { ctx->mc_na = 0; layout = 1; }
                 else {
-                    ctx->sub_elem.resize(w); ctx->sub_prob0.resize(w); ctx->sub_len.resize(w); ctx->sub_v0.resize(w); ctx->sub_pre.resize(w);
+                    ctx->sub_elem.resize(w); ctx->sub_prob0.resize(w); ctx->sub_len.resize(w); ctx->sub_v0.resize(w); ctx->sub_pre.resize(w); ctx->sub_walk0.resize(w);
                     ctx->n_sub = (int)w;
                     ctx->has_pre = false;
                     for (size_t sc = 0; sc < w; ++sc) ctx->has_pre = ctx->has_pre || ctx->sub_pre[sc] > 0;
@@ -1290,6 +1363,7 @@ try {
         }
         ctx->sub_elem.resize(w); ctx->sub_prob0.resize(w); ctx->sub_len.resize(w); ctx->sub_v0.resize(w);
         ctx->sub_pre.assign(w, 0); ctx->has_pre = false;
+        ctx->sub_walk0.assign(w, -1); ctx->has_walk = false;
         ctx->n_sub = (int)w;
     }
     ctx->wg_chains.clear(); ctx->queue.clear(); ctx->n_queue = 0; ctx->n_solo = 0; ctx->placement_checked = 0;
@@ -1307,7 +1381,7 @@ try {
                 for (int i = 0; i < ctx->sub_len[sc]; ++i) amin = std::min(amin, alpha_dev[ctx->sub_prob0[sc] + i]);
                 cost[sc] = ctx->sub_len[sc] * (ctx->elem_kind[e] == MXE_ENTROPY_NORMAL ? 4.0 : 3.0) +
                            (ctx->elem_kind[e] == MXE_ENTROPY_NORMAL ? 16.0 : 6.0) - 1e-3 * std::log10(amin) +
-                           0.7 * ctx->sub_pre[sc];                    // (the walk of a led piece: a landing every ~third alpha, MXE_X_WALK_RATIO)
+                           (ctx->sub_walk0[sc] >= 0 ? 2.0 : 0.7) * ctx->sub_pre[sc];     // (the walk of a led piece: on the scan's mesh a landing every ~third alpha, MXE_X_WALK_RATIO; on a ladder every rung)
             }
             ctx->queue.resize(ctx->n_sub);
             for (int sc = 0; sc < ctx->n_sub; ++sc) ctx->queue[sc] = sc;
@@ -1402,6 +1476,12 @@ try {
     HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_v0.p, ctx->sub_v0.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
     if (ctx->has_pre || ctx->mc_gst)     // (the device-memory-state build is the LEAD build: it reads the array)
         HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_pre.p, ctx->sub_pre.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->has_walk && ctx->has_pre) {
+        HIPCHK(ctx, ctx->dsub_walk0.ensure(std::max(ctx->n_sub, 1)));
+        HIPCHK(ctx, ctx->dwalk_alpha.ensure(std::max<size_t>(ctx->walk_alpha.size(), 1)));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->dsub_walk0.p, ctx->sub_walk0.data(), (size_t)ctx->n_sub * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->dwalk_alpha.p, ctx->walk_alpha.data(), ctx->walk_alpha.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
     if (!ctx->wg_chains.empty())
         HIPCHK(ctx, hipMemcpyAsync(ctx->dwg_chains.p, ctx->wg_chains.data(), ctx->wg_chains.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     if (layout != 4) ctx->excluded.clear();
@@ -1434,6 +1514,9 @@ static void fill_kparams(mxe_ctx* ctx, KParams& kp)
     kp.chain_elem = ctx->dchain_elem.p; kp.alpha = ctx->dalpha.p; kp.v0 = ctx->dv0.p;
     kp.chain_prob0 = ctx->dsub_prob0.p; kp.chain_len = ctx->dsub_len.p; kp.chain_v0 = ctx->dsub_v0.p;
     kp.chain_lead = ((ctx->has_pre || ctx->mc_gst) && ctx->mc_na > 0) ? ctx->dsub_pre.p : nullptr;
+    const bool walks = ctx->has_walk && ctx->has_pre && ctx->mc_na > 0;
+    kp.chain_walk0 = walks ? ctx->dsub_walk0.p : nullptr;
+    kp.walk_alpha = walks ? ctx->dwalk_alpha.p : nullptr;
     kp.init_tab = (ctx->has_init && ctx->mc_na > 0) ? ctx->dinit_tab.p : nullptr;
     kp.chain_init = ctx->dsub_init.p;
     kp.n_chain = ctx->n_sub;
@@ -1535,7 +1618,7 @@ try {
                 KParams k2 = kp;
                 k2.chain_elem = ctx->d2_elem.p; k2.chain_prob0 = ctx->d2_prob0.p; k2.chain_len = ctx->d2_len.p;
                 k2.chain_v0 = ctx->d2_v0.p; k2.v0 = ctx->dout_v.p;
-                k2.chain_lead = nullptr; k2.init_tab = nullptr; k2.chain_init = nullptr;
+                k2.chain_lead = nullptr; k2.init_tab = nullptr; k2.chain_init = nullptr; k2.chain_walk0 = nullptr; k2.walk_alpha = nullptr;
                 k2.n_chain = (int)Pn;
                 k2.prof = nullptr;                  // (diagnostic build: the stamps of the first pass stay)
                 mxe::MCExtra e2 = ex;
@@ -1735,7 +1818,7 @@ try {
     fill_kparams(ctx, kp);
     kp.chain_elem = ctx->dfin_elem.p; kp.chain_prob0 = ctx->dfin_prob0.p; kp.chain_len = ctx->dfin_len.p;
     kp.chain_v0 = ctx->dfin_v0.p; kp.v0 = ctx->dfin_start.p;
-    kp.chain_lead = nullptr; kp.init_tab = nullptr; kp.chain_init = nullptr;
+    kp.chain_lead = nullptr; kp.init_tab = nullptr; kp.chain_init = nullptr; kp.chain_walk0 = nullptr; kp.walk_alpha = nullptr;
     kp.n_chain = nr;
 #ifdef MXE_PROFILE
     // (diagnostic build: the stamps of THIS pass, rows 0 .. nr - 1 -- tools/finish_phases.py; those of the lock-step launch are gone)

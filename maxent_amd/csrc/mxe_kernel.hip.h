@@ -68,6 +68,10 @@ struct KParams {
     const double* init_tab;     // [n_class][MC_INIT_STRIDE] or nullptr
     const int* chain_init;      // [n_chain] class of the piece, -1: none
     const int* chain_lead;  // [n_chain] or nullptr: solve alpha[chain_prob0 - chain_lead] BEFORE the piece's first one (no record; 0 = none); lock-step kernel only
+    // (lock-step kernels) a led piece on a mesh too coarse to walk on walks a ladder of its own: chain_lead[c] alphas from
+    // walk_alpha[chain_walk0[c]] on (the first is its leading alpha); chain_walk0[c] < 0 or nullptr: the scan's mesh
+    const int* chain_walk0;     // [n_chain] or nullptr
+    const double* walk_alpha;   // or nullptr
     const double* alpha;    // [P]
     const double* v0;       // [n_parent][NP]   whitened basis
     // outputs, problem p = chain_prob0[chain] + i

@@ -167,8 +167,16 @@ void chain_kernel_lv(const KParams p, const MCExtra x)
         const int lead = p.chain_lead ? p.chain_lead[c] : 0;
         t.lead = lead;
         t.ia = -lead; t.niter = 0; t.nevals = 0; t.nact = 0; t.okprev = 0; t.bt = 0; t.capp = 0; t.wide = 0; t.slow = 0; t.dHp = 0.0;
-        for (int i = lane; i < min(t.clen + lead, ACAP); i += 64) s_alpha[wave][i] = p.alpha[(size_t)(t.prob0 - lead) + i];
-        t.alpha = p.alpha[(size_t)(t.prob0 - lead)];
+        // (the alphas of the walk come from the scan's own mesh -- the entries before the piece's first -- or, on a mesh too coarse to
+        //  walk on, from a ladder the library laid for this piece: KParams::walk_alpha from chain_walk0[c] on; both loads with indices
+        //  inside their arrays)
+        const int walk0 = (p.chain_walk0 && lead > 0) ? p.chain_walk0[c] : -1;
+        for (int i = lane; i < min(t.clen + lead, ACAP); i += 64) {
+            const double a_mesh = p.alpha[(size_t)max(t.prob0 - lead + i, 0)];
+            const double a_walk = p.walk_alpha ? p.walk_alpha[max(walk0, 0) + min(i, max(lead - 1, 0))] : a_mesh;
+            s_alpha[wave][i] = (walk0 >= 0 && i < lead) ? a_walk : a_mesh;
+        }
+        t.alpha = (walk0 >= 0) ? p.walk_alpha[walk0] : p.alpha[(size_t)(t.prob0 - lead)];
         t.mu = 0.0; t.muh = 0.0; t.Qprev = __builtin_nan("");
         t.chi2 = 0.0; t.S = 0.0; t.Hn2 = 1.0; t.wmax = 1.0; t.Q = 0.0; t.sc2 = 1.0; t.pred = 0.0;
         t.active = 1; t.scratch = 1;
