@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
 """condense the counter_collection CSVs of rocprofv3 --pmc runs (one directory per pass under <dir>) into one small
-table: mean per dispatch of mxe::chain_kernel_mc, for every counter"""
+table: mean per dispatch of one kernel (default mxe::chain_kernel_mc; second argument: another substring of the kernel name,
+third: prefix of the pass directories, default pmc_), for every counter"""
 import csv, glob, os, sys
 root = sys.argv[1]
+kernel = sys.argv[2] if len(sys.argv) > 2 else 'chain_kernel_mc'
+prefix = sys.argv[3] if len(sys.argv) > 3 else 'pmc_'
 rows = {}
-for path in glob.glob(os.path.join(root, 'pmc_*', '**', '*counter_collection.csv'), recursive=True):
+for path in glob.glob(os.path.join(root, prefix + '*', '**', '*counter_collection.csv'), recursive=True):
     with open(path) as f:
         for r in csv.DictReader(f):
-            if 'chain_kernel_mc' not in r.get('Kernel_Name', ''):
+            if kernel not in r.get('Kernel_Name', ''):
                 continue
             name, val = r['Counter_Name'], float(r['Counter_Value'])
             rows.setdefault(name, []).append(val)
