@@ -366,6 +366,81 @@ template <int J> __device__ __forceinline__ float half_bcast_f(float x) {
 __device__ __forceinline__ float wave_bcast_f(float x, int src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src));
 }
+#ifndef MXE_X_GJ_LOOKAHEAD
+#define MXE_X_GJ_LOOKAHEAD 1
+#endif
+#if MXE_X_GJ_LOOKAHEAD
+// Round 5: the same elimination with a SHORTER dependent chain per step and the chain of step j + 1 started before the trailing
+// update of step j is through (look-ahead).  A step used to be: swap -> three broadcasts -> determinant (2) -> reciprocal ->
+// two Newton refinements -> P^-1 (1) -> multipliers (2) -> update (2): twelve dependent instructions at 20-26 cycles each on a
+// lone wave (tools/dep_latency.hip), behind which the 2 (N/2 - j - 1) swizzles and as many multiply-adds of the trailing update
+// queued: ~450-520 cycles per step, 8.3 k of the 52 k cycles of a round (profiles/r03_g_serial_section.txt).  Now: the multipliers
+// as (numerator) x (1 / det) with the numerators formed beside the reciprocal, no refinement of v_rcp_f32 (1 ulp: the solve only
+// preconditions the step) -- eight dependent instructions --, and the order of the code is: update the NEXT pivot columns first,
+// start the next step's chain (swap, broadcasts, determinant, reciprocal, multipliers, right-hand side), then the rest of this
+// step's trailing update with the multipliers kept from before.
+template <int N>
+__device__ __forceinline__ bool gj2_solve64_f32(float (&A)[N / 2], float b, int i, float& z, bool& small_pivot)
+{
+    constexpr int NHALF = N / 2;
+#ifndef MXE_X_PIV_TAU
+#define MXE_X_PIV_TAU 1e-3f
+#endif
+    constexpr float PIV_TAU = MXE_X_PIV_TAU;    // pivots below this (the diagonal was scaled to [1, 4)): 24 bits are too few
+    bool ok = true;
+    small_pivot = false;
+    float ps = 1.0f, pc = 0.0f;                 // z_i = ps b_i + pc b_(i ^ 1)
+    float f0 = 0.0f, f1 = 0.0f;                 // multipliers of the step whose trailing update is being applied
+    float g0 = 0.0f, g1 = 0.0f;                 // ... of the step whose chain has been started (look-ahead)
+    // the chain of step kj: needs the columns 2 kj, 2 kj + 1 (register A[kj]) and b as the steps before left them
+    auto head = [&](auto KTag, float& m0, float& m1) {
+        constexpr int kj = decltype(KTag)::value, j = 2 * kj;
+        const unsigned x = __builtin_bit_cast(unsigned, A[kj]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        const float c0 = __builtin_bit_cast(float, (unsigned)sw[0]);      // column j (the lower half's values in both halves)
+        const float c1 = __builtin_bit_cast(float, (unsigned)sw[1]);      // column j + 1
+        const float pa = wave_bcast_f(c0, j), pb = wave_bcast_f(c1, j), pd = wave_bcast_f(c1, j + 1);
+        const float det = __builtin_fmaf(pa, pd, -pb * pb);
+        if (!(pa > 0.0f) || !(det > 0.0f)) ok = false;
+        if (pa < PIV_TAU || det < PIV_TAU * pa) small_pivot = true;      // (pivots: pa and det / pa)
+        const float inv = __builtin_amdgcn_rcpf(det);
+        // (f0, f1) = (c0, c1) P^-1,  P^-1 = [[pd, -pb], [-pb, pa]] / det: the numerators do not wait for the reciprocal
+        const float n0 = __builtin_fmaf(c0, pd, -c1 * pb), n1 = __builtin_fmaf(c1, pa, -c0 * pb);
+        const bool prow = (i >> 1) == kj;
+        if (prow) { ps = ((i & 1) ? pa : pd) * inv; pc = -pb * inv; }
+        m0 = prow ? 0.0f : n0 * inv;
+        m1 = prow ? 0.0f : n1 * inv;
+        const float b0 = wave_bcast_f(b, j), b1 = wave_bcast_f(b, j + 1);
+        b = __builtin_fmaf(-m1, b1, __builtin_fmaf(-m0, b0, b));
+    };
+    head(std::integral_constant<int, 0>{}, f0, f1);
+    auto step = [&](auto KTag) {
+        constexpr int kj = decltype(KTag)::value, j = 2 * kj;
+        if constexpr (kj + 1 < NHALF) {
+            // the columns of the next pivot block first ...
+            {
+                const float r0 = half_bcast_f<j>(A[kj + 1]), r1 = half_bcast_f<j + 1>(A[kj + 1]);
+                A[kj + 1] = __builtin_fmaf(-f1, r1, __builtin_fmaf(-f0, r0, A[kj + 1]));
+            }
+            // ... so that its chain runs beside the rest of this step's update
+            head(std::integral_constant<int, kj + 1>{}, g0, g1);
+#pragma unroll
+            for (int k0 = kj + 2; k0 < NHALF; k0 += 8) {
+                float r0[8], r1[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) if (k0 + r < NHALF) { r0[r] = half_bcast_f<j>(A[k0 + r]); r1[r] = half_bcast_f<j + 1>(A[k0 + r]); }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) if (k0 + r < NHALF) A[k0 + r] = __builtin_fmaf(-f1, r1[r], __builtin_fmaf(-f0, r0[r], A[k0 + r]));
+            }
+            f0 = g0; f1 = g1;
+        }
+    };
+    static_for_seq(std::make_integer_sequence<int, NHALF>{}, step);
+    const float bp = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, b), (1 << 10) | 0x1f));     // lane ^ 1
+    z = __builtin_fmaf(ps, b, pc * bp);
+    return ok;
+}
+#else
 template <int N>
 __device__ __forceinline__ bool gj2_solve64_f32(float (&A)[N / 2], float b, int i, float& z, bool& small_pivot)
 {
@@ -413,6 +488,74 @@ __device__ __forceinline__ bool gj2_solve64_f32(float (&A)[N / 2], float b, int 
     static_for_seq(std::make_integer_sequence<int, NHALF>{}, pivot2);
     const float bp = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, b), (1 << 10) | 0x1f));     // lane ^ 1
     z = __builtin_fmaf(ps, b, pc * bp);
+    return ok;
+}
+
+#endif
+// Round 5: the same system by a SYMMETRIC block elimination whose rank-2 update is ONE matrix instruction per pivot pair.
+// The elimination above is bound by the instructions a lone wave can issue (~76 per step at N = 32 -- 28 ds_swizzle and 28
+// multiply-adds of the trailing update among them --, 5.5 cycles each: 7.0-7.4 k cycles of the 51 k of a round,
+// profiles/r05_d_home_phases.txt).  Here the matrix lives in the accumulator layout of v_mfma_f32_32x32x2_f32 -- lane
+// (h = lane >> 5, n = lane & 31) holds column n of the rows 8 (v / 4) + 4 h + (v % 4), v = 0 .. 15 -- and is kept SYMMETRIC
+// where it is still read: sweeping the pivot pair J = {j, j + 1} with P = D[J][J], R = D[J][:], G = P^-1 R replaces
+//     D[i][n] <- D[i][n] - sum_k R_k[i] G_k[n]        (i, n not in J: the Schur complement, symmetric)
+//     D[i][J] <- G[.][i]                              (the swept columns: what Gauss-Jordan keeps as the multipliers of row i)
+// and both are the ONE product  D += A B  with  A (32 x 2): lane (k, i) = -R_k[i],  B (2 x 32): lane (k, n) = G_k[n] - [n in J]
+// P^-1[k][n - j]  (for n in J the symmetric entry D[i][n] = R_(n-j)[i] then turns into G_(n-j)[i]).  The operands come from the
+// two pivot ROWS alone -- two registers of the accumulator, one v_permlane32_swap each way --; no column is ever gathered.  The
+// right-hand side rides along in the lanes (lane n of either half: b_n): b_n <- b_n - sum_k B_k[n] b_(j+k), which is P^-1 b_J in the
+// pivot lanes.  Swept rows are not maintained (nothing reads them again); after N / 2 steps b is the solution.
+// Per step ~26 vector instructions + one MFMA of 16 passes instead of ~76: see tools/gj_mfma.hip for the cycles and the error.
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+template <int N>
+__device__ __forceinline__ bool gjm_solve_f32(floatx16& D, float b, int n_act, float& z, bool& small_pivot)
+{
+    static_assert(N <= 32 && N % 2 == 0, "one 32 x 32 accumulator tile");
+    constexpr int NHALF = N / 2;
+#ifndef MXE_X_PIV_TAU
+#define MXE_X_PIV_TAU 1e-3f
+#endif
+    constexpr float PIV_TAU = MXE_X_PIV_TAU;
+    bool ok = true;
+    small_pivot = false;
+    int ln = threadIdx.x & 63;
+    asm volatile("" : "+v"(ln));                  // (opaque: the lane masks below must not be hoisted out of the caller's loop)
+    const int n = ln & 31;
+    const bool upper = ln >= 32;
+    auto step = [&](auto KTag) {
+        constexpr int kj = decltype(KTag)::value, j = 2 * kj;
+        if (j < n_act) {                          // (wave-uniform; rows >= n_act are identity rows)
+            constexpr int v = 4 * (j / 8) + (j % 4), hj = (j % 8) / 4;       // rows j, j + 1: registers v, v + 1 of half hj
+            // Y0 / Y1: R_0[n] / R_1[n] in both halves (two independent swaps of the two accumulator registers with themselves);
+            // X: lane (k, n) = R_k[n]
+            const float r0 = D[v], r1 = D[v + 1];     // (as floats first: bit_cast of two vector elements in ONE declaration read element v twice)
+            unsigned a0 = __builtin_bit_cast(unsigned, r0), a1 = a0, c0 = __builtin_bit_cast(unsigned, r1), c1 = c0;
+            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(c0), "+v"(c1));        // (v_permlane32_swap exchanges its registers in place: copies)
+            const auto s0 = __builtin_amdgcn_permlane32_swap(a0, a1, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(c0, c1, false, false);
+            float Y0 = __builtin_bit_cast(float, (unsigned)s0[hj]), Y1 = __builtin_bit_cast(float, (unsigned)s1[hj]);
+            const float X = upper ? Y1 : Y0;
+            const float pa = wave_bcast_f(Y0, j), pb = wave_bcast_f(Y0, j + 1), pd = wave_bcast_f(Y1, j + 1);
+            const float det = __builtin_fmaf(pa, pd, -pb * pb);
+#ifdef GJM_DEBUG
+            if (ln == 0) printf("T step %d: v %d hj %d pa %g pb %g pd %g det %g\n", kj, v, hj, pa, pb, pd, det);
+#endif
+            if (!(pa > 0.0f) || !(det > 0.0f)) ok = false;
+            if (pa < PIV_TAU || det < PIV_TAU * pa) small_pivot = true;      // (pivots: pa and det / pa)
+            const float ninv = -__builtin_amdgcn_rcpf(det);
+            // -(G_k[n] - [n in J] P^-1[k][n - j]) = -(P^-1 (R - [n in J] e_(n-j)))_k: take the unit vectors off R in the pivot lanes.
+            // The numerators do not wait for the reciprocal; the operand of the matrix instruction is one multiplication behind it
+            Y0 = (n == j) ? Y0 - 1.0f : Y0;
+            Y1 = (n == j + 1) ? Y1 - 1.0f : Y1;
+            const float n0 = __builtin_fmaf(pd, Y0, -pb * Y1), n1 = __builtin_fmaf(pa, Y1, -pb * Y0);
+            const float Bop = (upper ? n1 : n0) * ninv;
+            const float bj = wave_bcast_f(b, j), bj1 = wave_bcast_f(b, j + 1);
+            b = __builtin_fmaf(__builtin_fmaf(n1, bj1, n0 * bj), ninv, b);
+            D = __builtin_amdgcn_mfma_f32_32x32x2f32(X, Bop, D, 0, 0, 0);
+        }
+    };
+    static_for_seq(std::make_integer_sequence<int, NHALF>{}, step);
+    z = b;
     return ok;
 }
 

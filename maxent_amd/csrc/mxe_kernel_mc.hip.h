@@ -508,6 +508,80 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
         return ok;
     };
 
+    // Round 5: the same system in the accumulator layout of v_mfma_f32_32x32x2_f32, eliminated by gjm_solve_f32 (mxe_kernel.hip.h):
+    // one matrix instruction per pivot pair instead of ~56 swizzles and multiply-adds.  Lane (h, n) holds column n of the rows
+    // 8 (v / 4) + 4 h + (v % 4), v = 0 .. 15; one instantiation for every size of the active block (steps beyond n_act are skipped).
+#ifndef MXE_X_GJ_MFMA
+#define MXE_X_GJ_MFMA 0       // (measured: the launch of the full batch 0.817 -> 0.852 ms with it, profiles/r05_experiments.txt 5.)
+#endif
+    auto gj_home_m = [&](double a, int n_act, double isc2, double& nrm_out, bool& small_pivot) -> bool {
+        const int q = wave;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                 // (opaque: what depends on the lane only must not be hoisted out of the round loop)
+        const int n = ln & 31, h = ln >> 5;
+        const double* Wq = Wt + (size_t)q * NPAIR * 256;
+        const double* rq = rhs + q * NP;
+        const double* cq = csc + q * NP;
+        const bool live = n < n_act;
+        const double sn = ssc[q * NP + n];
+        const double cn = live ? cq[n] * isc2 : 0.0;  // the tiles carry the factor sc2 of their operands
+        floatx16 D, D0;
+        {
+            // W: upper-triangular 16 x 16 tiles in the accumulator layout of the 16 x 16 MFMA -- entry (r, c), r <= c, in tile pair
+            // (r >> 4, c >> 4) at register r & 3, lane 16 ((r & 15) >> 2) + (c & 15).  All loads back to back, selected afterwards.
+            double wr[16], cr[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = 8 * (v / 4) + (v % 4) + 4 * h;
+                const int lo = min(row, n), hi = max(row, n);
+                const int mr = lo >> 4, mc = hi >> 4;
+                const int off = (mr * NT - mr * (mr - 1) / 2 + (mc - mr)) * 256 + (lo & 3) * 64 + ((lo & 15) >> 2) * 16 + (hi & 15);
+                wr[v] = Wq[off];
+                cr[v] = cq[row];
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = 8 * (v / 4) + (v % 4) + 4 * h;
+                double xv = (row < n_act) ? cn * wr[v] * cr[v] : 0.0;      // 0 in the rows and columns >= n_act
+                D0[v] = (float)xv;
+                if (row == n) xv = live ? fma(a * sn, sn, xv) : 1.0;
+                D[v] = (float)xv;
+            }
+        }
+        MXE_STAMPH(1);
+        float zf;
+        small_pivot = false;
+        const bool ok = gjm_solve_f32<32>(D, live ? (float)(rq[n] * sn) : 0.0f, n_act, zf, small_pivot);
+        const double z = (double)zf * sn;
+        // delta^T W delta = z^T (c W c) z for Bryan's bound, as the quadratic form itself (see gj_home): lane (h, n) sums its rows
+        // of column n, the halves are added, column n (= row n: symmetric) weighs in with z_n
+        float* zs = &s_zp[q][0][0];
+        if (h == 0) zs[n] = live ? zf : 0.0f;
+        wave_sync();
+        float y = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 zr = *reinterpret_cast<const float4*>(zs + 8 * g + 4 * h);
+            y = __builtin_fmaf(D0[4 * g + 0], zr.x, y); y = __builtin_fmaf(D0[4 * g + 1], zr.y, y);
+            y = __builtin_fmaf(D0[4 * g + 2], zr.z, y); y = __builtin_fmaf(D0[4 * g + 3], zr.w, y);
+        }
+        {
+            const unsigned yu = __builtin_bit_cast(unsigned, y);
+            unsigned ya = yu, yb = yu;
+            asm volatile("" : "+v"(ya), "+v"(yb));
+            const auto ys = __builtin_amdgcn_permlane32_swap(ya, yb, false, false);
+            const float yt = __builtin_bit_cast(float, (unsigned)ys[0]) + __builtin_bit_cast(float, (unsigned)ys[1]);
+            nrm_out = wave_sum((h == 0 && live) ? (double)(zf * yt) : 0.0);
+        }
+        MXE_STAMPH(3);
+        if (ok && live && h == 0) zz[q * NP + n] = z;
+        MXE_STAMPH(4);
+#ifdef MXE_PROFILE_HOME
+        prof_acc[6] += 1;
+#endif
+        return ok;
+    };
+
     // More than 32 coupled directions (NA = 48 / 64 builds): one row per lane, all N columns in registers, pivot rows by
     // v_readlane (gj1_solve_rows_f32).  Same scaling, same quadratic form for the norm of the step.
     auto gj_home_rows = [&](auto NTag, double a, int n_act, double isc2, double& nrm_out, bool& small_pivot) -> bool {
@@ -851,15 +925,19 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                     if constexpr (NA > 32) {
                         // (the build for more than 32 coupled directions: two sizes of the one-row-per-lane solve beside the
                         //  32-row two-half one)
-                        if (na <= 32) ok = gj_home(std::integral_constant<int, 32>{}, a, na, isc2, nrm_gj, small);
+                        if (na <= 32) ok = MXE_X_GJ_MFMA ? gj_home_m(a, na, isc2, nrm_gj, small) : gj_home(std::integral_constant<int, 32>{}, a, na, isc2, nrm_gj, small);
                         else if (na <= 48) ok = gj_home_rows(std::integral_constant<int, 48>{}, a, na, isc2, nrm_gj, small);
                         else ok = gj_home_rows(std::integral_constant<int, (NA > 48 ? 64 : 48)>{}, a, na, isc2, nrm_gj, small);
                     } else
+#if MXE_X_GJ_MFMA
+                    ok = gj_home_m(a, na, isc2, nrm_gj, small);
+#else
                     if (na <= 16) ok = gj_home(std::integral_constant<int, 16>{}, a, na, isc2, nrm_gj, small);
                     else if (na <= 20) ok = gj_home(std::integral_constant<int, 20>{}, a, na, isc2, nrm_gj, small);
                     else if (na <= 24) ok = gj_home(std::integral_constant<int, 24>{}, a, na, isc2, nrm_gj, small);
                     else if (na <= 28) ok = gj_home(std::integral_constant<int, 28>{}, a, na, isc2, nrm_gj, small);
                     else ok = gj_home(std::integral_constant<int, 32>{}, a, na, isc2, nrm_gj, small);
+#endif
                     // (a small pivot: the block is ill conditioned for 24 bits.  The step is still a descent direction --
                     //  an inexact Newton step -- but the iteration may crawl: the alpha is given up early, see step 4)
                     if (t.wide == 0 && __builtin_amdgcn_readfirstlane(__any(small ? 1 : 0))) t.wide = t.niter + 1;       // (pivots are wave-uniform)
