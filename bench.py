@@ -390,7 +390,22 @@ def many_objects_block(make, res_one, n_orb, n_alpha, n_jobs=4, repeats=6):
         out2 = mx.run_many(jobs)
         t_new.append(time.perf_counter() - t0)
         del out2
+    # eight objects (what the pool of solvers holds): nearer the steady state of launches in flight than a burst of four
+    more = jobs + [make(300 + k) for k in range(8 - n_jobs)] if n_jobs < 8 else jobs
+    t_eight = []
+    if len(more) == 8:
+        o8 = mx.run_many(more)
+        del o8
+        for _ in range(repeats):
+            for ew in more:
+                ew.maxent_result = None
+            t0 = time.perf_counter()
+            o8 = mx.run_many(more)
+            t_eight.append(time.perf_counter() - t0)
+            del o8
     return dict(api='maxent_amd.run_many([ew0 .. ew%d]) -- ElementwiseMaxEnt.run_async() on every object, then .result() in turn' % (n_jobs - 1),
+                eight_objects_ms=(1e3 * min(t_eight) if t_eight else None),
+                alpha_solves_per_s_eight_objects=(8 * n_orb * n_orb * n_alpha / min(t_eight) if t_eight else None),
                 jobs=n_jobs, problems=P,
                 run_many_ms=1e3 * min(t_many), sequential_runs_ms=1e3 * min(t_seq), run_many_new_data_ms=1e3 * min(t_new),
                 alpha_solves_per_s=P / min(t_many), alpha_solves_per_s_sequential=P / min(t_seq),

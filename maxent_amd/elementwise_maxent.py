@@ -317,7 +317,7 @@ class ElementwiseMaxEnt(object):
         self._solve_batches([batch])
         return self._finish_batch(batch)
 
-    def _prepare_batch(self, worker, jobs, per_job_D=None):
+    def _prepare_batch(self, worker, jobs, per_job_D=None, defer_last_load=None):
         """the specs of the elements of ``jobs`` that are to be solved (the others go to the result's zero
         elements); leaves ``worker`` loaded with the last element, as the reference does"""
         self.prepare_maxent_result(overwrite=False)
@@ -425,7 +425,12 @@ class ElementwiseMaxEnt(object):
                     if whole:
                         plan['live'] = live
                 if rest[-1] == len(jobs) - 1:
-                    self._load_element(worker, jobs[-1][0], jobs[-1][1])
+                    if defer_last_load is not None and arrays is not None:
+                        # (the state the phase leaves behind -- the worker loaded with its last element, as in the reference -- does
+                        #  not enter the launch: the caller makes it up behind the launch, beside the kernel)
+                        defer_last_load.append((worker, jobs[-1][0], jobs[-1][1]))
+                    else:
+                        self._load_element(worker, jobs[-1][0], jobs[-1][1])
         # (the keys of the result's records, made once: they were made three times per element -- 0.2 ms of a 16 x 16 run)
         keys = None
         if direct and len(jobs) > 1:
@@ -773,10 +778,15 @@ class ElementwiseMaxEnt(object):
             raise RuntimeError('this object has a run in flight: take its result() first')
         # both phases in ONE launch where the two workers share the kernel's decomposition
         self.maxent_diagonal.logtaker.message(VerbosityFlags.ElementInfo, 'Calculating diagonal elements.')
-        diag = self._prepare_batch(self.maxent_diagonal, self._diag_jobs())
+        later = []
+        diag = self._prepare_batch(self.maxent_diagonal, self._diag_jobs(), defer_last_load=later)
         self.maxent_offdiagonal.logtaker.message(VerbosityFlags.ElementInfo, 'Calculating off-diagonal elements.')
-        off = self._prepare_batch(self.maxent_offdiagonal, self._offdiag_jobs())
-        wait = self._solve_batches([diag, off], defer=True, in_flight=in_flight)
+        off = self._prepare_batch(self.maxent_offdiagonal, self._offdiag_jobs(), defer_last_load=later)
+        try:
+            wait = self._solve_batches([diag, off], defer=True, in_flight=in_flight)
+        finally:
+            for worker, element, re in later:         # (beside the kernel: the workers as the reference leaves them)
+                self._load_element(worker, element, re)
 
         def finish():
             wait()
