@@ -275,11 +275,13 @@ struct mxe_ctx {
     DevBuf<double> dwalk_alpha;
     DevBuf<double> dinit_tab;           // start states per class of pieces (KParams::init_tab)
     DevBuf<double> dgstate;             // omega-space state of the chains when it does not fit LDS (KParams::gstate)
-    DevBuf<int> dfin_budget;            // mxe_chains_finish: iterations every alpha may still spend
+    DevBuf<int> dfin_budget, dfin_out;  // mxe_chains_finish: iterations every entry may still spend; where it writes its record (-1: a rung)
+    DevBuf<double> dfin_alpha;          //   the alphas of the entries (mesh alphas and rungs)
     DevBuf<int> dfin_elem, dfin_prob0, dfin_len, dfin_v0;       // mxe_chains_finish: one piece per alpha that is solved again
     DevBuf<double> dfin_start;          //   and its start vector (the state the lock-step kernel left)
     int sel3_nc = 0;                    // scans of the launch the last mxe_select3_launch chose for (0: none since the chains were uploaded)
     int last_finished = 0;              // alphas the last mxe_chains_finish solved again
+    int last_rungs = 0;                 //   rungs it laid between them (coarse meshes)
     bool has_init = false;
     // mxe_eval_batch / mxe_audit scratch
     DevBuf<double> ev_x, ev_alpha, ev_scal, ev_vecw, ev_vecs, ev_mat;
@@ -1532,6 +1534,7 @@ static void fill_kparams(mxe_ctx* ctx, KParams& kp)
     kp.mc_maxiter = std::min(o.maxiter, std::max(MC_MAXITER, o.miniter + 8));     // (a caller's miniter above the limit moves it)
     kp.mc_abandon = 1;
     kp.prob_maxiter = nullptr;
+    kp.out_index = nullptr;
 }
 
 namespace {
@@ -1793,33 +1796,78 @@ try {
     const int NP = ctx->NP, na = ctx->n_alpha;
     std::vector<int> f_elem, f_prob0, f_len, f_v0;
     std::vector<size_t> f_src;                       // row of dout_v the run starts from
+    // The entries of the chains: the open alphas of the mesh and -- where the mesh is too coarse to step on (round 5) -- RUNGS in
+    // between.  What is left to this pass lies deep in the region where the entropy term no longer holds the solution (or couples
+    // more directions than the lock-step layout takes); there a warm step over the factor 1.9 of the reference's default mesh
+    // (alpha_meshes.py:81: 20 alphas from 20 down to 1e-4) took 500-2 300 evaluations where ten steps of 10 % take 35 each
+    // (profiles/r05_b_coarse_mesh.txt, tools/stress.py case 17).  A step over more than FIN_COARSE is therefore cut into equal
+    // rungs of at most FIN_RATIO; a rung gets FIN_RUNG_ITERS iterations, no record, and its cost is counted with the alpha it leads to.
+    constexpr double FIN_COARSE = 1.6, FIN_RATIO = 1.3;
+    constexpr int FIN_RUNG_ITERS = 10, FIN_RUNGS_MAX = 40;
+    const bool rungs_ok = !getenv("MXE_NO_FINISH_LADDER");
+    std::vector<double> halpha(P);
+    HIPCHK(ctx, hipMemcpy(halpha.data(), ctx->dalpha.p, P * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<double> e_alpha;                     // per entry
+    std::vector<int> e_out, e_budget;
+    int n_rungs = 0;
     for (int c = 0; c < ctx->n_chain; ++c)
         for (int i = 0; i < na; ) {
             if (!open[(size_t)c * na + i]) { ++i; continue; }
             int j = i;
             while (j < na && open[(size_t)c * na + j]) ++j;
-            f_elem.push_back(ctx->chain_elem[c]); f_prob0.push_back(c * na + i); f_len.push_back(j - i);
+            f_elem.push_back(ctx->chain_elem[c]); f_prob0.push_back((int)e_alpha.size());
             f_v0.push_back((int)f_v0.size());
             f_src.push_back((size_t)c * na + (i > 0 ? i - 1 : 0));
+            for (int k = i; k < j; ++k) {
+                const size_t pk = (size_t)c * na + k;
+                if (rungs_ok && k > 0) {
+                    const double a_from = halpha[pk - 1], a_to = halpha[pk];
+                    const double r = a_from > a_to ? a_from / a_to : a_to / a_from;
+                    if (r > FIN_COARSE) {
+                        int m = (int)std::ceil(std::log(r) / std::log(FIN_RATIO) - 1e-9);          // steps, the last of them the alpha itself
+                        m = std::max(2, std::min(m, FIN_RUNGS_MAX + 1));
+                        const double q = std::pow(a_to / a_from, 1.0 / m);
+                        for (int s2 = 1; s2 < m; ++s2) {
+                            e_alpha.push_back(a_from * std::pow(q, s2)); e_out.push_back(-1); e_budget.push_back(FIN_RUNG_ITERS);
+                            ++n_rungs;
+                        }
+                    }
+                }
+                e_alpha.push_back(halpha[pk]); e_out.push_back((int)pk);
+                // the caller's maxiter bounds the iterations of an alpha over BOTH passes, alpha by alpha as the reference caps them
+                // (levenberg_minimizer.py:155): every open alpha gets what the lock-step pass left of ITS budget -- an alpha that pass
+                // never touched (the rest of an abandoned piece, an excluded alpha: nit = 0) the whole of it.  (Until round 5 the pass had
+                // ONE budget, that of the open alpha with the most iterations behind it: ADVICE r04.)
+                e_budget.push_back(std::max(1, o.maxiter - nit[pk]));
+            }
+            f_len.push_back((int)e_alpha.size() - f_prob0.back());
             i = j;
         }
     const int nr = (int)f_elem.size();
+    const size_t ne = e_alpha.size();
     HIPCHK(ctx, ctx->dfin_elem.ensure(nr)); HIPCHK(ctx, ctx->dfin_prob0.ensure(nr));
     HIPCHK(ctx, ctx->dfin_len.ensure(nr)); HIPCHK(ctx, ctx->dfin_v0.ensure(nr));
     HIPCHK(ctx, ctx->dfin_start.ensure((size_t)nr * NP));
+    HIPCHK(ctx, ctx->dfin_alpha.ensure(ne)); HIPCHK(ctx, ctx->dfin_out.ensure(ne)); HIPCHK(ctx, ctx->dfin_budget.ensure(ne));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_elem.p, f_elem.data(), nr * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_prob0.p, f_prob0.data(), nr * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_len.p, f_len.data(), nr * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_v0.p, f_v0.data(), nr * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_alpha.p, e_alpha.data(), ne * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_out.p, e_out.data(), ne * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_budget.p, e_budget.data(), ne * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     for (int k = 0; k < nr; ++k)         // start vectors (whitened basis, row stride NP)
         HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_start.p + (size_t)k * NP, ctx->dout_v.p + f_src[k] * NP, NP * sizeof(double),
                                    hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, stream_wait(ctx->stream));          // (the host vectors are locals)
     KParams kp;
     fill_kparams(ctx, kp);
     kp.chain_elem = ctx->dfin_elem.p; kp.chain_prob0 = ctx->dfin_prob0.p; kp.chain_len = ctx->dfin_len.p;
     kp.chain_v0 = ctx->dfin_v0.p; kp.v0 = ctx->dfin_start.p;
     kp.chain_lead = nullptr; kp.init_tab = nullptr; kp.chain_init = nullptr; kp.chain_walk0 = nullptr; kp.walk_alpha = nullptr;
     kp.n_chain = nr;
+    kp.alpha = ctx->dfin_alpha.p; kp.out_index = ctx->dfin_out.p; kp.prob_maxiter = ctx->dfin_budget.p;
+    ctx->last_rungs = n_rungs;
 #ifdef MXE_PROFILE
     // (diagnostic build: the stamps of THIS pass, rows 0 .. nr - 1 -- tools/finish_phases.py; those of the lock-step launch are gone)
     if (ctx->dprof.p && (size_t)nr <= (size_t)ctx->n_sub + 8 * 1024) {
@@ -1827,18 +1875,6 @@ try {
         kp.prof = ctx->dprof.p;
     }
 #endif
-    {
-        // the caller's maxiter bounds the iterations of an alpha over BOTH passes, alpha by alpha as the reference caps them
-        // (levenberg_minimizer.py:155): every open alpha gets what the lock-step pass left of ITS budget -- an alpha that pass
-        // never touched (the rest of an abandoned piece, an excluded alpha: nit = 0) the whole of it.  (Until round 5 the pass had
-        // ONE budget, that of the open alpha with the most iterations behind it: ADVICE r04.)
-        std::vector<int> budget(P, o.maxiter);
-        for (size_t i = 0; i < P; ++i) if (open[i]) budget[i] = std::max(1, o.maxiter - nit[i]);
-        HIPCHK(ctx, ctx->dfin_budget.ensure(P));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_budget.p, budget.data(), P * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, stream_wait(ctx->stream));          // (budget is a local)
-        kp.prob_maxiter = ctx->dfin_budget.p;
-    }
     const int NW = 4;
     size_t lds = lds_bytes(NP, ctx->nwp, NW, false);
     hipError_t e;

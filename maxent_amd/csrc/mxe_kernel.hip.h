@@ -103,6 +103,10 @@ struct KParams {
     // (one-chain kernel) iterations problem p may still spend, or nullptr: maxiter for every alpha.  mxe_chains_finish sets it:
     // the caller's maxiter caps the iterations of ONE alpha over both passes (levenberg_minimizer.py:155 caps per alpha)
     const int* prob_maxiter;    // [P]
+    // (one-chain kernel, the finishing pass on a coarse mesh) the entries of a chain may be RUNGS between two alphas of the mesh:
+    // entry e = chain_prob0 + i writes its record to problem out_index[e], or nowhere when that is < 0 (a rung: a few iterations
+    // towards the next alpha of the mesh, whose record then counts the rung's iterations and evaluations as its own); nullptr: e
+    const int* out_index;       // [entries] or nullptr
 };
 
 #if defined(MXE_PROFILE) && defined(MXE_PROFILE_EVAL)
@@ -1399,7 +1403,7 @@ void chain_kernel(const KParams p)
     double chi2, S, dH2, Hn2, wmax, dumax;
     eval_pass(v, true, chi2, S, dH2, Hn2, wmax, dumax);
     accept_trial();                 // dl == 0: v unchanged
-    int nevals_pending = 1;
+    int nevals_pending = 1, niter_pending = 0;
 
     const int prob0 = p.chain_prob0[chain], clen = p.chain_len[chain];
     for (int ia = 0; ia < clen; ++ia) {
@@ -1607,7 +1611,15 @@ void chain_kernel(const KParams p)
             block_sync<SYNCW>();
         }
         // ---- results of this alpha (MaxEntResult fields, maxent_result.py:835-967)
-        const size_t prob = (size_t)prob0 + ia;
+        const long long po = p.out_index ? (long long)p.out_index[(size_t)prob0 + ia] : (long long)prob0 + ia;
+        if (po < 0) {
+            // a rung of a ladder: no record; what it cost is the next alpha's
+            nevals_pending += nevals;
+            niter_pending += n_iter;
+            MXE_STAMP(6);
+            continue;
+        }
+        const size_t prob = (size_t)po;
         if (p.out_H) {
             double* Ho = p.out_H + prob * nw;
             for (int i = tid; i < nw; i += T) {
@@ -1621,11 +1633,12 @@ void chain_kernel(const KParams p)
             p.out_chi2[prob] = chi2;
             p.out_S[prob] = S;
             p.out_Q[prob] = Q;
-            p.out_niter[prob] = n_iter;
+            p.out_niter[prob] = n_iter + niter_pending;
             p.out_conv[prob] = conv;
             p.out_nevals[prob] = nevals;
             p.out_nact[prob] = n_act_last;
         }
+        niter_pending = 0;
         MXE_STAMP(6);
     }
 #ifdef MXE_PROFILE

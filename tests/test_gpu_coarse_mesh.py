@@ -28,10 +28,10 @@ def solve(K, omega, Gs, kinds, err, alphas):
     v0 = np.stack([hostprep.initial_v(K.V, D, omega.delta, k) for k in kinds])
     out = ctx.solve_chains(np.arange(n), alphas, v0)
     info, depth = ctx.last_launch_info(), ctx.launch_depth()
+    audit = ctx.audit()['corr']          # (of the finished results: the launch below is for the clock and runs no finishing pass)
     ctx.launch()
     ctx.sync()
     ms = ctx.last_kernel_ms()
-    audit = ctx.audit()['corr']
     ctx.close()
     return out, info, depth, ms, audit
 
@@ -95,3 +95,19 @@ def test_the_reference_test_mesh_has_a_time_bound():
     res = None
     tm.run()                                               # (warm: the code object is loaded)
     assert tm.maxent_loop.last_launch['kernel_ms'] < 1.0, tm.maxent_loop.last_launch
+
+
+def test_the_reference_default_alpha_mesh_reaches_far_below_the_noise():
+    """``LogAlphaMesh()`` -- the reference's default, alpha_meshes.py:81: 20 alphas from 20 down to 1e-4, a factor 1.9 apart -- on 200 data
+    points ends at alpha~ = 0.02, where the last alphas couple more directions than the lock-step layout takes and are left to the
+    finishing pass (``mxe_chains_finish``).  A warm step over the factor 1.9 took 500-2 300 evaluations there (round 4: 921 / 486 /
+    2 269 for the last three alphas); the pass now lays rungs of <= 1.3 between the alphas of such a mesh
+    (``KParams::out_index``): tens of evaluations, the same minimisers (device audit)."""
+    tau, omega, K, G = synthetic.single_G(200, 500)
+    K.reduce_singular_space(1e-14)
+    alphas = np.array(mx.LogAlphaMesh()) * 200
+    out, info, depth, ms, audit = solve(K, omega, [G], [device.ENTROPY_NORMAL], synthetic.SIGMA * np.ones(200), alphas)
+    assert out['converged'].all()
+    assert np.nanmax(audit) < 1e-7, np.nanmax(audit)
+    assert out['n_evals'].max() <= 150, out['n_evals']            # (round 4: 2 269)
+    assert np.all(np.diff(out['chi2'][0]) < 0)                     # chi2 falls with alpha down to the last
