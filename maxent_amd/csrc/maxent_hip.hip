@@ -203,9 +203,10 @@ template <typename T> struct DevBuf {
         if (p) { hipDeviceSynchronize(); release(); }      // (growing: whoever still reads the old block finishes first, as hipFree made sure)
         size_t got = 0;
         void* q = g_pool.take(need, &got);
-        if (q) { p = (T*)q; bytes = got; n = count; return hipSuccess; }
+        static const bool poison = getenv("MXE_POISON_ALLOC") != nullptr;      // (debugging aid: nothing may rely on what a fresh block holds)
+        if (q) { p = (T*)q; bytes = got; n = count; if (poison) hipMemset(p, 0xA5, bytes); return hipSuccess; }
         hipError_t e = hipMalloc((void**)&p, need);
-        if (e == hipSuccess) { n = count; bytes = need; }
+        if (e == hipSuccess) { n = count; bytes = need; if (poison) hipMemset(p, 0xA5, bytes); }
         return e;
     }
     // (callers make sure nothing in flight uses the block: mxe_ctx_destroy waits for its stream first)
@@ -584,6 +585,7 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
     comm_release(ctx);
     ctx->dVx.release(); ctx->dsel3.release(); ctx->dgstate.release(); ctx->dgstate_mc.release(); ctx->dfin_elem.release(); ctx->dfin_prob0.release();
     ctx->dfin_len.release(); ctx->dfin_v0.release(); ctx->dfin_start.release();
+    ctx->dfin_budget.release(); ctx->dfin_out.release(); ctx->dfin_alpha.release();
     ctx->dlogdet.release(); ctx->dparent_elem.release(); ctx->dV.release(); ctx->dVt.release(); ctx->dVf.release(); ctx->dVtf.release(); ctx->dc.release(); ctx->dcinv.release();
     ctx->dghat.release(); ctx->dcperp.release(); ctx->dD.release(); ctx->dsumD.release();
     ctx->dalpha.release(); ctx->dv0.release(); ctx->delem_ds.release(); ctx->delem_kind.release();
@@ -1215,27 +1217,37 @@ try {
                 const double r = ac[i - 1] / a;
                 return r > MC_LADDER_COARSE || r < 1.0 / MC_LADDER_COARSE;
             };
-            auto emit_ladder = [&](int i) {
+            auto emit_ladder = [&](int i, int len = 1) {
                 const double a = ac[i];
                 const double top = std::max(hard_below, a * MC_LADDER_RATIO);
                 int rungs = (int)std::ceil(std::log(top / a) / std::log(MC_LADDER_RATIO) - 1e-9);
-                rungs = std::max(1, std::min(rungs, MC_LADDER_MAX));
+                rungs = std::max(1, std::min(rungs, std::min(MC_LADDER_MAX, 30 - len)));      // (rungs + alphas of the piece: the slot's table of 32)
                 const double ratio = std::pow(top / a, 1.0 / rungs);          // (equal rungs; more than MC_LADDER_MAX would not fit the slot's table)
                 const int w0 = (int)ctx->walk_alpha.size();
                 for (int k = 0; k < rungs; ++k) ctx->walk_alpha.push_back(a * std::pow(ratio, rungs - k));
-                emit(i, 1, rungs, w0);
+                emit(i, len, rungs, w0);
                 ctx->has_walk = true;
+            };
+            // A piece whose FIRST alpha is its hardest: the head of a scan that begins deep in the hard region, and every piece of an
+            // ASCENDING scan there (each starts from the default model at its smallest alpha: on 150 alphas rising from alpha~ = 0.5 at
+            // sigma = 4e-5 the head took 2 989 evaluations and did not converge, tools/stress.py case 17).  It is led down a ladder from
+            // N_data / 4 to its first alpha and goes on up its own mesh from there.
+            auto emit_plain = [&](int first, int len) {
+                const bool deep = ladder_ok && len <= 24 && ac[first] * (MC_LADDER_RATIO * MC_LADDER_RATIO) < hard_below &&
+                                  (first == 0 || ac[first - 1] < ac[first]);
+                if (deep) emit_ladder(first, len);
+                else emit(first, len, 0, -1);
             };
             {
                 // the part of the piece that is not led: cut at every hard alpha
                 int b = a0;
                 for (int i = a0; i < g0; ++i)
                     if (hard(i)) {
-                        if (i > b) emit(b, i - b, 0, -1);
+                        if (i > b) emit_plain(b, i - b);
                         emit_ladder(i);
                         b = i + 1;
                     }
-                if (g0 > b) emit(b, g0 - b, 0, -1);
+                if (g0 > b) emit_plain(b, g0 - b);
             }
             for (int b0 = g0; b0 < a1; ++b0) {
                 if (hard(b0)) emit_ladder(b0);
@@ -1487,6 +1499,22 @@ try {
     if (!ctx->wg_chains.empty())
         HIPCHK(ctx, hipMemcpyAsync(ctx->dwg_chains.p, ctx->wg_chains.data(), ctx->wg_chains.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     if (layout != 4) ctx->excluded.clear();
+    {
+        // every problem belongs to exactly one piece, or to the list the finishing pass takes (checked: a problem that nothing
+        // covers would keep whatever the result buffers held before)
+        std::vector<char> cov(P, 0);
+        size_t twice = 0;
+        for (int sc = 0; sc < ctx->n_sub; ++sc)
+            for (int i = 0; i < ctx->sub_len[sc]; ++i) { char& c = cov[(size_t)ctx->sub_prob0[sc] + i]; if (c) ++twice; c = 1; }
+        for (int x : ctx->excluded) { char& c = cov[(size_t)x]; if (c) ++twice; c = 1; }
+        size_t missing = 0;
+        for (size_t i = 0; i < P; ++i) if (!cov[i]) ++missing;
+        if (missing || twice) {
+            fprintf(stderr, "mxe_chains_upload: %zu problems covered by no piece, %zu by two (layout %d, %d pieces, %zu excluded)\n",
+                    missing, twice, layout, ctx->n_sub, ctx->excluded.size());
+            return MXE_ERR_STATE;
+        }
+    }
     if (!ctx->excluded.empty()) {
         HIPCHK(ctx, ctx->dexcluded.ensure(ctx->excluded.size()));
         HIPCHK(ctx, hipMemcpyAsync(ctx->dexcluded.p, ctx->excluded.data(), ctx->excluded.size() * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1802,8 +1830,10 @@ try {
     // (alpha_meshes.py:81: 20 alphas from 20 down to 1e-4) took 500-2 300 evaluations where ten steps of 10 % take 35 each
     // (profiles/r05_b_coarse_mesh.txt, tools/stress.py case 17).  A step over more than FIN_COARSE is therefore cut into equal
     // rungs of at most FIN_RATIO; a rung gets FIN_RUNG_ITERS iterations, no record, and its cost is counted with the alpha it leads to.
-    constexpr double FIN_COARSE = 1.6, FIN_RATIO = 1.3;
-    constexpr int FIN_RUNG_ITERS = 10, FIN_RUNGS_MAX = 40;
+    constexpr double FIN_COARSE = 1.6;
+    const double FIN_RATIO = getenv("MXE_FIN_RATIO") ? std::max(1.05, atof(getenv("MXE_FIN_RATIO"))) : 1.3;
+    const int FIN_RUNG_ITERS = getenv("MXE_FIN_RUNG_ITERS") ? std::max(1, atoi(getenv("MXE_FIN_RUNG_ITERS"))) : 10;
+    constexpr int FIN_RUNGS_MAX = 40;
     const bool rungs_ok = !getenv("MXE_NO_FINISH_LADDER");
     std::vector<double> halpha(P);
     HIPCHK(ctx, hipMemcpy(halpha.data(), ctx->dalpha.p, P * sizeof(double), hipMemcpyDeviceToHost));
@@ -1817,7 +1847,32 @@ try {
             while (j < na && open[(size_t)c * na + j]) ++j;
             f_elem.push_back(ctx->chain_elem[c]); f_prob0.push_back((int)e_alpha.size());
             f_v0.push_back((int)f_v0.size());
-            f_src.push_back((size_t)c * na + (i > 0 ? i - 1 : 0));
+            // (a run at the head of a scan starts from the state its first alpha was left in -- if it was ever evaluated: a led piece
+            //  that gives up during its WALK leaves no record of its own alpha, and the vector in the result buffer is then whatever
+            //  the block held before: the start vector of the scan instead.  SIZE_MAX marks that)
+            const size_t p_head = (size_t)c * na + i;
+            f_src.push_back(i > 0 ? p_head - 1 : ((nit[p_head] > 0 || nev[p_head] > 0) ? p_head : (size_t)-1 - (size_t)c));
+            if (rungs_ok && i == 0 && f_src.back() > (size_t)-1 - (size_t)ctx->n_chain - 1) {
+                // a run that begins at the head of a scan from the default model, deep in the hard region (an ascending mesh, or a
+                // mesh that lies there altogether): rungs from N_data / 4 down to its first alpha, like the led pieces of the
+                // lock-step kernel (mxe_chains_upload: emit_ladder) -- the cold start at alpha~ = 0.5 of tools/stress.py case 17 ran
+                // into maxiter
+                const double a_to = halpha[p_head];
+                const double a_from = 0.25 * ctx->ds[ctx->elem_ds[ctx->chain_elem[c]]].n_rows;
+                // (only where the mesh goes on FINE from there -- the rising mesh of case 17: 148 -> 150 of 150 converged, 61 -> 8 ms;
+                //  case 5: 29 -> 4.5 ms.  With three alphas five decades apart, alpha~ = 0.06 at sigma = 1e-5 on 40 data points, the
+                //  cold start with its full budget converged 129 of 192 and the rungs 99-108 at any ratio and budget tried: case 93)
+                const bool fine_head = na > 1 && std::max(halpha[p_head + 1] / a_to, a_to / halpha[p_head + 1]) <= FIN_COARSE;
+                if (fine_head && a_to * FIN_RATIO * FIN_RATIO < a_from) {
+                    int m = (int)std::ceil(std::log(a_from / a_to) / std::log(FIN_RATIO) - 1e-9);
+                    m = std::max(2, std::min(m, FIN_RUNGS_MAX + 1));
+                    const double q = std::pow(a_to / a_from, 1.0 / m);
+                    for (int s2 = 0; s2 < m; ++s2) {
+                        e_alpha.push_back(a_from * std::pow(q, s2)); e_out.push_back(-1); e_budget.push_back(s2 == 0 ? 3 * FIN_RUNG_ITERS : FIN_RUNG_ITERS);
+                        ++n_rungs;
+                    }
+                }
+            }
             for (int k = i; k < j; ++k) {
                 const size_t pk = (size_t)c * na + k;
                 if (rungs_ok && k > 0) {
@@ -1856,9 +1911,11 @@ try {
     HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_alpha.p, e_alpha.data(), ne * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_out.p, e_out.data(), ne * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_budget.p, e_budget.data(), ne * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    for (int k = 0; k < nr; ++k)         // start vectors (whitened basis, row stride NP)
-        HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_start.p + (size_t)k * NP, ctx->dout_v.p + f_src[k] * NP, NP * sizeof(double),
-                                   hipMemcpyDeviceToDevice, ctx->stream));
+    for (int k = 0; k < nr; ++k) {       // start vectors (whitened basis, row stride NP)
+        const bool from_v0 = f_src[k] > (size_t)-1 - (size_t)ctx->n_chain - 1;
+        const double* from = from_v0 ? ctx->dv0.p + ((size_t)-1 - f_src[k]) * NP : ctx->dout_v.p + f_src[k] * NP;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->dfin_start.p + (size_t)k * NP, from, NP * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    }
     HIPCHK(ctx, stream_wait(ctx->stream));          // (the host vectors are locals)
     KParams kp;
     fill_kparams(ctx, kp);
