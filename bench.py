@@ -947,6 +947,15 @@ def main():
             dog.cancel()
         return
 
+    # the rounds of the workgroups of the timed launch (mxe_launch_depth): the build of the full batch does not count them in the
+    # timed region (a memset node per launch); one launch with the switch on, outside it -- the tail of the launch as a number
+    os.environ['MXE_COUNT_ROUNDS'] = '1'
+    try:
+        ctx.launch()
+        ctx.sync()
+        depth_timed = ctx.launch_depth()
+    finally:
+        del os.environ['MXE_COUNT_ROUNDS']
     ctx.launch()
     info = ctx.last_launch_info()
     # (mxe_chains_finish -- the alphas a lock-step launch gives up on, solved again in the one-chain layout -- is not part
@@ -1072,6 +1081,10 @@ def main():
     line['one_at_a_time_ms'] = line['ms_per_step']
     line['one_at_a_time_value'] = line['value']
     line['evals_per_solve'] = float(out['n_evals'].mean())
+    line['launch_depth'] = dict(max_rounds=int(depth_timed['max_rounds'][0]), mean_rounds=float(depth_timed['mean_rounds'][0]),
+                                note='Newton rounds of the persistent workgroups of the timed launch (lock-step: one round = one evaluation of '
+                                     'every busy slot of a workgroup): the launch is as long as its slowest workgroups, the mean is what a '
+                                     'perfectly balanced launch would take (profiles/r05_experiments.txt)')
     line['watchdog_fired'] = False
     line['in_flight_ok'] = None
     if in_flight_region is not None:

@@ -1602,6 +1602,12 @@ try {
     const mxe_opts& o = ctx->opts;
     KParams kp;
     fill_kparams(ctx, kp);
+    if (getenv("MXE_COUNT_ROUNDS") && ctx->mc_na > 0 && kp.chain_lead == nullptr && ctx->lv_mode == 0) {
+        // a diagnostic launch that counts the rounds of its workgroups (mxe_launch_depth) also where the shipped build does not --
+        // <32, 2> without led pieces compiles the store out --: the build for led pieces with no piece led, the same schedule
+        HIPCHK(ctx, hipMemsetAsync(ctx->dsub_pre.p, 0, (size_t)std::max(ctx->n_sub, 1) * sizeof(int), ctx->stream));
+        kp.chain_lead = ctx->dsub_pre.p;
+    }
 #ifdef MXE_PROFILE
     HIPCHK(ctx, ctx->dprof.ensure(((size_t)ctx->n_sub + 8 * 1024) * 8));   // rows: chain (v2) or workgroup*8 + wave (lock-step)
     HIPCHK(ctx, hipMemsetAsync(ctx->dprof.p, 0, ((size_t)ctx->n_sub + 8 * 1024) * 64, ctx->stream));
@@ -1689,7 +1695,8 @@ try {
         // layout (MCExtra: the pointer is the table of chain ids in the static one).  Not <32, 2> without led pieces -- the batch
         // that fills the GPU: the memset node alone is 1.5 us of its 812 (A/B: profiles/r04_experiments.txt)
         ctx->rounds_n[0] = ctx->rounds_n[1] = 0;
-        if (ex.n_queue > 0 && (kp.chain_lead != nullptr || WGPC == 1)) {
+        // (MXE_COUNT_ROUNDS: there as well -- a diagnostic launch, bench.py: launch_depth)
+        if (ex.n_queue > 0 && (kp.chain_lead != nullptr || WGPC == 1 || getenv("MXE_COUNT_ROUNDS"))) {
             ctx->rounds_n[0] = ctx->n_wg;
             HIPCHK(ctx, ctx->drounds.ensure((size_t)ctx->n_wg));
             HIPCHK(ctx, hipMemsetAsync(ctx->drounds.p, 0, (size_t)ctx->n_wg * sizeof(int), ctx->stream));

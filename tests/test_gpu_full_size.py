@@ -183,6 +183,23 @@ def test_the_solo_schedule_is_dropped_where_the_placement_rule_does_not_hold(cfg
     assert depth['max_rounds'] == [0, 0]       # (the build of the batch that fills the GPU does not count its rounds: see mxe_launch_depth)
 
 
+def test_the_depth_of_the_full_batch_launch_behind_its_switch(cfg4, monkeypatch):
+    """MXE_COUNT_ROUNDS: the launch of the batch that fills the GPU counts the rounds of its workgroups too (a diagnostic launch:
+    bench.py reports it as launch_depth) -- the slowest workgroups run 38-46 rounds where the mean runs 33-34: the tail that
+    profiles/r05_experiments.txt is about, as a number"""
+    batch, ctx, out, info = cfg4
+    ctx.upload_chains(np.arange(256, dtype=np.int32), batch['alphas'], batch['v0'])      # (the default schedule: other tests re-cut the fixture's chains)
+    monkeypatch.setenv('MXE_COUNT_ROUNDS', '1')
+    ctx.launch()
+    ctx.sync()
+    d = ctx.launch_depth()
+    monkeypatch.delenv('MXE_COUNT_ROUNDS')
+    assert 30 <= d['mean_rounds'][0] <= 37 and 38 <= d['max_rounds'][0] <= 50, d
+    ctx.launch()
+    ctx.sync()
+    assert ctx.launch_depth()['max_rounds'] == [0, 0]
+
+
 def test_batches_in_flight_are_cut_into_fewer_pieces_and_give_the_same_answers(cfg4):
     """mxe_opts.in_flight = n: the caller keeps n batches of this size in flight (bench.py --in-flight n: n contexts take the
     steps in turn), so each is cut into about 1 / n as many cold-started pieces -- fewer evaluations per alpha, the same fixed
