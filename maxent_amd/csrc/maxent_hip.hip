@@ -1563,6 +1563,8 @@ static void fill_kparams(mxe_ctx* ctx, KParams& kp)
     kp.mc_abandon = 1;
     kp.prob_maxiter = nullptr;
     kp.out_index = nullptr;
+    kp.dbg_hist = nullptr;
+    { const char* e = getenv("MXE_STUCK_SKIP"); kp.stuck_skip = e ? atoi(e) : 1; }
 }
 
 namespace {
@@ -1932,6 +1934,14 @@ try {
     kp.n_chain = nr;
     kp.alpha = ctx->dfin_alpha.p; kp.out_index = ctx->dfin_out.p; kp.prob_maxiter = ctx->dfin_budget.p;
     ctx->last_rungs = n_rungs;
+#ifdef MXE_DEBUG_HIST
+    DevBuf<double> dhist;
+    if (getenv("MXE_DEBUG_HIST_FILE")) {
+        HIPCHK(ctx, dhist.ensure(ne * 48));
+        HIPCHK(ctx, hipMemsetAsync(dhist.p, 0, ne * 48 * sizeof(double), ctx->stream));
+        kp.dbg_hist = dhist.p;
+    }
+#endif
 #ifdef MXE_PROFILE
     // (diagnostic build: the stamps of THIS pass, rows 0 .. nr - 1 -- tools/finish_phases.py; those of the lock-step launch are gone)
     if (ctx->dprof.p && (size_t)nr <= (size_t)ctx->n_sub + 8 * 1024) {
@@ -1954,6 +1964,26 @@ try {
     }
     HIPCHK(ctx, e);
     HIPCHK(ctx, stream_wait(ctx->stream));
+#ifdef MXE_DEBUG_HIST
+    if (kp.dbg_hist) {
+        std::vector<double> hh(ne * 48);
+        HIPCHK(ctx, hipMemcpy(hh.data(), dhist.p, ne * 48 * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<int> cv(P);
+        HIPCHK(ctx, hipMemcpy(cv.data(), ctx->dout_conv.p, P * sizeof(int), hipMemcpyDeviceToHost));
+        std::vector<int> ni(P);
+        HIPCHK(ctx, hipMemcpy(ni.data(), ctx->dout_niter.p, P * sizeof(int), hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(getenv("MXE_DEBUG_HIST_FILE"), "a")) {
+            for (size_t en = 0; en < ne; ++en) {
+                if (e_out[en] < 0) continue;
+                fprintf(f, "%d %d %d %.6e", e_out[en], cv[e_out[en]], ni[e_out[en]], e_alpha[en]);
+                for (int m = 0; m < 48; ++m) fprintf(f, "%s%.3e", (m % 16 == 0) ? " | " : " ", hh[en * 48 + m]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+        dhist.release();
+    }
+#endif
     // the counters of the records: both passes (whole arrays: one copy each way)
     std::vector<int> nit2(P), nev2(P);
     HIPCHK(ctx, hipMemcpy(nit2.data(), ctx->dout_niter.p, P * sizeof(int), hipMemcpyDeviceToHost));

@@ -107,6 +107,8 @@ struct KParams {
     // entry e = chain_prob0 + i writes its record to problem out_index[e], or nowhere when that is < 0 (a rung: a few iterations
     // towards the next alpha of the mesh, whose record then counts the rung's iterations and evaluations as its own); nullptr: e
     const int* out_index;       // [entries] or nullptr
+    int stuck_skip;             // an alpha held at one damping stops trying the smaller ones at every iteration (the damping loop of chain_kernel)
+    double* dbg_hist;           // (diagnostic build -DMXE_DEBUG_HIST) [entries][16]: the stopping quantity of an alpha at fixed iteration counts
 };
 
 #if defined(MXE_PROFILE) && defined(MXE_PROFILE_EVAL)
@@ -1415,6 +1417,7 @@ void chain_kernel(const KParams p)
         bool failed = false;
         double relH_prev = 1e300;
         double mu_hint = 0.0;       // damping the last damped step of this alpha needed
+        int stuck = 0;              // consecutive iterations that ended at that same damping
 
         const int maxit = p.prob_maxiter ? p.prob_maxiter[(size_t)prob0 + ia] : p.maxiter;
         for (int it = 0; it < maxit && !failed; ++it) {
@@ -1457,9 +1460,18 @@ void chain_kernel(const KParams p)
             if (stop && it >= p.miniter) { conv = 1; break; }
 
             // ---- damped Newton step with Bryan's step bound ----
-            double mu = 0.0;
+            // An alpha that crawls -- hundreds of iterations at one heavy damping, each of which first tries the undamped
+            // step and the damping below and has both refused (profiles/r05_experiments.txt section 6) -- pays three or four
+            // evaluations for every step it takes.  After four iterations at the same damping those two tries are made every
+            // eighth iteration only; the others start at the damping that was accepted.  (Trying the damping below at every
+            // iteration, or every second, keeps 2 of the 4 alphas in 367 359 of the stress set that this costs -- they converge
+            // within ten iterations of maxiter -- for 20 % and 7 % more time.)
+            double mu = (p.stuck_skip && stuck >= 4 && (it & 7) != 0) ? mu_hint : 0.0;
             double chi2t = 0.0, St = 0.0, dH2t = 0.0, Hn2t = 0.0, wmaxt = 0.0, dumaxt = 0.0;
             bool accepted = false, scaled = false, predicted = false;
+#ifdef MXE_DEBUG_HIST
+            double sc_cur = 1.0, dnorm = 0.0;   // the factor the step in dl was shortened by, and its length before
+#endif
             int spec_cnt = 0;                   // dampings of this iteration whose solutions are in zzs (gj_solve_spec)
             double spec_mu[4] = {0.0, 0.0, 0.0, 0.0};
             while (true) {
@@ -1512,6 +1524,9 @@ void chain_kernel(const KParams p)
                     block_reduce<NW, 1>(x1, dummy, red);
                     block_sync<SYNCW>();
                     scaled = false;
+#ifdef MXE_DEBUG_HIST
+                    sc_cur = 1.0; dnorm = x1[0];
+#endif
                     if (!(x1[0] <= step_lim)) {
                         // an undamped Newton step beyond Bryan's bound is shortened onto it (same
                         // direction) instead of being recomputed with damping; it is then accepted
@@ -1519,6 +1534,9 @@ void chain_kernel(const KParams p)
                         if (mu == 0.0 && x1[0] < 1e300) {
                             const double sc = sqrt(step_lim / x1[0]);
                             for (int k = tid; k < NP; k += T) dl[k] *= sc;
+#ifdef MXE_DEBUG_HIST
+                            sc_cur = sc;
+#endif
                             block_sync<SYNCW>();
                             scaled = true;
                         } else good = false;
@@ -1574,6 +1592,7 @@ void chain_kernel(const KParams p)
             MXE_STAMP(5);
             chi2 = chi2t; S = St; Hn2 = Hn2t; wmax = wmaxt;
             Qprev = Q;
+            stuck = (mu > 0.0 && mu == mu_hint) ? stuck + 1 : 0;
             mu_hint = mu;
             Q = 0.5 * chi2 - alpha * S;
             ++n_iter;
@@ -1583,6 +1602,15 @@ void chain_kernel(const KParams p)
             // the noise of the data, few data points) were reported converged with exact Newton corrections up to 9e-4
             // (profiles/r03_i_small_sigma.txt).
             const double undamped = (mu > 0.0) ? 1.0 + mu / alpha : 1.0;
+#ifdef MXE_DEBUG_HIST
+            if (p.dbg_hist && tid == 0) {
+                // slots: iteration 10, 20, 40, 60, 80, 100, 150, 200, 300, 400, 500, 600, 700, 800, 900, last
+                constexpr int marks[15] = {10, 20, 40, 60, 80, 100, 150, 200, 300, 400, 500, 600, 700, 800, 900};
+                double* hrow = p.dbg_hist + ((size_t)prob0 + ia) * 48;
+                for (int m = 0; m < 15; ++m) if (n_iter == marks[m]) { hrow[m] = fmin(relH, relH_next) * undamped; hrow[16 + m] = mu / alpha; hrow[32 + m] = dnorm * sc_cur * sc_cur / step_lim; }
+                hrow[15] = fmin(relH, relH_next) * undamped; hrow[31] = mu / alpha; hrow[47] = dnorm * sc_cur * sc_cur / step_lim;
+            }
+#endif
             if (p.tol_h > 0.0 && fmin(relH, relH_next) * undamped < p.tol_h && n_iter > p.miniter) { conv = 1; break; }
             if constexpr (!F64) {
                 // binary32 noise floor: an undamped Newton correction that is already small and no

@@ -76,6 +76,36 @@ def test_hard_scans_converge_at_least_where_the_reference_does():
     assert done == 3
 
 
+def test_an_alpha_held_at_one_damping_stops_paying_for_the_smaller_ones(monkeypatch):
+    """Stress case 43 (error bars far below the noise): its deep alphas crawl for hundreds of iterations at one heavy
+    damping, and every iteration first tried the undamped step and the damping below and had both refused.  After four
+    iterations at one damping those tries are now made every eighth iteration (MXE_STUCK_SKIP, default on): the same
+    alphas converge to the same spectra for far fewer evaluations."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import stress
+    c = [x for x in stress.cases(44, 7) if x['case'] == 43][0]
+    tau, omega, K, Gmat, D, err, alphas, elems, kinds, v0 = stress.inputs(c)
+    outs = {}
+    for skip in ('0', '1'):
+        monkeypatch.setenv('MXE_STUCK_SKIP', skip)
+        ctx = device.DeviceContext(K.U, K.S, K.V)
+        ds = ctx.add_dataset(err)
+        n = len(elems)
+        ctx.set_elements([ds] * n, [Gmat[i, j] for i, j in elems], np.tile(D, (n, 1)), kinds)
+        out = ctx.solve_chains(np.arange(n), alphas, v0, want_v=False)
+        conv = out['converged'].astype(bool)
+        assert ctx.audit()['corr'][conv].max() < 1e-6
+        outs[skip] = (conv.copy(), out['H'].copy(), int(out['n_evals'].sum()), int(out['n_iter'].max()))
+        ctx.close()
+    assert outs['0'][3] > 300                               # (the case does crawl)
+    assert outs['1'][0].sum() >= outs['0'][0].sum()
+    both = outs['0'][0] & outs['1'][0]
+    d = np.linalg.norm(outs['1'][1][both] - outs['0'][1][both], axis=-1) / np.linalg.norm(outs['0'][1][both], axis=-1)
+    assert d.max() < 1e-6, d.max()
+    assert outs['1'][2] < 0.7 * outs['0'][2], (outs['1'][2], outs['0'][2])
+
+
 def test_a_damped_step_is_not_taken_for_convergence():
     """Error bars a hundred times below the noise of the data (40 ... 100 data points): many small alphas need heavy damping
     at every iteration.  A damped step is short because of its damping: the one-chain kernel (the finishing pass) reported such
