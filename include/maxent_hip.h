@@ -265,6 +265,14 @@ int  mxe_chains_fetch(mxe_ctx* ctx, double* out_v, double* out_H,
                       double* out_chi2, double* out_S, double* out_Q,
                       int32_t* out_niter, int32_t* out_converged,
                       int32_t* out_nevals);
+/* The two blocks of per-alpha scalars queued behind the launch on the context's stream, so that a caller with jobs in flight on
+ * several contexts finds them in its memory when the kernel has finished instead of copying them out, job after job, when all
+ * kernels are done: out_chi2_S_Q [3][P] (chi2 | S | Q), out_niter_converged_nevals [3][P].  Both should be page-locked
+ * (mxe_host_alloc), or the runtime stages them.  mxe_chains_fetch given exactly these destinations waits for the stream and
+ * copies nothing; mxe_chains_finish, when it solves anything again, makes the next fetch copy afresh.  The destinations must
+ * stay allocated until a call that waits for the stream has returned.  Replaces nothing of the reference (its per-alpha
+ * scalars are Python floats as they are made, maxent_loop.py:330-353): plumbing of the asynchronous boundary. */
+int  mxe_chains_prefetch(mxe_ctx* ctx, double* out_chi2_S_Q, int32_t* out_niter_converged_nevals);
 /* log det(I + M W / alpha~) at the returned point of every problem of the last launch,
  * [n_chain][n_alpha], over all n_s kept singular directions (M = S U^T diag(1/err^2) U S,
  * W = V^T diag(w) V).  It is the only expensive term of NormalLogProbability
@@ -374,6 +382,10 @@ int  mxe_select3_fetch(mxe_ctx* ctx, int32_t* out_index, double* out_H_selected)
  * other two when somebody looks at them (result.analyzer_results[...]['A_out'], maxent_result.py:600-640 of the reference
  * reads one analyzer's A_out at a time).  The rows stay valid until the next mxe_select3_launch / mxe_chains_upload. */
 int  mxe_select3_fetch_rows(mxe_ctx* ctx, int32_t* out_index, int first, int count, double* out_H_selected);
+/* The copies of mxe_select3_fetch_rows queued behind the selection kernel (see mxe_chains_prefetch): the indices into memory of
+ * the context, the rows into out_H_selected (page-locked; to stay allocated until a call that waits for the stream has
+ * returned).  mxe_select3_fetch_rows with the same first / count / out_H_selected then waits and converts the indices. */
+int  mxe_select3_prefetch_rows(mxe_ctx* ctx, int first, int count, double* out_H_selected);
 /* n_rows hidden images of the last launch by problem index (chain * n_alpha + i), [n_rows][n_omega]:
  * what an analyzer needs (one row per scan) without moving all of H */
 int  mxe_fetch_rows(mxe_ctx* ctx, int n_rows, const int32_t* problem_index, double* out_H);

@@ -582,11 +582,20 @@ class BatchSolver(object):
         claim_H, claim_v = Claim(self, 0, 'H', (n, n_alpha, self.n_omega)), Claim(self, 0, 'v', (n, n_alpha, self.n_s))
         self._pending.append(weakref.ref(claim_H))
         self._pending.append(weakref.ref(claim_v))
-        out = c.result_arrays()
+        # (scalars, flags and the default analyzer's rows are copied out behind the kernels, into one page-locked block: with
+        #  jobs in flight on several contexts they are in memory when rest() is called instead of being copied then)
+        ahead = select is not None and early_select
+        out = c.result_arrays(pinned_rows=1 if ahead else None)
         conv = np.empty(out['converged'].shape, dtype=bool)
         picks = None
+        if ahead:
+            c.prefetch(out)
         if select is not None:
-            idx, row = c.select3_arrays(1)
+            if ahead:
+                idx, row = np.empty((3, n), dtype=np.int32), out['_rows']
+                c.select3_prefetch_rows(eager, 1, row)
+            else:
+                idx, row = c.select3_arrays(1)
             rows = [LazyRows(self, 0, w, n, self.n_omega) for w in range(3)]
             rows[eager]._val = row[0]
             for w in range(3):

@@ -121,7 +121,8 @@ struct HostPool {
     std::mutex mu;
     std::map<void*, size_t> live;                // handed out: base -> bytes
     std::vector<std::pair<void*, size_t>> idle;
-    static constexpr size_t KEEP = 3;
+    static constexpr size_t KEEP = 24;     // (the scalars and rows of jobs in flight are ~1 MB blocks, several per job)
+    static constexpr size_t KEEP_BIG = 3, BIG = (size_t)16 << 20;
     void* take(size_t bytes) {
         std::lock_guard<std::mutex> lk(mu);
         int best = -1;
@@ -141,7 +142,14 @@ struct HostPool {
         live.erase(it);
         idle.emplace_back(p, bytes);
         void* drop = nullptr;
-        if (idle.size() > KEEP) { drop = idle.front().first; idle.erase(idle.begin()); }
+        // (of the large blocks -- all H of a launch -- three are kept, as before; the oldest goes first)
+        size_t big = 0;
+        for (auto& b : idle) big += b.second >= BIG;
+        if (big > KEEP_BIG) {
+            for (size_t i = 0; i < idle.size(); ++i) if (idle[i].second >= BIG) { drop = idle[i].first; idle.erase(idle.begin() + i); break; }
+        } else if (idle.size() - big > KEEP) {
+            for (size_t i = 0; i < idle.size(); ++i) if (idle[i].second < BIG) { drop = idle[i].first; idle.erase(idle.begin() + i); break; }
+        }
         lk.unlock();
         if (drop) (void)hipHostFree(drop);
     }
@@ -260,6 +268,15 @@ struct mxe_ctx {
     DevBuf<float> dVf, dVtf;          // binary32 copies of dV / dVt (mxe_opts.precision = F32)
     DevBuf<double> dsel3;                        // mxe_select3_launch: [3][n_chain] indices | [3][n_chain][n_omega] rows
     std::vector<double> h_sel3;
+    // copies queued behind the launch (mxe_chains_prefetch / mxe_select3_prefetch_rows): where to, until a launch, an upload or a
+    // finishing pass that ran makes them stale.  The fetch calls given the same destinations then only wait.
+    double* pre_d = nullptr; int32_t* pre_i = nullptr; bool pre_scaled = false;
+    double* pre_rows = nullptr; int pre_first = 0, pre_count = 0; bool pre_index = false;
+    double* h_sel3_pinned = nullptr; size_t h_sel3_pinned_n = 0;
+    // mxe_elements_update_data projects on the device: Uhat | err of every data set, built at its first call
+    DevBuf<double> dproj_U, dproj_err, dproj_G;
+    DevBuf<long long> dproj_off;                 // [n_ds][3]: offset of Uhat, offset of err, rows
+    bool proj_ready = false;
     DevBuf<double> dV, dVx, dVt, dc, dcinv, dghat, dcperp, dD, dsumD, dalpha, dv0;
     DevBuf<int> delem_ds, delem_kind, dchain_elem, dsub_prob0, dsub_len, dsub_v0, dwg_chains;
     // H, chi2, S, Q live back to back in ONE allocation (dout_pack) so that a
@@ -583,6 +600,8 @@ void mxe_ctx_destroy(mxe_ctx* ctx)
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);      // (the blocks go back to the pool: nothing in flight may use them)
     comm_release(ctx);
+    if (ctx->h_sel3_pinned) { (void)hipHostFree(ctx->h_sel3_pinned); ctx->h_sel3_pinned = nullptr; ctx->h_sel3_pinned_n = 0; }
+    ctx->dproj_U.release(); ctx->dproj_err.release(); ctx->dproj_G.release(); ctx->dproj_off.release();
     ctx->dVx.release(); ctx->dsel3.release(); ctx->dgstate.release(); ctx->dgstate_mc.release(); ctx->dfin_elem.release(); ctx->dfin_prob0.release();
     ctx->dfin_len.release(); ctx->dfin_v0.release(); ctx->dfin_start.release();
     ctx->dfin_budget.release(); ctx->dfin_out.release(); ctx->dfin_alpha.release();
@@ -612,7 +631,7 @@ try {
     int rc = build_dataset(ctx, n_rows, U_rot, err, d);
     if (rc != MXE_OK) return rc;
     ctx->ds.push_back(std::move(d));
-    ctx->ds_dirty = true;
+    ctx->ds_dirty = true; ctx->proj_ready = false;
     ctx->chains_ready = false;
     if (id) *id = (int)ctx->ds.size() - 1;
     return MXE_OK;
@@ -622,7 +641,7 @@ MXE_CATCH_ALL
 int mxe_dataset_clear(mxe_ctx* ctx)
 {
     if (!ctx) return MXE_ERR_ARG;
-    ctx->ds.clear(); ctx->ds_dirty = true; ctx->n_elem = 0; ctx->chains_ready = false;
+    ctx->ds.clear(); ctx->ds_dirty = true; ctx->proj_ready = false; ctx->n_elem = 0; ctx->chains_ready = false;
     return MXE_OK;
 }
 
@@ -715,6 +734,47 @@ try {
 }
 MXE_CATCH_ALL
 
+namespace {
+// project_elements for one element per workgroup, the same operations in the same order with every product and sum rounded on
+// its own (no contraction into fused multiply-adds: the host code has none either), so that new data staged this way give
+// the bits mxe_elements_set gives: ghat_k = sum_i Uhat_ik G_i / err_i summed over i in turn, the residual row by row, its
+// squares summed in turn.
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256)
+void project_kernel(const double* __restrict__ G, const int* __restrict__ elem_ds, const long long* __restrict__ ds_off,
+                    const double* __restrict__ U, const double* __restrict__ err, int ns, int NP,
+                    double* __restrict__ ghat, double* __restrict__ cperp, int rows_max, const long long* __restrict__ G_off)
+{
+    extern __shared__ double psh[];
+    double* Gt = psh; double* gh = psh + rows_max; double* r2 = gh + NP;
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const long long* o = ds_off + 3 * (size_t)elem_ds[e];
+    const double* Ud = U + o[0]; const double* ed = err + o[1]; const int rows = (int)o[2];
+    const double* Ge = G + G_off[e];
+    for (int i = tid; i < rows; i += 256) Gt[i] = Ge[i] / ed[i];
+    __syncthreads();
+    for (int k = tid; k < NP; k += 256) {
+        double acc = 0.0;
+        if (k < ns) for (int i = 0; i < rows; ++i) { const double pr = Ud[(size_t)i * ns + k] * Gt[i]; acc = acc + pr; }
+        gh[k] = acc;
+        ghat[(size_t)e * NP + k] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < rows; i += 256) {
+        double r = Gt[i];
+        for (int k = 0; k < ns; ++k) { const double pr = Ud[(size_t)i * ns + k] * gh[k]; r = r - pr; }
+        r2[i] = r * r;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double cp = 0.0;
+        for (int i = 0; i < rows; ++i) cp = cp + r2[i];
+        cperp[e] = cp;
+    }
+}
+#pragma clang fp contract(fast)
+}
+
 int mxe_elements_update_data(mxe_ctx* ctx, int n_elem, const double* G, const int64_t* G_offset)
 try {
     if (!ctx || !G || !G_offset) return MXE_ERR_ARG;
@@ -722,6 +782,49 @@ try {
     if (n_elem != ctx->n_elem) return MXE_ERR_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int ns = ctx->n_s, NP = ctx->NP;
+    // the data of the elements as ONE span of the caller's array (what set_elements of maxent_amd.device builds; anything else
+    // goes through the host projection)
+    long long lo = 0, hi = 0; int rows_max = 0; bool span = true;
+    for (int e = 0; e < n_elem && span; ++e) {
+        const int rows = ctx->ds[ctx->elem_ds[e]].n_rows;
+        rows_max = std::max(rows_max, rows);
+        if (G_offset[e] < 0) span = false;
+        if (e == 0) { lo = G_offset[e]; hi = lo + rows; }
+        else { lo = std::min<long long>(lo, G_offset[e]); hi = std::max<long long>(hi, G_offset[e] + rows); }
+    }
+    size_t total_rows = 0;
+    for (int e = 0; e < n_elem; ++e) total_rows += ctx->ds[ctx->elem_ds[e]].n_rows;
+    const size_t lds = ((size_t)2 * rows_max + NP) * 8;
+    if (span && (size_t)(hi - lo) <= 2 * total_rows && lds <= 64 * 1024 && !getenv("MXE_HOST_PROJECTION")) {
+        if (!ctx->proj_ready) {
+            std::vector<double> hU, herr; std::vector<long long> off;
+            for (const DataSet& D : ctx->ds) {
+                off.push_back((long long)hU.size()); off.push_back((long long)herr.size()); off.push_back(D.n_rows);
+                hU.insert(hU.end(), D.Uhat.begin(), D.Uhat.end());
+                herr.insert(herr.end(), D.err.begin(), D.err.end());
+            }
+            HIPCHK(ctx, ctx->dproj_U.ensure(hU.size()));
+            HIPCHK(ctx, ctx->dproj_err.ensure(herr.size()));
+            HIPCHK(ctx, ctx->dproj_off.ensure(off.size()));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->dproj_U.p, hU.data(), hU.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->dproj_err.p, herr.data(), herr.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->dproj_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, stream_wait(ctx->stream));
+            ctx->proj_ready = true;
+        }
+        std::vector<long long> goff(n_elem);
+        for (int e = 0; e < n_elem; ++e) goff[e] = G_offset[e] - lo;
+        HIPCHK(ctx, ctx->dproj_G.ensure((size_t)(hi - lo) + (size_t)n_elem));
+        // (offsets behind the data in the same allocation: two copies, one wait)
+        long long* dgoff = (long long*)(ctx->dproj_G.p + (hi - lo));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->dproj_G.p, G + lo, (size_t)(hi - lo) * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(dgoff, goff.data(), (size_t)n_elem * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(project_kernel, dim3(n_elem), dim3(256), lds, ctx->stream, ctx->dproj_G.p, ctx->delem_ds.p, ctx->dproj_off.p,
+                           ctx->dproj_U.p, ctx->dproj_err.p, ns, NP, ctx->dghat.p, ctx->dcperp.p, rows_max, dgoff);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, stream_wait(ctx->stream));       // (goff is the caller-side vector of this call; G the caller's array)
+        return MXE_OK;
+    }
     std::vector<double> hghat((size_t)n_elem * NP, 0.0), hcperp(n_elem);
     project_all(ctx, n_elem, ctx->elem_ds.data(), G, G_offset, hghat.data(), hcperp.data());    // (as mxe_elements_set: the same bits)
     // (behind whatever the stream still runs with the old data)
@@ -1601,6 +1704,7 @@ try {
     if (!ctx) return MXE_ERR_ARG;
     if (!ctx->chains_ready) return MXE_ERR_STATE;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->pre_d = nullptr; ctx->pre_i = nullptr; ctx->pre_rows = nullptr; ctx->pre_index = false;
     const mxe_opts& o = ctx->opts;
     KParams kp;
     fill_kparams(ctx, kp);
@@ -1824,6 +1928,7 @@ try {
     int n = 0;
     for (int i : todo) if (nit[i] < o.maxiter) { open[i] = 1; ++n; }
     if (n == 0) return MXE_OK;
+    ctx->pre_d = nullptr; ctx->pre_i = nullptr; ctx->pre_rows = nullptr; ctx->pre_index = false;   // (what was copied out behind the launch is about to change)
     // The alphas to solve again, as the reference would have reached them: every run of consecutive open alphas of a scan is
     // ONE warm-started chain that begins at the solution of the alpha before it (a converged neighbour: 3-5 iterations
     // per alpha, where the cold-started piece the lock-step kernel gave up on was stuck far from the minimiser -- on inputs
@@ -2011,15 +2116,20 @@ try {
     // (chi2 | S | Q and niter | converged | nevals are one block each on the device: a caller whose arrays lie the same way --
     //  maxent_amd.device.DeviceContext.fetch allocates them so -- gets each block in ONE copy; six copies of 100-200 KB
     //  cost 0.15 ms behind a launch of 0.8 ms)
-    if (out_chi2 && out_S == out_chi2 + P && out_Q == out_S + P)
+    const bool pre = ctx->pre_d && out_chi2 == ctx->pre_d && out_S == out_chi2 + P && out_Q == out_S + P &&
+                     out_niter == ctx->pre_i && out_converged == out_niter + P && out_nevals == out_converged + P;
+    if (pre) {}                                  // (mxe_chains_prefetch queued both blocks behind the launch: they are there)
+    else if (out_chi2 && out_S == out_chi2 + P && out_Q == out_S + P)
         HIPCHK(ctx, hipMemcpy(out_chi2, ctx->dout_chi2.p, 3 * P * 8, hipMemcpyDeviceToHost));
     else {
         if (out_chi2) HIPCHK(ctx, hipMemcpy(out_chi2, ctx->dout_chi2.p, P * 8, hipMemcpyDeviceToHost));
         if (out_S) HIPCHK(ctx, hipMemcpy(out_S, ctx->dout_S.p, P * 8, hipMemcpyDeviceToHost));
         if (out_Q) HIPCHK(ctx, hipMemcpy(out_Q, ctx->dout_Q.p, P * 8, hipMemcpyDeviceToHost));
     }
-    if (out_Q && ctx->chi2_factor != 1.0) for (size_t i = 0; i < P; ++i) out_Q[i] *= ctx->chi2_factor;
-    if (out_niter && out_converged == out_niter + P && out_nevals == out_converged + P)
+    if (out_Q && ctx->chi2_factor != 1.0 && !(pre && ctx->pre_scaled)) for (size_t i = 0; i < P; ++i) out_Q[i] *= ctx->chi2_factor;
+    if (pre) ctx->pre_scaled = true;
+    if (pre) {}
+    else if (out_niter && out_converged == out_niter + P && out_nevals == out_converged + P)
         HIPCHK(ctx, hipMemcpy(out_niter, ctx->dout_niter.p, 3 * P * 4, hipMemcpyDeviceToHost));
     else {
         if (out_niter) HIPCHK(ctx, hipMemcpy(out_niter, ctx->dout_niter.p, P * 4, hipMemcpyDeviceToHost));
@@ -2043,6 +2153,47 @@ try {
             }
         }
     }
+    return MXE_OK;
+}
+MXE_CATCH_ALL
+
+namespace {
+// Results written into page-locked host memory by the compute queue (mxe_chains_prefetch, mxe_select3_prefetch_rows).  A
+// hipMemcpyAsync behind a kernel parks a DMA engine until that kernel is through, and the uploads of the NEXT job (new data on
+// another context's stream) queued up behind it: mxe_elements_update_data took 0.9 ms instead of 0.3 with four jobs in flight.
+struct CopySeg { const uint32_t* src; uint32_t* dst; size_t words; };
+__global__ __launch_bounds__(256)
+void copy_out_kernel(CopySeg a, CopySeg b)
+{
+    const size_t stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (size_t i = t0; i < a.words; i += stride) a.dst[i] = a.src[i];
+    for (size_t i = t0; i < b.words; i += stride) b.dst[i] = b.src[i];
+}
+hipError_t copy_out(void* dst_a, const void* src_a, size_t bytes_a, void* dst_b, const void* src_b, size_t bytes_b, bool mapped, hipStream_t s)
+{
+    if (!mapped || (bytes_a & 3) || (bytes_b & 3)) {
+        hipError_t e = bytes_a ? hipMemcpyAsync(dst_a, src_a, bytes_a, hipMemcpyDeviceToHost, s) : hipSuccess;
+        if (e == hipSuccess && bytes_b) e = hipMemcpyAsync(dst_b, src_b, bytes_b, hipMemcpyDeviceToHost, s);
+        return e;
+    }
+    CopySeg a{(const uint32_t*)src_a, (uint32_t*)dst_a, bytes_a / 4}, b{(const uint32_t*)src_b, (uint32_t*)dst_b, bytes_b / 4};
+    const size_t words = std::max(a.words, b.words);
+    const int blocks = (int)std::min<size_t>(64, (words + 255) / 256);
+    hipLaunchKernelGGL(copy_out_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, s, a, b);
+    return hipGetLastError();
+}
+}
+
+int mxe_chains_prefetch(mxe_ctx* ctx, double* out_chi2_S_Q, int32_t* out_niter_converged_nevals)
+try {
+    if (!ctx || !out_chi2_S_Q || !out_niter_converged_nevals) return MXE_ERR_ARG;
+    if (!ctx->launched) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)ctx->n_chain * ctx->n_alpha;
+    ctx->pre_d = nullptr; ctx->pre_i = nullptr;
+    const bool mapped = g_host.holds(out_chi2_S_Q, 3 * P * 8) && g_host.holds(out_niter_converged_nevals, 3 * P * 4);
+    HIPCHK(ctx, copy_out(out_chi2_S_Q, ctx->dout_chi2.p, 3 * P * 8, out_niter_converged_nevals, ctx->dout_niter.p, 3 * P * 4, mapped, ctx->stream));
+    ctx->pre_d = out_chi2_S_Q; ctx->pre_i = out_niter_converged_nevals; ctx->pre_scaled = false;
     return MXE_OK;
 }
 MXE_CATCH_ALL
@@ -2557,6 +2708,7 @@ try {
     double* sel = ctx->dout_Q.p + P;
     double* idx = sel + nc * nw;
     HIPCHK(ctx, ctx->dsel3.ensure(3 * nc * (nw + 1)));
+    ctx->pre_rows = nullptr; ctx->pre_index = false;
     hipLaunchKernelGGL(mxe::linefit_kernel, dim3(ctx->n_chain), dim3(64), ((size_t)9 * ctx->n_alpha + 6) * sizeof(double), ctx->stream,
                        ctx->dalpha.p, ctx->dout_chi2.p, ctx->dout_H.p, ctx->n_alpha, ctx->n_omega, p2_deg, sel, idx,
                        ctx->dout_S.p, gamma, ctx->dsel3.p, ctx->dsel3.p + 3 * nc);
@@ -2573,6 +2725,12 @@ try {
     if (!ctx->launched || !ctx->dsel3.p || ctx->sel3_nc != ctx->n_chain) return MXE_ERR_STATE;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t nc = ctx->n_chain, nw = ctx->n_omega;
+    if (ctx->pre_index && ctx->h_sel3_pinned_n >= 3 * nc && (count == 0 || (out_H_selected == ctx->pre_rows && first == ctx->pre_first && count == ctx->pre_count))) {
+        // (mxe_select3_prefetch_rows queued these copies behind the selection kernel)
+        HIPCHK(ctx, stream_wait(ctx->stream));
+        if (out_index) for (size_t i = 0; i < 3 * nc; ++i) out_index[i] = (int32_t)ctx->h_sel3_pinned[i];
+        return MXE_OK;
+    }
     if (out_index) {
         ctx->h_sel3.resize(3 * nc);
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_sel3.data(), ctx->dsel3.p, 3 * nc * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -2581,6 +2739,31 @@ try {
     if (out_H_selected && count > 0)
         HIPCHK(ctx, d2h_pipelined(out_H_selected, ctx->dsel3.p + 3 * nc + (size_t)first * nc * nw, (size_t)count * nc * nw * 8, ctx->stream));
     if (out_index) for (size_t i = 0; i < 3 * nc; ++i) out_index[i] = (int32_t)ctx->h_sel3[i];
+    return MXE_OK;
+}
+MXE_CATCH_ALL
+
+extern "C" int mxe_select3_prefetch_rows(mxe_ctx* ctx, int first, int count, double* out_H_selected /*[count][n_chain][n_omega] or NULL*/)
+try {
+    if (!ctx || first < 0 || count < 0 || first + count > 3 || (count > 0 && !out_H_selected)) return MXE_ERR_ARG;
+    if (!ctx->launched || !ctx->dsel3.p || ctx->sel3_nc != ctx->n_chain) return MXE_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t nc = ctx->n_chain, nw = ctx->n_omega;
+    ctx->pre_rows = nullptr; ctx->pre_index = false;
+    if (ctx->h_sel3_pinned_n < 3 * nc) {
+        if (ctx->h_sel3_pinned) { (void)hipHostFree(ctx->h_sel3_pinned); ctx->h_sel3_pinned = nullptr; ctx->h_sel3_pinned_n = 0; }
+        HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_sel3_pinned, 3 * nc * 8, hipHostMallocDefault));
+        ctx->h_sel3_pinned_n = 3 * nc;
+    }
+    const size_t row_bytes = (size_t)count * nc * nw * 8;
+    const bool mapped = count == 0 || g_host.holds(out_H_selected, row_bytes);
+    if (mapped)
+        HIPCHK(ctx, copy_out(ctx->h_sel3_pinned, ctx->dsel3.p, 3 * nc * 8, out_H_selected, ctx->dsel3.p + 3 * nc + (size_t)first * nc * nw, row_bytes, true, ctx->stream));
+    else {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_sel3_pinned, ctx->dsel3.p, 3 * nc * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(out_H_selected, ctx->dsel3.p + 3 * nc + (size_t)first * nc * nw, row_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ctx->pre_index = true; ctx->pre_rows = count > 0 ? out_H_selected : nullptr; ctx->pre_first = first; ctx->pre_count = count;
     return MXE_OK;
 }
 MXE_CATCH_ALL

@@ -109,6 +109,8 @@ SYMBOLS = [
     ('mxe_select3_launch', ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double]),
     ('mxe_select3_fetch', ctypes.c_int, [_vp, _ip, _dp]),
     ('mxe_select3_fetch_rows', ctypes.c_int, [_vp, _ip, ctypes.c_int, ctypes.c_int, _dp]),
+    ('mxe_select3_prefetch_rows', ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _dp]),
+    ('mxe_chains_prefetch', ctypes.c_int, [_vp, _dp, _ip]),
     ('mxe_fetch_rows', ctypes.c_int, [_vp, ctypes.c_int, _ip, _dp]),
     ('mxe_shard_plan', ctypes.c_int, [ctypes.c_int, ctypes.c_int, _ip, _ip, _ip]),
     ('mxe_comm_unique_id', ctypes.c_int, [ctypes.c_char_p]),
@@ -218,13 +220,13 @@ def default_opts(**kw):
     return o
 
 
-def pinned_empty(shape, dtype=np.float64):
+def pinned_empty(shape, dtype=np.float64, min_bytes=1 << 20):
     """an uninitialised array in page-locked host memory (``mxe_host_alloc``; the block goes back to the library's pool with
-    the last view of it) -- the destination of the large device-to-host copies; plain ``np.empty`` for small arrays or when
-    the runtime cannot pin that much"""
+    the last view of it) -- the destination of the large device-to-host copies; plain ``np.empty`` for arrays below
+    ``min_bytes`` or when the runtime cannot pin that much"""
     dtype = np.dtype(dtype)
     n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
-    if n < (1 << 20):
+    if n < min_bytes or n == 0:
         return np.empty(shape, dtype=dtype)
     lib = load_library()
     p = lib.mxe_host_alloc(n)
@@ -452,13 +454,38 @@ class DeviceContext(object):
         self._check(self._lib.mxe_chains_finish(self._h, ctypes.byref(n)), 'mxe_chains_finish')
         return int(n.value)
 
-    def result_arrays(self):
+    def result_arrays(self, pinned_rows=None):
         """the per-alpha arrays :meth:`fetch` fills, uninitialised: chi2 / S / Q and n_iter / converged / n_evals as the
-        rows of ONE block each -- the library then brings each block in one copy"""
+        rows of ONE block each -- the library then brings each block in one copy.  ``pinned_rows`` = n: both blocks and
+        ``_rows`` [n][n_chain][n_omega] (the destination of :meth:`select3_prefetch_rows`) in one page-locked allocation,
+        for :meth:`prefetch`"""
         nc, na = self._n_chain, self._n_alpha
-        d = np.empty((3, nc, na))
-        i = np.empty((3, nc, na), dtype=np.int32)
-        return dict(chi2=d[0], S=d[1], Q=d[2], n_iter=i[0], converged=i[1], n_evals=i[2])
+        if pinned_rows is None:
+            d = np.empty((3, nc, na))
+            i = np.empty((3, nc, na), dtype=np.int32)
+            return dict(chi2=d[0], S=d[1], Q=d[2], n_iter=i[0], converged=i[1], n_evals=i[2])
+        nd, ni, nr = 3 * nc * na * 8, 3 * nc * na * 4, int(pinned_rows) * nc * self.n_omega * 8
+        ni += (-ni) % 8
+        buf = pinned_empty((nd + ni + nr,), np.uint8, min_bytes=0)
+        d = buf[:nd].view(np.float64).reshape(3, nc, na)
+        i = buf[nd:nd + 3 * nc * na * 4].view(np.int32).reshape(3, nc, na)
+        rows = buf[nd + ni:].view(np.float64).reshape(int(pinned_rows), nc, self.n_omega)
+        return dict(chi2=d[0], S=d[1], Q=d[2], n_iter=i[0], converged=i[1], n_evals=i[2], _d=d, _i=i, _rows=rows)
+
+    def prefetch(self, out):
+        """``mxe_chains_prefetch``: the scalars of the launch copied into ``out`` (of ``result_arrays(pinned_rows=...)``) behind
+        the kernel; :meth:`fetch` with the same ``out`` then waits and copies nothing"""
+        self._check(self._lib.mxe_chains_prefetch(self._h, _p(out['_d']), _p(out['_i'])), 'mxe_chains_prefetch')
+        self._held = getattr(self, '_held', [])
+        self._held.append(out)          # (the destinations of copies in flight stay allocated until a call has waited for the stream)
+
+    def select3_prefetch_rows(self, first, count, rows):
+        """``mxe_select3_prefetch_rows``: behind :meth:`select3_launch`; :meth:`select3_fetch_rows` with the same arguments
+        then waits and converts the indices"""
+        self._check(self._lib.mxe_select3_prefetch_rows(self._h, int(first), int(count), _p(rows) if count > 0 else None),
+                    'mxe_select3_prefetch_rows')
+        self._held = getattr(self, '_held', [])
+        self._held.append(rows)
 
     def fetch(self, want_v=True, want_H=True, out=None):
         """``out``: the arrays of :meth:`result_arrays`, made by the caller before the launch"""
@@ -473,6 +500,7 @@ class DeviceContext(object):
             self._h, _p(v), _p(H), _p(out['chi2']), _p(out['S']), _p(out['Q']),
             _p(out['n_iter']), _p(out['converged']), _p(out['n_evals'])),
             'mxe_chains_fetch')
+        self._held = []                 # (the stream has been waited for)
         out['v'] = v
         out['H'] = H
         return out

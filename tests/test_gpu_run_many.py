@@ -158,9 +158,10 @@ def test_fields_served_from_the_launch_arrays_are_those_assembled_from_records(h
     assert np.allclose(np.array(res.chi2), fast['chi2'], rtol=1e-9, equal_nan=True)
 
 
-def test_new_data_on_the_same_object_updates_only_the_data_on_the_device():
+def test_new_data_on_the_same_object_updates_only_the_data_on_the_device(monkeypatch):
     """set_G_tau_data again (every iteration of a self-consistency loop): mxe_elements_update_data -- the chains stay staged --
-    and the answers are those of a fresh object on those data"""
+    and the answers are those of a fresh object on those data, to the bit: the projection of the new data runs on the device
+    (project_kernel) with the operations of the host's in the host's order, no fused multiply-adds"""
     tau, omega, K, G1, _ = synthetic.matrix_G(3, 100, 200, noise_seed=1)
     _, _, _, G2, _ = synthetic.matrix_G(3, 100, 200, noise_seed=2)
 
@@ -178,4 +179,9 @@ def test_new_data_on_the_same_object_updates_only_the_data_on_the_device():
     r2 = np.array(ew.run().chi2)
     assert np.all(np.isfinite(r2)) and np.linalg.norm(r2 - r1) > 1e-3 * np.linalg.norm(r1)
     ref = np.array(make(G2).run().chi2)
-    assert np.allclose(r2, ref, rtol=1e-9)
+    assert np.array_equal(r2, ref)
+    monkeypatch.setenv('MXE_HOST_PROJECTION', '1')      # (the host's projection, threaded: what other layouts of G fall back to)
+    ew.set_G_tau_data(tau, G1)
+    assert np.array_equal(np.array(ew.run().chi2), r1)
+    ew.set_G_tau_data(tau, G2)
+    assert np.array_equal(np.array(ew.run().chi2), ref)
