@@ -376,6 +376,26 @@ def many_objects_block(make, res_one, n_orb, n_alpha, n_jobs=4, repeats=6):
         out = mx.run_many(jobs)
         t_many.append(time.perf_counter() - t0)
     t_many = t_many[2:]                                 # (the first passes re-cut the chains for mxe_opts.in_flight = n_jobs)
+    # the jobs cut for the company they have (same_cut=False: mxe_opts.in_flight = n_jobs, fewer cold-started pieces)
+    t_cut, out_cut = [], None
+    for _ in range(repeats + 2):
+        clear()
+        out_cut = None
+        t0 = time.perf_counter()
+        out_cut = mx.run_many(jobs, same_cut=False)
+        t_cut.append(time.perf_counter() - t0)
+    t_cut = t_cut[2:]
+    rel_A = lambda rs: float(max(np.max(np.abs(np.asarray(r.A_out) - a)) / np.max(np.abs(a)) for r, (a, _) in zip(rs, seq_keep)))
+    cut_A = rel_A(out_cut)
+    cut_chi2 = float(max(np.nanmax(np.abs(np.asarray(r.chi2) - c) / np.abs(c)) for r, (_, c) in zip(out_cut, seq_keep)))
+    del out_cut
+    # two sequential run() calls of the SAME object (round 5: the full batch repeats bit for bit -- the partial h of a workgroup's
+    # four waves are summed pairwise, no longer by four atomic additions in whatever order they arrive)
+    clear()
+    rerun_A = rel_A([ew.run() for ew in jobs])
+    for _ in range(2):                                  # (back to the cut of run())
+        clear()
+        out = mx.run_many(jobs)
     same_A = bool(all(np.array_equal(np.asarray(r.A_out), a) for r, (a, _) in zip(out, seq_keep)))
     worst_A = float(max(np.max(np.abs(np.asarray(r.A_out) - a)) / np.max(np.abs(a)) for r, (a, _) in zip(out, seq_keep)))
     worst_chi2 = float(max(np.nanmax(np.abs(np.asarray(r.chi2) - c) / np.abs(c)) for r, (_, c) in zip(out, seq_keep)))
@@ -408,13 +428,17 @@ def many_objects_block(make, res_one, n_orb, n_alpha, n_jobs=4, repeats=6):
                 alpha_solves_per_s_eight_objects=(8 * n_orb * n_orb * n_alpha / min(t_eight) if t_eight else None),
                 jobs=n_jobs, problems=P,
                 run_many_ms=1e3 * min(t_many), sequential_runs_ms=1e3 * min(t_seq), run_many_new_data_ms=1e3 * min(t_new),
+                run_many_cut_for_in_flight_ms=1e3 * min(t_cut), alpha_solves_per_s_cut_for_in_flight=P / min(t_cut),
+                cut_for_in_flight_A_out_max_rel_diff=cut_A, cut_for_in_flight_chi2_max_rel_diff=cut_chi2,
+                sequential_rerun_A_out_max_rel_diff=rerun_A,
                 alpha_solves_per_s=P / min(t_many), alpha_solves_per_s_sequential=P / min(t_seq),
                 alpha_solves_per_s_new_data=P / min(t_new),
                 A_out_bitwise_equal_to_sequential_runs=same_A, A_out_max_rel_diff=worst_A, chi2_max_rel_diff=worst_chi2,
                 all_converged=conv, kernels=kernels,
-                note='the jobs in flight are cut for mxe_opts.in_flight = %d (fewer cold-started pieces): their iterates differ from the '
-                     'one-at-a-time cut within the stopping tolerance (A_out_max_rel_diff); the analyzers pick the same alphas '
-                     'unless two candidates tie at that level' % n_jobs)
+                note='run_many keeps the cut of run(): every field bit for bit what the sequential calls return (A_out_bitwise_equal_to_'
+                     'sequential_runs; A_out_max_rel_diff and chi2_max_rel_diff are then 0).  cut_for_in_flight: run_many(jobs, '
+                     'same_cut=False), mxe_opts.in_flight = %d (fewer cold-started pieces): other iterates, the same minimisers within '
+                     'the stopping tolerance; the analyzers pick the same alphas unless two candidates tie at that level' % n_jobs)
 
 
 def scaling_projection(batch, opts, k_ms_full, n_alpha, n_launch=30):

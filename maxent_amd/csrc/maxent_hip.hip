@@ -473,7 +473,7 @@ size_t mc_lds_bytes(int NA, int nwp, int wgpc, int nwv = 4, bool gst = false)
 {
     const int NT = NA / 16, NPAIR = NT * (NT + 1) / 2;
     if (gst) nwp = 0;                        // (u, H, sw in device memory: MCExtra::gstate)
-    const size_t doubles = 8 * 4 * 64 + 2 * 64 + 64 * 4 + (wgpc == 2 ? 1 : nwv) * 4 * 64 + nwv * 32 + 2 * 4 * 64 +   // vectors, c, 1/c, step, h, sums, solve scales
+    const size_t doubles = 8 * 4 * 64 + 2 * 64 + 64 * 4 + (wgpc == 2 ? 2 : nwv) * 4 * 64 + nwv * 32 + 2 * 4 * 64 +   // vectors, c, 1/c, step, h, sums, solve scales
                            (wgpc == 2 ? (size_t)MXE_X_UL * 256 + (size_t)nwp * 4 : (size_t)2 * nwp * 4) +
                            (size_t)4 * NPAIR * 256;                                                  // u, H, Gram tiles
     const size_t floats = (size_t)nwp * 4;                                              // sw

@@ -224,7 +224,13 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
     double* cc   = eacc + MCC * NP;              // [NP]
     double* ci   = cc + NP;                      // [NP]
     double* vecI = ci + NP;                      // [NP][MCC]   step / v, chain minor (row-pass operand)
-    constexpr int HPW = UREG ? 1 : NWV;          // copies of the partial h: one per wave, or one summed with atomics
+    // copies of the partial h: one per wave, or (UREG) one per PAIR of waves, summed with atomics.  Two additions onto zero give
+    // a + b whichever comes first, and the two pair sums are added in a fixed order (the accept step): the h of a round does not
+    // depend on the order in which the waves arrive.  With ONE copy for the four waves (rounds 2-4) it did, in the last bit, and a
+    // launch of the full batch did not repeat bit for bit -- half of its chi2 moved by ~1e-10 from run to run.  (The Gram tiles
+    // are sums of four binary32 values in binary64: exact, so in any order, unless the partials differ by more than 2^27.)
+    constexpr int HPW = UREG ? 2 : NWV;
+    static_assert(!UREG || NWV == 4, "the pair copies of h are laid out for four waves");
     double* hpart = vecI + NP * MCC;             // [HPW][MCC chains][NP]
     double* red  = hpart + HPW * MCC * NP;       // [NWV waves][32]
     double* ssc  = red + NWV * 32;               // [MCC][NP]   binary32 solve: power-of-two scale of row / column k, ~ 1 / sqrt(c_k^2 wmax + alpha)
@@ -1019,7 +1025,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
 #pragma unroll
                 for (int idx = 0; idx < (MCC * NPAIR * 128 + T - 1) / T; ++idx)
                     if (tid + idx * T < MCC * NPAIR * 128) Wz[tid + idx * T] = double2{0.0, 0.0};
-                if (UREG) hpart[tid] = 0.0;              // [MCC][NP] = 256 sums of h, added to in step 3
+                if (UREG) { hpart[tid] = 0.0; hpart[T + tid] = 0.0; }   // [2][MCC][NP] = 2 x 256 sums of h, added to in step 3
             }
             const int j = lane & 3;                              // slot of this lane's results
             const int drow = 4 * ((lane >> 2) & 3) + (lane >> 4);      // result row inside the tile
@@ -1285,7 +1291,7 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                 const int hj = lane & 3, hcol = 4 * ((lane >> 2) & 3) + (lane >> 4);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    if (UREG) __hip_atomic_fetch_add(hpart + hj * NP + 16 * t + hcol, hp[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (UREG) __hip_atomic_fetch_add(hpart + ((wave >> 1) * MCC + hj) * NP + 16 * t + hcol, hp[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else hpart[(wave * MCC + hj) * NP + 16 * t + hcol] = hp[t];
                 }
             }

@@ -204,19 +204,24 @@ class PendingRun(object):
         return self._result
 
 
-def run_many(objects, in_flight=None):
+def run_many(objects, in_flight=None, same_cut=True):
     """``[ew.run() for ew in objects]`` with the jobs IN FLIGHT together: every object is prepared, staged and launched before
     the first is waited for (one thread, no wait between the launches), then each is completed in turn while the kernels of
-    the others run.  Results, field for field, are those of the sequential ``run()`` calls.  ``in_flight``: jobs on the GPU at a
-    time (default: all of them, at most eight)."""
+    the others run.  ``in_flight``: jobs on the GPU at a time (default: all of them, at most eight).  Every job is cut into
+    pieces as ``run()`` cuts it, so every field of every result is, bit for bit, what the sequential calls return.
+    ``same_cut=False`` cuts a job for the company it has (``mxe_opts.in_flight``: fewer cold-started pieces, 0.65 instead of
+    0.74 ms of GPU time per 16 x 16 x 100-alpha job with four in flight): other iterates, the same minimisers within the
+    stopping tolerance (A_out to ~1e-10) -- through this API the host's work per job hides the difference (four jobs: 3.8 ms
+    either way); a caller of the C interface with its own pipeline sees it (bench.py, value_in_flight)."""
     objects = list(objects)
     n = max(1, min(8, len(objects) if in_flight is None else int(in_flight)))
+    cut = 1 if same_cut else n
     results, window = [None] * len(objects), []
     for k, ew in enumerate(objects):
         if len(window) >= n:
             j, h = window.pop(0)
             results[j] = h.result()
-        window.append((k, ew.run_async(in_flight=n) if hasattr(ew, 'run_async') else _Ran(ew.run())))
+        window.append((k, ew.run_async(in_flight=cut) if hasattr(ew, 'run_async') else _Ran(ew.run())))
     for j, h in window:
         results[j] = h.result()
     return results

@@ -200,6 +200,25 @@ def test_the_depth_of_the_full_batch_launch_behind_its_switch(cfg4, monkeypatch)
     assert ctx.launch_depth()['max_rounds'] == [0, 0]
 
 
+def test_the_full_batch_repeats_bit_for_bit(cfg4):
+    """chain_kernel_mc<32, 2>, 512 workgroups that take their pieces from a queue in whatever order they get to it: three
+    launches of the same chains return the same bits -- v, H, chi2, S, Q, the iteration and evaluation counts.  A piece does not
+    depend on its company in the workgroup, and the partial h of the four waves are summed in pairs (two additions onto zero
+    commute), the pair sums in a fixed order; rounds 2-4 added the four with LDS atomics as they arrived and half the chi2 of
+    this batch moved by ~1e-10 from launch to launch."""
+    batch, ctx, out, info = cfg4
+    ctx.upload_chains(np.arange(256, dtype=np.int32), batch['alphas'], batch['v0'])
+    runs = []
+    for _ in range(3):
+        ctx.launch()
+        ctx.finish()
+        runs.append(ctx.fetch())
+    assert 'chain_kernel_mc<32, 2>' in ctx.last_launch_info()['kernel'] and ctx.last_launch_info()['n_workgroups'] == 512
+    for r in runs[1:]:
+        for k in ('v', 'H', 'chi2', 'S', 'Q', 'n_iter', 'n_evals', 'converged'):
+            assert np.array_equal(r[k], runs[0][k], equal_nan=True), k
+
+
 def test_batches_in_flight_are_cut_into_fewer_pieces_and_give_the_same_answers(cfg4):
     """mxe_opts.in_flight = n: the caller keeps n batches of this size in flight (bench.py --in-flight n: n contexts take the
     steps in turn), so each is cut into about 1 / n as many cold-started pieces -- fewer evaluations per alpha, the same fixed

@@ -50,15 +50,15 @@ def test_run_many_returns_what_the_sequential_runs_return(n_jobs):
     seq = [snapshot(ew.run()) for ew in jobs]
     for ew in jobs:
         ew.maxent_result = None
-    res = mx.run_many(jobs)
+    res = mx.run_many(jobs, same_cut=False)
     assert len(res) == n_jobs and all(r is ew.maxent_result for r, ew in zip(res, jobs))
     for k, (r, s) in enumerate(zip(res, seq)):
         got = snapshot(r)
         assert np.all(got['converged'] == 1) and np.array_equal(got['alpha'], s['alpha'])
         for f in FIELDS + ('A_out',):
             assert got[f].shape == s[f].shape, (k, f)
-            # (jobs in flight are cut into fewer cold-started pieces -- mxe_opts.in_flight --: other iterates, the same minimisers to
-            #  the stopping tolerance; the gate against the truth is 1e-6)
+            # (same_cut=False: jobs in flight are cut into fewer cold-started pieces -- mxe_opts.in_flight --: other iterates, the
+            #  same minimisers to the stopping tolerance; the gate against the truth is 1e-6)
             assert np.all(np.isfinite(got[f]))
             rel = np.linalg.norm(got[f] - s[f]) / np.linalg.norm(s[f])
             assert rel < 1e-7, (k, f, rel)
@@ -68,6 +68,27 @@ def test_run_many_returns_what_the_sequential_runs_return(n_jobs):
     assert np.linalg.norm(np.asarray(res[0].chi2) - np.asarray(res[1].chi2)) > 0
     # every object had contexts of its own while in flight, and the launches of the jobs were cut for n_jobs in flight
     assert all(len(ew.last_launches) >= 2 for ew in jobs)
+
+
+@pytest.mark.parametrize('shape', [(3, 100, 200, 30), (16, 200, 500, 100)])
+def test_run_many_is_the_sequential_runs_bit_for_bit(shape):
+    """the default (``same_cut=True``): the jobs are in flight together and each is cut as ``run()`` cuts it -- every field, the
+    spectra and the analyzers' choices are bitwise those of the sequential calls.  The second shape is
+    the BASELINE batch (chain_kernel_mc<32, 2>, 512 workgroups): until round 5 its launch did not repeat bit for bit even when
+    run() was called twice -- four atomic additions per partial h in the order the waves arrived; they are summed in pairs now"""
+    jobs = [make(*shape, 20 + k) for k in range(4)]
+    seq = [snapshot(ew.run()) for ew in jobs]
+    wgs = [ew.last_launches[-1]['n_workgroups'] for ew in jobs]
+    for ew in jobs:
+        ew.maxent_result = None
+    res = mx.run_many(jobs)
+    for k, (r, s) in enumerate(zip(res, seq)):
+        got = snapshot(r)
+        for f in FIELDS + ('A_out', 'converged', 'alpha'):
+            assert np.array_equal(got[f], s[f], equal_nan=True), (k, f)
+        for name in got['picks']:
+            assert np.array_equal(got['picks'][name], s['picks'][name]), (k, name)
+    assert [ew.last_launches[-1]['n_workgroups'] for ew in jobs] == wgs      # (the cut of run(), not the one for four in flight)
 
 
 def test_run_async_with_the_cut_of_one_job_is_run():

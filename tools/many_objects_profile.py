@@ -44,7 +44,7 @@ t0 = time.perf_counter()
 hs = []
 marks = []
 for ew in jobs:
-    hs.append(ew.run_async(in_flight=n_jobs))
+    hs.append(ew.run_async())
     marks.append(time.perf_counter())
 outs = []
 for h in hs:
