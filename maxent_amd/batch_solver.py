@@ -588,6 +588,7 @@ class BatchSolver(object):
         out = c.result_arrays(pinned_rows=1 if ahead else None)
         conv = np.empty(out['converged'].shape, dtype=bool)
         picks = None
+        ahead = ahead and out.get('_pinned', False)     # (no page-locked block to be had: copied out when waited for, as before)
         if ahead:
             c.prefetch(out)
         if select is not None:

@@ -228,13 +228,38 @@ def pinned_empty(shape, dtype=np.float64, min_bytes=1 << 20):
     n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
     if n < min_bytes or n == 0:
         return np.empty(shape, dtype=dtype)
+    if n < (1 << 20) + (1 << 21) and _small_pinned[0] + n > SMALL_PINNED_LIMIT:
+        return np.empty(shape, dtype=dtype)              # (results a caller keeps hold their blocks: see SMALL_PINNED_LIMIT)
     lib = load_library()
     p = lib.mxe_host_alloc(n)
     if not p:
         return np.empty(shape, dtype=dtype)
     buf = (ctypes.c_char * n).from_address(p)
-    weakref.finalize(buf, lib.mxe_host_free, p)          # (every view keeps ``buf`` alive through its base)
+    weakref.finalize(buf, _host_free, lib, p, n)         # (every view keeps ``buf`` alive through its base)
+    if n < (1 << 20) + (1 << 21):
+        _small_pinned[0] += n
     return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+# The scalars and rows of a launch (DeviceContext.result_arrays(pinned_rows=...): ~2 MB per 16 x 16 x 100 job) live in page-locked
+# memory as long as the result that holds them; a caller who keeps hundreds of results would pin gigabytes.  Beyond this many
+# bytes of such blocks alive, further ones are ordinary memory (and are then copied out when the result is waited for, as before).
+SMALL_PINNED_LIMIT = 256 << 20
+_small_pinned = [0]
+
+
+def _host_free(lib, p, n):
+    if n < (1 << 20) + (1 << 21):
+        _small_pinned[0] -= n
+    lib.mxe_host_free(p)
+
+
+def is_pinned(a):
+    """whether ``a`` lies in a block of :func:`pinned_empty`"""
+    b = a
+    while getattr(b, 'base', None) is not None:
+        b = b.base
+    return isinstance(b, ctypes.Array)
 
 
 def _c(a, dtype=np.float64):
@@ -470,7 +495,8 @@ class DeviceContext(object):
         d = buf[:nd].view(np.float64).reshape(3, nc, na)
         i = buf[nd:nd + 3 * nc * na * 4].view(np.int32).reshape(3, nc, na)
         rows = buf[nd + ni:].view(np.float64).reshape(int(pinned_rows), nc, self.n_omega)
-        return dict(chi2=d[0], S=d[1], Q=d[2], n_iter=i[0], converged=i[1], n_evals=i[2], _d=d, _i=i, _rows=rows)
+        return dict(chi2=d[0], S=d[1], Q=d[2], n_iter=i[0], converged=i[1], n_evals=i[2], _d=d, _i=i, _rows=rows,
+                    _pinned=is_pinned(buf))
 
     def prefetch(self, out):
         """``mxe_chains_prefetch``: the scalars of the launch copied into ``out`` (of ``result_arrays(pinned_rows=...)``) behind

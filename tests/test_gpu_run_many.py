@@ -11,7 +11,7 @@ import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import maxent_amd as mx                                      # noqa: E402
-from maxent_amd import synthetic                             # noqa: E402
+from maxent_amd import device, synthetic                     # noqa: E402
 
 pytestmark = pytest.mark.gpu
 FIELDS = ('chi2', 'S', 'Q', 'H', 'A')
@@ -89,6 +89,28 @@ def test_run_many_is_the_sequential_runs_bit_for_bit(shape):
         for name in got['picks']:
             assert np.array_equal(got['picks'][name], s['picks'][name]), (k, name)
     assert [ew.last_launches[-1]['n_workgroups'] for ew in jobs] == wgs      # (the cut of run(), not the one for four in flight)
+
+
+def test_without_page_locked_blocks_the_results_are_copied_when_waited_for(monkeypatch):
+    """the scalars and rows of a job go into one page-locked block behind the kernels (mxe_chains_prefetch); results a caller keeps hold
+    their blocks, so beyond ``device.SMALL_PINNED_LIMIT`` bytes a job gets ordinary memory and the copies of round 4: the same bits"""
+    jobs = [make(3, 100, 200, 30, 40 + k) for k in range(2)]
+    res = mx.run_many(jobs)
+    a = [snapshot(r) for r in res]
+    assert device._small_pinned[0] > 0                  # (the blocks of the two results)
+    del res
+    for ew in jobs:
+        ew.maxent_result = None
+    import gc
+    gc.collect()
+    monkeypatch.setattr(device, 'SMALL_PINNED_LIMIT', 0)
+    before = device._small_pinned[0]
+    res = mx.run_many(jobs)
+    assert device._small_pinned[0] == before
+    b = [snapshot(r) for r in res]
+    for x, y in zip(a, b):
+        for f in FIELDS + ('A_out', 'converged'):
+            assert np.array_equal(x[f], y[f], equal_nan=True), f
 
 
 def test_run_async_with_the_cut_of_one_job_is_run():
