@@ -212,9 +212,11 @@ template <typename T> struct DevBuf {
         size_t got = 0;
         void* q = g_pool.take(need, &got);
         static const bool poison = getenv("MXE_POISON_ALLOC") != nullptr;      // (debugging aid: nothing may rely on what a fresh block holds)
-        if (q) { p = (T*)q; bytes = got; n = count; if (poison) hipMemset(p, 0xA5, bytes); return hipSuccess; }
+        // (the fill runs on the null stream and the contexts' streams do not wait for that one: it has to be through before
+        //  anybody writes the block -- without the wait a staged array now and then came out with the pattern in it)
+        if (q) { p = (T*)q; bytes = got; n = count; if (poison) { hipMemset(p, 0xA5, bytes); hipDeviceSynchronize(); } return hipSuccess; }
         hipError_t e = hipMalloc((void**)&p, need);
-        if (e == hipSuccess) { n = count; bytes = need; if (poison) hipMemset(p, 0xA5, bytes); }
+        if (e == hipSuccess) { n = count; bytes = need; if (poison) { hipMemset(p, 0xA5, bytes); hipDeviceSynchronize(); } }
         return e;
     }
     // (callers make sure nothing in flight uses the block: mxe_ctx_destroy waits for its stream first)
@@ -1695,6 +1697,35 @@ void add_counts_kernel(int* __restrict__ niter, int* __restrict__ nevals, const 
 }
 }  // namespace
 
+namespace {
+// Diagnostic (MXE_POISON_LDS = 1: NaN, 2: a pattern of finite values that changes from launch to launch): every CU's LDS is
+// written over before a chain kernel starts, so that nothing can lean on what an earlier kernel left there -- the LDS is not
+// cleared between kernels, and a read of a cell nobody wrote gives the same answer run after run until the launches before it
+// change.  One workgroup of the full 160 KB per CU, and a second wave of them for good measure.
+__global__ __launch_bounds__(256)
+void scribble_lds_kernel(unsigned long long pattern, int words, unsigned long long* sink)
+{
+    extern __shared__ unsigned long long sl[];
+    for (int i = threadIdx.x; i < words; i += 256) sl[i] = pattern ? (0x3ff0000000000000ull | ((pattern + (unsigned long long)i * 0x9E3779B97F4A7C15ull) & 0x000fffffffffffffull)) : 0x7ff8000000000000ull;
+    __syncthreads();
+    if (sink && sl[(threadIdx.x * 7) % words] == 1) sink[0] = 1;       // (keeps the stores)
+    __builtin_amdgcn_s_sleep(64);
+}
+hipError_t scribble_lds(hipStream_t s)
+{
+    static const int mode = getenv("MXE_POISON_LDS") ? atoi(getenv("MXE_POISON_LDS")) : 0;
+    if (!mode) return hipSuccess;
+    static unsigned long long launches = 0;
+    const int bytes = 160 * 1024;
+    hipError_t e = hipFuncSetAttribute((const void*)scribble_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    ++launches;
+    const unsigned long long pat = mode == 1 ? 0ull : (launches * 0x2545F4914F6CDD1Dull | 1ull);
+    hipLaunchKernelGGL(scribble_lds_kernel, dim3(512), dim3(256), bytes, s, pat, bytes / 8, (unsigned long long*)nullptr);
+    return hipGetLastError();
+}
+}  // namespace
+
 // tolerance of the binary32 first pass of a two-pass launch: far enough above the rounding floor of h = V^T H in binary32
 // (~2e-7 of |H|) to be reached without crawling, close enough for ONE binary64 Newton step to land below 1e-9
 constexpr double LV_TOL1 = 1e-5;
@@ -1708,6 +1739,7 @@ try {
     const mxe_opts& o = ctx->opts;
     KParams kp;
     fill_kparams(ctx, kp);
+    HIPCHK(ctx, scribble_lds(ctx->stream));      // (diagnostic, MXE_POISON_LDS)
     if (getenv("MXE_COUNT_ROUNDS") && ctx->mc_na > 0 && kp.chain_lead == nullptr && ctx->lv_mode == 0) {
         // a diagnostic launch that counts the rounds of its workgroups (mxe_launch_depth) also where the shipped build does not --
         // <32, 2> without led pieces compiles the store out --: the build for led pieces with no piece led, the same schedule
@@ -2057,6 +2089,7 @@ try {
     const int NW = 4;
     size_t lds = lds_bytes(NP, ctx->nwp, NW, false);
     hipError_t e;
+    HIPCHK(ctx, scribble_lds(ctx->stream));      // (diagnostic, MXE_POISON_LDS)
     if (lds > 160 * 1024) {
         // (a frequency mesh beyond the LDS -- the lock-step launch kept its state in device memory --: so does this one)
         lds = lds_bytes(NP, ctx->nwp, NW, false, true);
