@@ -133,7 +133,10 @@ typedef struct mxe_opts {
                                 below the noise of the data: the lock-step build with the 64-row block),
                                 and, with wg_per_cu = 0, a batch that fills the GPU at two workgroups per
                                 CU (the binary64 kernel that runs that way: 0.81 against 1.24 ms on the
-                                16 x 16 x 100 batch; wg_per_cu = 1 keeps chain_kernel_lv);
+                                16 x 16 x 100 batch; wg_per_cu = 1 keeps chain_kernel_lv), and a frequency
+                                mesh whose basis does not fit the LDS as binary32 (n_omega > 512: one chain
+                                per workgroup in binary32 takes 3.6-7.8 ms where the binary64 lock-step
+                                kernel takes 0.5-1.7; lds_basis = 2 or chains_per_wg = 1 keep that kernel);
                                 mxe_last_launch_info names the kernel that ran.  For the fp32-vs-fp64 tolerance sweep of BASELINE config 5
                                 (tools/cfg5_tolerance_sweep.py)                                 */
     int32_t wg_per_cu;       /* lock-step layout: workgroups per CU.  0 = auto (2 where the kernel has a

@@ -1067,6 +1067,16 @@ try {
             ctx->opts.precision = MXE_PRECISION_F64;
         }
     }
+    if (o.precision == MXE_PRECISION_F32 && !lv_fits && NP == 64 && o.lds_basis != 2 && !getenv("MXE_NO_LDS_BASIS") &&
+        o.chains_per_wg != 1 && o.tol_d <= 0.0 && o.decouple_tol > 0.0) {
+        // A frequency mesh whose basis does not fit the LDS as binary32 (n_omega > 512, or n_s x (n_omega_pad + 4) floats beyond what
+        // the slots leave): the binary32 request would run one chain per workgroup with V streamed from the L2 by every chain --
+        // 3.6-7.8 ms where the binary64 lock-step kernel takes 0.5-1.7 (8 x 8 and 16 x 16 elements x 100 alpha at n_omega = 640 ...
+        // 1500), and stops at its rounding floor besides (audit 8e-4 against 1e-8).  Binary32 is asked for as the cheaper
+        // arithmetic: the launch is promoted like the two cases above.  lds_basis = 2 or chains_per_wg = 1 keep the one-chain
+        // binary32 kernel (BASELINE config 5's tolerance sweep on such a mesh asks for it that way).
+        ctx->opts.precision = MXE_PRECISION_F64;
+    }
     ctx->lv_mode = 0;
     // ---- (sub-)chains: an alpha scan may be cut into pieces that are cold-started
     //      from the same v0 (the minimiser of each alpha does not depend on the path)

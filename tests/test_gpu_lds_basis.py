@@ -109,11 +109,19 @@ def test_chain_kernel_lv_against_the_reference_anchored_truth_cfg3():
         assert rel_l2(out['H'][c], ref['H']).max() < 1e-4
 
 
-def test_a_basis_that_does_not_fit_the_lds_keeps_the_one_chain_binary32_kernel():
-    batch = bench.build_batch(2, 100, 1000, 10, 0)           # n_omega_pad = 1024: 56 x 1028 floats are 230 KB
+def test_a_binary32_request_on_a_basis_that_does_not_fit_the_lds_is_promoted():
+    """n_omega_pad = 1024: 56 x 1028 floats are 230 KB, chain_kernel_lv cannot hold them.  The one-chain binary32 kernel -- V
+    streamed from the L2 by every chain -- takes 3.6-7.8 ms where the binary64 lock-step kernel takes 0.5-1.7 (8 x 8 / 16 x 16
+    elements x 100 alpha, n_omega 640 ... 1500) and stops at a rounding floor of ~1e-3: binary32 is asked for as the cheaper
+    arithmetic, so the launch is promoted (missing 5).  lds_basis = 2 keeps the one-chain binary32 kernel."""
+    batch = bench.build_batch(2, 100, 1000, 10, 0)
     out, info, _ = solve(batch, precision=device.PRECISION_F32)
-    assert info['kernel'].startswith('mxe::chain_kernel<') and 'float' in info['kernel'], info
-    assert out['converged'].all()
+    assert info['kernel'].startswith('mxe::chain_kernel_mc<'), info
+    assert out['converged'].all() and np.nanmax(out['audit']) < 1e-6
+    old, info_old, _ = solve(batch, precision=device.PRECISION_F32, lds_basis=2)
+    assert info_old['kernel'].startswith('mxe::chain_kernel<') and 'float' in info_old['kernel'], info_old
+    assert old['converged'].all()
+    assert rel_l2(old['H'], out['H']).max() < 2e-3
 
 
 def test_binary32_first_pass_then_one_binary64_step_per_alpha():

@@ -100,7 +100,11 @@ def test_frequency_mesh_beyond_the_lds(n_omega, precision):
             for ia in (0, 2):
                 assert np.linalg.norm(out['H'][c, ia] - truth[ia]) / np.linalg.norm(truth[ia]) < 1e-6
     else:
-        o32 = ctx.solve_chains(np.arange(n), alphas, v0, device.default_opts(precision=precision))
+        # (a binary32 request on a mesh whose basis does not fit the LDS is promoted to the binary64 lock-step kernel -- round 5 --;
+        #  lds_basis = 2 keeps the one-chain binary32 kernel, here with its state in device memory)
+        ctx.solve_chains(np.arange(n), alphas, v0, device.default_opts(precision=precision))
+        assert ctx.last_launch_info()['kernel'].startswith('mxe::chain_kernel_mc<32, 1')
+        o32 = ctx.solve_chains(np.arange(n), alphas, v0, device.default_opts(precision=precision, lds_basis=2))
         assert 'float, device-memory state' in ctx.last_launch_info()['kernel']
         assert o32['converged'].all()
         assert rel_l2(o32['H'], out['H']).max() < 1e-3
