@@ -474,34 +474,36 @@ def scaling_projection(batch, opts, k_ms_full, n_alpha, n_launch=30):
         # one rank; with --gpus N every rank keeps one context so far -- the gather would need a communicator per context): a
         # shard alone does not fill the GPU and is bound by the depth of its chains, several of them side by side are not
         which = [e for e in range(n_elem) if e % N == slow]
-        fl_opts = device.default_opts(in_flight=4)
-        lanes = []
-        for _ in range(4):
-            c = stage(batch, 0, which)
-            c.upload_chains(np.arange(len(which), dtype=np.int32), batch['alphas'], batch['v0'][which], fl_opts)
-            lanes.append(c)
-        for k in range(16):
-            lanes[k % 4].launch(); lanes[k % 4].select_launch(0)
-        for c in lanes:
-            c.sync()
-        t0 = time.perf_counter()
-        for k in range(4 * n_launch):
-            lanes[k % 4].launch(); lanes[k % 4].select_launch(0)
-        for c in lanes:
-            c.sync()
-        fl_ms = 1e3 * (time.perf_counter() - t0) / (4 * n_launch)
-        lanes[0].launch()
-        fl_left = lanes[0].finish()
-        fl_res = lanes[0].fetch(want_v=False, want_H=False)
-        fl_aud = float(np.nanmax(lanes[0].audit()['corr']))
-        fl_info = lanes[0].last_launch_info()
-        for c in lanes:
-            c.close()
-        out['N=%d' % N]['four_in_flight'] = dict(
-            ms_per_step_slowest_rank=fl_ms, speedup_before_gather=k_ms_full / fl_ms, kernel=fl_info['kernel'],
-            workgroups=fl_info['n_workgroups'], converged=int(fl_res['converged'].sum()), left_to_finish=int(fl_left), audit_max=fl_aud,
-            note='step = chain kernel + device line fit of the shard, four contexts in turn, timed by the host clock; speed-up against '
-                 'the one-batch kernel time of the whole batch, like the line above it')
+        # (N = 8 with EIGHT as well: at 3 200 alpha-solves per rank four steps in flight fill half the GPU -- VERDICT r04 item 5)
+        for n_fl, key in ((4, 'four_in_flight'),) + (((8, 'eight_in_flight'),) if N == 8 else ()):
+            fl_opts = device.default_opts(in_flight=n_fl)
+            lanes = []
+            for _ in range(n_fl):
+                c = stage(batch, 0, which)
+                c.upload_chains(np.arange(len(which), dtype=np.int32), batch['alphas'], batch['v0'][which], fl_opts)
+                lanes.append(c)
+            for k in range(4 * n_fl):
+                lanes[k % n_fl].launch(); lanes[k % n_fl].select_launch(0)
+            for c in lanes:
+                c.sync()
+            t0 = time.perf_counter()
+            for k in range(n_fl * n_launch):
+                lanes[k % n_fl].launch(); lanes[k % n_fl].select_launch(0)
+            for c in lanes:
+                c.sync()
+            fl_ms = 1e3 * (time.perf_counter() - t0) / (n_fl * n_launch)
+            lanes[0].launch()
+            fl_left = lanes[0].finish()
+            fl_res = lanes[0].fetch(want_v=False, want_H=False)
+            fl_aud = float(np.nanmax(lanes[0].audit()['corr']))
+            fl_info = lanes[0].last_launch_info()
+            for c in lanes:
+                c.close()
+            out['N=%d' % N][key] = dict(
+                ms_per_step_slowest_rank=fl_ms, speedup_before_gather=k_ms_full / fl_ms, kernel=fl_info['kernel'],
+                workgroups=fl_info['n_workgroups'], converged=int(fl_res['converged'].sum()), left_to_finish=int(fl_left), audit_max=fl_aud,
+                note='step = chain kernel + device line fit of the shard, %d contexts in turn, timed by the host clock; speed-up against '
+                     'the one-batch kernel time of the whole batch, like the line above it' % n_fl)
     # the bound, from this run: a shard that does not fill the GPU is as long as its deepest workgroup (rounds counted by the
     # kernel, mxe_launch_depth) times what a round takes there (the shard's kernel time / that depth)
     deep = [out['N=%d' % N]['rounds_deepest_workgroup'][out['N=%d' % N]['slowest_rank']] for N in (2, 4, 8)]
