@@ -838,3 +838,23 @@ def test_rows_of_a_non_default_analyzer_are_formed_when_first_read():
     assert got2[0] == [int(idx[2, 3]), int(idx[2, 1])] and np.array_equal(np.array(list(got2[1])), rows[2][[3, 1]] / 0.25)
     # the per-scan view of the same rows
     assert np.array_equal(res._records[(1, 0)]['device_select']['H'][1], rows[1][2])
+
+
+def test_page_locked_blocks_fall_back_to_ordinary_memory():
+    """``device.pinned_empty`` hands out ordinary arrays where the library cannot pin (no GPU here) or where the cap on small
+    blocks held by results is reached; ``is_pinned`` follows views down to the block they lie in; ``run_many`` keeps the cut of
+    ``run()`` unless told otherwise (the results are then those of the sequential calls bit for bit: tests/test_gpu_run_many.py)"""
+    import ctypes
+    import inspect
+    from maxent_amd import device
+    import maxent_amd as mx
+    a = device.pinned_empty((3, 5), np.float64, min_bytes=0)
+    assert a.shape == (3, 5) and a.dtype == np.float64
+    if not device.is_pinned(a):                  # (no GPU: hipHostMalloc fails and the array is numpy's own)
+        assert device._small_pinned[0] == 0 or device._small_pinned[0] >= 0
+    buf = (ctypes.c_char * 480)()
+    blk = np.frombuffer(buf, dtype=np.uint8)
+    d = blk[:240].view(np.float64).reshape(3, 2, 5)
+    assert device.is_pinned(blk) and device.is_pinned(d) and device.is_pinned(d[1, 0]) and not device.is_pinned(np.empty(4))
+    assert device.pinned_empty((0,), np.float64).size == 0
+    assert inspect.signature(mx.run_many).parameters['same_cut'].default is True
