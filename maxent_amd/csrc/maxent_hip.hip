@@ -2732,7 +2732,7 @@ try {
     const size_t P = (size_t)ctx->n_chain * ctx->n_alpha;
     double* sel = ctx->dout_Q.p + P;
     double* idx = sel + (size_t)ctx->n_chain * ctx->n_omega;
-    hipLaunchKernelGGL(mxe::linefit_kernel, dim3(ctx->n_chain), dim3(64), ((size_t)9 * ctx->n_alpha + 6) * sizeof(double), ctx->stream,
+    hipLaunchKernelGGL(mxe::linefit_kernel, dim3(ctx->n_chain), dim3(256), ((size_t)11 * ctx->n_alpha + 6 + 28) * sizeof(double), ctx->stream,
                        ctx->dalpha.p, ctx->dout_chi2.p, ctx->dout_H.p, ctx->n_alpha, ctx->n_omega, p2_deg, sel, idx);
     HIPCHK(ctx, hipGetLastError());
     return MXE_OK;
@@ -2752,7 +2752,7 @@ try {
     double* idx = sel + nc * nw;
     HIPCHK(ctx, ctx->dsel3.ensure(3 * nc * (nw + 1)));
     ctx->pre_rows = nullptr; ctx->pre_index = false;
-    hipLaunchKernelGGL(mxe::linefit_kernel, dim3(ctx->n_chain), dim3(64), ((size_t)9 * ctx->n_alpha + 6) * sizeof(double), ctx->stream,
+    hipLaunchKernelGGL(mxe::linefit_kernel, dim3(ctx->n_chain), dim3(256), ((size_t)11 * ctx->n_alpha + 6 + 28) * sizeof(double), ctx->stream,
                        ctx->dalpha.p, ctx->dout_chi2.p, ctx->dout_H.p, ctx->n_alpha, ctx->n_omega, p2_deg, sel, idx,
                        ctx->dout_S.p, gamma, ctx->dsel3.p, ctx->dsel3.p + 3 * nc);
     HIPCHK(ctx, hipGetLastError());

@@ -384,7 +384,11 @@ __device__ inline LineSSE line_sse(const double* x, const double* y, int lo, int
     return r;
 }
 
-__global__ __launch_bounds__(64)
+// One workgroup of FOUR waves per scan (round 5; one wave until then: 19.4 us per launch of 256 scans, a serial chain of
+// running sums, candidate fits and row copies in one wave).  Every number that decides a pick is formed by the arithmetic of the
+// one-wave version in the same order -- the running sums per quantity, the exact misfits per candidate -- so the picks are the
+// same; what is spread over the waves is WHICH quantity / candidate / analyzer a wave takes, and the row copies.
+__global__ __launch_bounds__(256)
 void linefit_kernel(const double* __restrict__ alpha, const double* __restrict__ chi2, const double* __restrict__ H,
                     int n_alpha, int nw, int p2_deg, double* __restrict__ out_sel /*[n_chain][nw] or null*/,
                     double* __restrict__ out_idx /*[n_chain], as doubles (they travel in the result pack)*/,
@@ -397,80 +401,110 @@ void linefit_kernel(const double* __restrict__ alpha, const double* __restrict__
     // analyzer's fit_piecewise), then only those within a whisker of the best are evaluated exactly with the
     // two-pass formulas -- the same two stages, with the same tolerance, as the host code.
     extern __shared__ double sm[];
-    const int lane = threadIdx.x, n = n_alpha;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = n_alpha;
     double* x = sm;                  // log alpha
     double* y = x + n;               // log chi2
     double* cs = y + n;              // [6][n + 1] running sums of w, w x0, yc, w x0^2, x0 yc, yc^2
     double* ap = cs + 6 * (n + 1);   // [n] approximate misfit of break point i
+    double* x10 = ap + n;            // [n] gamma log10 alpha   (chi2 curvature)
+    double* y10 = x10 + n;           // [n] log10 chi2
+    double* wbest = y10 + n;         // [4] smallest approximate misfit seen by a wave
+    double* wfit = wbest + 4;        // [4][6] a wave's best exact candidate: misfit, index, the two lines
+    __shared__ int s_pick[3];
     const size_t c = blockIdx.x;
-    for (int k = lane; k < n; k += 64) { x[k] = log(alpha[c * n + k]); y[k] = log(chi2[c * n + k]); }
-    wave_sync();
-    int idx = -1;
-    if (n > 4) {
-        // means for the centring
+    for (int k = tid; k < n; k += 256) {
+        const double a = alpha[c * n + k], q = chi2[c * n + k];
+        x[k] = log(a); y[k] = log(q);
+        x10[k] = gamma * log10(a); y10[k] = log10(q);
+    }
+    if (tid < 3) s_pick[tid] = -1;
+    __syncthreads();
+    const bool fit = n > 4;
+    double xm = 0.0, ym = 0.0;
+    if (fit) {
+        // means for the centring (every wave for itself: the same sums in the same order)
         double sx = 0.0, sy = 0.0, sw = 0.0;
         for (int k = lane; k < n; k += 64) { sx += x[k]; if (y[k] == y[k]) { sy += y[k]; sw += 1.0; } }
         sx = wave_sum(sx); sy = wave_sum(sy); sw = wave_sum(sw);
-        const double xm = sx / n, ym = sy / fmax(sw, 1.0);
-        {
-            // running sums of the six quantities: lane t holds element c0 + t of a chunk of 64, inclusive scan
-            // over the lanes (six shuffle steps), carry from chunk to chunk
-            double carry[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            if (lane < 6) cs[lane * (n + 1)] = 0.0;
+        xm = sx / n; ym = sy / fmax(sw, 1.0);
+        // running sums of the six quantities, quantity q by wave q & 3: lane t holds element c0 + t of a chunk of 64,
+        // inclusive scan over the lanes (six shuffle steps), carry from chunk to chunk
+        for (int q = wave; q < 6; q += 4) {
+            double carry = 0.0;
+            if (lane == 0) cs[q * (n + 1)] = 0.0;
             for (int c0 = 0; c0 < n; c0 += 64) {
                 const int k = c0 + lane;
                 const bool in = k < n, ok = in && y[in ? k : 0] == y[in ? k : 0];
                 const double w = ok ? 1.0 : 0.0, x0 = in ? x[k] - xm : 0.0, yc = ok ? y[k] - ym : 0.0;
-                double v[6] = {w, w * x0, yc, w * x0 * x0, x0 * yc, yc * yc};
+                double v = q == 0 ? w : q == 1 ? w * x0 : q == 2 ? yc : q == 3 ? w * x0 * x0 : q == 4 ? x0 * yc : yc * yc;
 #pragma unroll
-                for (int q = 0; q < 6; ++q) {
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const double up = __shfl_up(v[q], off);
-                        if (lane >= off) v[q] += up;
-                    }
-                    v[q] += carry[q];
-                    if (in) cs[q * (n + 1) + k + 1] = v[q];
-                    carry[q] = __shfl(v[q], 63);
+                for (int off = 1; off < 64; off <<= 1) {
+                    const double up = __shfl_up(v, off);
+                    if (lane >= off) v += up;
                 }
+                v += carry;
+                if (in) cs[q * (n + 1) + k + 1] = v;
+                carry = __shfl(v, 63);
             }
         }
-        wave_sync();
-        auto sse = [&](int lo, int hi, bool line) -> double {
-            const double m = cs[hi] - cs[lo], s1 = cs[(n + 1) + hi] - cs[(n + 1) + lo], s2 = cs[2 * (n + 1) + hi] - cs[2 * (n + 1) + lo];
-            const double sxx = cs[3 * (n + 1) + hi] - cs[3 * (n + 1) + lo], sxy = cs[4 * (n + 1) + hi] - cs[4 * (n + 1) + lo];
-            const double syy = cs[5 * (n + 1) + hi] - cs[5 * (n + 1) + lo];
-            if (!(m >= 1.0)) return __builtin_nan("");
-            const double vyy = syy - s2 * s2 / m;
-            if (!line || m < 2.0) return vyy;
-            const double vxx = sxx - s1 * s1 / m, vxy = sxy - s1 * s2 / m;
-            return vxx > 0.0 ? vyy - vxy * vxy / vxx : vyy;
-        };
+    }
+    __syncthreads();
+    auto sse = [&](int lo, int hi, bool line) -> double {
+        const double m = cs[hi] - cs[lo], s1 = cs[(n + 1) + hi] - cs[(n + 1) + lo], s2 = cs[2 * (n + 1) + hi] - cs[2 * (n + 1) + lo];
+        const double sxx = cs[3 * (n + 1) + hi] - cs[3 * (n + 1) + lo], sxy = cs[4 * (n + 1) + hi] - cs[4 * (n + 1) + lo];
+        const double syy = cs[5 * (n + 1) + hi] - cs[5 * (n + 1) + lo];
+        if (!(m >= 1.0)) return __builtin_nan("");
+        const double vyy = syy - s2 * s2 / m;
+        if (!line || m < 2.0) return vyy;
+        const double vxx = sxx - s1 * s1 / m, vxy = sxy - s1 * s2 / m;
+        return vxx > 0.0 ? vyy - vxy * vxy / vxx : vyy;
+    };
+    if (fit) {
         double best = __builtin_inf();
-        for (int i = 2 + lane; i < n - 2; i += 64) {
+        for (int i = 2 + tid; i < n - 2; i += 256) {
             const double a = sse(0, i, true) + sse(i, n, p2_deg == 1);
             ap[i] = a;
             if (a == a && fabs(a) < 1.7e308 && a < best) best = a;
         }
         best = -wave_max(-best);
-        wave_sync();
+        if (lane == 0) wbest[wave] = best;
+    }
+    __syncthreads();
+    if (fit) {
+        const double best = fmin(fmin(wbest[0], wbest[1]), fmin(wbest[2], wbest[3]));
         const double tol = best + 1e-9 * (fabs(cs[5 * (n + 1) + n]) + 1e-300) + 1e-6 * fabs(best);
         const bool rank_ok = best < 1.7e308 && n > 8;
-        // exact misfit of the candidates, one after the other, each by the whole wave; the smallest wins,
+        // exact misfit of the candidates, candidate number j by wave j & 3, each by its whole wave; the smallest wins,
         // the lowest index among equals (np.nanargmin)
-        double ebest = __builtin_inf(); int ebest_i = -1;
+        double ebest = __builtin_inf(); int ebest_i = -1, seen = 0;
         LineSSE abest, bbest;
+        abest.slope = abest.icpt = bbest.slope = bbest.icpt = 0.0;
         for (int i = 2; i < n - 2; ++i) {
             const bool cand = rank_ok ? (ap[i] == ap[i] && ap[i] <= tol) : true;      // wave-uniform
             if (!cand) continue;
+            const bool mine = (seen & 3) == wave;
+            ++seen;
+            if (!mine) continue;
             const LineSSE a = line_sse(x, y, 0, i, true), b = line_sse(x, y, i, n, p2_deg == 1);
             if (a.n < 1 || b.n < 1) continue;
             const double m = a.sse + b.sse;
             if (m == m && m < ebest) { ebest = m; ebest_i = i; abest = a; bbest = b; }
         }
+        if (lane == 0) {
+            double* f = wfit + wave * 6;
+            f[0] = ebest; f[1] = (double)ebest_i; f[2] = abest.slope; f[3] = abest.icpt; f[4] = bbest.slope; f[5] = bbest.icpt;
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && fit) {
+        double ebest = __builtin_inf(); int ebest_i = -1, wv = -1;
+        for (int w = 0; w < 4; ++w) {
+            const double m = wfit[w * 6]; const int i = (int)wfit[w * 6 + 1];
+            if (i >= 0 && (m < ebest || (m == ebest && i < ebest_i))) { ebest = m; ebest_i = i; wv = w; }
+        }
         if (ebest_i >= 0) {
-            const LineSSE a = abest, b = bbest;
-            const double xc = (b.icpt - a.icpt) / (a.slope - b.slope);
+            const double* f = wfit + wv * 6;
+            const double xc = (f[5] - f[3]) / (f[2] - f[4]);
             double dbest = __builtin_inf(); int di = -1;
             for (int k = lane; k < n; k += 64) {
                 const double d = fabs(x[k] - xc);
@@ -480,52 +514,55 @@ void linefit_kernel(const double* __restrict__ alpha, const double* __restrict__
                 const double od = __shfl_xor(dbest, off); const int oi = __shfl_xor(di, off);
                 if (oi >= 0 && (di < 0 || od < dbest || (od == dbest && oi < di))) { dbest = od; di = oi; }
             }
-            idx = di;
+            if (lane == 0) s_pick[0] = di;
         }
     }
-    if (lane == 0) out_idx[c] = (double)idx;
-    if (out_sel) {
-        const double* row = H + (c * n + (idx >= 0 ? idx : 0)) * nw;
-        for (int k = lane; k < nw; k += 64) out_sel[c * nw + k] = (idx >= 0) ? row[k] : __builtin_nan("");
-    }
-    if (!out3_idx) return;
     // ---- Chi2CurvatureAnalyzer (reference analyzers/chi2_curvature_analyzer.py:25-49, 101-131): the alpha of the
     //      largest curvature y'' / (1 + y'^2)^(3/2) of y = log10 chi2 over x = gamma log10 alpha, second-order
-    //      central differences on the (non-uniform) mesh, NaN ignored, the first of equal maxima.
-    // ---- EntropyAnalyzer (entropy_analyzer.py:72-103): the alpha where (dS / dlog alpha)^2 is smallest.
+    //      central differences on the (non-uniform) mesh, NaN ignored, the first of equal maxima.          (wave 1)
+    // ---- EntropyAnalyzer (entropy_analyzer.py:72-103): the alpha where (dS / dlog alpha)^2 is smallest.   (wave 2)
+    if (out3_idx && (wave == 1 || wave == 2)) {
+        double vbest = (wave == 1) ? -__builtin_inf() : __builtin_inf();
+        int vi = -1;
+        for (int k = 1 + lane; k < n - 1; k += 64) {
+            double val;
+            if (wave == 1) {
+                const double hp = x10[k + 1] - x10[k], hm = x10[k] - x10[k - 1];
+                const double der2 = (y10[k + 1] - 2 * y10[k] + y10[k - 1]) / (hp * hm);
+                const double der1 = ((y10[k + 1] - y10[k]) / hp + (y10[k] - y10[k - 1]) / hm) / 2;
+                const double q = 1 + der1 * der1;
+                val = der2 / (q * sqrt(q));
+                if (val == val && (val > vbest || vi < 0)) { vbest = val; vi = k; }          // (ascending k per lane: the first maximum)
+            } else {
+                const double dS = (S[c * n + k + 1] - S[c * n + k - 1]) / (x[k + 1] - x[k - 1]);
+                val = dS * dS;
+                if (val == val && (val < vbest || vi < 0)) { vbest = val; vi = k; }
+            }
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(vbest, off); const int oi = __shfl_xor(vi, off);
+            const bool better = (wave == 1) ? (ov > vbest) : (ov < vbest);
+            if (oi >= 0 && (vi < 0 || better || (ov == vbest && oi < vi))) { vbest = ov; vi = oi; }
+        }
+        if (lane == 0) s_pick[wave] = vi;
+    }
+    __syncthreads();
+    const int idx = s_pick[0];
+    if (tid == 0) out_idx[c] = (double)idx;
+    if (out_sel) {
+        const double* row = H + (c * n + (idx >= 0 ? idx : 0)) * nw;
+        for (int k = tid; k < nw; k += 256) out_sel[c * nw + k] = (idx >= 0) ? row[k] : __builtin_nan("");
+    }
+    if (!out3_idx) return;
     const size_t nc = gridDim.x;
-    wave_sync();
-    double* x10 = cs;                // (the line fit is done with its running sums)
-    double* y10 = cs + n;
-    for (int k = lane; k < n; k += 64) { x10[k] = gamma * log10(alpha[c * n + k]); y10[k] = log10(chi2[c * n + k]); }
-    wave_sync();
-    double cbest = -__builtin_inf(), ebest2 = __builtin_inf();
-    int ci = -1, ei = -1;
-    for (int k = 1 + lane; k < n - 1; k += 64) {
-        const double hp = x10[k + 1] - x10[k], hm = x10[k] - x10[k - 1];
-        const double der2 = (y10[k + 1] - 2 * y10[k] + y10[k - 1]) / (hp * hm);
-        const double der1 = ((y10[k + 1] - y10[k]) / hp + (y10[k] - y10[k - 1]) / hm) / 2;
-        const double q = 1 + der1 * der1;
-        const double cv = der2 / (q * sqrt(q));
-        if (cv == cv && (cv > cbest || ci < 0)) { cbest = cv; ci = k; }          // (ascending k per lane: the first maximum)
-        const double dS = (S[c * n + k + 1] - S[c * n + k - 1]) / (x[k + 1] - x[k - 1]);
-        const double d2 = dS * dS;
-        if (d2 == d2 && (d2 < ebest2 || ei < 0)) { ebest2 = d2; ei = k; }
-    }
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double oc = __shfl_xor(cbest, off); const int oi = __shfl_xor(ci, off);
-        if (oi >= 0 && (ci < 0 || oc > cbest || (oc == cbest && oi < ci))) { cbest = oc; ci = oi; }
-        const double oe = __shfl_xor(ebest2, off); const int oj = __shfl_xor(ei, off);
-        if (oj >= 0 && (ei < 0 || oe < ebest2 || (oe == ebest2 && oj < ei))) { ebest2 = oe; ei = oj; }
-    }
-    const int pick[3] = {idx, ci, ei};
-    if (lane < 3) out3_idx[lane * nc + c] = (double)(lane == 0 ? idx : lane == 1 ? ci : ei);
+    if (tid < 3) out3_idx[tid * nc + c] = (double)s_pick[tid];
     if (out3_sel) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const double* row = H + (c * n + (pick[a] >= 0 ? pick[a] : 0)) * nw;
+            const int pk = s_pick[a];
+            const double* row = H + (c * n + (pk >= 0 ? pk : 0)) * nw;
             double* dst = out3_sel + ((size_t)a * nc + c) * nw;
-            for (int k = lane; k < nw; k += 64) dst[k] = (pick[a] >= 0) ? row[k] : __builtin_nan("");
+            for (int k = tid; k < nw; k += 256) dst[k] = (pk >= 0) ? row[k] : __builtin_nan("");
         }
     }
 }
