@@ -787,13 +787,20 @@ class ElementwiseMaxEnt(object):
         diag = self._prepare_batch(self.maxent_diagonal, self._diag_jobs(), defer_last_load=later)
         self.maxent_offdiagonal.logtaker.message(VerbosityFlags.ElementInfo, 'Calculating off-diagonal elements.')
         off = self._prepare_batch(self.maxent_offdiagonal, self._offdiag_jobs(), defer_last_load=later)
+        def load_last():                              # (the workers as the reference leaves them: loaded with their last element)
+            while later:
+                worker, element, re = later.pop(0)
+                self._load_element(worker, element, re)
         try:
             wait = self._solve_batches([diag, off], defer=True, in_flight=in_flight)
-        finally:
-            for worker, element, re in later:         # (beside the kernel: the workers as the reference leaves them)
-                self._load_element(worker, element, re)
+        except BaseException:
+            load_last()
+            raise
 
         def finish():
+            # (before the wait, beside the kernel -- and not between this job's launch and the next job's: with four jobs in flight
+            #  the 0.08 ms per job delayed every later launch)
+            load_last()
             wait()
             if self._finish_deferred([diag, off]):
                 self._mark_imaginary_diagonal(self.maxent_result)
