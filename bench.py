@@ -27,6 +27,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -701,6 +702,28 @@ def in_flight_comm_region(batch, mine, local_rank, rank, world, counts, full, ar
     return elapsed, check, t_comm
 
 
+PHASE = ['start-up']         # what a rank is doing, for the watchdog of a multi-rank run
+
+
+def start_watchdog(rank, world, args, seconds=None):
+    """The first run between two GPUs must say what happened: a rank that sits in a collective nobody else
+    reaches would hang until the driver's limit with no record.  Every rank names the phase it is in (``PHASE``); when the whole run
+    takes longer than MXE_BENCH_TIMEOUT seconds (900) the rank says where it was on stderr, rank 0 prints a line with value = null
+    and the error, and the process leaves with code 7."""
+    def stuck():
+        msg = 'bench.py: rank %d of %d did not finish within the time limit; it was in: %s' % (rank, world, PHASE[0])
+        print(msg, file=sys.stderr, flush=True)
+        if rank == 0:
+            print(json.dumps(dict(metric='alpha-solves/s', value=None, unit='alpha-solves/s', n_gpus=world, steps=args.steps,
+                                  warmup=args.warmup, ms_per_step=None, higher_is_better=True, scaling=args.scaling, vs_baseline=None,
+                                  dtype='f64', data='synthetic', error=msg, watchdog_fired=True)), flush=True)
+        os._exit(7)
+    dog = threading.Timer(float(os.environ.get('MXE_BENCH_TIMEOUT', '900')) if seconds is None else seconds, stuck)
+    dog.daemon = True
+    dog.start()
+    return dog
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -748,6 +771,8 @@ def main():
         if args.gpus > 1:
             sys.exit(2)
     use_comm = world > 1 or args.force_comm
+    if world > 1:
+        start_watchdog(rank, world, args)
     default_workload = (args.n_orb, args.n_tau, args.n_omega, args.n_alpha) == (16, 200, 500, 100) and args.cut_for_in_flight <= 1
 
     pool_baseline = None
@@ -774,7 +799,9 @@ def main():
     full = args.gather == 'full'
     counts = None
     if use_comm:
+        PHASE[0] = 'communicator set-up (ncclCommInitRank of all ranks, one all-reduce)'
         comm_setup(ctx, rank, world)
+        PHASE[0] = 'after the communicator set-up'
 
         def per(n):
             return n * args.n_alpha * (args.n_omega if full else 0) + 3 * n * args.n_alpha + n * (args.n_omega + 1)
@@ -825,13 +852,16 @@ def main():
                 c.sync()
         barrier()
 
+    PHASE[0] = 'warm-up steps (launch, line fit, gather to rank 0)'
     for _ in range(args.warmup):
         one_step()
+    PHASE[0] = 'barrier behind the warm-up'
     barrier()
     settle()
     # ---- THE timed region: K steps through ONE context, one batch at a time (what rounds 1-3 timed; ``value`` is this region
     # again since round 5 -- ADVICE r04: rounds compare like with like; the steps-in-flight figure is value_in_flight) ----
     barrier()
+    PHASE[0] = 'the timed region: K steps (launch, line fit, gather to rank 0)'
     ctx.timing_mark()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -839,10 +869,12 @@ def main():
     t_enq = time.perf_counter()
     ctx.sync()                       # on rank 0: every gather of the region has landed
     t_drained = time.perf_counter()
+    PHASE[0] = 'barrier behind the timed region'
     barrier()
     elapsed = time.perf_counter() - t0
     if use_comm:
         elapsed = float(ctx.allreduce([elapsed], 'max')[0])
+    PHASE[0] = 'behind the timed region (kernel time, self-check, extras)'
     host_split = dict(enqueue_ms=1e3 * (t_enq - t0), wait_ms=1e3 * (t_drained - t_enq))
     # ... and behind it (as in rounds 1-3) the dominant kernel's own duration: HIP events around launches on the library's
     # stream, back to back, one launch at a time.  (Where it is taken matters by 1-3 % on these boxes: right behind the

@@ -858,3 +858,19 @@ def test_page_locked_blocks_fall_back_to_ordinary_memory():
     assert device.is_pinned(blk) and device.is_pinned(d) and device.is_pinned(d[1, 0]) and not device.is_pinned(np.empty(4))
     assert device.pinned_empty((0,), np.float64).size == 0
     assert inspect.signature(mx.run_many).parameters['same_cut'].default is True
+
+
+def test_a_multi_rank_bench_that_hangs_says_where(tmp_path):
+    """bench.start_watchdog: a rank that does not finish within the limit names the phase it was in on stderr, rank 0 prints a JSON
+    line with value = null and the error, exit code 7 (the first run between two GPUs has never happened: VERDICT r04 item 8)"""
+    import json
+    import subprocess
+    import sys
+    code = ("import sys, time, types; sys.path.insert(0, %r); import bench; "
+            "bench.PHASE[0] = 'communicator set-up'; "
+            "bench.start_watchdog(0, 2, types.SimpleNamespace(steps=5, warmup=1, scaling='strong'), seconds=0.3); time.sleep(30)" % ROOT)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 7
+    assert 'rank 0 of 2' in r.stderr and 'communicator set-up' in r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['value'] is None and line['watchdog_fired'] is True and line['n_gpus'] == 2 and 'communicator set-up' in line['error']
