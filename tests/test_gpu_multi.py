@@ -511,3 +511,23 @@ def test_elementwise_variants_assemble_the_same_arrays_every_way(herm, cplx, ids
             assert np.array_equal(np.asarray(getattr(res3, name)), got[name], equal_nan=True), name
     finally:
         BatchSolver.POOL_SIZE = keep
+
+
+def test_bench_main_with_the_communicator_path_in_loop_back():
+    """``python bench.py --force-comm``: main()'s multi-rank path -- communicator through the id file, the steps with a gather behind
+    every one, barriers and the maximum over the ranks through ncclAllReduce, rank 0's self-check of what it gathered -- as a process of
+    its own with the one rank this box has (the packs go to the rank itself).  The first run between two GPUs starts from here."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT='29437')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--force-comm', '--no-cpu-baseline', '--no-extras',
+                        '--steps', '6', '--warmup', '2', '--n-orb', '4', '--n-tau', '100', '--n-omega', '200', '--n-alpha', '20'],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['value'] > 0 and line['n_gpus'] == 1 and line['steps'] == 6 and line['watchdog_fired'] is False
+    assert line['config']['gather_checked'] is True
+    assert line['config']['converged_on_rank0'] == line['config']['problems_on_rank0'] == 16 * 20
