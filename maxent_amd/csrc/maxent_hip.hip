@@ -1124,6 +1124,22 @@ try {
             // (rounded UP when batches share the GPU: 4 pieces per scan x 4 batches 0.647 ms per batch, 3 x 4: 0.690)
             const int want = (int)std::max(1LL, (2LL * n_slots + (nfl > 1 ? std::max(1LL, weight) - 1 : 0)) / std::max(1LL, weight));
             split = std::max(1, std::min(want, n_alpha / 2));
+            // A batch with more scans than that rule has pieces for (two pieces per slot would be fewer than six per scan: 32 x 32
+            // elements and beyond) was left with one to four long pieces per scan, 1.1-2.3 per slot -- and a slot that takes one piece
+            // more than its neighbours then runs half a launch longer: 48 x 48 x 100 alphas 9.6 ms, 23 M alpha-solves/s, where six
+            // pieces per scan take 5.6 ms, 40.8 M (tools/batch_size_sweep.sh, profiles/r05_experiments.txt 11.).  There the count
+            // is chosen by what it costs: the cold start of a piece, 4 evaluations against 2 per alpha of its length, and the
+            // imbalance of a queue of pieces of one size, half a piece per slot.  (Batches in flight fill each other's gaps: fewest
+            // pieces, as above.)
+            if (nfl == 1 && want < 6 && n_alpha >= 16) {
+                double best = 1e300; int bs = split;
+                for (int sp = std::max(1, want); sp <= std::min(16, n_alpha / 4); ++sp) {
+                    const double len = (double)n_alpha / sp, per_slot = (double)sp * (double)weight / n_slots;
+                    const double loss = 4.0 / (4.0 + 2.0 * len) + 0.5 / per_slot;
+                    if (loss < best) { best = loss; bs = sp; }
+                }
+                split = bs;
+            }
             // (the binary32 streaming variant stops an alpha at its rounding floor, which a cold start reaches
             //  from further away: it keeps pieces of at least six alphas, at most 16 per scan)
             if (o.precision == MXE_PRECISION_F32 && !f32_lv) split = std::max(1, std::min(std::min(want, 16), n_alpha / 6));

@@ -252,3 +252,29 @@ def test_batches_in_flight_are_cut_into_fewer_pieces_and_give_the_same_answers(c
         ctx0.upload_chains(np.arange(256, dtype=np.int32), batch['alphas'], batch['v0'], device.default_opts(in_flight=-1))
     ctx0.upload_chains(np.arange(256, dtype=np.int32), batch['alphas'], batch['v0'])       # (the fixture's state back)
     ctx0.launch(); ctx0.finish()
+
+
+def test_a_batch_of_more_scans_than_slots_is_cut_by_what_the_pieces_cost():
+    """40 x 40 elements x 40 alphas: 1 600 scans for 2 048 slots.  The rule of the BASELINE batch -- two pieces per slot -- leaves such
+    a batch one piece per scan, and the slots that take a second scan run twice as long as the others (48 x 48 x 100: 9.6 ms where
+    six pieces per scan take 5.6; round 5).  The count now weighs a piece's cold start against the imbalance of the queue: more,
+    shorter pieces -- the same answers, every alpha through the audit, and a shorter launch than the scans left whole."""
+    batch = bench.build_batch(40, 40, 100, 40, 0)
+    ctx = bench.stage(batch, 0)
+    n = len(batch['elems'])
+    res = {}
+    for name, split in (('auto', 0), ('whole scans', 1)):
+        ctx.upload_chains(np.arange(n, dtype=np.int32), batch['alphas'], batch['v0'], device.default_opts(alpha_split=split))
+        ts = []
+        for _ in range(4):
+            ctx.launch(); ctx.sync(); ts.append(ctx.last_kernel_ms())
+        left = ctx.finish()
+        out = ctx.fetch(want_v=False)
+        assert out['converged'].all() and left == 0, name
+        assert np.nanmax(ctx.audit()['corr']) < 1e-6, name
+        res[name] = (min(ts), np.array(out['H']), float(out['n_evals'].mean()))
+    ctx.close()
+    assert res['auto'][2] > res['whole scans'][2]                       # (more cold starts ...)
+    assert res['auto'][0] < 0.85 * res['whole scans'][0], (res['auto'][0], res['whole scans'][0])     # (... and a shorter launch)
+    d = np.linalg.norm(res['auto'][1] - res['whole scans'][1], axis=-1) / np.linalg.norm(res['whole scans'][1], axis=-1)
+    assert d.max() < 1e-6, d.max()
