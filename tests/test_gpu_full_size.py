@@ -255,18 +255,18 @@ def test_batches_in_flight_are_cut_into_fewer_pieces_and_give_the_same_answers(c
 
 
 def test_a_batch_of_more_scans_than_slots_is_cut_by_what_the_pieces_cost():
-    """40 x 40 elements x 40 alphas: 1 600 scans for 2 048 slots.  The rule of the BASELINE batch -- two pieces per slot -- leaves such
+    """46 x 46 elements x 40 alphas: 2 116 scans for 2 048 slots.  The rule of the BASELINE batch -- two pieces per slot -- leaves such
     a batch one piece per scan, and the slots that take a second scan run twice as long as the others (48 x 48 x 100: 9.6 ms where
     six pieces per scan take 5.6; round 5).  The count now weighs a piece's cold start against the imbalance of the queue: more,
     shorter pieces -- the same answers, every alpha through the audit, and a shorter launch than the scans left whole."""
-    batch = bench.build_batch(40, 40, 100, 40, 0)
+    batch = bench.build_batch(46, 40, 100, 40, 0)
     ctx = bench.stage(batch, 0)
     n = len(batch['elems'])
     res = {}
     for name, split in (('auto', 0), ('whole scans', 1)):
         ctx.upload_chains(np.arange(n, dtype=np.int32), batch['alphas'], batch['v0'], device.default_opts(alpha_split=split))
         ts = []
-        for _ in range(4):
+        for _ in range(5):
             ctx.launch(); ctx.sync(); ts.append(ctx.last_kernel_ms())
         left = ctx.finish()
         out = ctx.fetch(want_v=False)
