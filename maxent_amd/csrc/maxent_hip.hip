@@ -23,6 +23,7 @@
 #include <vector>
 #include <mutex>
 #include <thread>
+#include <array>
 #include <tuple>
 
 using mxe::KParams;
@@ -1579,12 +1580,34 @@ try {
                 HIPCHK(ctx, stream_wait(ctx->stream));          // (the host vectors go out of scope)
             }
         } else {
-            // static layout: group by data set, four per workgroup, -1 pads
+            // static layout (several data sets: a workgroup streams ONE basis, its four pieces come from one data set and it takes no
+            // others): group by data set, four per workgroup, -1 pads.  The four pieces of a workgroup run in lock-step until the
+            // longest is through, so pieces of like cost go together (the estimate the queue of the one-data-set launch is ordered
+            // by), and the workgroups with the longest pieces are dispatched first: with a data set per element the BASELINE batch
+            // 2.13 -> 1.29 ms, with two data sets 1.42 -> 0.95 (tools/many_datasets.py, profiles/r05_experiments.txt 12.)
+            std::vector<double> cost(ctx->n_sub);
+            for (int sc = 0; sc < ctx->n_sub; ++sc) {
+                const int e = ctx->sub_elem[sc];
+                double amin = 1e300;
+                for (int i = 0; i < ctx->sub_len[sc]; ++i) amin = std::min(amin, alpha_dev[ctx->sub_prob0[sc] + i]);
+                cost[sc] = ctx->sub_len[sc] * (ctx->elem_kind[e] == MXE_ENTROPY_NORMAL ? 4.0 : 3.0) +
+                           (ctx->elem_kind[e] == MXE_ENTROPY_NORMAL ? 16.0 : 6.0) - 1e-3 * std::log10(amin) +
+                           (ctx->sub_walk0[sc] >= 0 ? 2.0 : 0.7) * ctx->sub_pre[sc];
+            }
             std::vector<std::vector<int>> by_ds(ctx->ds.size());
             for (int sc = 0; sc < ctx->n_sub; ++sc) by_ds[ctx->elem_ds[ctx->sub_elem[sc]]].push_back(sc);
-            for (auto& g : by_ds)
-                for (size_t i0 = 0; i0 < g.size(); i0 += 4)
-                    for (int q = 0; q < 4; ++q) ctx->wg_chains.push_back(i0 + q < g.size() ? g[i0 + q] : -1);
+            std::vector<std::pair<double, std::array<int, 4>>> wgs;
+            const bool sorted = !getenv("MXE_NO_SORTED_STATIC");
+            for (auto& g : by_ds) {
+                if (sorted) std::stable_sort(g.begin(), g.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+                for (size_t i0 = 0; i0 < g.size(); i0 += 4) {
+                    std::array<int, 4> w4;
+                    for (int q = 0; q < 4; ++q) w4[q] = i0 + q < g.size() ? g[i0 + q] : -1;
+                    wgs.emplace_back(cost[g[i0]], w4);
+                }
+            }
+            if (sorted) std::stable_sort(wgs.begin(), wgs.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+            for (auto& w : wgs) for (int q = 0; q < 4; ++q) ctx->wg_chains.push_back(w.second[q]);
             ctx->n_wg = (int)ctx->wg_chains.size() / 4;
         }
     } else {

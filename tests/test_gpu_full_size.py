@@ -278,3 +278,35 @@ def test_a_batch_of_more_scans_than_slots_is_cut_by_what_the_pieces_cost():
     assert res['auto'][0] < 0.85 * res['whole scans'][0], (res['auto'][0], res['whole scans'][0])     # (... and a shorter launch)
     d = np.linalg.norm(res['auto'][1] - res['whole scans'][1], axis=-1) / np.linalg.norm(res['whole scans'][1], axis=-1)
     assert d.max() < 1e-6, d.max()
+
+
+def test_several_data_sets_pieces_of_like_cost_share_a_workgroup(cfg4, monkeypatch):
+    """The BASELINE batch with TWO data sets (two error bars: elements alternate): a workgroup streams one basis, so its four pieces
+    come from one data set and it takes no others (static layout, no queue).  Its slots run in lock-step until the longest piece is
+    through: pieces of like cost go together and the longest workgroups first (round 5: 1.42 -> 0.95 ms; a data set per element
+    2.13 -> 1.29 ms, tools/many_datasets.py).  A piece does not depend on its company: the answers are the same bits either way."""
+    batch = cfg4[0]
+    K = batch['K']
+    n = len(batch['elems'])
+    res = {}
+    for name, env in (('sorted', None), ('scan order', '1')):
+        if env:
+            monkeypatch.setenv('MXE_NO_SORTED_STATIC', env)
+        ctx = device.DeviceContext(K.U, K.S, K.V, device=0)
+        ds = [ctx.add_dataset(batch['err'] * (1.0 + 1e-3 * k)) for k in range(2)]
+        ctx.set_elements([ds[e % 2] for e in range(n)], [batch['Gmat'][batch['elems'][e]] for e in range(n)],
+                         np.tile(batch['D'], (n, 1)), batch['kinds'])
+        ctx.upload_chains(np.arange(n, dtype=np.int32), batch['alphas'], batch['v0'])
+        ts = []
+        for _ in range(5):
+            ctx.launch(); ctx.sync(); ts.append(ctx.last_kernel_ms())
+        assert ctx.finish() == 0
+        out = ctx.fetch(want_v=False)
+        assert out['converged'].all() and np.nanmax(ctx.audit()['corr']) < 1e-6
+        res[name] = (min(ts), np.array(out['H']), np.array(out['chi2']), np.array(out['n_evals']))
+        ctx.close()
+        if env:
+            monkeypatch.delenv('MXE_NO_SORTED_STATIC')
+    for k in (1, 2, 3):
+        assert np.array_equal(res['sorted'][k], res['scan order'][k])
+    assert res['sorted'][0] < 0.85 * res['scan order'][0], (res['sorted'][0], res['scan order'][0])
