@@ -1715,6 +1715,7 @@ static void fill_kparams(mxe_ctx* ctx, KParams& kp)
     kp.gstate = nullptr;
     kp.mc_maxiter = std::min(o.maxiter, std::max(MC_MAXITER, o.miniter + 8));     // (a caller's miniter above the limit moves it)
     kp.mc_abandon = 1;
+    { const char* e = getenv("MXE_MC_MAXEVALS"); kp.mc_maxevals = e ? atoi(e) : 3 * kp.mc_maxiter; }
     kp.prob_maxiter = nullptr;
     kp.out_index = nullptr;
     kp.dbg_hist = nullptr;

@@ -107,6 +107,7 @@ struct KParams {
     // entry e = chain_prob0 + i writes its record to problem out_index[e], or nowhere when that is < 0 (a rung: a few iterations
     // towards the next alpha of the mesh, whose record then counts the rung's iterations and evaluations as its own); nullptr: e
     const int* out_index;       // [entries] or nullptr
+    int mc_maxevals;            // lock-step kernels: evaluations an alpha may cost before it is handed over like one that ran out of damping
     int stuck_skip;             // an alpha held at one damping stops trying the smaller ones at every iteration (the damping loop of chain_kernel)
     double* dbg_hist;           // (diagnostic build -DMXE_DEBUG_HIST) [entries][16]: the stopping quantity of an alpha at fixed iteration counts
 };

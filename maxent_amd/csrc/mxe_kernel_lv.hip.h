@@ -375,7 +375,7 @@ void chain_kernel_lv(const KParams p, const MCExtra x)
                         } else {
                             t.mu = (t.mu == 0.0) ? fmax(p.mu_first * t.alpha, t.muh / p.mu_grow) : t.mu * p.mu_grow;
                             t.scratch = 1; t.bt = 0;
-                            if (!(t.mu <= p.mu_max * t.alpha)) { finish_alpha = true; failed = true; }
+                            if (!(t.mu <= p.mu_max * t.alpha) || t.nevals >= p.mc_maxevals) { finish_alpha = true; failed = true; }    // (see chain_kernel_mc)
                         }
                     } else {
                         // accepted (the stopping rule of chain_kernel_mc, see there)

@@ -738,7 +738,10 @@ void chain_kernel_mc(const KParams p, const MCExtra x)
                             // need it at every iteration)
                             t.mu = (t.mu == 0.0) ? fmax(p.mu_first * t.alpha, t.muh / p.mu_grow) : t.mu * p.mu_grow;
                             t.scratch = 1; t.bt = 0;
-                            if (!(t.mu <= p.mu_max * t.alpha)) { finish_alpha = true; failed = true; }
+                            // (out of range -- or out of evaluations: the limit of 32 counts ACCEPTED steps, and an alpha whose every
+                            //  step takes a dozen dampings held its workgroup, and with it the launch, for 470 rounds: 5.2 ms for a
+                            //  batch of 0.5 ms; profiles/r05_experiments.txt 13.)
+                            if (!(t.mu <= p.mu_max * t.alpha) || t.nevals >= p.mc_maxevals) { finish_alpha = true; failed = true; }
                         }
                     } else {
                         // accepted
