@@ -239,15 +239,58 @@ def _one_at_a_time(method):
     return locked
 
 
+DEVICE_DIRECTIONS = 64          # singular directions the lock-step kernels hold (mxe_kernel_mc.hip.h: NP = 64)
+KEEP_BOUND = 1e-8               # largest |delta u| the dropped directions may cause (the parity gate is 1e-6)
+
+
+def directions_to_keep(K, specs=None, arrays=None):
+    """How many singular directions of ``K`` the device has to solve this job with: ``None`` (all), or 64 when there are more and
+    the others cannot be told from zero in it.
+
+    More than 64 singular values above the reference's absolute threshold (1e-14, maxent_loop.py:91,184) come with many data
+    points -- 1 000 imaginary times: 79 -- and the device then has only its one-chain kernel with a 128 x 128 Newton matrix
+    (15-80 x slower than the lock-step kernels).  But those directions sit at the rounding floor of the decomposition
+    (S_64 / S_0 ~ 2e-16).  At the minimiser every direction obeys  alpha v_k = -c_k rho_k,  c_k = S_k / sigma,
+    rho_k = c_k h_k - ghat_k  (grad Q = W g with W non-singular), so a dropped direction would have carried
+    |v_k| <= c_k (|ghat_k| + c_k |h_k|) / alpha, and u = V v changes by at most the sum of these (|V| <= 1).  The job keeps 64
+    directions when that sum, with 1 for c_k |h_k| and the smallest alpha and error bar of each element, stays below
+    ``KEEP_BOUND`` for every element; the v it returns are zero in the others."""
+    S = np.asarray(K.S, dtype=float)
+    n_s = S.shape[0]
+    if n_s <= DEVICE_DIRECTIONS or K.rotation is not None or os.environ.get('MAXENT_AMD_ALL_DIRECTIONS'):
+        return None
+    tail, Ut = S[DEVICE_DIRECTIONS:], np.asarray(K.U)[:, DEVICE_DIRECTIONS:]
+    try:
+        if arrays is not None:
+            G = np.asarray(arrays['G'], dtype=float)
+            err = np.asarray(arrays['err'], dtype=float) * np.ones((1, G.shape[1]))
+            if err.shape[0] not in (1, G.shape[0]):
+                err = err[np.asarray(arrays['sel'])]                    # (rows per class of elements)
+            amin = float(np.min(arrays['alpha']))                       # (the smallest alpha of the job, for every element)
+        else:
+            if any(sp.get('U_rot') is not None for sp in specs):
+                return None
+            G = np.stack([np.asarray(sp['G'], dtype=float) for sp in specs])
+            err = np.stack([np.asarray(sp['err'], dtype=float) * np.ones(G.shape[1]) for sp in specs])
+            amin = np.array([np.min(sp['alpha']) for sp in specs], dtype=float)
+        ghat = np.abs((G / err) @ Ut)                                   # [element][dropped direction]
+        c = tail[None, :] / np.min(err, axis=1)[:, None]
+        bound = np.sum(c * (ghat + 1.0), axis=1) / amin
+    except Exception:
+        return None
+    return DEVICE_DIRECTIONS if np.all(np.isfinite(bound)) and float(np.max(bound)) <= KEEP_BOUND else None
+
+
 class BatchSolver(object):
-    def __init__(self, K, device_ids=(0,)):
+    def __init__(self, K, device_ids=(0,), keep=None):
         K.S                                         # decompose if needed
         self.device_ids = tuple(int(d) for d in device_ids)
         if not self.device_ids:
             raise ValueError('at least one device is needed')
         self._token = self._kernel_token(K)
+        self._keep = keep
         U = None if K.rotation is not None else K.U
-        self.ctxs = [device.DeviceContext(U, K.S, K.V, device=d) for d in self.device_ids]
+        self.ctxs = [device.DeviceContext(U, K.S, K.V, device=d, keep=keep) for d in self.device_ids]
         self.n_s, self.n_omega = self.ctxs[0].n_s, self.ctxs[0].n_omega
         if len(self.ctxs) > 1:
             device.comm_init_local(self.ctxs)
@@ -277,8 +320,8 @@ class BatchSolver(object):
     _pooled = []                                    # most recently used first
     POOL_SIZE = 8                                   # (eight jobs in flight on one kernel: maxent_amd.run_many)
 
-    def _same_contents(self, K, device_ids):
-        if self.device_ids != device_ids or not self.ctxs[0]._h or (K.rotation is None) != self._token[3]:
+    def _same_contents(self, K, device_ids, keep=None):
+        if self.device_ids != device_ids or not self.ctxs[0]._h or (K.rotation is None) != self._token[3] or self._keep != keep:
             return False
         for a, b in zip(self._token[:3], (K._U, K._S, K._V)):
             if a is b:
@@ -288,30 +331,31 @@ class BatchSolver(object):
         return True
 
     @classmethod
-    def for_kernel(cls, K, device_ids=(0,)):
+    def for_kernel(cls, K, device_ids=(0,), keep=None):
         K.S
         device_ids = tuple(int(d) for d in device_ids)
         held = K.__dict__.get('_batch_solvers')
         if held is None:
             held = K.__dict__['_batch_solvers'] = {}
-        s = held.get(device_ids)
+        key = device_ids if keep is None else device_ids + ('keep', int(keep))
+        s = held.get(key)
         if s is not None and cls._same_token(s._token, cls._kernel_token(K)) and s.ctxs[0]._h and not s._busy:
             return s           # (a solver with a batch in flight -- solve_begin without its end -- is nobody else's)
         if cls.POOL_SIZE <= 0:                       # no pool: every kernel object its own contexts
             if s is not None and not s._busy:
                 s.close()
-            s = held[device_ids] = cls(K, device_ids)
+            s = held[key] = cls(K, device_ids, keep)
             return s
         with cls._pool_lock:
             found = None
             for cand in cls._pooled:
                 # (not one whose last results somebody still holds unfetched: they would have to come to the host
                 #  first -- 102 MB for a 16 x 16 x 100 job --, a context of its own is cheaper)
-                if not cand._busy and cand._same_contents(K, device_ids) and not cand._alive():
+                if not cand._busy and cand._same_contents(K, device_ids, keep) and not cand._alive():
                     found = cand
                     break
             if found is None:
-                found = cls(K, device_ids)
+                found = cls(K, device_ids, keep)
             else:
                 cls._pooled.remove(found)
                 found._token = cls._kernel_token(K)        # (equal arrays: the staged basis is that of K)
@@ -323,7 +367,7 @@ class BatchSolver(object):
         for old in retired:
             if not old._alive():
                 old.close()                         # (one with results out lives as long as they do: they hold it)
-        held[device_ids] = found
+        held[key] = found
         return found
 
     @classmethod

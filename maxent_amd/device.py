@@ -336,7 +336,10 @@ class DeviceContext(object):
     ``reduce_singular_space`` (reference kernels.py:53-122).
     """
 
-    def __init__(self, U, S, V, device=0):
+    def __init__(self, U, S, V, device=0, keep=None):
+        """``keep``: stage only the first ``keep`` singular directions on the device (the caller has made sure that the others
+        cannot be told from zero in its job: :func:`maxent_amd.batch_solver.directions_to_keep`).  The context still speaks
+        ``n_s`` directions to its caller: start vectors are cut, returned v are filled up with zeros."""
         self._lib = load_library()
         self._h = _vp(None)
         S = _c(S)
@@ -352,11 +355,17 @@ class DeviceContext(object):
             self.n_tau = int(U.shape[0])
         else:
             self.n_tau = 1
+        self._n_s_dev = self.n_s
+        if keep is not None and int(keep) < self.n_s:
+            if U is None or int(keep) < 1:
+                raise ValueError('keep needs the unrotated U and at least one direction')
+            self._n_s_dev = int(keep)
+            U, S, V = _c(U[:, :self._n_s_dev]), _c(S[:self._n_s_dev]), _c(V[:, :self._n_s_dev])
         if device_count() < 1:
             raise MaxEntDeviceError('no HIP device visible; the solver has no '
                                     'CPU fallback')
         self._check(self._lib.mxe_ctx_create(
-            int(device), self.n_tau, self.n_omega, self.n_s,
+            int(device), self.n_tau, self.n_omega, self._n_s_dev,
             _p(U), _p(S), _p(V), ctypes.byref(self._h)), 'mxe_ctx_create')
         self.device = int(device)
         self._n_chain = 0
@@ -387,6 +396,8 @@ class DeviceContext(object):
         """(U, err) pair -> whitened basis; returns the data-set id."""
         if U_rot is not None:
             U_rot = _c(U_rot)
+            if self._n_s_dev < self.n_s:
+                U_rot = _c(U_rot[:, :self._n_s_dev])
             n_rows = U_rot.shape[0]
         else:
             n_rows = self.n_tau
@@ -458,6 +469,8 @@ class DeviceContext(object):
             al = np.ascontiguousarray(np.broadcast_to(al, (len(el), al.shape[0])))
         n_chain, n_alpha = al.shape
         v0 = _c(v0).reshape(n_chain, self.n_s)
+        if self._n_s_dev < self.n_s:
+            v0 = _c(v0[:, :self._n_s_dev])
         if opts is None:
             opts = default_opts()
         self._check(self._lib.mxe_chains_upload(self._h, n_chain, n_alpha,
@@ -520,13 +533,17 @@ class DeviceContext(object):
             out = self.result_arrays()
         elif out['chi2'].shape != (nc, na):
             raise ValueError('result arrays of another launch')
-        v = np.empty((nc, na, self.n_s)) if want_v else None
+        v = np.empty((nc, na, self._n_s_dev)) if want_v else None
         H = pinned_empty((nc, na, self.n_omega)) if want_H else None
         self._check(self._lib.mxe_chains_fetch(
             self._h, _p(v), _p(H), _p(out['chi2']), _p(out['S']), _p(out['Q']),
             _p(out['n_iter']), _p(out['converged']), _p(out['n_evals'])),
             'mxe_chains_fetch')
         self._held = []                 # (the stream has been waited for)
+        if v is not None and self._n_s_dev < self.n_s:
+            full = np.zeros((nc, na, self.n_s))
+            full[..., :self._n_s_dev] = v
+            v = full
         out['v'] = v
         out['H'] = H
         return out
@@ -556,6 +573,8 @@ class DeviceContext(object):
         """``mxe_eval_batch``: cost function and derivative ingredients at caller-supplied points.
         ``x``: (P, n_s) vectors v, or (P, n_omega) hidden images with ``input_is_H``.  ``want``: any of
         Q, chi2, S, H, u, w, q, h, g, W, W2.  Returns a dict of arrays."""
+        if self._n_s_dev < self.n_s:
+            raise MaxEntDeviceError('eval_batch on a context that keeps %d of %d singular directions' % (self._n_s_dev, self.n_s))
         el = _c(np.atleast_1d(elem_of_problem), np.int32)
         P = len(el)
         al = _c(np.broadcast_to(np.asarray(alpha_scaled, dtype=float), (P,)))

@@ -71,8 +71,9 @@ def solve_elements(K, specs, minimizer, device_id=0, waves_per_chain=0,
     if not specs and arrays is None:
         done = ([], dict(kernel_ms=0.0))
         return (lambda: done) if defer else done
-    from .batch_solver import BatchSolver
-    solver = BatchSolver.for_kernel(K, (device_id,) if device_ids is None else device_ids)
+    from .batch_solver import BatchSolver, directions_to_keep
+    solver = BatchSolver.for_kernel(K, (device_id,) if device_ids is None else device_ids,
+                                    keep=directions_to_keep(K, specs, arrays))
     extra = dict(in_flight=int(in_flight)) if in_flight and in_flight > 1 else {}
     opts = minimizer.to_opts(waves_per_chain=waves_per_chain, chi2_factor=float(chi2_factor), **extra)
     if arrays is not None:

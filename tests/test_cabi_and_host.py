@@ -874,3 +874,26 @@ def test_a_multi_rank_bench_that_hangs_says_where(tmp_path):
     assert 'rank 0 of 2' in r.stderr and 'communicator set-up' in r.stderr
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line['value'] is None and line['watchdog_fired'] is True and line['n_gpus'] == 2 and 'communicator set-up' in line['error']
+
+
+def test_the_device_keeps_64_singular_directions_only_where_the_others_cannot_matter():
+    """batch_solver.directions_to_keep: 1 000 imaginary times give 79 singular values above the reference's 1e-14; the ones beyond the
+    64th sit at the rounding floor of the decomposition, and at the minimiser a direction carries |v_k| <= c_k (|ghat_k| + ...) / alpha.
+    64 are kept when the sum of these bounds over the dropped directions is below 1e-8 for every element -- not with error bars of
+    1e-9 (c_k a hundred thousand times larger), not with a rotated kernel, not when there are at most 64 anyway."""
+    from maxent_amd import synthetic, batch_solver as bs
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(2, 1000, 200)
+    K.reduce_singular_space(1e-14)
+    assert len(K.S) > 64
+    G = Gmat.reshape(-1, 1000)
+    alpha = np.geomspace(1e4, 1e-2, 20)[None, :] * 1000
+    arrays = dict(G=G, err=synthetic.SIGMA * np.ones((1, 1000)), alpha=alpha, sel=np.zeros(4, dtype=int))
+    assert bs.directions_to_keep(K, None, arrays) == 64
+    specs = [dict(G=g, err=synthetic.SIGMA * np.ones(1000), alpha=alpha[0], U_rot=None) for g in G]
+    assert bs.directions_to_keep(K, specs, None) == 64
+    assert bs.directions_to_keep(K, None, dict(arrays, err=1e-9 * np.ones((1, 1000)))) is None
+    assert bs.directions_to_keep(K, None, dict(arrays, alpha=alpha * 1e-9)) is None
+    assert bs.directions_to_keep(K, [dict(specs[0], U_rot=np.eye(3))], None) is None
+    tau2, omega2, K2, Gmat2, _ = synthetic.matrix_G(2, 100, 200)
+    K2.reduce_singular_space(1e-14)
+    assert len(K2.S) <= 64 and bs.directions_to_keep(K2, None, dict(arrays, G=Gmat2.reshape(-1, 100), err=1e-4 * np.ones((1, 100)))) is None

@@ -251,3 +251,44 @@ def test_off_diagonal_batch_with_64_coupled_directions_needs_no_finishing_pass()
     np.testing.assert_allclose(b['chi2'], a['chi2'], rtol=1e-6)
     assert np.nanmax(ctx.audit()['corr']) < 1e-8
     ctx.close()
+
+
+def test_a_thousand_data_points_run_in_the_lock_step_kernel(monkeypatch):
+    """1 000 imaginary times: 70-79 singular values above the reference's threshold, more than the 64 the lock-step kernels hold --
+    until round 5 such a job ran in the one-chain kernel with its 128 x 128 Newton matrix (16 x 16 x 100 alphas: 18.8 ms against
+    0.92).  The host layer now stages 64 directions where the others cannot be told from zero in the job
+    (batch_solver.directions_to_keep): the lock-step kernel runs, the answers are those of all directions to the stopping
+    tolerance and pass the gate against the extended-precision fixed point reached from the ORACLE's iterates (which keep every
+    direction: reference kernels.py:53-122, maxent_loop.py:184); v comes back with zeros in the directions that were not staged."""
+    n_tau, n_omega, n_alpha = 1000, 300, 12
+    tau, omega, K, Gmat, _ = synthetic.matrix_G(2, n_tau, n_omega)
+
+    def run():
+        ew = mx.ElementwiseMaxEnt(use_hermiticity=False)
+        ew.set_verbosity(mx.VerbosityFlags.Quiet)
+        ew.set_G_tau_data(tau, Gmat)
+        ew.omega = omega
+        ew.alpha_mesh = mx.LogAlphaMesh(alpha_min=1e-2, alpha_max=1e3, n_points=n_alpha)
+        ew.set_error(synthetic.SIGMA)
+        r = ew.run()
+        return ew, np.array(r.A), np.array(r.H), np.array(r.v), np.array(r.chi2), ew.last_launches[-1]['kernel']
+    ew, A, H, v, chi2, kernel = run()
+    n_s = len(ew.maxent_diagonal.K.S)
+    assert n_s > 64 and v.shape[-1] == n_s
+    assert kernel.startswith('mxe::chain_kernel_mc<'), kernel
+    assert np.all(v[..., 64:] == 0.0) and np.any(v[..., :64] != 0.0)
+    monkeypatch.setenv('MAXENT_AMD_ALL_DIRECTIONS', '1')
+    ew2, A2, H2, v2, chi22, kernel2 = run()
+    assert kernel2.startswith('mxe::chain_kernel<'), kernel2
+    assert np.abs(v2[..., 64:]).max() < 1e-8                    # (what the dropped directions would have carried)
+    assert (np.linalg.norm(A - A2, axis=-1) / np.linalg.norm(A2, axis=-1)).max() < 1e-7
+    np.testing.assert_allclose(chi2, chi22, rtol=1e-6)
+    # against the truth reached from the reference's algorithm on ALL directions
+    Kk = ew2.maxent_diagonal.K
+    alphas = np.array(ew.alpha_mesh) * n_tau
+    D = np.asarray(ew.maxent_diagonal.D.D)
+    for (i, j), ent in (((0, 0), 'normal'), ((0, 1), 'plusminus')):
+        p = R.Problem(np.array(Kk.K), Kk.U, Kk.S, Kk.V, Gmat[i, j], synthetic.SIGMA * np.ones(n_tau), D, entropy=ent)
+        truth, _ = anchor.truth_rows(p, omega.delta, alphas, n_tau, (0, n_alpha - 1), ent)
+        for ia in (0, n_alpha - 1):
+            assert anchor.rel_l2_checked(H[i, j, ia], truth[ia]) < 1e-6, (i, j, ia)
