@@ -254,7 +254,8 @@ def directions_to_keep(K, specs=None, arrays=None):
     rho_k = c_k h_k - ghat_k  (grad Q = W g with W non-singular), so a dropped direction would have carried
     |v_k| <= c_k (|ghat_k| + c_k |h_k|) / alpha, and u = V v changes by at most the sum of these (|V| <= 1).  The job keeps 64
     directions when that sum, with 1 for c_k |h_k| and the smallest alpha and error bar of each element, stays below
-    ``KEEP_BOUND`` for every element; the v it returns are zero in the others."""
+    ``KEEP_BOUND`` for every element; the v it returns are zero in the others.  Only for ONE error bar per element and an
+    unrotated kernel: there M = S U^T diag(1 / err^2) U S is diagonal and rho_k is the direction's own."""
     S = np.asarray(K.S, dtype=float)
     n_s = S.shape[0]
     if n_s <= DEVICE_DIRECTIONS or K.rotation is not None or os.environ.get('MAXENT_AMD_ALL_DIRECTIONS'):
@@ -273,6 +274,8 @@ def directions_to_keep(K, specs=None, arrays=None):
             G = np.stack([np.asarray(sp['G'], dtype=float) for sp in specs])
             err = np.stack([np.asarray(sp['err'], dtype=float) * np.ones(G.shape[1]) for sp in specs])
             amin = np.array([np.min(sp['alpha']) for sp in specs], dtype=float)
+        if np.any(np.max(err, axis=1) != np.min(err, axis=1)):
+            return None         # (error bars that vary over the data points couple the directions through M = S U^T diag(1 / err^2) U S)
         ghat = np.abs((G / err) @ Ut)                                   # [element][dropped direction]
         c = tail[None, :] / np.min(err, axis=1)[:, None]
         bound = np.sum(c * (ghat + 1.0), axis=1) / amin

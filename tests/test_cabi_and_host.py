@@ -894,6 +894,7 @@ def test_the_device_keeps_64_singular_directions_only_where_the_others_cannot_ma
     assert bs.directions_to_keep(K, None, dict(arrays, err=1e-9 * np.ones((1, 1000)))) is None
     assert bs.directions_to_keep(K, None, dict(arrays, alpha=alpha * 1e-9)) is None
     assert bs.directions_to_keep(K, [dict(specs[0], U_rot=np.eye(3))], None) is None
+    assert bs.directions_to_keep(K, None, dict(arrays, err=synthetic.SIGMA * (1.0 + 0.1 * np.arange(1000) / 1000.0)[None, :])) is None   # (error bars that vary)
     tau2, omega2, K2, Gmat2, _ = synthetic.matrix_G(2, 100, 200)
     K2.reduce_singular_space(1e-14)
     assert len(K2.S) <= 64 and bs.directions_to_keep(K2, None, dict(arrays, G=Gmat2.reshape(-1, 100), err=1e-4 * np.ones((1, 100)))) is None
