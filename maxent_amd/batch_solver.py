@@ -240,7 +240,7 @@ def _one_at_a_time(method):
 
 
 DEVICE_DIRECTIONS = 64          # singular directions the lock-step kernels hold (mxe_kernel_mc.hip.h: NP = 64)
-KEEP_BOUND = 1e-8               # largest |delta u| the dropped directions may cause (the parity gate is 1e-6)
+KEEP_BOUND = 1e-7               # largest |delta u| = |delta H / H| the dropped directions may cause (the parity gate is 1e-6; the bound overestimates tenfold)
 
 
 def directions_to_keep(K, specs=None, arrays=None):
