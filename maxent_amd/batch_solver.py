@@ -252,15 +252,15 @@ def directions_to_keep(K, specs=None, arrays=None):
     (15-80 x slower than the lock-step kernels).  But those directions sit at the rounding floor of the decomposition
     (S_64 / S_0 ~ 2e-16).  At the minimiser every direction obeys  alpha v_k = -c_k rho_k,  c_k = S_k / sigma,
     rho_k = c_k h_k - ghat_k  (grad Q = W g with W non-singular), so a dropped direction would have carried
-    |v_k| <= c_k (|ghat_k| + c_k |h_k|) / alpha, and u = V v changes by at most the sum of these (|V| <= 1).  The job keeps 64
-    directions when that sum, with 1 for c_k |h_k| and the smallest alpha and error bar of each element, stays below
-    ``KEEP_BOUND`` for every element; the v it returns are zero in the others.  Only for ONE error bar per element and an
+    |v_k| <= c_k (|ghat_k| + c_k |h_k|) / alpha, and u = V v changes by at most the 2-norm of these (the rows of V are at most of
+    unit length).  The job keeps 64 directions -- or 128, where 64 are too few and there are more: a mesh of 2 000 frequencies on
+    1 000 data points leaves 991 'singular values' above 1e-14, the rounding floor of that decomposition -- when that norm, with
+    the smallest alpha of the job, stays below ``KEEP_BOUND`` for every element; the v it returns are zero in the others.  Only for ONE error bar per element and an
     unrotated kernel: there M = S U^T diag(1 / err^2) U S is diagonal and rho_k is the direction's own."""
     S = np.asarray(K.S, dtype=float)
     n_s = S.shape[0]
     if n_s <= DEVICE_DIRECTIONS or K.rotation is not None or os.environ.get('MAXENT_AMD_ALL_DIRECTIONS'):
         return None
-    tail, Ut = S[DEVICE_DIRECTIONS:], np.asarray(K.U)[:, DEVICE_DIRECTIONS:]
     try:
         if arrays is not None:
             G = np.asarray(arrays['G'], dtype=float)
@@ -268,20 +268,30 @@ def directions_to_keep(K, specs=None, arrays=None):
             if err.shape[0] not in (1, G.shape[0]):
                 err = err[np.asarray(arrays['sel'])]                    # (rows per class of elements)
             amin = float(np.min(arrays['alpha']))                       # (the smallest alpha of the job, for every element)
+            sumD = float(np.max(np.sum(np.abs(np.asarray(arrays['D'], dtype=float)), axis=-1)))
         else:
             if any(sp.get('U_rot') is not None for sp in specs):
                 return None
             G = np.stack([np.asarray(sp['G'], dtype=float) for sp in specs])
             err = np.stack([np.asarray(sp['err'], dtype=float) * np.ones(G.shape[1]) for sp in specs])
-            amin = np.array([np.min(sp['alpha']) for sp in specs], dtype=float)
+            amin = float(min(np.min(sp['alpha']) for sp in specs))
+            sumD = float(max(np.sum(np.abs(np.asarray(sp['D'], dtype=float))) for sp in specs))
         if np.any(np.max(err, axis=1) != np.min(err, axis=1)):
             return None         # (error bars that vary over the data points couple the directions through M = S U^T diag(1 / err^2) U S)
-        ghat = np.abs((G / err) @ Ut)                                   # [element][dropped direction]
-        c = tail[None, :] / np.min(err, axis=1)[:, None]
-        bound = np.sum(c * (ghat + 1.0), axis=1) / amin
+        ghat_all = np.abs((G / err) @ np.asarray(K.U)[:, DEVICE_DIRECTIONS:])          # [element][direction beyond the 64th]
+        c_all = S[None, DEVICE_DIRECTIONS:] / err[:, :1]
+        h1 = 1e3 * max(1.0, sumD)                                       # |h_k| = |V_k^T H| <= |H|_2: generous
+        per = c_all * (ghat_all + c_all * h1)                           # |v_k| alpha of a dropped direction, at most
+        for keep in (DEVICE_DIRECTIONS, 2 * DEVICE_DIRECTIONS):
+            if keep >= n_s:
+                break
+            # u = V v and the rows of V are at most of unit length: |delta u_i| <= |v_dropped|_2
+            bound = np.sqrt(np.sum(per[:, keep - DEVICE_DIRECTIONS:] ** 2, axis=1)) / amin
+            if np.all(np.isfinite(bound)) and float(np.max(bound)) <= KEEP_BOUND:
+                return keep
     except Exception:
         return None
-    return DEVICE_DIRECTIONS if np.all(np.isfinite(bound)) and float(np.max(bound)) <= KEEP_BOUND else None
+    return None
 
 
 class BatchSolver(object):
@@ -293,6 +303,14 @@ class BatchSolver(object):
         self._token = self._kernel_token(K)
         self._keep = keep
         U = None if K.rotation is not None else K.U
+        if (len(K.S) if keep is None else keep) > 2 * DEVICE_DIRECTIONS:
+            S = np.asarray(K.S)
+            raise device.MaxEntDeviceError(
+                'the kernel has %d singular values above its threshold and the device solves with at most %d; those beyond the '
+                'first ~60 usually are the rounding floor of the decomposition (here S[%d] / S[0] = %.1e) and could not be '
+                'dropped for this job (error bars far below the noise of the data, a rotated kernel or error bars that vary): '
+                'K.reduce_singular_space(threshold) with a threshold above that floor' % (
+                    len(S), 2 * DEVICE_DIRECTIONS, 2 * DEVICE_DIRECTIONS, S[2 * DEVICE_DIRECTIONS] / S[0]))
         self.ctxs = [device.DeviceContext(U, K.S, K.V, device=d, keep=keep) for d in self.device_ids]
         self.n_s, self.n_omega = self.ctxs[0].n_s, self.ctxs[0].n_omega
         if len(self.ctxs) > 1:

@@ -887,9 +887,10 @@ def test_the_device_keeps_64_singular_directions_only_where_the_others_cannot_ma
     assert len(K.S) > 64
     G = Gmat.reshape(-1, 1000)
     alpha = np.geomspace(1e4, 1e-2, 20)[None, :] * 1000
-    arrays = dict(G=G, err=synthetic.SIGMA * np.ones((1, 1000)), alpha=alpha, sel=np.zeros(4, dtype=int))
+    D = synthetic.flat_D(omega)
+    arrays = dict(G=G, err=synthetic.SIGMA * np.ones((1, 1000)), alpha=alpha, sel=np.zeros(4, dtype=int), D=D[None, :])
     assert bs.directions_to_keep(K, None, arrays) == 64
-    specs = [dict(G=g, err=synthetic.SIGMA * np.ones(1000), alpha=alpha[0], U_rot=None) for g in G]
+    specs = [dict(G=g, err=synthetic.SIGMA * np.ones(1000), alpha=alpha[0], U_rot=None, D=D) for g in G]
     assert bs.directions_to_keep(K, specs, None) == 64
     assert bs.directions_to_keep(K, None, dict(arrays, err=1e-9 * np.ones((1, 1000)))) is None
     assert bs.directions_to_keep(K, None, dict(arrays, alpha=alpha * 1e-9)) is None
@@ -897,4 +898,12 @@ def test_the_device_keeps_64_singular_directions_only_where_the_others_cannot_ma
     assert bs.directions_to_keep(K, None, dict(arrays, err=synthetic.SIGMA * (1.0 + 0.1 * np.arange(1000) / 1000.0)[None, :])) is None   # (error bars that vary)
     tau2, omega2, K2, Gmat2, _ = synthetic.matrix_G(2, 100, 200)
     K2.reduce_singular_space(1e-14)
+    # a mesh of 2 000 frequencies on 1 000 data points: 991 'singular values' above the absolute 1e-14 (the rounding floor of that
+    # decomposition): 64 are kept at error bars of 1e-4; at 1e-9 nothing can be dropped and the job is beyond the device (n_s <= 128)
+    tau3, omega3, K3, G3 = synthetic.single_G(1000, 2000)
+    K3.reduce_singular_space(1e-14)
+    assert len(K3.S) > 128
+    sp3 = dict(G=G3, err=1e-4 * np.ones(1000), alpha=alpha[0], U_rot=None, D=synthetic.flat_D(omega3))
+    assert bs.directions_to_keep(K3, [sp3], None) == 64
+    assert bs.directions_to_keep(K3, [dict(sp3, err=1e-9 * np.ones(1000))], None) is None
     assert len(K2.S) <= 64 and bs.directions_to_keep(K2, None, dict(arrays, G=Gmat2.reshape(-1, 100), err=1e-4 * np.ones((1, 100)))) is None
